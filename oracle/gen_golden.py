@@ -1,0 +1,432 @@
+"""TEST INFRASTRUCTURE — build-container only.
+
+Generates the golden fixtures under tests/golden/ by running the UNMODIFIED
+reference (/root/reference, imported through oracle/refshim.py) on tiny seeded
+configurations.  Fixtures are data only: inputs, weights and the reference's
+outputs as fp32/int arrays in .npz files (plus JSON for configs).  Re-run with
+
+    python -m oracle.gen_golden            # all groups
+    python -m oracle.gen_golden g1 g4      # some groups
+
+Groups:
+  g1  LocalLoraLinear per-adapter outputs + scaling dict
+  g2  one decoder layer: routed prefill and cached decode
+  g3  splice (equal-length and ragged batches, labels, masks)
+  g4  tiny end-to-end: CLIP tower + mlp2x_gelu + splice + 2-layer LLM + greedy ids
+  g5  encoders / projectors (clip, ...)
+  g6  merge script file-level outputs
+  g7  dense-merge equivalence
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import refshim
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _np(t):
+    if isinstance(t, torch.Tensor):
+        t = t.detach()
+        if t.dtype == torch.bool:
+            return t.numpy()
+        if t.is_floating_point():
+            return t.float().numpy()
+        return t.numpy()
+    return np.asarray(t)
+
+
+def _save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: _np(v) for k, v in arrays.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def _sd(module, prefix="sd::", clip_prefix=None):
+    """state_dict with the reference-era (transformers==4.31) key grammar: HF 5.x dropped the
+    'vision_model.' wrapper of CLIPVisionModel; real checkpoints carry it, so fixtures do too."""
+    out = {}
+    for k, v in module.state_dict().items():
+        if clip_prefix is not None and k.startswith(clip_prefix) and not k.startswith(clip_prefix + "vision_model."):
+            k = clip_prefix + "vision_model." + k[len(clip_prefix):]
+        out[prefix + k] = v
+    return out
+
+
+def _randomize_lora(model, seed=1):
+    """reset_lora_parameters leaves B = 0; give every adapter a non-zero B so composition matters."""
+    g = torch.Generator().manual_seed(seed)
+    for n, p in model.named_parameters():
+        if ".lora_B." in n:
+            p.data = torch.randn(p.shape, generator=g) * 0.05
+        if "prefix_tokens" in n or "suffix_tokens" in n:
+            p.data = torch.randn(p.shape, generator=g) * 0.02
+
+
+def tiny_llm_config(ml, modal=("vision", "audio"), reset="default-vision=0.5,default-audio=0.25", layers=2,
+                    prefix_tokens=0, hidden=32, heads=4, inter=64, vocab=97, r=4, alpha=8):
+    cfg = ml.MultimodalConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                              num_attention_heads=heads, num_key_value_heads=heads, max_position_embeddings=256,
+                              rms_norm_eps=1e-5, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    cfg.lora_r, cfg.lora_alpha, cfg.lora_dropout = r, alpha, 0.0
+    cfg.lora_strategy = "modal+language"
+    for m in modal:
+        setattr(cfg, f"mm_{m}_encoder", f"fake/{m}")
+    cfg.reset_scaling_weights = reset
+    cfg.pretraining_tp = 1
+    cfg.rope_scaling = None
+    cfg.local_prefix_tokens = prefix_tokens
+    cfg.local_suffix_tokens = prefix_tokens
+    return cfg
+
+
+def cfg_json(cfg, extra=None):
+    keys = ["vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+            "num_key_value_heads", "max_position_embeddings", "rms_norm_eps", "lora_r", "lora_alpha", "lora_strategy",
+            "reset_scaling_weights", "local_prefix_tokens", "local_suffix_tokens", "mm_vision_encoder",
+            "mm_audio_encoder", "mm_video_encoder", "mm_point_encoder", "pad_token_id", "eos_token_id"]
+    d = {k: getattr(cfg, k, None) for k in keys}
+    d.update(extra or {})
+    return json.dumps(d)
+
+
+# ----------------------------------------------------------------------------
+def g1():
+    ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
+    torch.manual_seed(11)
+    names = ["default", "audio", "vision", "video"]
+    lin = ml.LocalLoraLinear(names, 24, 40, 4, 8, 0.0, bias=False,
+                             reset_scaling_weights="default-video=0.333,default-audio=0.5,default-vision=0.25,audio=1.5")
+    lin.eval()
+    _randomize_lora(lin, 3)
+    x = torch.randn(2, 7, 24)
+    outs = lin(x, active_adapters=names + ["point"])      # 'point' is unknown -> base output (:127-129)
+    base = lin(x)
+    arrays = {"x": x, "out::base": base}
+    for k, v in outs.items():
+        arrays[f"out::{k}"] = v
+    arrays.update(_sd(lin))
+    _save("g1_lora_linear", meta=np.array(json.dumps({
+        "modal_names": names, "lora_r": 4, "lora_alpha": 8,
+        "reset_scaling_weights": lin.reset_scaling_weights,
+        "scaling": lin.scaling, "adapters": list(lin.lora_A.keys()),
+        "default_adapter_names": lin.default_adapter_names, "merge_default_weights": lin.merge_default_weights})),
+        **arrays)
+
+
+def g2():
+    ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
+    torch.manual_seed(12)
+    cfg = tiny_llm_config(ml, layers=2)
+    model = ml.MultimodalLlamaForCausalLM(cfg).eval()
+    _randomize_lora(model, 5)
+    B, L = 2, 9
+    x = torch.randn(B, L, cfg.hidden_size)
+    mm = {"vision": torch.zeros(B, L, dtype=torch.bool), "audio": torch.zeros(B, L, dtype=torch.bool)}
+    mm["vision"][0, 2:5] = True
+    mm["vision"][1, 1:3] = True
+    mm["audio"][0, 6:8] = True
+    mm["default"] = (mm["vision"].int() + mm["audio"].int()) == 0
+    am = torch.ones(B, L, dtype=torch.bool)
+    am[1, -2:] = False       # right padding on sample 1
+    with torch.no_grad():
+        out = model.model(inputs_embeds=x, attention_mask=am, modal_attention_mask=mm, use_cache=True)
+        h_pre, kv = out[0], out[1]
+        # decode step with cache (modal mask dropped inside the layer, :435-438)
+        x1 = torch.randn(B, 1, cfg.hidden_size)
+        am1 = torch.ones(B, L + 1, dtype=torch.bool)
+        out1 = model.model(inputs_embeds=x1, attention_mask=am1, past_key_values=kv, modal_attention_mask=mm,
+                           use_cache=True)
+        # unrouted prefill (modal mask None)
+        out_nr = model.model(inputs_embeds=x, attention_mask=am, modal_attention_mask=None, use_cache=True)
+        logits = model.lm_head(h_pre)
+    arrays = dict(x=x, attention_mask=am, x1=x1, hidden_prefill=h_pre, hidden_decode=out1[0],
+                  hidden_prefill_unrouted=out_nr[0], logits_prefill=logits,
+                  k0=kv[0][0], v0=kv[0][1], k1_dec=out1[1][1][0])
+    for k, v in mm.items():
+        arrays[f"mask::{k}"] = v
+    arrays.update(_sd(model))
+    _save("g2_decoder", meta=np.array(cfg_json(cfg, {"modal_names": model.modal_names})), **arrays)
+
+
+def g3():
+    ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
+    torch.manual_seed(13)
+    cfg = tiny_llm_config(ml, modal=("vision", "audio", "video"), reset=None, layers=1, hidden=16, heads=2, inter=32)
+    model = ml.MultimodalLlamaForCausalLM(cfg).eval()
+    H = cfg.hidden_size
+
+    class FakeEnc(nn.Module):
+        def __init__(self, n, d):
+            super().__init__()
+            self.n, self.d = n, d
+            self.p = nn.Parameter(torch.zeros(1))
+
+        @property
+        def dummy_inputs(self):
+            return torch.zeros(1, self.n, self.d)
+
+        def forward(self, x, **kw):
+            return x
+
+    class FakeAudio(FakeEnc):
+        @property
+        def dummy_inputs(self):
+            return {"audio_inputs": torch.zeros(1, self.n, self.d)}
+
+        def forward(self, audio_inputs, audio_padding_mask=None):
+            return audio_inputs, None
+
+    class FakeVideo(FakeEnc):
+        @property
+        def dummy_inputs(self):
+            return torch.zeros(1, 2, self.n // 2, self.d)
+
+        def forward(self, x):
+            return x        # (b, t, n, d)
+
+    model.model.modal_encoders = nn.ModuleDict({"audio": FakeAudio(3, H), "vision": FakeEnc(4, H), "video": FakeVideo(6, H)})
+    model.model.modal_projectors = nn.ModuleDict({m: nn.Identity() for m in ("audio", "vision", "video")})
+    pre = {m: torch.randn(1, 2, H) for m in ("default", "audio", "vision", "video")}
+    suf = {m: torch.randn(1, 1, H) for m in ("default", "audio", "vision", "video")}
+
+    def run(tag, ids, labels, am, modal_inputs, use_ps=True):
+        with torch.no_grad():
+            _, am2, _, emb, lab, mam = model.prepare_inputs_labels_for_multimodal(
+                ids, am, None, labels, modal_inputs, pre if use_ps else None, suf if use_ps else None)
+        arrays = {f"{tag}::input_ids": ids, f"{tag}::attention_mask_in": am, f"{tag}::embeds": emb,
+                  f"{tag}::attention_mask": am2}
+        if labels is not None:
+            arrays[f"{tag}::labels_in"] = labels
+            arrays[f"{tag}::labels"] = lab
+        for k, v in mam.items():
+            arrays[f"{tag}::mask::{k}"] = v
+        for k, v in modal_inputs.items():
+            if isinstance(v, dict):
+                arrays[f"{tag}::modal::{k}"] = v["audio_inputs"]
+            else:
+                arrays[f"{tag}::modal::{k}"] = v
+        return arrays
+
+    arrays = {}
+    V, A, VD = -200, -203, -204
+    # (a) equal-length batch, vision+audio each, video absent (dummy path), with labels
+    ids = torch.tensor([[1, 5, V, 13, 7, A, 13, 9, 10], [1, 6, A, 13, 8, V, 13, 11, 12]])
+    labels = ids.clone(); labels[:, :4] = -100
+    mi = {"vision": torch.randn(2, 4, H), "audio": {"audio_inputs": torch.randn(2, 3, H)}}
+    arrays.update(run("eq", ids, labels, torch.ones_like(ids, dtype=torch.bool), mi))
+    # (b) ragged: sample 0 has two images, sample 1 has video only; labels given (needed by the reference's ragged branch)
+    ids = torch.tensor([[1, V, 13, V, 13, 20, 21], [1, 22, VD, 13, 23, 24, 25]])
+    labels = ids.clone(); labels[:, :2] = -100
+    am = torch.ones_like(ids, dtype=torch.bool)
+    mi = {"vision": torch.randn(2, 4, H), "video": torch.randn(1, 2, 3, H)}
+    # NB: audio absent here -> reference stacks an empty list for it in the ragged branch
+    # (Appendix B); drop audio from the model for this case.
+    enc_bak, proj_bak = model.model.modal_encoders, model.model.modal_projectors
+    model.model.modal_encoders = nn.ModuleDict({"vision": enc_bak["vision"], "video": enc_bak["video"]})
+    model.model.modal_projectors = nn.ModuleDict({"vision": nn.Identity(), "video": nn.Identity()})
+    cfg.mm_audio_encoder = None
+    arrays.update(run("ragged", ids, labels, am, mi))
+    # (c) no prefix/suffix, no labels, equal length, sentinel first/last positions
+    ids = torch.tensor([[V, 13, 30, 31, VD], [VD, 13, 32, 33, V]])
+    mi = {"vision": torch.randn(2, 4, H), "video": torch.randn(2, 2, 3, H)}
+    arrays.update(run("edge", ids, None, torch.ones_like(ids, dtype=torch.bool), mi, use_ps=False))
+    model.model.modal_encoders, model.model.modal_projectors = enc_bak, proj_bak
+    cfg.mm_audio_encoder = "fake/audio"
+    for m in pre:
+        arrays[f"prefix::{m}"] = pre[m]
+        arrays[f"suffix::{m}"] = suf[m]
+    arrays["embed_tokens"] = model.model.embed_tokens.weight
+    _save("g3_splice", **arrays)
+
+
+def _tiny_clip_dir(tmp, hidden=32, layers=3, heads=4, inter=64, image=28, patch=14, seed=21):
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    torch.manual_seed(seed)
+    c = CLIPVisionConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
+                         image_size=image, patch_size=patch, projection_dim=16)
+    m = CLIPVisionModel(c).eval()
+    for p in m.parameters():       # HF init leaves biases at 0 / LN at 1: randomise so every term matters
+        p.data = torch.randn_like(p) * 0.05 + (1.0 if p.ndim == 1 and "norm" in "" else 0.0)
+    for n, p in m.named_parameters():
+        if "layer_norm" in n or "layrnorm" in n or "layernorm" in n:
+            if n.endswith("weight"):
+                p.data = 1.0 + 0.1 * torch.randn_like(p)
+    d = os.path.join(tmp, "clip-tiny")
+    m.save_pretrained(d, safe_serialization=False)
+    json.dump({"crop_size": image, "do_center_crop": True, "do_normalize": True, "do_resize": True,
+               "image_mean": [0.48145466, 0.4578275, 0.40821073], "image_std": [0.26862954, 0.26130258, 0.27577711],
+               "size": image, "image_processor_type": "CLIPImageProcessor"},
+              open(os.path.join(d, "preprocessor_config.json"), "w"))
+    return d, c
+
+
+def g4():
+    """Tiny end-to-end through the reference classes: CLIPVisionTower -> mlp2x_gelu -> splice -> 2-layer LLM."""
+    ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
+    ce = refshim.import_ref("modelcompose.model.multimodal_encoder.clip_encoder")
+    pb = refshim.import_ref("modelcompose.model.multimodal_projector.builder")
+    with tempfile.TemporaryDirectory() as tmp:
+        clip_dir, ccfg = _tiny_clip_dir(tmp)
+        torch.manual_seed(14)
+        cfg = tiny_llm_config(ml, modal=("vision",), reset="default-vision=0.5", layers=2, prefix_tokens=2)
+        cfg.mm_vision_encoder = clip_dir
+        cfg.mm_vision_select_layer = -2
+        cfg.mm_vision_select_feature = "patch"
+        cfg.mm_projector_type = "mlp2x_gelu"
+        model = ml.MultimodalLlamaForCausalLM(cfg).eval()
+        args = types.SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature="patch")
+        tower = ce.CLIPVisionTower(clip_dir, args, delay_load=False)
+        pcfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=ccfg.hidden_size, hidden_size=cfg.hidden_size)
+        proj = pb.build_vision_projector(pcfg)
+        for p in proj.parameters():
+            p.data = torch.randn_like(p) * 0.1
+        model.model.modal_encoders = nn.ModuleDict({"vision": tower})
+        model.model.modal_projectors = nn.ModuleDict({"vision": proj})
+        _randomize_lora(model, 7)
+        model.eval()
+        B = 2
+        V = -200
+        g = torch.Generator().manual_seed(3)
+        ids = torch.cat([torch.ones(B, 1, dtype=torch.long), torch.randint(3, 97, (B, 4), generator=g),
+                         torch.full((B, 1), V), torch.full((B, 1), 13), torch.randint(3, 97, (B, 5), generator=g)], dim=1)
+        pixels = torch.randn(B, 3, 28, 28, generator=g)
+        n_new = 8
+        with torch.no_grad():
+            feats = tower(pixels)
+            out = model(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool),
+                        modal_inputs={"vision": pixels}, use_cache=True)
+            logits0 = out.logits
+            # hand-written 4.31-style greedy loop
+            kv = out.past_key_values
+            nxt = logits0[:, -1].argmax(-1)
+            gen = [nxt]
+            steps_logits = [logits0[:, -1]]
+            am = torch.ones(B, logits0.shape[1], dtype=torch.bool)
+            for _ in range(n_new - 1):
+                am = torch.cat([am, torch.ones(B, 1, dtype=torch.bool)], dim=1)
+                o = model(input_ids=nxt[:, None], attention_mask=am, past_key_values=kv,
+                          modal_inputs={"vision": pixels}, use_cache=True)
+                kv = o.past_key_values
+                steps_logits.append(o.logits[:, -1])
+                nxt = o.logits[:, -1].argmax(-1)
+                gen.append(nxt)
+        arrays = dict(input_ids=ids, pixels=pixels, clip_features=feats, logits_prefill=logits0,
+                      gen_ids=torch.stack(gen, 1), step_logits=torch.stack(steps_logits, 1))
+        arrays.update(_sd(model, clip_prefix="model.modal_encoders.vision.vision_tower."))
+        extra = {"modal_names": model.modal_names, "mm_projector_type": "mlp2x_gelu", "mm_vision_select_layer": -2,
+                 "clip": {"hidden_size": ccfg.hidden_size, "intermediate_size": ccfg.intermediate_size,
+                          "num_hidden_layers": ccfg.num_hidden_layers, "num_attention_heads": ccfg.num_attention_heads,
+                          "image_size": ccfg.image_size, "patch_size": ccfg.patch_size,
+                          "layer_norm_eps": ccfg.layer_norm_eps, "hidden_act": ccfg.hidden_act}}
+        d = json.loads(cfg_json(cfg, extra))
+        d["mm_vision_encoder"] = "clip-tiny"
+        _save("g4_e2e_vision", meta=np.array(json.dumps(d)), **arrays)
+
+
+def g6():
+    """File-level golden for merge_checkpoints('online-merge-reset-...') (merge_unimodal_modelcompose.py:28-145)."""
+    refshim.install()
+    import importlib
+    mm = importlib.import_module("merge_unimodal_modelcompose")
+    torch.manual_seed(16)
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = []
+        inputs = {}
+        for modal, enc_key in (("video", "mm_video_encoder"), ("audio", "mm_audio_encoder"), ("vision", "mm_vision_encoder")):
+            d = os.path.join(tmp, f"ckpt-{modal}")
+            os.makedirs(d)
+            w = {}
+            for i in range(2):
+                for lin in ("self_attn.q_proj", "mlp.down_proj"):
+                    for ab, shape in (("A", (4, 8)), ("B", (8, 4))):
+                        w[f"model.layers.{i}.{lin}.lora_{ab}.default.weight"] = torch.randn(shape)
+                        w[f"model.layers.{i}.{lin}.lora_{ab}.{modal}.weight"] = torch.randn(shape)
+            w[f"model.modal_projectors.{modal}.0.weight"] = torch.randn(8, 6)
+            w[f"prefix_tokens.{modal}"] = torch.randn(1, 2, 8)
+            torch.save(w, os.path.join(d, "adapter_model.bin"))
+            c = {"model_type": "multimodal", enc_key: f"/ckpts/{modal}", "lora_r": 4, "lora_alpha": 8,
+                 "lora_strategy": "modal+language", "local_prefix_tokens": 2, "hidden_size": 8,
+                 f"mm_{modal}_projector_type": "mlp2x_gelu"}
+            json.dump(c, open(os.path.join(d, "config.json"), "w"))
+            paths.append(d)
+            inputs[modal] = (w, c)
+        out = os.path.join(tmp, "merged")
+        strat = "online-merge-reset-default-video=0.333,default-audio=0.333,default-vision=0.333"
+        mm.merge_checkpoints(paths, out, strat)
+        merged = torch.load(os.path.join(out, "adapter_model.bin"))
+        mcfg = json.load(open(os.path.join(out, "config.json")))
+        info = open(os.path.join(out, "merge_info.txt")).read().replace(tmp, "<TMP>")
+        arrays = {}
+        for modal, (w, c) in inputs.items():
+            for k, v in w.items():
+                arrays[f"in::{modal}::{k}"] = v
+        for k, v in merged.items():
+            arrays[f"out::{k}"] = v
+        meta = {"strategy": strat, "order": ["video", "audio", "vision"],
+                "in_configs": {m: c for m, (w, c) in inputs.items()}, "out_config": mcfg, "merge_info": info}
+        _save("g6_merge", meta=np.array(json.dumps(meta)), **arrays)
+
+
+def g7():
+    """Dense-merge equivalence W + Σ c·(α/r)·B·A  vs branch form, through the reference layer."""
+    ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
+    torch.manual_seed(17)
+    names = ["default", "audio", "vision"]
+    lin = ml.LocalLoraLinear(names, 48, 32, 8, 16, 0.0, bias=False,
+                             reset_scaling_weights="default-audio=0.333,default-vision=0.667").eval()
+    _randomize_lora(lin, 9)
+    x = torch.randn(3, 5, 48)
+    outs = lin(x, active_adapters=names)
+    arrays = {"x": x}
+    for k, v in outs.items():
+        arrays[f"out::{k}"] = v
+    arrays.update(_sd(lin))
+    _save("g7_dense_merge", meta=np.array(json.dumps({"modal_names": names, "lora_r": 8, "lora_alpha": 16,
+                                                      "reset_scaling_weights": lin.reset_scaling_weights,
+                                                      "scaling": lin.scaling})), **arrays)
+
+
+def g5_clip():
+    ce = refshim.import_ref("modelcompose.model.multimodal_encoder.clip_encoder")
+    with tempfile.TemporaryDirectory() as tmp:
+        clip_dir, ccfg = _tiny_clip_dir(tmp, hidden=64, layers=3, heads=4, inter=128, image=42, patch=14, seed=31)
+        args = types.SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature="patch")
+        tower = ce.CLIPVisionTower(clip_dir, args, delay_load=False).eval()
+        torch.manual_seed(5)
+        px = torch.randn(2, 3, 42, 42)
+        with torch.no_grad():
+            f = tower(px)
+            hs = tower.vision_tower(px, output_hidden_states=True).hidden_states
+            tower.select_feature = "cls_patch"; tower.select_layer = -1
+            f_last = tower(px)
+        arrays = dict(pixels=px, features=f, features_last_cls=f_last, hs0=hs[0], hs1=hs[1])
+        arrays.update(_sd(tower.vision_tower, clip_prefix=""))
+        meta = {"hidden_size": 64, "intermediate_size": 128, "num_hidden_layers": 3, "num_attention_heads": 4,
+                "image_size": 42, "patch_size": 14, "layer_norm_eps": ccfg.layer_norm_eps, "hidden_act": ccfg.hidden_act}
+        _save("g5_clip", meta=np.array(json.dumps(meta)), **arrays)
+
+
+GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g6": g6, "g7": g7}
+
+
+def main(argv):
+    refshim.install()
+    todo = argv or list(GROUPS)
+    for g in todo:
+        print(f"== {g}")
+        GROUPS[g]()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,101 @@
+"""Oracle (TEST INFRASTRUCTURE): end-to-end composed model on the CPU.
+
+encode (per-modality encoder -> projector -> prefix|feat|suffix)  multimodal_arch.py:197-268
+splice                                                              multimodal_arch.py:287-459
+LocalLoRA llama prefill + greedy decode                             multimodal_llama.py:676-767 and the
+  transformers==4.31 greedy_search loop (third-party; restated: argmax of logits[:, -1], feed
+  input_ids[:, -1:] + tuple KV cache, stop on EOS / max_new_tokens, finished rows emit pad).
+Also the timed ``cpu_baseline`` of bench.py.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import encoders as enc
+from . import llm, splice
+
+
+class OracleModel:
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: llm.LLMConfig, meta: dict, emulate: Optional[str] = None):
+        self.sd, self.cfg, self.meta, self.emulate = sd, cfg, meta, emulate
+        self.modals = [m for m in cfg.modal_names if m != "default"]
+        self.prefix = {k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("prefix_tokens.")} or None
+        self.suffix = {k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("suffix_tokens.")} or None
+
+    @classmethod
+    def from_state_dict(cls, sd, meta, emulate=None):
+        cfg = llm.LLMConfig(
+            vocab_size=meta["vocab_size"], hidden_size=meta["hidden_size"], intermediate_size=meta["intermediate_size"],
+            num_hidden_layers=meta["num_hidden_layers"], num_attention_heads=meta["num_attention_heads"],
+            num_key_value_heads=meta["num_key_value_heads"], max_position_embeddings=meta["max_position_embeddings"],
+            rms_norm_eps=meta["rms_norm_eps"], lora_r=meta["lora_r"], lora_alpha=meta["lora_alpha"],
+            lora_strategy=meta.get("lora_strategy"), modal_names=tuple(meta["modal_names"]),
+            reset_scaling_weights=meta.get("reset_scaling_weights"), pad_token_id=meta.get("pad_token_id", 0),
+            eos_token_id=meta.get("eos_token_id", 2))
+        return cls(sd, cfg, meta, emulate)
+
+    # -- encoders -----------------------------------------------------------
+    def _sub(self, prefix):
+        n = len(prefix)
+        return {k[n:]: v for k, v in self.sd.items() if k.startswith(prefix)}
+
+    def encode_modal(self, modal: str, x):
+        if modal == "vision":
+            c = enc.ClipVisionConfig(**self.meta["clip"])
+            sdv = self._sub("model.modal_encoders.vision.vision_tower.")
+            f = enc.clip_vision_tower(x, sdv, c, self.meta.get("mm_vision_select_layer", -2),
+                                      self.meta.get("mm_vision_select_feature", "patch"))
+            return enc.projector(f, self.sd, "model.modal_projectors.vision", self.meta.get("mm_projector_type", "linear"))
+        from . import encoders_extra as ex      # audio / video / point (added with their fixtures)
+        return ex.encode(self, modal, x)
+
+    # -- forward ------------------------------------------------------------
+    def prepare(self, input_ids, modal_inputs, attention_mask=None, labels=None):
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
+        fns = {m: (lambda x, m=m: self.encode_modal(m, x)) for m in self.modals}
+        feats, fmask = splice.encode_modal_inputs(modal_inputs, self.modals, fns, self.prefix, self.suffix, skip_absent=True)
+        return splice.prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, list(modal_inputs), feats,
+                                                           fmask, self.sd["model.embed_tokens.weight"])
+
+    def prefill(self, input_ids, modal_inputs, attention_mask=None, last_only=False):
+        am, emb, _, mam = self.prepare(input_ids, modal_inputs, attention_mask)
+        if self.cfg.lora_strategy not in ("modal", "modal+language"):          # multimodal_llama.py:703-704
+            mam = None
+        h, kv = llm.model_forward(self.sd, self.cfg, inputs_embeds=emb, attention_mask=am, modal_attention_mask=mam,
+                                  emulate=self.emulate)
+        if last_only:
+            h = h[:, -1:]
+        return llm.lm_logits(h, self.sd), kv, am
+
+    def decode_step(self, token_ids, kv, am):
+        am = torch.ones((am.shape[0], kv[-1][-1].shape[-2] + 1), dtype=am.dtype)  # multimodal_arch.py:290-293
+        h, kv = llm.model_forward(self.sd, self.cfg, input_ids=token_ids[:, None], attention_mask=am, past_key_values=kv,
+                                  emulate=self.emulate)
+        return llm.lm_logits(h, self.sd)[:, -1], kv, am
+
+    def generate(self, input_ids, modal_inputs, max_new_tokens=128, ignore_eos=False, return_logits=False):
+        """Greedy; returns the NEW ids (B, n).  With ignore_eos=False rows that hit EOS emit pad afterwards
+        and the loop stops once every row has finished (transformers 4.31 greedy_search)."""
+        logits, kv, am = self.prefill(input_ids, modal_inputs, last_only=True)
+        last = logits[:, -1]
+        B = input_ids.shape[0]
+        unfinished = torch.ones(B, dtype=torch.long)
+        pad = self.cfg.pad_token_id if self.cfg.pad_token_id is not None else self.cfg.eos_token_id
+        out, all_logits = [], []
+        for step in range(max_new_tokens):
+            all_logits.append(last)
+            nxt = last.argmax(-1)
+            if not ignore_eos:
+                nxt = nxt * unfinished + pad * (1 - unfinished)
+                unfinished = unfinished * (nxt != self.cfg.eos_token_id).long()
+            out.append(nxt)
+            if (not ignore_eos and unfinished.max() == 0) or step == max_new_tokens - 1:
+                break
+            last, kv, am = self.decode_step(nxt, kv, am)
+        ids = torch.stack(out, 1)
+        if return_logits:
+            return ids, torch.stack(all_logits, 1)
+        return ids

@@ -1,0 +1,174 @@
+"""Pins the CPU oracle against fixtures produced by the reference itself
+(oracle/gen_golden.py, run in the build container).  CPU only."""
+import json
+
+import torch
+
+from conftest import load_golden
+from oracle import encoders as enc
+from oracle import llm, splice
+
+TOL = dict(rtol=1e-4, atol=2e-5)
+
+
+def cfg_from_meta(meta, modal_names=None):
+    return llm.LLMConfig(
+        vocab_size=meta["vocab_size"], hidden_size=meta["hidden_size"], intermediate_size=meta["intermediate_size"],
+        num_hidden_layers=meta["num_hidden_layers"], num_attention_heads=meta["num_attention_heads"],
+        num_key_value_heads=meta["num_key_value_heads"], max_position_embeddings=meta["max_position_embeddings"],
+        rms_norm_eps=meta["rms_norm_eps"], lora_r=meta["lora_r"], lora_alpha=meta["lora_alpha"],
+        lora_strategy=meta["lora_strategy"], modal_names=tuple(modal_names or meta["modal_names"]),
+        reset_scaling_weights=meta["reset_scaling_weights"])
+
+
+def test_g1_lora_linear_adapters_and_scaling():
+    a, meta, sd = load_golden("g1_lora_linear")
+    cfg = llm.LLMConfig(lora_r=meta["lora_r"], lora_alpha=meta["lora_alpha"], modal_names=tuple(meta["modal_names"]),
+                        reset_scaling_weights=meta["reset_scaling_weights"])
+    names, scaling, dnames, merge = llm.adapter_plan(cfg)
+    assert names == meta["adapters"]
+    assert dnames == meta["default_adapter_names"]
+    assert merge == meta["merge_default_weights"]
+    for k, v in meta["scaling"].items():
+        assert abs(scaling[k] - v) < 1e-12
+    sd = {"lin." + k: v for k, v in sd.items()}
+    outs = llm.lora_linear(a["x"], sd, "lin", cfg, list(meta["modal_names"]) + ["point"])
+    for k in outs:
+        torch.testing.assert_close(outs[k], a[f"out::{k}"], **TOL)
+    torch.testing.assert_close(llm.lora_linear(a["x"], sd, "lin", cfg, None), a["out::base"], **TOL)
+    # unknown adapter falls back to the base output
+    torch.testing.assert_close(outs["point"], a["out::base"], **TOL)
+
+
+def test_g7_dense_merge_equals_branch_form():
+    a, meta, sd = load_golden("g7_dense_merge")
+    cfg = llm.LLMConfig(lora_r=meta["lora_r"], lora_alpha=meta["lora_alpha"], modal_names=tuple(meta["modal_names"]),
+                        reset_scaling_weights=meta["reset_scaling_weights"])
+    sd = {"lin." + k: v for k, v in sd.items()}
+    for ad in meta["modal_names"]:
+        w = llm.merged_weight(sd, "lin", cfg, ad)
+        y = torch.nn.functional.linear(a["x"], w)
+        torch.testing.assert_close(y, a[f"out::{ad}"], rtol=1e-4, atol=1e-5)
+
+
+def test_g2_decoder_routed_prefill_and_decode():
+    a, meta, sd = load_golden("g2_decoder")
+    cfg = cfg_from_meta(meta)
+    mm = {k[6:]: v for k, v in a.items() if k.startswith("mask::")}
+    # the reference iterates the mask dict in insertion order: vision, audio, default
+    mm = {k: mm[k] for k in ("vision", "audio", "default")}
+    h, kv = llm.model_forward(sd, cfg, inputs_embeds=a["x"], attention_mask=a["attention_mask"], modal_attention_mask=mm)
+    torch.testing.assert_close(h, a["hidden_prefill"], **TOL)
+    torch.testing.assert_close(kv[0][0], a["k0"], **TOL)
+    torch.testing.assert_close(kv[0][1], a["v0"], **TOL)
+    torch.testing.assert_close(llm.lm_logits(h, sd), a["logits_prefill"], **TOL)
+    B, L = a["x"].shape[:2]
+    h1, kv1 = llm.model_forward(sd, cfg, inputs_embeds=a["x1"], attention_mask=torch.ones(B, L + 1, dtype=torch.bool),
+                                modal_attention_mask=mm, past_key_values=kv)
+    torch.testing.assert_close(h1, a["hidden_decode"], **TOL)
+    torch.testing.assert_close(kv1[1][0], a["k1_dec"], **TOL)
+    hn, _ = llm.model_forward(sd, cfg, inputs_embeds=a["x"], attention_mask=a["attention_mask"])
+    torch.testing.assert_close(hn, a["hidden_prefill_unrouted"], **TOL)
+
+
+def test_g2_premerged_weights_reproduce_routed_forward():
+    """Device-path formulation: per-adapter dense weights + per-token routing == reference mask-sum."""
+    a, meta, sd = load_golden("g2_decoder")
+    cfg = cfg_from_meta(meta)
+    mm = {k[6:]: v for k, v in a.items() if k.startswith("mask::")}
+    merged = llm.premerge_state_dict(sd, cfg, emulate=None)
+    # route: build a per-token weight choice by running each adapter's dense model on all tokens is NOT
+    # equivalent (attention mixes tokens), so check the layer-0 q projection only.
+    x = llm.rms_norm(a["x"], sd["model.layers.0.input_layernorm.weight"], cfg.rms_norm_eps)
+    ref = llm._route(llm.lora_linear(x, sd, "model.layers.0.self_attn.q_proj", cfg, cfg.modal_names), mm, x)
+    got = torch.zeros_like(ref)
+    for ad in cfg.modal_names:
+        y = torch.nn.functional.linear(x, merged[ad]["model.layers.0.self_attn.q_proj.weight"])
+        got = torch.where(mm[ad].unsqueeze(-1), y, got)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
+
+
+def _splice_case(a, tag, modal_inputs_keys, modals, prefix, suffix, embed):
+    ids = a[f"{tag}::input_ids"]
+    am = a[f"{tag}::attention_mask_in"]
+    labels = a.get(f"{tag}::labels_in")
+    inputs = {m: a[f"{tag}::modal::{m}"] for m in modal_inputs_keys}
+
+    def mk(m):
+        def f(x):
+            if x is None:       # absent modality: reference runs dummy zeros; never spliced
+                return torch.zeros(1, 1, embed.shape[1])
+            if m == "video":
+                b, t, n, d = x.shape
+                return x.reshape(b, t * n, d)
+            return x
+        return f
+
+    feats, fmask = splice.encode_modal_inputs(inputs, modals, {m: mk(m) for m in modals}, prefix, suffix)
+    am2, emb, lab, mam = splice.prepare_inputs_labels_for_multimodal(ids, am, labels, modal_inputs_keys, feats, fmask, embed)
+    torch.testing.assert_close(emb, a[f"{tag}::embeds"], rtol=0, atol=0)
+    assert torch.equal(am2, a[f"{tag}::attention_mask"])
+    if labels is not None:
+        assert torch.equal(lab, a[f"{tag}::labels"])
+    exp_masks = {k.split("::")[-1]: v for k, v in a.items() if k.startswith(f"{tag}::mask::")}
+    assert set(mam) == set(exp_masks)
+    for k in exp_masks:
+        assert torch.equal(mam[k], exp_masks[k]), k
+
+
+def test_g3_splice_bit_exact():
+    a, _, _ = load_golden("g3_splice")
+    embed = a["embed_tokens"]
+    pre = {k.split("::")[1]: v for k, v in a.items() if k.startswith("prefix::")}
+    suf = {k.split("::")[1]: v for k, v in a.items() if k.startswith("suffix::")}
+    _splice_case(a, "eq", ["vision", "audio"], ["audio", "vision", "video"], pre, suf, embed)
+    _splice_case(a, "ragged", ["vision", "video"], ["vision", "video"], pre, suf, embed)
+    _splice_case(a, "edge", ["vision", "video"], ["vision", "video"], None, None, embed)
+
+
+def test_g5_clip_tower():
+    a, meta, sd = load_golden("g5_clip")
+    cfg = enc.ClipVisionConfig(**meta)
+    hs = enc.clip_vision_hidden_states(a["pixels"], sd, cfg)
+    torch.testing.assert_close(hs[0], a["hs0"], **TOL)
+    torch.testing.assert_close(hs[1], a["hs1"], **TOL)
+    f = enc.clip_vision_tower(a["pixels"], sd, cfg, -2, "patch")
+    torch.testing.assert_close(f, a["features"], **TOL)
+    f = enc.clip_vision_tower(a["pixels"], sd, cfg, -1, "cls_patch")
+    torch.testing.assert_close(f, a["features_last_cls"], **TOL)
+
+
+def test_g4_end_to_end_vision_greedy_ids():
+    from oracle import pipeline
+    a, meta, sd = load_golden("g4_e2e_vision")
+    model = pipeline.OracleModel.from_state_dict(sd, meta)
+    logits, kv, _ = model.prefill(a["input_ids"], {"vision": a["pixels"]})
+    torch.testing.assert_close(logits, a["logits_prefill"], rtol=2e-4, atol=5e-5)
+    ids, step_logits = model.generate(a["input_ids"], {"vision": a["pixels"]}, max_new_tokens=a["gen_ids"].shape[1],
+                                      ignore_eos=True, return_logits=True)
+    assert torch.equal(ids, a["gen_ids"])
+    torch.testing.assert_close(step_logits, a["step_logits"], rtol=2e-4, atol=5e-5)
+
+
+def test_g6_merge_checkpoints_file_level(tmp_path):
+    import os
+    from oracle import merge as omerge
+    a, meta, _ = load_golden("g6_merge")
+    paths = []
+    for modal in meta["order"]:
+        d = tmp_path / f"ckpt-{modal}"
+        d.mkdir()
+        w = {k.split("::", 2)[2]: v for k, v in a.items() if k.startswith(f"in::{modal}::")}
+        torch.save(w, d / "adapter_model.bin")
+        json.dump(meta["in_configs"][modal], open(d / "config.json", "w"))
+        paths.append(str(d))
+    out = tmp_path / "merged"
+    omerge.merge_checkpoints(paths, str(out), meta["strategy"])
+    got = torch.load(out / "adapter_model.bin")
+    exp = {k[5:]: v for k, v in a.items() if k.startswith("out::")}
+    assert sorted(got) == sorted(exp)
+    for k in exp:
+        assert torch.equal(got[k], exp[k]), k
+    assert json.load(open(out / "config.json")) == meta["out_config"]
+    info = open(out / "merge_info.txt").read().replace(str(tmp_path), "<TMP>")
+    assert info == meta["merge_info"]
