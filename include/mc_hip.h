@@ -1,0 +1,89 @@
+/* mc_hip.h — C ABI of libmc_hip.so, the MI355X (gfx950) forward/generation path for ModelCompose.
+ *
+ * Boundary rules: plain pointers and sizes only, no torch types.  Every pointer is a
+ * BORROWED device pointer valid for the duration of the call (the caller — PyTorch-ROCm in the shipped
+ * host layer — owns all memory); `stream` is a hipStream_t (pass torch's current HIP stream).  Launches
+ * are asynchronous on that stream and graph-capturable (no allocation / synchronisation inside).
+ * Return value: 0 = ok, 1 = invalid argument, 2 = HIP error; mc_last_error() returns the thread-local
+ * message.  The Python wrapper raises ValueError for 1 (the reference raises ValueError on shape errors,
+ * multimodal_llama.py:297-318) and RuntimeError for 2.
+ *
+ * The reference has no FFI seam (it is pure Python on third-party CUDA wheels); each entry point below
+ * names the reference computation it replaces (paths relative to /root/reference/modelcompose).
+ * dtype: bf16 storage, fp32 accumulation.
+ */
+#ifndef MC_HIP_H
+#define MC_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_ABI_VERSION 1
+
+/* activation codes for mc_gemm_bf16 */
+#define MC_ACT_NONE 0
+#define MC_ACT_GELU 1        /* exact erf GELU: multimodal_projector/builder.py:208-215 (nn.GELU)          */
+#define MC_ACT_QUICK_GELU 2  /* x*sigmoid(1.702x): CLIP MLP (transformers CLIPMLP via clip_encoder.py:53) */
+#define MC_ACT_SILU 3        /* ACT2FN['silu']: model/language_model/multimodal_llama.py:361               */
+
+const char* mc_last_error(void);
+int mc_abi_version(void);
+int mc_device_info(int* cu_count, int64_t* hbm_bytes, char* arch, int arch_len);
+
+/* ---- weights ---------------------------------------------------------------------------------------
+ * Packed layout (see csrc/gemm.hip): [ceil16(N)/16][ceil64(K)/32][64 lanes][8] bf16, zero padded.        */
+int mc_packed_weight_elems(int N, int K, int64_t* out_elems);
+int mc_pack_weight_bf16(const void* w_rowmajor, int64_t ldw, void* packed, int N, int K, void* stream);
+int mc_unpack_weight_bf16(const void* packed, void* w_rowmajor, int N, int K, void* stream);
+
+/* W' = W + sum_i scale[i] * B_i * A_i  -> packed (and optionally row-major).  Replaces the per-forward
+ * composition of LocalLoraLinear.forward (model/language_model/multimodal_llama.py:130-157) and restates
+ * scripts/evaluate_delta_weights.py:8-15.  at_list[i] = A_i^T [K, r]; b_list[i] = B_i [N, r]; r % 32 == 0. */
+int mc_compose_weight_bf16(const void* w_rowmajor, int64_t ldw, const void* const* at_list, const void* const* b_list,
+                           const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
+                           int N, int K, void* stream);
+
+/* ---- linear: out[M,N] = act(alpha * x[M,K] W^T + bias) + residual -----------------------------------
+ * Replaces F.linear at multimodal_llama.py:122 (LocalLoRA base GEMM), :720 (lm_head), the CLIP / projector
+ * linears.  K must be a multiple of 64 (zero padded), x rows 16-byte aligned.  out_f32 != 0 -> fp32 out.  */
+int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* bias, const void* residual, int64_t ldr,
+                 void* out, int64_t ldo, int M, int N, int K, int act, int out_f32, float alpha, void* stream);
+
+/* ---- norms: LlamaRMSNorm (multimodal_llama.py:405-406, :482) / nn.LayerNorm (CLIP blocks) -------------- */
+int mc_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* out, int64_t ldo, int M, int D, float eps, void* stream);
+int mc_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, void* out, int64_t ldo, int M, int D,
+                      float eps, void* stream);
+
+/* ---- RoPE + KV-cache append (multimodal_llama.py:281-289; apply_rotary_pos_emb of transformers 4.31) ----
+ * qkv rows are in routed order; row_b / row_pos / row_t give batch entry, absolute position and query index. */
+int mc_rope_kv_bf16(const void* qkv, int64_t ld, const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t,
+                    const float* cos_table, const float* sin_table, void* q_out, void* k_cache, void* v_cache, int M,
+                    int H, int Hkv, int D, int Lq, int Smax, void* stream);
+
+/* ---- attention (multimodal_llama.py:295-312; CLIPAttention) ------------------------------------------- */
+int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
+                         int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
+                         int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B, int H, int Hkv, int Lq,
+                         int S, int D, int causal, int q_offset, float scale, void* stream);
+int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* bytes);
+int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                        const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o, int64_t o_sb, void* workspace,
+                        const int32_t* kv_lens, int B, int H, int Hkv, int S, int D, int nsplit, float scale, void* stream);
+
+/* ---- row kernels ---------------------------------------------------------------------------------- */
+int mc_silu_mul_bf16(const void* gate_up, int64_t ld, void* out, int64_t ldo, int M, int I, void* stream);   /* :392-394 */
+int mc_copy_rows_bf16(const void* src, int64_t ld_src, const int32_t* src_idx, void* dst, int64_t ld_dst,
+                      const int32_t* dst_idx, int n_rows, int D, void* stream);       /* splice: multimodal_arch.py:349-378 */
+int mc_embed_rows_bf16(const void* table, int64_t ld_table, const int64_t* ids, void* dst, int64_t ld_dst,
+                       const int32_t* dst_idx, int n_rows, int D, void* stream);      /* embed_tokens */
+int mc_argmax_f32(const void* x, int64_t ld, int64_t* out, int M, int N, void* stream);  /* greedy_search argmax */
+int mc_im2col_bf16(const void* in, void* out, int B, int C, int Hin, int Win, int kh, int kw, int sh, int sw, int Kp,
+                   void* stream);                                                     /* patch-embed conv */
+int mc_vit_assemble_bf16(const void* patches, const void* cls, const void* pos, void* out, int B, int T, int D, void* stream);
+int mc_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,86 @@
+"""ctypes binding of libmc_hip.so (C ABI: include/mc_hip.h).  Fails loudly if the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_l = C.c_int64
+c_f = C.c_float
+
+# name -> argtypes  (every function returns int status unless noted)
+_SIGS = {
+    "mc_abi_version": [],
+    "mc_device_info": [C.POINTER(c_i), C.POINTER(c_l), C.c_char_p, c_i],
+    "mc_packed_weight_elems": [c_i, c_i, C.POINTER(c_l)],
+    "mc_pack_weight_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
+    "mc_unpack_weight_bf16": [c_p, c_p, c_i, c_i, c_p],
+    "mc_compose_weight_bf16": [c_p, c_l, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_f), c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p],
+    "mc_gemm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "mc_rmsnorm_bf16": [c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
+    "mc_layernorm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
+    "mc_rope_kv_bf16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "mc_attn_prefill_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
+                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "mc_attn_decode_workspace_bytes": [c_i, c_i, c_i, c_i, C.POINTER(c_l)],
+    "mc_attn_decode_bf16": [c_p, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
+                            c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "mc_silu_mul_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    "mc_copy_rows_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
+    "mc_embed_rows_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
+    "mc_argmax_f32": [c_p, c_l, c_p, c_i, c_i, c_p],
+    "mc_im2col_bf16": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "mc_vit_assemble_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "mc_add_bf16": [c_p, c_p, c_p, c_l, c_p],
+}
+# optional symbols added by later ABI revisions are bound if present
+_OPTIONAL: dict = {}
+
+
+class MCError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(list(_SIGS) + ["mc_last_error"])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MCError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"(or `make -C modelcompose_amd/csrc`). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.mc_last_error.restype = C.c_char_p
+    L.mc_last_error.argtypes = []
+    for name, args in {**_SIGS, **_OPTIONAL}.items():
+        fn = getattr(L, name, None)
+        if fn is None:
+            if name in _OPTIONAL:
+                continue
+            raise MCError(f"libmc_hip.so does not export {name}")
+        fn.argtypes = args
+        fn.restype = c_i
+    v = L.mc_abi_version()
+    if v != ABI_VERSION:
+        raise MCError(f"libmc_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild")
+    _lib = L
+    return L
+
+
+def check(status: int, what: str = ""):
+    if status == 0:
+        return
+    msg = lib().mc_last_error().decode("utf-8", "replace")
+    if status == 1:
+        raise ValueError(f"{what}: {msg}")
+    raise MCError(f"{what}: {msg}")

@@ -1,0 +1,347 @@
+// Softmax attention for gfx950 (bf16 storage, fp32 softmax / accumulation).
+//
+// Replaces LocalLoraAttention.forward's  softmax_fp32(QK^T/sqrt(d) + mask)·V
+// (modelcompose/model/language_model/multimodal_llama.py:295-312; the additive causal+padding
+// mask of transformers==4.31 LlamaModel._prepare_decoder_attention_mask becomes an index test)
+// and the bidirectional CLIPAttention of the vision/video towers.
+//
+//   attn_prefill_kernel : flash-style, no LxS score matrix in HBM.  One workgroup = 4 waves = 64 query
+//       rows of one (batch, head); K/V tiles of 64 keys are staged in LDS (K XOR-swizzled for
+//       conflict-free ds_read_b128, V row-major and consumed through ds_read_b64_tr_b16).
+//       Scores are computed transposed (S^T = K·Q^T) so each lane owns one query column: the row
+//       statistics are lane-local and P feeds the second MFMA (O^T = V^T·P^T) straight from registers.
+//   attn_decode_kernel  : one query row per (batch, head), HBM-bound KV stream straight to VGPRs,
+//       split over the KV length (flash-decoding) + a small combine kernel.
+#include "common.h"
+
+struct AttnParams {
+    const bf16_t* q; int64_t q_sb, q_st, q_sh;     // strides in elements; head_dim contiguous
+    const bf16_t* k; int64_t k_sb, k_st, k_sh;
+    const bf16_t* v; int64_t v_sb, v_st, v_sh;
+    bf16_t* o; int64_t o_row_stride;               // out[row*o_row_stride + h*D + d]
+    const int32_t* out_map;                        // optional [B*Lq] -> output row (-1 = skip)
+    const int32_t* kv_lens;                        // optional [B] valid keys per batch entry
+    int B, H, Hkv, Lq, S;
+    int causal, q_offset;                          // query t has absolute position t + q_offset
+    float scale_log2e;                             // softmax scale * log2(e)
+};
+
+#define NEG_BIG (-1.0e30f)
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
+    constexpr int ROWB = D * 2;              // bytes per K/V row
+    constexpr int CH = ROWB / 16;            // 16-byte chunks per row
+    constexpr int KS = D / 32;               // MFMA k-steps over the head dim
+    constexpr int DB = D / 16;               // 16-wide d blocks of the output
+    __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB];
+    char* kl = lds;
+    char* vl = lds + 64 * ROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
+
+    // Q fragments (B operand: col = query c, k = d)
+    bf16x8 qf[KS];
+    {
+        const int t = min(q0 + c, p.Lq - 1);
+        const bf16_t* qp = p.q + b * p.q_sb + t * p.q_st + h * p.q_sh + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
+    }
+    const int q_abs = q0 + c + p.q_offset;   // absolute position of this lane's query
+
+    f32x4 oacc[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    // number of key tiles this workgroup needs
+    int last_key = kvlen;                    // exclusive
+    if (p.causal) last_key = min(last_key, blockIdx.x * 64 + 63 + p.q_offset + 1);
+    const int ntiles = (last_key + 63) / 64;
+
+    const bf16_t* kbase = p.k + b * p.k_sb + hk * p.k_sh;
+    const bf16_t* vbase = p.v + b * p.v_sb + hk * p.v_sh;
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();     // previous tile fully consumed
+        // ---- stage K (swizzled) and V (linear): 64 rows x CH chunks each
+#pragma unroll
+        for (int it = 0; it < (64 * CH) / 256; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx / CH, ch = idx % CH;
+            const int key = min(kt * 64 + row, p.S - 1);
+            const u32x4 kv4 = *(const u32x4*)(kbase + key * p.k_st + ch * 8);
+            const u32x4 vv4 = *(const u32x4*)(vbase + key * p.v_st + ch * 8);
+            int sw;
+            if (CH == 16) sw = ch ^ (row & 15); else sw = ch ^ ((row >> 1) & 7);
+            *(u32x4*)(kl + row * ROWB + sw * 16) = kv4;
+            *(u32x4*)(vl + row * ROWB + ch * 16) = vv4;
+        }
+        __syncthreads();
+
+        // ---- S^T[key][query] = K · Q^T
+        f32x4 s[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = kb * 16 + c;     // A operand row = key
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ch = ks * 4 + g;
+                int sw;
+                if (CH == 16) sw = ch ^ (row & 15); else sw = ch ^ ((row >> 1) & 7);
+                const bf16x8 kf = *(const bf16x8*)(kl + row * ROWB + sw * 16);
+                s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- mask, online softmax (lane owns query column c; keys 16kb + 4g + r)
+        float tmax = NEG_BIG;
+        bool valid[4][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 64 + kb * 16 + g * 4 + r;
+                const bool ok = key < kvlen && (!p.causal || key <= q_abs);
+                valid[kb][r] = ok;
+                const float sv = s[kb][r] * p.scale_log2e;
+                s[kb][r] = sv;
+                tmax = ok ? fmaxf(tmax, sv) : tmax;
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float lsum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = valid[kb][r] ? exp2f(s[kb][r] - m_new) : 0.f;
+                const bf16_t pb = (bf16_t)pv;
+                lsum += (float)pb;           // normalise with the rounded probabilities actually multiplied
+                pf[kb >> 1][(kb & 1) * 4 + r] = pb;
+            }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int i = 0; i < DB; ++i) oacc[i] *= alpha;
+
+        // ---- O^T[d][query] += V^T · P^T ; V fragments through the transposing LDS read
+        const int tq = (lane & 15) >> 2, tp = lane & 3;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int key_lo = (2 * pr) * 16 + g * 4 + tq;
+            const int key_hi = (2 * pr + 1) * 16 + g * 4 + tq;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(vl + key_lo * ROWB + (db * 16 + tp * 4) * 2));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(vl + key_hi * ROWB + (db * 16 + tp * 4) * 2));
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[pr], oacc[db], 0, 0, 0);
+            }
+        }
+    }
+    // ---- finalize: total row sum over the 4 lane groups that share query c
+    float l = l_run;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const int t = q0 + c;
+    if (t < p.Lq) {
+        const int64_t row = p.out_map ? p.out_map[b * p.Lq + t] : (int64_t)b * p.Lq + t;
+        if (row >= 0) {
+            bf16_t* op = p.o + row * p.o_row_stride + h * D;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                bf16x4 ov = {(bf16_t)(oacc[db][0] * inv), (bf16_t)(oacc[db][1] * inv), (bf16_t)(oacc[db][2] * inv),
+                             (bf16_t)(oacc[db][3] * inv)};
+                *(bf16x4*)(op + db * 16 + g * 4) = ov;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// decode: Lq == 1
+// ------------------------------------------------------------------------------------------
+struct DecodeParams {
+    const bf16_t* q; int64_t q_sb, q_sh;
+    const bf16_t* k; int64_t k_sb, k_st, k_sh;
+    const bf16_t* v; int64_t v_sb, v_st, v_sh;
+    bf16_t* o; int64_t o_sb;                       // out[b*o_sb + h*D + d]
+    float* ws;                                     // [B*H, nsplit, D + 2] partials (m, l, acc)
+    const int32_t* kv_lens;
+    int B, H, Hkv, S, nsplit;
+    float scale_log2e;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
+    constexpr int LPK = D / 8;               // lanes per key
+    constexpr int KPW = 64 / LPK;            // keys per wave load
+    __shared__ float red[4][D + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    const int hk = h / (p.H / p.Hkv);
+    const int split = blockIdx.y;
+    const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
+    const int per = (kvlen + p.nsplit - 1) / p.nsplit;
+    const int j0 = split * per, j1 = min(j0 + per, kvlen);
+    const int slot = lane / LPK, dl = (lane % LPK) * 8;
+
+    float qv[8];
+    {
+        const bf16x8 q8 = *(const bf16x8*)(p.q + b * p.q_sb + h * p.q_sh + dl);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = (float)q8[i] * p.scale_log2e;
+    }
+    const bf16_t* kb = p.k + b * p.k_sb + hk * p.k_sh + dl;
+    const bf16_t* vb = p.v + b * p.v_sb + hk * p.v_sh + dl;
+    float m = NEG_BIG, l = 0.f, acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+
+    constexpr int UN = 4;
+    for (int j = j0 + wave * KPW; j < j1; j += 4 * KPW * UN) {
+        bf16x8 k8[UN], v8[UN];
+        int key[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            key[u] = j + u * 4 * KPW + slot;
+            const int kc = min(key[u], p.S - 1);
+            k8[u] = __builtin_nontemporal_load((const bf16x8*)(kb + (int64_t)kc * p.k_st));
+            v8[u] = __builtin_nontemporal_load((const bf16x8*)(vb + (int64_t)kc * p.v_st));
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sdot += qv[i] * (float)k8[u][i];
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
+            const bool ok = key[u] < j1;
+            const float mn = ok ? fmaxf(m, sdot) : m;
+            const float a = exp2f(m - mn);
+            const float pv = ok ? exp2f(sdot - mn) : 0.f;
+            m = mn;
+            l = l * a + pv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pv * (float)v8[u][i];
+        }
+    }
+    // merge the KPW key slots of the wave (lanes with equal dl)
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+        const float mn = fmaxf(m, m2);
+        const float a1 = exp2f(m - mn), a2 = exp2f(m2 - mn);
+        l = l * a1 + l2 * a2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float o2 = __shfl_xor(acc[i], o, 64);
+            acc[i] = acc[i] * a1 + o2 * a2;
+        }
+        m = mn;
+    }
+    if (slot == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[wave][dl + i] = acc[i];
+        if (dl == 0) { red[wave][D] = m; red[wave][D + 1] = l; }
+    }
+    __syncthreads();
+    if (tid < D) {
+        float mm = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red[w][D]);
+        float ll = 0.f, aa = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = exp2f(red[w][D] - mm);
+            ll += red[w][D + 1] * a;
+            aa += red[w][tid] * a;
+        }
+        if (p.nsplit == 1) {
+            p.o[b * p.o_sb + h * D + tid] = (bf16_t)(ll > 0.f ? aa / ll : 0.f);
+        } else {
+            float* w = p.ws + ((int64_t)bh * p.nsplit + split) * (D + 2);
+            w[tid] = aa;
+            if (tid == 0) { w[D] = mm; w[D + 1] = ll; }
+        }
+    }
+}
+
+template <int D>
+__global__ void attn_decode_combine_kernel(DecodeParams p) {
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H, d = threadIdx.x;
+    const float* w = p.ws + (int64_t)bh * p.nsplit * (D + 2);
+    float mm = NEG_BIG;
+    for (int s = 0; s < p.nsplit; ++s) mm = fmaxf(mm, w[s * (D + 2) + D]);
+    float ll = 0.f, aa = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const float a = exp2f(w[s * (D + 2) + D] - mm);
+        ll += w[s * (D + 2) + D + 1] * a;
+        aa += w[s * (D + 2) + d] * a;
+    }
+    p.o[b * p.o_sb + h * D + d] = (bf16_t)(ll > 0.f ? aa / ll : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb,
+                                    int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                    void* o, int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B,
+                                    int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
+                                    void* stream) {
+    MC_CHECK_ARG(q && k && v && o, "mc_attn_prefill_bf16: null pointer");
+    MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_prefill_bf16: head_dim %d not supported (64 or 128)", D);
+    MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Lq > 0 && S > 0, "mc_attn_prefill_bf16: bad shape");
+    MC_CHECK_ARG((q_st % 8 | q_sh % 8 | k_st % 8 | k_sh % 8 | v_st % 8 | v_sh % 8 | q_sb % 8 | k_sb % 8 | v_sb % 8) == 0,
+                 "mc_attn_prefill_bf16: strides must be multiples of 8 elements");
+    AttnParams p{(const bf16_t*)q, q_sb, q_st, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
+                 (bf16_t*)o, o_row_stride, out_map, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
+                 scale * 1.4426950408889634f};
+    dim3 grid((Lq + 63) / 64, H, B);
+    if (D == 128) attn_prefill_kernel<128><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else attn_prefill_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* bytes) {
+    *bytes = (int64_t)B * H * nsplit * (D + 2) * 4;
+    return 0;
+}
+
+extern "C" int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
+                                   int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
+                                   int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S,
+                                   int D, int nsplit, float scale, void* stream) {
+    MC_CHECK_ARG(q && k && v && o, "mc_attn_decode_bf16: null pointer");
+    MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_decode_bf16: head_dim %d not supported (64 or 128)", D);
+    MC_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || workspace), "mc_attn_decode_bf16: nsplit>1 needs a workspace");
+    MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && S > 0, "mc_attn_decode_bf16: bad shape");
+    DecodeParams p{(const bf16_t*)q, q_sb, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
+                   (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f};
+    dim3 grid(B * H, nsplit);
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 128) {
+        attn_decode_kernel<128><<<grid, 256, 0, s>>>(p);
+        if (nsplit > 1) attn_decode_combine_kernel<128><<<B * H, 128, 0, s>>>(p);
+    } else {
+        attn_decode_kernel<64><<<grid, 256, 0, s>>>(p);
+        if (nsplit > 1) attn_decode_combine_kernel<64><<<B * H, 64, 0, s>>>(p);
+    }
+    MC_CHECK_LAUNCH();
+    return 0;
+}

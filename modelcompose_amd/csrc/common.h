@@ -1,0 +1,71 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, bf16 storage, fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define MC_WAVE 64
+
+// activation codes shared with include/mc_hip.h
+enum { MC_ACT_NONE = 0, MC_ACT_GELU = 1, MC_ACT_QUICK_GELU = 2, MC_ACT_SILU = 3 };
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float mc_act(float x, int act) {
+    switch (act) {
+        case MC_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case MC_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case MC_ACT_SILU: return x / (1.0f + __expf(-x));
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024; `red` is >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// host-side error plumbing (capi.cpp owns the storage)
+void mc_set_error(const char* fmt, ...);
+#define MC_CHECK_ARG(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            mc_set_error(__VA_ARGS__);   \
+            return 1;                    \
+        }                                \
+    } while (0)
+#define MC_CHECK_LAUNCH()                                                   \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            mc_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return 2;                                                       \
+        }                                                                   \
+    } while (0)

@@ -1,0 +1,361 @@
+// bf16 linear layers for gfx950:  out[M,N] = act(x[M,K] · W[N,K]^T + bias) (+ residual)
+//
+// Replaces every F.linear on the hot path of the reference
+// (modelcompose/model/language_model/multimodal_llama.py:122 LocalLoraLinear base GEMM,
+//  :262-268/:335-336/:380-394 projections, :720 lm_head; CLIP / projector linears).
+//
+// HBM layout of a weight ("packed"): the row-major [N,K] checkpoint tensor is re-tiled once at
+// load time into 1-KiB MFMA fragments:  block (nb, kb) covers rows 16nb..16nb+15, cols 32kb..32kb+31
+// and stores lane l = (q<<4 | r) -> 8 contiguous bf16 = W[16nb + r][32kb + 8q .. +7].
+// Blocks are ordered nb-major, kb-minor.  One 16-byte-per-lane wave load (1 KiB, fully coalesced)
+// is then exactly the A operand of v_mfma_f32_16x16x32_bf16, for both kernels below:
+//   * gemm_tile_kernel   (M > 64, MFMA-bound): 128x128x64 tiles, LDS-DMA (global_load_lds) double buffer.
+//   * gemm_skinny_kernel (M <= 64, HBM-bound): weights streamed straight to VGPRs, K split over
+//     the 8 waves of a workgroup, x fragments from L2, one LDS reduction.
+// MFMA roles: A = weight fragment (rows = n), B = activation fragment (cols = m) so that a lane
+// ends up with 4 consecutive n for one token m  ->  8-byte packed bf16 stores.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int N, int K, int Np,
+                                   int Kp, int64_t ldw) {
+    // one thread per 16-byte fragment piece
+    const int64_t nfrag = (int64_t)(Np / 16) * (Kp / 32) * 64;
+    for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < nfrag; f += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(f & 63);
+        const int64_t blk = f >> 6;
+        const int kb = (int)(blk % (Kp / 32));
+        const int nb = (int)(blk / (Kp / 32));
+        const int n = nb * 16 + (lane & 15);
+        const int k = kb * 32 + (lane >> 4) * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (n < N && k + j < K) ? w[(int64_t)n * ldw + k + j] : (bf16_t)0.0f;
+        *(bf16x8*)(out + f * 8) = v;
+    }
+}
+
+__global__ void unpack_weight_kernel(const bf16_t* __restrict__ p, bf16_t* __restrict__ w, int N, int K, int Kp) {
+    const int64_t total = (int64_t)N * K;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K), k = (int)(i % K);
+        const int64_t blk = (int64_t)(n >> 4) * (Kp / 32) + (k >> 5);
+        const int lane = (((k & 31) >> 3) << 4) | (n & 15);
+        w[i] = p[blk * 512 + lane * 8 + (k & 7)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// epilogue shared by both kernels: lane owns out[m][n..n+3]
+// ------------------------------------------------------------------------------------------
+struct Epilogue {
+    const bf16_t* bias;      // [N] or null
+    const bf16_t* residual;  // [M, ldr] or null
+    int64_t ldr;
+    void* out;
+    int64_t ldo;
+    int act;
+    int out_f32;
+    float alpha;             // scale applied to the accumulator before bias
+};
+
+__device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n, f32x4 v) {
+    float r[4] = {v[0] * e.alpha, v[1] * e.alpha, v[2] * e.alpha, v[3] * e.alpha};
+    if (e.bias) {
+        bf16x4 b = *(const bf16x4*)(e.bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] += (float)b[i];
+    }
+    if (e.act != MC_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = mc_act(r[i], e.act);
+    }
+    if (e.residual) {
+        bf16x4 b = *(const bf16x4*)(e.residual + (int64_t)m * e.ldr + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] += (float)b[i];
+    }
+    if (e.out_f32) {
+        f32x4 o = {r[0], r[1], r[2], r[3]};
+        *(f32x4*)((float*)e.out + (int64_t)m * e.ldo + n) = o;
+    } else {
+        bf16x4 o = {(bf16_t)r[0], (bf16_t)r[1], (bf16_t)r[2], (bf16_t)r[3]};
+        *(bf16x4*)((bf16_t*)e.out + (int64_t)m * e.ldo + n) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// large-M kernel
+// ------------------------------------------------------------------------------------------
+#define TN 128   // weight rows per tile
+#define TM 128   // tokens per tile
+#define TK 64
+#define TILE_BYTES (TN * TK * 2)   // 16 KiB per operand per stage
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                           const bf16_t* __restrict__ wp, int M, int N, int K,
+                                                           Epilogue ep, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [stage][W 16K | X 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave >> 1, wave_m = wave & 1;
+
+    // --- XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
+    // contiguous chunk of the logical tile order, then walk tiles in groups of 8 m-tiles per n-tile column.
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = bid / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP);
+    const int tm = first_m + (bid % per_group) % gsz;
+    const int tn = (bid % per_group) / gsz;
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    const int kblocks = K >> 5;           // 32-wide k blocks in the packed weight
+    const int nblocks = (N + 15) >> 4;
+    const int nt = K / TK;
+
+    // per-lane global sources -------------------------------------------------
+    // W: wave w stages fragment blocks c = 4w..4w+3 of the 16 (8 nb x 2 kb) in a stage
+    const bf16_t* wsrc[4];
+    int wdst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = wave * 4 + i;
+        const int nbl = c >> 1, kbl = c & 1;
+        int nb = (n0 >> 4) + nbl;
+        nb = min(nb, nblocks - 1);
+        wsrc[i] = wp + ((int64_t)nb * kblocks + kbl) * 512 + lane * 8;
+        wdst[i] = c * 1024;
+    }
+    // X: wave w stages row groups c = 4w..4w+3 (8 rows x 128 B each); XOR swizzle on the SOURCE chunk
+    const bf16_t* xsrc[4];
+    int xdst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = wave * 4 + i;
+        const int row = c * 8 + (lane >> 3);
+        const int gch = (lane & 7) ^ (lane >> 3);      // (lds chunk) ^ (row & 7)
+        int m = min(m0 + row, M - 1);
+        xsrc[i] = x + (int64_t)m * ldx + gch * 8;
+        xdst[i] = TILE_BYTES + c * 1024;
+    }
+
+    auto stage = [&](int t, int buf) {
+        char* base = smem + buf * (2 * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[i] + (int64_t)t * 2 * 512), (lds_void*)(base + wdst[i]), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xsrc[i] + (int64_t)t * TK), (lds_void*)(base + xdst[i]), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets
+    const int c16 = lane & 15, q4 = lane >> 4;
+    int woff[4], xrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) woff[i] = ((wave_n * 4 + i) * 2) * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xrow[j] = wave_m * 64 + j * 16 + c16;
+
+    stage(0, 0);
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, buf ^ 1);
+        const char* wb = smem + buf * (2 * TILE_BYTES);
+        const char* xb = wb + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(wb + woff[i] + kk * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = xrow[j];
+                const int ch = (kk * 4 + q4) ^ (row & 7);
+                xf[j] = *(const bf16x8*)(xb + row * 128 + ch * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+
+    // epilogue: acc[i][j][r] = out[m = ... + c16][n = ... + 4*q4 + r]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wave_m * 64 + j * 16 + c16;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wave_n * 64 + i * 16 + q4 * 4;
+            if (n < N) epilogue_store4(ep, m, n, acc[i][j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// skinny kernel: M <= 16*MB, one 16-row weight block-row per workgroup, K split over 8 waves
+// ------------------------------------------------------------------------------------------
+#define SK_WAVES 8
+#define SK_UNROLL 8
+
+template <int MB>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                                    const bf16_t* __restrict__ wp, int M, int N, int K,
+                                                                    Epilogue ep) {
+    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][MB][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = blockIdx.x;
+    const int kblocks = K >> 5;
+    // contiguous K slice per wave
+    const int per = (kblocks + SK_WAVES - 1) / SK_WAVES;
+    const int kb0 = wave * per;
+    const int kb1 = min(kb0 + per, kblocks);
+    const int c16 = lane & 15, q4 = lane >> 4;
+
+    const bf16_t* wptr = wp + ((int64_t)nb * kblocks + kb0) * 512 + lane * 8;
+    const bf16_t* xptr[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+        const int m = min(b * 16 + c16, M - 1);
+        xptr[b] = x + (int64_t)m * ldx + kb0 * 32 + q4 * 8;
+    }
+    f32x4 acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int kb = kb0;
+    for (; kb + SK_UNROLL <= kb1; kb += SK_UNROLL) {
+        bf16x8 wf[SK_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SK_UNROLL; ++u) wf[u] = __builtin_nontemporal_load((const bf16x8*)(wptr + u * 512));
+#pragma unroll
+        for (int u = 0; u < SK_UNROLL; ++u) {
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+                bf16x8 xf = *(const bf16x8*)(xptr[b] + u * 32);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc[b], 0, 0, 0);
+            }
+        }
+        wptr += SK_UNROLL * 512;
+#pragma unroll
+        for (int b = 0; b < MB; ++b) xptr[b] += SK_UNROLL * 32;
+    }
+    for (; kb < kb1; ++kb) {
+        bf16x8 wf = __builtin_nontemporal_load((const bf16x8*)wptr);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            bf16x8 xf = *(const bf16x8*)(xptr[b]);
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[b], 0, 0, 0);
+            xptr[b] += 32;
+        }
+        wptr += 512;
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave][b][lane][0] = acc[b];
+    __syncthreads();
+    // waves 0..MB-1 each reduce + store one m-block
+    if (wave < MB) {
+        f32x4 s = *(f32x4*)&red[0][wave][lane][0];
+#pragma unroll
+        for (int w = 1; w < SK_WAVES; ++w) {
+            f32x4 t = *(f32x4*)&red[w][wave][lane][0];
+            s += t;
+        }
+        const int m = wave * 16 + c16;
+        const int n = nb * 16 + q4 * 4;
+        if (m < M && n < N) epilogue_store4(ep, m, n, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------
+extern "C" int mc_packed_weight_elems(int N, int K, int64_t* out_elems) {
+    const int64_t Np = (N + 15) / 16 * 16, Kp = (K + 63) / 64 * 64;
+    *out_elems = Np * Kp;
+    return 0;
+}
+
+extern "C" int mc_pack_weight_bf16(const void* w, int64_t ldw, void* packed, int N, int K, void* stream) {
+    MC_CHECK_ARG(w && packed && N > 0 && K > 0, "mc_pack_weight_bf16: bad arguments N=%d K=%d", N, K);
+    const int Np = (N + 15) / 16 * 16, Kp = (K + 63) / 64 * 64;
+    const int64_t nfrag = (int64_t)(Np / 16) * (Kp / 32) * 64;
+    const int grid = (int)min((int64_t)4096, (nfrag + 255) / 256);
+    pack_weight_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)w, (bf16_t*)packed, N, K, Np, Kp, ldw);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mc_unpack_weight_bf16(const void* packed, void* w, int N, int K, void* stream) {
+    MC_CHECK_ARG(w && packed && N > 0 && K > 0, "mc_unpack_weight_bf16: bad arguments");
+    const int Kp = (K + 63) / 64 * 64;
+    const int64_t total = (int64_t)N * K;
+    const int grid = (int)min((int64_t)4096, (total + 255) / 256);
+    unpack_weight_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)packed, (bf16_t*)w, N, K, Kp);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// x: [M, K] bf16 row-major with leading dimension ldx (elements); K here is the PADDED K (multiple of 64,
+// the columns K_real..K-1 of x must be zero or the weight pad rows zero — packed weights are zero padded).
+// N may be any positive value; packed weight has ceil16(N) rows.
+extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* bias, const void* residual,
+                            int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int act, int out_f32, float alpha,
+                            void* stream) {
+    MC_CHECK_ARG(x && w_packed && out, "mc_gemm_bf16: null pointer");
+    MC_CHECK_ARG(M > 0 && N > 0 && K > 0, "mc_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+    MC_CHECK_ARG(K % 64 == 0, "mc_gemm_bf16: K=%d must be a multiple of 64 (pad activations/weights)", K);
+    MC_CHECK_ARG(N % 4 == 0, "mc_gemm_bf16: N=%d must be a multiple of 4", N);
+    MC_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "mc_gemm_bf16: x must be 16-byte aligned rows (ldx=%lld)", (long long)ldx);
+    MC_CHECK_ARG(ldo % 4 == 0, "mc_gemm_bf16: ldo=%lld must be a multiple of 4", (long long)ldo);
+    MC_CHECK_ARG(!residual || ldr % 4 == 0, "mc_gemm_bf16: ldr must be a multiple of 4");
+    Epilogue ep{(const bf16_t*)bias, (const bf16_t*)residual, ldr, out, ldo, act, out_f32, alpha};
+    hipStream_t s = (hipStream_t)stream;
+    if (M <= 64) {
+        const int grid = (N + 15) / 16;
+        const int mb = (M + 15) / 16;
+        switch (mb) {
+            case 1: gemm_skinny_kernel<1><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
+            case 2: gemm_skinny_kernel<2><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
+            case 3: gemm_skinny_kernel<3><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
+            default: gemm_skinny_kernel<4><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
+        }
+    } else {
+        const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
+        static bool attr_set = false;
+        const int lds = 4 * TILE_BYTES;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_set = true;
+        }
+        gemm_tile_kernel<<<tiles_m * tiles_n, 256, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep,
+                                                             tiles_m, tiles_n);
+    }
+    MC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,217 @@
+"""Thin torch-tensor wrappers over the C ABI (include/mc_hip.h).  PyTorch provides device memory and
+the current HIP stream; all arithmetic happens in libmc_hip.so.  No CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3}
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _req(t: torch.Tensor, dtype=BF16, name="tensor"):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device (HIP) tensor; this path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def ceil_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class PackedWeight:
+    """A linear weight in the MFMA-fragment layout of csrc/gemm.hip (+ optional bf16 bias)."""
+    __slots__ = ("data", "N", "K", "Kp", "bias")
+
+    def __init__(self, data, N, K, bias=None):
+        self.data, self.N, self.K, self.Kp, self.bias = data, N, K, ceil_to(K, 64), bias
+
+    @property
+    def nbytes(self):
+        return self.data.numel() * 2
+
+
+def packed_elems(N: int, K: int) -> int:
+    return ceil_to(N, 16) * ceil_to(K, 64)
+
+
+def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> PackedWeight:
+    """[N, K] row-major (any float dtype, device) -> PackedWeight."""
+    w = _req(w.to(BF16), BF16, "weight")
+    if w.dim() != 2:
+        raise ValueError("weight must be 2-D [N, K]")
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    N, K = w.shape
+    if out is None:
+        out = torch.empty(packed_elems(N, K), dtype=BF16, device=w.device)
+    _lib.check(_lib.lib().mc_pack_weight_bf16(_p(w), w.stride(0), _p(out), N, K, _stream()), "mc_pack_weight_bf16")
+    b = None if bias is None else _req(bias.to(BF16).contiguous(), BF16, "bias")
+    return PackedWeight(out, N, K, b)
+
+
+def unpack_weight(pw: PackedWeight) -> torch.Tensor:
+    out = torch.empty(pw.N, pw.K, dtype=BF16, device=pw.data.device)
+    _lib.check(_lib.lib().mc_unpack_weight_bf16(_p(pw.data), _p(out), pw.N, pw.K, _stream()), "mc_unpack_weight_bf16")
+    return out
+
+
+def compose_weight(w: Optional[torch.Tensor], terms: Sequence, N: int, K: int, rowmajor_out: bool = False):
+    """W' = W + Σ scale·B·A  ->  PackedWeight.  terms = [(A [r,K], B [N,r], scale), ...] (device tensors)."""
+    dev = (w if w is not None else terms[0][0]).device
+    n = len(terms)
+    r = 0
+    ats, bs = [], []
+    for (a, b, s) in terms:
+        r0 = a.shape[0]
+        rp = ceil_to(r0, 32)
+        at = a.to(BF16).t().contiguous()                 # [K, r]
+        bb = b.to(BF16).contiguous()                     # [N, r]
+        if rp != r0:
+            at = torch.nn.functional.pad(at, (0, rp - r0))
+            bb = torch.nn.functional.pad(bb, (0, rp - r0))
+        if r and rp != r:
+            raise ValueError("all LoRA terms of one linear must share the rank")
+        r = rp
+        ats.append(at)
+        bs.append(bb)
+    out = torch.empty(packed_elems(N, K), dtype=BF16, device=dev)
+    rm = torch.empty(N, K, dtype=BF16, device=dev) if rowmajor_out else None
+    if w is not None:
+        w = _req(w.to(BF16), BF16, "w")
+        if w.stride(1) != 1:
+            w = w.contiguous()
+    at_arr = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in ats])
+    b_arr = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in bs])
+    sc = (C.c_float * max(n, 1))(*[float(t[2]) for t in terms])
+    _lib.check(_lib.lib().mc_compose_weight_bf16(_p(w), 0 if w is None else w.stride(0), at_arr, b_arr, sc, n, r, _p(out),
+                                                 _p(rm), K, N, K, _stream()), "mc_compose_weight_bf16")
+    pw = PackedWeight(out, N, K)
+    return (pw, rm) if rowmajor_out else pw
+
+
+def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           out_f32: bool = False, alpha: float = 1.0, bias: bool = True) -> torch.Tensor:
+    """out[M,N] = act(alpha * x W^T + b) + residual.  x: [M, Kp] bf16 (Kp = K padded to 64, pad columns zero)."""
+    _req(x, BF16, "x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be 2-D with contiguous rows")
+    M, Kx = x.shape
+    if Kx != w.Kp:
+        raise ValueError(f"x has {Kx} columns, weight expects K padded to {w.Kp}")
+    if out is None:
+        out = torch.empty(M, w.N, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    b = w.bias if bias else None
+    _lib.check(_lib.lib().mc_gemm_bf16(_p(x), x.stride(0), _p(w.data), _p(b), _p(residual),
+                                       0 if residual is None else residual.stride(0), _p(out), out.stride(0), M, w.N, w.Kp,
+                                       ACT[act], 1 if out_f32 else 0, alpha, _stream()), "mc_gemm_bf16")
+    return out
+
+
+def rmsnorm(x, w, eps, out=None):
+    _req(x, BF16, "x")
+    M, D = x.shape
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().mc_rmsnorm_bf16(_p(x), x.stride(0), _p(w), _p(out), out.stride(0), M, D, eps, _stream()), "mc_rmsnorm_bf16")
+    return out
+
+
+def layernorm(x, w, b, eps, out=None):
+    _req(x, BF16, "x")
+    M, D = x.shape
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().mc_layernorm_bf16(_p(x), x.stride(0), _p(w), _p(b), _p(out), out.stride(0), M, D, eps, _stream()), "mc_layernorm_bf16")
+    return out
+
+
+def rope_kv(qkv, row_b, row_pos, row_t, cos, sin, q_out, k_cache, v_cache, H, Hkv, D, Lq, Smax):
+    M = qkv.shape[0]
+    _lib.check(_lib.lib().mc_rope_kv_bf16(_p(qkv), qkv.stride(0), _p(row_b), _p(row_pos), _p(row_t), _p(cos), _p(sin), _p(q_out),
+                                          _p(k_cache), _p(v_cache), M, H, Hkv, D, Lq, Smax, _stream()), "mc_rope_kv_bf16")
+
+
+def attn_prefill(q, k, v, out, B, H, Hkv, Lq, S, D, q_strides, k_strides, v_strides, o_row_stride, causal, q_offset=0,
+                 scale=None, out_map=None, kv_lens=None):
+    scale = (1.0 / math.sqrt(D)) if scale is None else scale
+    _lib.check(_lib.lib().mc_attn_prefill_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_row_stride,
+                                               _p(out_map), _p(kv_lens), B, H, Hkv, Lq, S, D, 1 if causal else 0, q_offset,
+                                               scale, _stream()), "mc_attn_prefill_bf16")
+    return out
+
+
+def attn_decode(q, k, v, out, B, H, Hkv, S, D, q_strides, k_strides, v_strides, o_sb, nsplit=1, workspace=None, scale=None,
+                kv_lens=None):
+    scale = (1.0 / math.sqrt(D)) if scale is None else scale
+    if nsplit > 1 and workspace is None:
+        workspace = torch.empty(B * H * nsplit * (D + 2), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().mc_attn_decode_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_sb,
+                                              _p(workspace), _p(kv_lens), B, H, Hkv, S, D, nsplit, scale, _stream()),
+               "mc_attn_decode_bf16")
+    return out
+
+
+def silu_mul(gate_up, I, out=None):
+    M = gate_up.shape[0]
+    out = torch.empty(M, I, dtype=BF16, device=gate_up.device) if out is None else out
+    _lib.check(_lib.lib().mc_silu_mul_bf16(_p(gate_up), gate_up.stride(0), _p(out), out.stride(0), M, I, _stream()), "mc_silu_mul_bf16")
+    return out
+
+
+def copy_rows(src, dst, n_rows, src_idx=None, dst_idx=None):
+    D = src.shape[-1]
+    _lib.check(_lib.lib().mc_copy_rows_bf16(_p(src), src.stride(-2), _p(src_idx), _p(dst), dst.stride(-2), _p(dst_idx), n_rows, D,
+                                            _stream()), "mc_copy_rows_bf16")
+    return dst
+
+
+def embed_rows(table, ids, dst, dst_idx=None):
+    n = ids.numel()
+    _lib.check(_lib.lib().mc_embed_rows_bf16(_p(table), table.stride(0), _p(ids), _p(dst), dst.stride(-2), _p(dst_idx), n,
+                                             table.shape[1], _stream()), "mc_embed_rows_bf16")
+    return dst
+
+
+def argmax(logits_f32, out=None):
+    M, N = logits_f32.shape
+    out = torch.empty(M, dtype=torch.int64, device=logits_f32.device) if out is None else out
+    _lib.check(_lib.lib().mc_argmax_f32(_p(logits_f32), logits_f32.stride(0), _p(out), M, N, _stream()), "mc_argmax_f32")
+    return out
+
+
+def im2col(x, kh, kw, sh, sw, Kp=None):
+    _req(x, BF16, "x")
+    x = x.contiguous()
+    B, Cc, Hh, Ww = x.shape
+    K = Cc * kh * kw
+    Kp = ceil_to(K, 64) if Kp is None else Kp
+    oh, ow = (Hh - kh) // sh + 1, (Ww - kw) // sw + 1
+    out = torch.empty(B * oh * ow, Kp, dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().mc_im2col_bf16(_p(x), _p(out), B, Cc, Hh, Ww, kh, kw, sh, sw, Kp, _stream()), "mc_im2col_bf16")
+    return out, oh, ow
+
+
+def vit_assemble(patches, cls, pos, B, T, D):
+    out = torch.empty(B, T + (1 if cls is not None else 0), D, dtype=BF16, device=patches.device)
+    _lib.check(_lib.lib().mc_vit_assemble_bf16(_p(patches), _p(cls), _p(pos), _p(out), B, T, D, _stream()), "mc_vit_assemble_bf16")
+    return out
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    _lib.check(_lib.lib().mc_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "mc_add_bf16")
+    return out

@@ -1,0 +1,269 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against a plain PyTorch fp32 reference of
+the same op (inputs are bf16-valued so the only difference is fp32-accumulation order + one bf16 rounding).
+Tolerances are written next to each check."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from modelcompose_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def rand_bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def close_bf16(got, ref, rel=2 ** -7, abs_=None):
+    """bf16 output of an fp32-accumulated op: one rounding = 2^-9 relative; allow 2^-7 of the row scale."""
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    scale = ref.abs().max().item()
+    abs_ = rel * scale if abs_ is None else abs_
+    err = (got - ref).abs().max().item()
+    assert err <= abs_, f"max err {err} > {abs_} (ref scale {scale})"
+
+
+def test_pack_unpack_roundtrip_bit_exact(ops):
+    for (N, K) in [(16, 64), (40, 100), (4096, 4096), (1000, 588)]:
+        w = dev(rand_bf(N, K, seed=N + K))
+        pw = ops.pack_weight(w)
+        assert pw.data.numel() == ops.packed_elems(N, K)
+        back = ops.unpack_weight(pw)
+        assert torch.equal(back, w)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (16, 256, 64), (17, 512, 128), (33, 4096, 1024), (64, 11008, 4096),
+                                   (65, 128, 64), (128, 128, 128), (200, 4096, 4096), (1000, 11008, 4096),
+                                   (300, 1000, 640), (577, 1024, 4096), (130, 32000, 256)])
+def test_gemm_matches_fp32_matmul(ops, M, N, K):
+    x = dev(rand_bf(M, K, seed=1))
+    w = dev(rand_bf(N, K, scale=K ** -0.5, seed=2))
+    pw = ops.pack_weight(w)
+    got = ops.linear(x, pw)
+    ref = x.float() @ w.float().t()
+    close_bf16(got, ref)
+
+
+@pytest.mark.parametrize("M", [8, 300])
+@pytest.mark.parametrize("act", ["none", "gelu", "quick_gelu", "silu"])
+def test_gemm_epilogue_bias_act_residual(ops, M, act):
+    N, K = 384, 192
+    Kp = ops.ceil_to(K, 64)
+    x = dev(rand_bf(M, K, seed=3))
+    xp = F.pad(x, (0, Kp - K))
+    w = dev(rand_bf(N, K, scale=K ** -0.5, seed=4))
+    b = dev(rand_bf(N, seed=5))
+    res = dev(rand_bf(M, N, seed=6))
+    pw = ops.pack_weight(w, b)
+    got = ops.linear(xp, pw, act=act, residual=res, alpha=0.5)
+    y = 0.5 * (x.float() @ w.float().t()) + b.float()
+    y = {"none": lambda t: t, "gelu": F.gelu, "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t), "silu": F.silu}[act](y)
+    close_bf16(got, y + res.float())
+    got32 = ops.linear(xp, pw, act=act, out_f32=True, alpha=0.5)
+    assert got32.dtype == torch.float32
+    # fp32 output: only accumulation-order error (K=192 products of O(1) values) -> 1e-4 relative to scale
+    close_bf16(got32, y, rel=1e-4)
+
+
+def test_gemm_argument_errors(ops):
+    x = dev(rand_bf(4, 96))
+    pw = ops.pack_weight(dev(rand_bf(32, 96)))
+    with pytest.raises(ValueError):
+        ops.linear(x, pw)                       # x not padded to 128 columns
+    with pytest.raises(ValueError):
+        ops.linear(x.cpu(), pw)                 # no CPU fallback
+
+
+def test_rmsnorm_layernorm(ops):
+    for (M, D) in [(5, 4096), (130, 1024), (3, 384), (2, 16384)]:
+        x = dev(rand_bf(M, D, seed=7))
+        w = dev((1 + 0.1 * torch.randn(D)).to(BF))
+        b = dev((0.1 * torch.randn(D)).to(BF))
+        xf = x.float()
+        ref = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
+        close_bf16(ops.rmsnorm(x, w, 1e-5), ref)
+        ref = F.layer_norm(xf, (D,), w.float(), b.float(), 1e-5)
+        close_bf16(ops.layernorm(x, w, b, 1e-5), ref)
+
+
+def test_rope_kv_scatter_matches_oracle(ops):
+    from oracle import llm
+    B, L, H, Hkv, D, Smax = 2, 5, 4, 2, 128, 16
+    past = 3
+    qkv = rand_bf(B * L, (H + 2 * Hkv) * D, seed=8)
+    perm = torch.randperm(B * L, generator=torch.Generator().manual_seed(1))       # routed order != sequence order
+    row_b = (perm // L).int()
+    row_t = (perm % L).int()
+    row_pos = row_t + past
+    cos, sin = llm.rope_tables(D, 64)
+    q_out = torch.zeros(B, L, H, D, dtype=BF, device="cuda")
+    kc = torch.zeros(B, Hkv, Smax, D, dtype=BF, device="cuda")
+    vc = torch.zeros_like(kc)
+    ops.rope_kv(dev(qkv), dev(row_b), dev(row_pos), dev(row_t), dev(cos[:, :D // 2].contiguous()), dev(sin[:, :D // 2].contiguous()),
+                q_out, kc, vc, H, Hkv, D, L, Smax)
+    # oracle on sequence-ordered rows
+    seq = torch.empty_like(qkv)
+    seq[perm] = qkv
+    s = seq.float().view(B, L, -1)
+    q = s[..., :H * D].view(B, L, H, D).transpose(1, 2)
+    k = s[..., H * D:(H + Hkv) * D].view(B, L, Hkv, D).transpose(1, 2)
+    v = s[..., (H + Hkv) * D:].view(B, L, Hkv, D).transpose(1, 2)
+    pos = (torch.arange(L) + past)[None].expand(B, L)
+    c, sn = cos[pos].unsqueeze(1), sin[pos].unsqueeze(1)
+    qr = q * c + llm.rotate_half(q) * sn
+    kr = k * c + llm.rotate_half(k) * sn
+    close_bf16(q_out.transpose(1, 2), qr)
+    close_bf16(kc[:, :, past:past + L], kr)
+    assert torch.equal(vc[:, :, past:past + L].cpu(), v.to(BF))
+    assert kc[:, :, :past].abs().max().item() == 0 and kc[:, :, past + L:].abs().max().item() == 0
+
+
+def _ref_attn(q, k, v, causal, q_offset, kv_lens, scale):
+    # q [B,H,L,D], k/v [B,Hkv,S,D] fp32
+    B, H, L, D = q.shape
+    Hkv, S = k.shape[1], k.shape[2]
+    k = k.repeat_interleave(H // Hkv, dim=1)
+    v = v.repeat_interleave(H // Hkv, dim=1)
+    s = (q @ k.transpose(-1, -2)) * scale
+    j = torch.arange(S)[None, None, None, :]
+    mask = torch.zeros(B, 1, L, S, dtype=torch.bool)
+    if causal:
+        t = torch.arange(L)[None, None, :, None] + q_offset
+        mask |= j > t
+    if kv_lens is not None:
+        mask |= j >= kv_lens.view(B, 1, 1, 1)
+    s = s.masked_fill(mask, float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("D,H,Hkv,L,S,causal", [(128, 4, 4, 70, 70, True), (128, 8, 2, 200, 200, True), (64, 4, 4, 577, 577, False),
+                                                (64, 3, 3, 9, 9, False), (128, 2, 2, 33, 97, True), (64, 2, 2, 32, 300, False)])
+def test_attn_prefill(ops, D, H, Hkv, L, S, causal):
+    B = 2
+    q = rand_bf(B, L, H, D, seed=9)
+    k = rand_bf(B, Hkv, S, D, seed=10)
+    v = rand_bf(B, Hkv, S, D, seed=11)
+    kv_lens = torch.tensor([S, max(1, S - 5)], dtype=torch.int32)
+    q_off = S - L if causal else 0
+    out = torch.zeros(B * L, H * D, dtype=BF, device="cuda")
+    ops.attn_prefill(dev(q), dev(k), dev(v), out, B, H, Hkv, L, S, D, (L * H * D, H * D, D), (Hkv * S * D, D, S * D),
+                     (Hkv * S * D, D, S * D), H * D, causal, q_off, kv_lens=dev(kv_lens))
+    ref = _ref_attn(q.float().transpose(1, 2), k.float(), v.float(), causal, q_off, kv_lens, 1 / math.sqrt(D))
+    ref = ref.transpose(1, 2).reshape(B * L, H * D)
+    # P is rounded to bf16 before P·V (2^-9 relative per term) and the output once more: 2^-6 of the output scale
+    close_bf16(out, ref, rel=2 ** -6)
+
+
+def test_attn_prefill_out_map_and_qkv_fused_layout(ops):
+    """CLIP-style fused QKV buffer [B*T, 3*Dm] and a routed output map."""
+    B, T, H, D = 2, 50, 4, 64
+    Dm = H * D
+    qkv = rand_bf(B * T, 3 * Dm, seed=12)
+    d = dev(qkv)
+    perm = torch.randperm(B * T, generator=torch.Generator().manual_seed(2)).int()
+    out = torch.zeros(B * T, Dm, dtype=BF, device="cuda")
+    st = (T * 3 * Dm, 3 * Dm, D)
+    ops.attn_prefill(d, d[:, Dm:], d[:, 2 * Dm:], out, B, H, H, T, T, D, st, st, st, Dm, False, 0, out_map=dev(perm))
+    x = qkv.float().view(B, T, 3, H, D)
+    ref = _ref_attn(x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2), False, 0, None, D ** -0.5)
+    ref = ref.transpose(1, 2).reshape(B * T, Dm)
+    got = torch.empty_like(out)
+    got = out[dev(perm.long())]
+    close_bf16(got, ref, rel=2 ** -6)
+
+
+@pytest.mark.parametrize("D,H,Hkv,S,nsplit", [(128, 32, 32, 700, 1), (128, 32, 32, 700, 4), (128, 8, 2, 33, 3), (64, 4, 4, 1000, 8),
+                                              (128, 4, 4, 1, 1)])
+def test_attn_decode(ops, D, H, Hkv, S, nsplit):
+    B, Smax = 3, S + 7
+    q = rand_bf(B, H, D, seed=13)
+    k = rand_bf(B, Hkv, Smax, D, seed=14)
+    v = rand_bf(B, Hkv, Smax, D, seed=15)
+    kv_lens = torch.tensor([S, max(1, S - 1), max(1, S // 2)], dtype=torch.int32)
+    out = torch.zeros(B, H * D, dtype=BF, device="cuda")
+    ops.attn_decode(dev(q), dev(k), dev(v), out, B, H, Hkv, Smax, D, (H * D, D), (Hkv * Smax * D, D, Smax * D),
+                    (Hkv * Smax * D, D, Smax * D), H * D, nsplit=nsplit, kv_lens=dev(kv_lens))
+    ref = _ref_attn(q.float().unsqueeze(2), k.float(), v.float(), False, 0, kv_lens, 1 / math.sqrt(D)).squeeze(2).reshape(B, H * D)
+    close_bf16(out, ref, rel=2 ** -7)
+
+
+def test_silu_mul_copy_embed_argmax(ops):
+    M, I = 37, 11008
+    gu = dev(rand_bf(M, 2 * I, seed=16))
+    ref = F.silu(gu[:, :I].float()) * gu[:, I:].float()
+    close_bf16(ops.silu_mul(gu, I), ref)
+    # copy rows: gather + scatter, bit exact
+    src = dev(rand_bf(20, 256, seed=17))
+    si = torch.tensor([3, 3, 19, 0, -1], dtype=torch.int32)
+    di = torch.tensor([4, 0, 1, -1, 2], dtype=torch.int32)
+    dst = torch.full((6, 256), 7.0, dtype=BF, device="cuda")
+    ops.copy_rows(src, dst, 5, dev(si), dev(di))
+    exp = torch.full((6, 256), 7.0, dtype=BF)
+    exp[4], exp[0], exp[1], exp[2] = src[3].cpu(), src[3].cpu(), src[19].cpu(), 0
+    assert torch.equal(dst.cpu(), exp)
+    table = dev(rand_bf(100, 512, seed=18))
+    ids = torch.tensor([5, 99, 0, 5], dtype=torch.int64)
+    out = torch.zeros(4, 512, dtype=BF, device="cuda")
+    ops.embed_rows(table, dev(ids), out)
+    assert torch.equal(out.cpu(), table.cpu()[ids])
+    logits = torch.randn(5, 32000)
+    logits[2, 100] = logits[2, 31999] = 50.0          # tie -> lowest index
+    assert torch.equal(ops.argmax(dev(logits)).cpu(), logits.argmax(-1)) and ops.argmax(dev(logits))[2].item() == 100
+
+
+def test_im2col_patch_embed_equals_conv(ops):
+    for (B, Cc, Hh, Ww, kh, kw, sh, sw, Co) in [(2, 3, 28, 28, 14, 14, 14, 14, 32), (1, 1, 128, 204, 16, 16, 10, 10, 48)]:
+        x = rand_bf(B, Cc, Hh, Ww, seed=19)
+        w = rand_bf(Co, Cc, kh, kw, scale=0.05, seed=20)
+        cols, oh, ow = ops.im2col(dev(x), kh, kw, sh, sw)
+        pw = ops.pack_weight(dev(w.view(Co, -1)))
+        got = ops.linear(cols, pw).view(B, oh * ow, Co)
+        ref = F.conv2d(x.float(), w.float(), stride=(sh, sw)).flatten(2).transpose(1, 2)
+        close_bf16(got, ref)
+
+
+def test_vit_assemble_and_add(ops):
+    B, T, D = 2, 9, 64
+    p, cls, pos = rand_bf(B * T, D, seed=21), rand_bf(D, seed=22), rand_bf(T + 1, D, seed=23)
+    got = ops.vit_assemble(dev(p), dev(cls), dev(pos), B, T, D)
+    ref = torch.cat([cls.float().expand(B, 1, D), p.float().view(B, T, D)], 1) + pos.float()[None]
+    close_bf16(got, ref, rel=2 ** -8)
+    a, b = rand_bf(1024, seed=24), rand_bf(1024, seed=25)
+    close_bf16(ops.add(dev(a), dev(b)), a.float() + b.float(), rel=2 ** -8)
+
+
+@pytest.mark.parametrize("N,K,r,nt", [(64, 256, 32, 1), (4096, 4096, 128, 3), (100, 200, 8, 2), (11008, 4096, 128, 4)])
+def test_compose_weight_dense_merge(ops, N, K, r, nt):
+    """W' = bf16(W + Σ s·B·A) with fp32 accumulation; differs from the fp32 formula by one bf16 rounding."""
+    w = rand_bf(N, K, scale=0.02, seed=26)
+    terms = [(rand_bf(r, K, scale=K ** -0.5, seed=30 + i), rand_bf(N, r, scale=0.01, seed=40 + i), 0.333 * (i + 1)) for i in range(nt)]
+    pw, rm = ops.compose_weight(dev(w), [(dev(a), dev(b), s) for a, b, s in terms], N, K, rowmajor_out=True)
+    ref = w.float()
+    for a, b, s in terms:
+        ref = ref + s * (b.float() @ a.float())
+    close_bf16(rm, ref, rel=2 ** -8)
+    assert torch.equal(ops.unpack_weight(pw), rm)        # packed and row-major outputs hold the same values
+    # and it multiplies like the branch form of LocalLoraLinear.forward
+    x = rand_bf(8, K, seed=50)
+    xp = F.pad(dev(x), (0, ops.ceil_to(K, 64) - K))
+    y = ops.linear(xp, pw)
+    yb = x.float() @ w.float().t()
+    for a, b, s in terms:
+        yb = yb + s * ((x.float() @ a.float().t()) @ b.float().t())
+    close_bf16(y, yb, rel=2 ** -6)
