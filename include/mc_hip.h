@@ -83,6 +83,40 @@ int mc_im2col_bf16(const void* in, void* out, int B, int C, int Hin, int Win, in
 int mc_vit_assemble_bf16(const void* patches, const void* cls, const void* pos, void* out, int B, int T, int D, void* stream);
 int mc_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 
+/* ---- device-resident greedy-loop state: [pos(B) | kvlen(B) | iota(B) | zeros(B) | step | pad(3)] int32 ---- */
+int mc_decode_state_init(int32_t* state, const int32_t* prompt_lens, int B, int step0, void* stream);
+int mc_decode_state_advance(int32_t* state, int B, void* stream);
+int mc_argmax_step_f32(const void* x, int64_t ld, int64_t* next_ids, int64_t* out_ids, int64_t ld_out, const int32_t* step_ptr,
+                       int M, int N, void* stream);
+
+/* ---- composed Vicuna backbone runtime (csrc/llm_runtime.cpp) -------------------------------------------
+ * Replaces MultimodalLlamaModel.forward + lm_head (model/language_model/multimodal_llama.py:488-619, :720) and the
+ * greedy loop driven by model.generate (eval/model_multimodal_qa_loader.py:94-102).  The handle owns only host
+ * tables of borrowed device pointers; KV cache, workspace and decode state are caller-owned device buffers.      */
+typedef struct mc_llm_config {
+    int hidden, inter, n_layers, n_heads, n_kv_heads, head_dim, vocab, n_adapters, max_pos;
+    float rms_eps;
+} mc_llm_config;
+
+int mc_llm_create(const mc_llm_config* cfg, void** handle);
+int mc_llm_destroy(void* handle);
+/* layer_w[(layer*n_adapters + adapter)*4 + {0:qkv,1:o,2:gate_up,3:down}] = packed weights (fused q|k|v rows, gate|up rows);
+ * cos/sin tables [max_pos, head_dim/2] fp32 (LlamaRotaryEmbedding of transformers 4.31, computed in fp32).        */
+int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* const* in_norms, const void* const* post_norms,
+                       const void* final_norm, const void* lm_head_packed, const void* embed_table, const float* cos_table,
+                       const float* sin_table);
+int mc_llm_set_option(void* handle, const char* name, int value);        /* "use_graph" */
+int mc_llm_workspace_bytes(void* handle, int M, int B, int Lq, int64_t* bytes);
+/* Prefill over M rows in routed order.  group_start / group_adapter are HOST arrays (n_groups+1 / n_groups); the other
+ * int32 arrays are device arrays: row_b/row_pos/row_t [M], out_map [B*Lq] (sequence slot -> routed row, -1 = padding),
+ * kv_lens [B], last_rows [B] (routed row of each sample's last token).  x_routed is updated in place.             */
+int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups, const int32_t* group_start, const int32_t* group_adapter,
+                   const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t, const int32_t* out_map,
+                   const int32_t* kv_lens, const int32_t* last_rows, int B, int Lq, void* k_cache, void* v_cache, int Smax,
+                   void* workspace, void* hidden_out, float* logits_out, int64_t* next_ids, void* stream);
+int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids, int64_t* out_ids, int64_t ld_out, int32_t* state,
+                  void* k_cache, void* v_cache, int Smax, void* workspace, float* logits_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

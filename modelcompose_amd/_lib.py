@@ -40,6 +40,26 @@ _SIGS = {
     "mc_vit_assemble_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "mc_add_bf16": [c_p, c_p, c_p, c_l, c_p],
 }
+
+
+class LlmConfigC(C.Structure):
+    """struct mc_llm_config (include/mc_hip.h)."""
+    _fields_ = [(n, C.c_int) for n in ("hidden", "inter", "n_layers", "n_heads", "n_kv_heads", "head_dim", "vocab", "n_adapters",
+                                       "max_pos")] + [("rms_eps", C.c_float)]
+
+
+_SIGS.update({
+    "mc_decode_state_init": [c_p, c_p, c_i, c_i, c_p],
+    "mc_decode_state_advance": [c_p, c_i, c_p],
+    "mc_argmax_step_f32": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
+    "mc_llm_create": [C.POINTER(LlmConfigC), C.POINTER(c_p)],
+    "mc_llm_destroy": [c_p],
+    "mc_llm_set_weights": [c_p, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_p), c_p, c_p, c_p, c_p, c_p],
+    "mc_llm_set_option": [c_p, C.c_char_p, c_i],
+    "mc_llm_workspace_bytes": [c_p, c_i, c_i, c_i, C.POINTER(c_l)],
+    "mc_llm_prefill": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
+    "mc_llm_decode": [c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
+})
 # optional symbols added by later ABI revisions are bound if present
 _OPTIONAL: dict = {}
 

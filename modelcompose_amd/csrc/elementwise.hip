@@ -356,3 +356,73 @@ extern "C" int mc_add_bf16(const void* a, const void* b, void* out, int64_t n, v
     MC_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// device-resident greedy-loop state (so that every decode step is the same launch sequence and can be
+// replayed from a hipGraph):  state = [pos(B) | kvlen(B) | iota(B) | zeros(B) | step | pad(3)]
+__global__ void decode_state_init_kernel(int32_t* state, const int32_t* prompt_lens, int B, int step0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        state[i] = prompt_lens[i] + step0;          // position of the token fed next
+        state[B + i] = prompt_lens[i] + step0 + 1;  // keys visible to it (itself included)
+        state[2 * B + i] = i;
+        state[3 * B + i] = 0;
+    }
+    if (i == 0) state[4 * B] = step0;
+}
+
+__global__ void decode_state_advance_kernel(int32_t* state, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { state[i] += 1; state[B + i] += 1; }
+    if (i == 0) state[4 * B] += 1;
+}
+
+// argmax + append: next_ids[b] = argmax(logits[b]); out_ids[b*ld + step] = next_ids[b]
+__global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restrict__ x, int64_t ld, int64_t* __restrict__ next_ids,
+                                                          int64_t* __restrict__ out_ids, int64_t ld_out, const int32_t* __restrict__ step_ptr,
+                                                          int N) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const float* r = x + (int64_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float v = r[i];
+        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(best, o, 64);
+        const int i2 = __shfl_xor(idx, o, 64);
+        if (v2 > best || (v2 == best && i2 < idx)) { best = v2; idx = i2; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        next_ids[blockIdx.x] = idx;
+        if (out_ids) out_ids[blockIdx.x * ld_out + (step_ptr ? *step_ptr : 0)] = idx;
+    }
+}
+
+extern "C" int mc_decode_state_init(int32_t* state, const int32_t* prompt_lens, int B, int step0, void* stream) {
+    MC_CHECK_ARG(state && prompt_lens && B > 0, "mc_decode_state_init: bad arguments");
+    decode_state_init_kernel<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(state, prompt_lens, B, step0);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mc_decode_state_advance(int32_t* state, int B, void* stream) {
+    decode_state_advance_kernel<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(state, B);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mc_argmax_step_f32(const void* x, int64_t ld, int64_t* next_ids, int64_t* out_ids, int64_t ld_out,
+                                  const int32_t* step_ptr, int M, int N, void* stream) {
+    MC_CHECK_ARG(x && next_ids && M > 0 && N > 0, "mc_argmax_step_f32: bad arguments");
+    argmax_step_kernel<<<M, 256, 0, (hipStream_t)stream>>>((const float*)x, ld, next_ids, out_ids, ld_out, step_ptr, N);
+    MC_CHECK_LAUNCH();
+    return 0;
+}

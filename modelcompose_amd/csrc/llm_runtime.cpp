@@ -1,0 +1,313 @@
+// Host-side runtime of the composed Vicuna backbone: the 32-layer loop, the routed (per-adapter) GEMM
+// groups and the device-resident greedy loop, with no Python between kernels.
+//
+// Mirrors, on the device, modelcompose/model/language_model/multimodal_llama.py:
+//   MultimodalLlamaModel.forward (:488-619)  -> mc_llm_prefill / mc_llm_decode layer loops
+//   MultimodalLlamaDecoderLayer.forward (:408-468), LocalLoraAttention (:210-342), LocalLoraMLP (:363-396)
+//   lm_head (:720) + greedy argmax of transformers' greedy_search (model_multimodal_qa_loader.py:94-102)
+// LocalLoRA routing: hidden rows are kept grouped by adapter ("routed order"); every token has exactly one
+// active adapter (multimodal_arch.py:452-453), so each group runs ONE dense GEMM against that adapter's
+// pre-composed weight (mc_compose_weight_bf16) instead of all adapters on all tokens + mask-sum (:262-268).
+// During decode the modal mask is dropped (:435-438): adapter 0 ('default') only.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/mc_hip.h"
+
+void mc_set_error(const char* fmt, ...);
+
+namespace {
+
+struct Llm {
+    mc_llm_config cfg;
+    std::vector<const void*> layer_w;       // [(layer*n_adapters + adapter)*4 + {qkv,o,gate_up,down}]
+    std::vector<const void*> in_norm, post_norm;
+    const void* final_norm = nullptr;
+    const void* lm_head = nullptr;
+    const void* embed = nullptr;
+    const float* cos_t = nullptr;
+    const float* sin_t = nullptr;
+    bool weights_set = false;
+    // decode graph cache
+    hipGraphExec_t graph_exec = nullptr;
+    struct Key { int B, Smax; const void *kc, *vc, *ws, *state, *next_ids, *out_ids, *logits; int64_t ld_out; } gkey{};
+    bool use_graph = true;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Ws {          // carve-up of the caller-provided workspace
+    char *n, *qkv, *qseq, *attn, *gu, *inter, *xl, *nl, *logits;
+    size_t total;
+};
+
+Ws carve(const mc_llm_config& c, int M, int B, int Lq, char* base) {
+    const size_t hd = c.hidden, qkvd = (size_t)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    Ws w;
+    w.n = take((size_t)M * hd * 2);
+    w.qkv = take((size_t)M * qkvd * 2);
+    w.qseq = take((size_t)B * Lq * c.n_heads * c.head_dim * 2);
+    w.attn = take((size_t)M * hd * 2);
+    w.gu = take((size_t)M * 2 * c.inter * 2);
+    w.inter = take((size_t)M * c.inter * 2);
+    w.xl = take((size_t)B * hd * 2);
+    w.nl = take((size_t)B * hd * 2);
+    w.logits = take((size_t)B * c.vocab * 4);
+    w.total = off;
+    return w;
+}
+
+#define RUN(call)                    \
+    do {                             \
+        int rc__ = (call);           \
+        if (rc__ != 0) return rc__;  \
+    } while (0)
+
+int check_handle(Llm* m, const char* fn) {
+    if (!m) { mc_set_error("%s: null handle", fn); return 1; }
+    if (!m->weights_set) { mc_set_error("%s: mc_llm_set_weights has not been called", fn); return 1; }
+    return 0;
+}
+
+// one decoder layer over rows grouped by adapter; x is updated in place
+int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t* gstart, const int32_t* gadapter,
+                  const Ws& w, const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t, const int32_t* out_map,
+                  const int32_t* kv_lens, int B, int Lq, char* kc, char* vc, int Smax, bool decode, int nsplit, void* attn_ws,
+                  void* stream) {
+    const mc_llm_config& c = m->cfg;
+    const int64_t hd = c.hidden, D = c.head_dim, H = c.n_heads, Hkv = c.n_kv_heads;
+    const int64_t qkvd = (H + 2 * Hkv) * D;
+    const size_t kv_layer = (size_t)B * Hkv * Smax * D * 2;
+    char* kcl = kc + (size_t)layer * kv_layer;
+    char* vcl = vc + (size_t)layer * kv_layer;
+    const float scale = 1.0f / sqrtf((float)D);
+    auto W = [&](int adapter, int which) { return m->layer_w[((size_t)layer * c.n_adapters + adapter) * 4 + which]; };
+
+    RUN(mc_rmsnorm_bf16(x, hd, m->in_norm[layer], w.n, hd, M, (int)hd, c.rms_eps, stream));
+    for (int g = 0; g < n_groups; ++g) {
+        const int r0 = gstart[g], mg = gstart[g + 1] - r0;
+        if (mg <= 0) continue;
+        RUN(mc_gemm_bf16(w.n + (size_t)r0 * hd * 2, hd, W(gadapter[g], 0), nullptr, nullptr, 0, w.qkv + (size_t)r0 * qkvd * 2, qkvd, mg,
+                         (int)qkvd, (int)hd, MC_ACT_NONE, 0, 1.0f, stream));
+    }
+    RUN(mc_rope_kv_bf16(w.qkv, qkvd, row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, M, (int)H, (int)Hkv, (int)D, Lq,
+                        Smax, stream));
+    if (decode) {
+        RUN(mc_attn_decode_bf16(w.qseq, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl, Hkv * Smax * D, D,
+                                (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit, scale,
+                                stream));
+    } else {
+        RUN(mc_attn_prefill_bf16(w.qseq, (int64_t)Lq * H * D, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
+                                 Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, out_map, kv_lens, B, (int)H, (int)Hkv, Lq, Smax,
+                                 (int)D, 1, 0, scale, stream));
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        const int r0 = gstart[g], mg = gstart[g + 1] - r0;
+        if (mg <= 0) continue;
+        char* xr = x + (size_t)r0 * hd * 2;
+        RUN(mc_gemm_bf16(w.attn + (size_t)r0 * hd * 2, hd, W(gadapter[g], 1), nullptr, xr, hd, xr, hd, mg, (int)hd, (int)hd, MC_ACT_NONE,
+                         0, 1.0f, stream));
+    }
+    RUN(mc_rmsnorm_bf16(x, hd, m->post_norm[layer], w.n, hd, M, (int)hd, c.rms_eps, stream));
+    const int64_t I = c.inter;
+    for (int g = 0; g < n_groups; ++g) {
+        const int r0 = gstart[g], mg = gstart[g + 1] - r0;
+        if (mg <= 0) continue;
+        RUN(mc_gemm_bf16(w.n + (size_t)r0 * hd * 2, hd, W(gadapter[g], 2), nullptr, nullptr, 0, w.gu + (size_t)r0 * 2 * I * 2, 2 * I, mg,
+                         (int)(2 * I), (int)hd, MC_ACT_NONE, 0, 1.0f, stream));
+    }
+    RUN(mc_silu_mul_bf16(w.gu, 2 * I, w.inter, I, M, (int)I, stream));
+    for (int g = 0; g < n_groups; ++g) {
+        const int r0 = gstart[g], mg = gstart[g + 1] - r0;
+        if (mg <= 0) continue;
+        char* xr = x + (size_t)r0 * hd * 2;
+        RUN(mc_gemm_bf16(w.inter + (size_t)r0 * I * 2, I, W(gadapter[g], 3), nullptr, xr, hd, xr, hd, mg, (int)hd, (int)I, MC_ACT_NONE, 0,
+                         1.0f, stream));
+    }
+    return 0;
+}
+
+int head_forward(Llm* m, const char* xl, int B, const Ws& w, float* logits, void* stream) {
+    const mc_llm_config& c = m->cfg;
+    RUN(mc_rmsnorm_bf16(xl, c.hidden, m->final_norm, w.nl, c.hidden, B, c.hidden, c.rms_eps, stream));
+    RUN(mc_gemm_bf16(w.nl, c.hidden, m->lm_head, nullptr, nullptr, 0, logits, c.vocab, B, c.vocab, c.hidden, MC_ACT_NONE, 1, 1.0f,
+                     stream));
+    return 0;
+}
+
+int decode_nsplit(const mc_llm_config& c, int B) {
+    int ns = 1;
+    while (B * c.n_heads * ns < 256 && ns < 16) ns *= 2;
+    return ns;
+}
+
+}  // namespace
+
+extern "C" int mc_llm_create(const mc_llm_config* cfg, void** handle) {
+    if (!cfg || !handle) { mc_set_error("mc_llm_create: null argument"); return 1; }
+    if (cfg->hidden <= 0 || cfg->hidden % 64 || cfg->inter % 64 || cfg->n_layers <= 0 || cfg->n_adapters <= 0 ||
+        cfg->n_heads % cfg->n_kv_heads || (cfg->head_dim != 64 && cfg->head_dim != 128) ||
+        cfg->n_heads * cfg->head_dim != cfg->hidden || cfg->vocab % 4) {
+        mc_set_error("mc_llm_create: unsupported geometry hidden=%d inter=%d heads=%d kv=%d head_dim=%d vocab=%d", cfg->hidden,
+                     cfg->inter, cfg->n_heads, cfg->n_kv_heads, cfg->head_dim, cfg->vocab);
+        return 1;
+    }
+    Llm* m = new Llm();
+    m->cfg = *cfg;
+    *handle = m;
+    return 0;
+}
+
+extern "C" int mc_llm_destroy(void* handle) {
+    Llm* m = (Llm*)handle;
+    if (!m) return 0;
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    delete m;
+    return 0;
+}
+
+extern "C" int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* const* in_norms,
+                                  const void* const* post_norms, const void* final_norm, const void* lm_head_packed,
+                                  const void* embed_table, const float* cos_table, const float* sin_table) {
+    Llm* m = (Llm*)handle;
+    if (!m || !layer_w || !in_norms || !post_norms || !final_norm || !lm_head_packed || !embed_table || !cos_table || !sin_table) {
+        mc_set_error("mc_llm_set_weights: null argument");
+        return 1;
+    }
+    const size_t n = (size_t)m->cfg.n_layers * m->cfg.n_adapters * 4;
+    m->layer_w.assign(layer_w, layer_w + n);
+    for (size_t i = 0; i < n; ++i)
+        if (!m->layer_w[i]) { mc_set_error("mc_llm_set_weights: null weight pointer at index %zu", i); return 1; }
+    m->in_norm.assign(in_norms, in_norms + m->cfg.n_layers);
+    m->post_norm.assign(post_norms, post_norms + m->cfg.n_layers);
+    m->final_norm = final_norm; m->lm_head = lm_head_packed; m->embed = embed_table;
+    m->cos_t = cos_table; m->sin_t = sin_table;
+    m->weights_set = true;
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    return 0;
+}
+
+extern "C" int mc_llm_set_option(void* handle, const char* name, int value) {
+    Llm* m = (Llm*)handle;
+    if (!m || !name) { mc_set_error("mc_llm_set_option: null argument"); return 1; }
+    if (!strcmp(name, "use_graph")) { m->use_graph = value != 0; return 0; }
+    mc_set_error("mc_llm_set_option: unknown option '%s'", name);
+    return 1;
+}
+
+extern "C" int mc_llm_workspace_bytes(void* handle, int M, int B, int Lq, int64_t* bytes) {
+    Llm* m = (Llm*)handle;
+    if (!m || !bytes || M <= 0 || B <= 0 || Lq <= 0) { mc_set_error("mc_llm_workspace_bytes: bad arguments"); return 1; }
+    Ws w = carve(m->cfg, M, B, Lq, nullptr);
+    int64_t attn_ws = 0;
+    mc_attn_decode_workspace_bytes(B, m->cfg.n_heads, m->cfg.head_dim, 16, &attn_ws);
+    *bytes = (int64_t)w.total + attn_ws + 256;
+    return 0;
+}
+
+extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups, const int32_t* group_start,
+                              const int32_t* group_adapter, const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t,
+                              const int32_t* out_map, const int32_t* kv_lens, const int32_t* last_rows, int B, int Lq,
+                              void* k_cache, void* v_cache, int Smax, void* workspace, void* hidden_out, float* logits_out,
+                              int64_t* next_ids, void* stream) {
+    Llm* m = (Llm*)handle;
+    RUN(check_handle(m, "mc_llm_prefill"));
+    if (!x_routed || !group_start || !group_adapter || !row_b || !row_pos || !row_t || !out_map || !k_cache || !v_cache || !workspace ||
+        M <= 0 || B <= 0 || Lq <= 0 || n_groups <= 0 || Smax < Lq) {
+        mc_set_error("mc_llm_prefill: bad arguments (M=%d B=%d Lq=%d Smax=%d groups=%d)", M, B, Lq, Smax, n_groups);
+        return 1;
+    }
+    for (int g = 0; g < n_groups; ++g)
+        if (group_adapter[g] < 0 || group_adapter[g] >= m->cfg.n_adapters || group_start[g + 1] < group_start[g] || group_start[g + 1] > M) {
+            mc_set_error("mc_llm_prefill: bad group %d (adapter %d rows %d..%d)", g, group_adapter[g], group_start[g], group_start[g + 1]);
+            return 1;
+        }
+    const mc_llm_config& c = m->cfg;
+    Ws w = carve(c, M, B, Lq, (char*)workspace);
+    for (int l = 0; l < c.n_layers; ++l)
+        RUN(layer_forward(m, l, (char*)x_routed, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
+                          Lq, (char*)k_cache, (char*)v_cache, Smax, false, 1, nullptr, stream));
+    if (hidden_out)   // final norm over all rows (forward() API: logits for every position, :720)
+        RUN(mc_rmsnorm_bf16(x_routed, c.hidden, m->final_norm, hidden_out, c.hidden, M, c.hidden, c.rms_eps, stream));
+    if (last_rows && (logits_out || next_ids)) {
+        RUN(mc_copy_rows_bf16(x_routed, c.hidden, last_rows, w.xl, c.hidden, nullptr, B, c.hidden, stream));
+        float* lg = logits_out ? logits_out : (float*)w.logits;
+        RUN(head_forward(m, w.xl, B, w, lg, stream));
+        if (next_ids) RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, nullptr, 0, nullptr, B, c.vocab, stream));
+    }
+    return 0;
+}
+
+static int decode_one_step(Llm* m, int B, int64_t* next_ids, int64_t* out_ids, int64_t ld_out, int32_t* state, void* k_cache,
+                           void* v_cache, int Smax, const Ws& w, void* attn_ws, int nsplit, float* logits_step, void* stream) {
+    const mc_llm_config& c = m->cfg;
+    static const int32_t gstart[2] = {0, 0};
+    int32_t gs[2] = {0, B};
+    (void)gstart;
+    const int32_t gad[1] = {0};
+    const int32_t* pos = state;
+    const int32_t* kvlen = state + B;
+    const int32_t* iota = state + 2 * B;
+    const int32_t* zeros = state + 3 * B;
+    const int32_t* step = state + 4 * B;
+    RUN(mc_embed_rows_bf16(m->embed, c.hidden, next_ids, w.xl, c.hidden, nullptr, B, c.hidden, stream));
+    for (int l = 0; l < c.n_layers; ++l)
+        RUN(layer_forward(m, l, w.xl, B, 1, gs, gad, w, iota, pos, zeros, nullptr, kvlen, B, 1, (char*)k_cache, (char*)v_cache, Smax, true,
+                          nsplit, attn_ws, stream));
+    float* lg = logits_step ? logits_step : (float*)w.logits;
+    RUN(head_forward(m, w.xl, B, w, lg, stream));
+    RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, out_ids, ld_out, step, B, c.vocab, stream));
+    RUN(mc_decode_state_advance(state, B, stream));
+    return 0;
+}
+
+// Greedy decode of n_steps tokens entirely on the device.  next_ids [B] holds the token fed first (the prefill's
+// argmax) and is updated in place; out_ids[b*ld_out + step] receives each new token, step read from the device state.
+// logits_out (optional) [n_steps][B][vocab] fp32 for parity tests (disables graph replay).
+extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids, int64_t* out_ids, int64_t ld_out, int32_t* state,
+                             void* k_cache, void* v_cache, int Smax, void* workspace, float* logits_out, void* stream) {
+    Llm* m = (Llm*)handle;
+    RUN(check_handle(m, "mc_llm_decode"));
+    if (!next_ids || !state || !k_cache || !v_cache || !workspace || B <= 0 || n_steps < 0) {
+        mc_set_error("mc_llm_decode: bad arguments");
+        return 1;
+    }
+    const mc_llm_config& c = m->cfg;
+    Ws w = carve(c, B, B, 1, (char*)workspace);
+    void* attn_ws = (char*)workspace + w.total;
+    const int nsplit = decode_nsplit(c, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (m->use_graph && !logits_out && n_steps > 1) {
+        Llm::Key key{B, Smax, k_cache, v_cache, workspace, state, next_ids, out_ids, nullptr, ld_out};
+        if (!m->graph_exec || memcmp(&key, &m->gkey, sizeof(key)) != 0) {
+            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                int rc = decode_one_step(m, B, next_ids, out_ids, ld_out, state, k_cache, v_cache, Smax, w, attn_ws, nsplit, nullptr, stream);
+                e = hipStreamEndCapture(s, &graph);
+                if (rc == 0 && e == hipSuccess && graph) {
+                    e = hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0);
+                    if (e != hipSuccess) m->graph_exec = nullptr;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();
+            if (m->graph_exec) m->gkey = key;
+        }
+        if (m->graph_exec) {
+            for (int i = 0; i < n_steps; ++i) {
+                hipError_t e = hipGraphLaunch(m->graph_exec, s);
+                if (e != hipSuccess) { mc_set_error("mc_llm_decode: hipGraphLaunch: %s", hipGetErrorString(e)); return 2; }
+            }
+            return 0;
+        }
+    }
+    for (int i = 0; i < n_steps; ++i)
+        RUN(decode_one_step(m, B, next_ids, out_ids, ld_out, state, k_cache, v_cache, Smax, w, attn_ws, nsplit,
+                            logits_out ? logits_out + (size_t)i * B * c.vocab : nullptr, stream));
+    return 0;
+}

@@ -1,0 +1,532 @@
+"""MultimodalLlamaForCausalLM on the HIP path.
+
+Host-side mirror of the reference's model API (same method names, argument meaning and error behaviour):
+  modelcompose/model/language_model/multimodal_llama.py:622-767  MultimodalLlamaForCausalLM
+  modelcompose/model/multimodal_arch.py:169-459                  MultimodalMetaForCausalLM (encode / splice)
+All arithmetic runs in libmc_hip.so (include/mc_hip.h); PyTorch only owns device memory and the stream.
+Composition: at load every LocalLoRA linear is expanded into one dense weight per routed adapter
+(W + Σ scale·B·A, csrc/compose.hip), so a forward is plain GEMMs over adapter-grouped rows."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from ..constants import IGNORE_INDEX, MODAL_TOKEN_INDEXES
+from .config import MultimodalConfig, adapter_plan, composition_terms, infer_modals
+from .splice import SplicePlan, plan_splice, routed_layout
+
+BF16 = torch.bfloat16
+LINEARS = (("self_attn", ("q_proj", "k_proj", "v_proj", "o_proj")), ("mlp", ("gate_proj", "up_proj", "down_proj")))
+
+
+class CausalLMOutputWithPast:
+    """Field-compatible stand-in for transformers.modeling_outputs.CausalLMOutputWithPast."""
+
+    def __init__(self, loss=None, logits=None, past_key_values=None, hidden_states=None, attentions=None):
+        self.loss, self.logits, self.past_key_values = loss, logits, past_key_values
+        self.hidden_states, self.attentions = hidden_states, attentions
+
+    def __getitem__(self, i):
+        return tuple(v for v in (self.loss, self.logits, self.past_key_values) if v is not None)[i]
+
+
+_LlmConfigC = _lib.LlmConfigC
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class MultimodalLlamaModel:
+    """`.get_model()` object: embed_tokens, modal_encoders / modal_projectors dicts (multimodal_arch.py:33-63)."""
+
+    def __init__(self, config):
+        self.config = config
+        self.embed_tokens = None            # [vocab, hidden] bf16 device tensor
+        self.modal_encoders: Dict[str, object] = {}
+        self.modal_projectors: Dict[str, object] = {}
+
+    def get_modal_encoders(self):
+        return self.modal_encoders or None
+
+    def get_modal_encoder(self, modal):
+        return self.modal_encoders[modal]
+
+    def get_modal_projectors(self):
+        return self.modal_projectors or None
+
+    def get_modal_projector(self, modal):
+        return self.modal_projectors[modal]
+
+
+class MultimodalLlamaForCausalLM:
+    config_class = MultimodalConfig
+
+    def __init__(self, config: MultimodalConfig, device="cuda"):
+        if not torch.cuda.is_available():
+            raise _lib.MCError("MultimodalLlamaForCausalLM needs a HIP device: this path has no CPU fallback")
+        _lib.lib()          # fail loudly when libmc_hip.so is missing
+        self.config = config
+        self.device = torch.device(device)
+        self.dtype = BF16
+        self.model = MultimodalLlamaModel(config)
+        self.modal_names = infer_modals(config)                       # :631
+        self.prefix_tokens: Optional[Dict[str, torch.Tensor]] = None   # :633-649
+        self.suffix_tokens: Optional[Dict[str, torch.Tensor]] = None
+        self._raw: Dict[str, torch.Tensor] = {}                        # host copy of llm tensors in reference key grammar
+        self._handle = C.c_void_p(0)
+        self._keep = []                                                # device tensors referenced by the C handle
+        self._cache = {}
+        self.use_graph = True
+
+    # ------------------------------------------------------------------ reference accessors
+    def get_model(self):
+        return self.model
+
+    def get_vision_tower(self):
+        return self.model.get_modal_encoders()
+
+    def get_modal_encoders(self):
+        return self.model.get_modal_encoders()
+
+    def get_modal_encoder(self, modal):
+        return self.model.get_modal_encoder(modal)
+
+    def get_modal_projectors(self):
+        return self.model.get_modal_projectors()
+
+    def get_modal_projector(self, modal):
+        return self.model.get_modal_projector(modal)
+
+    def get_modal_processors(self):                                    # multimodal_arch.py:190-195
+        return {k: getattr(v, "modal_processor", None) for k, v in self.model.modal_encoders.items()}
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.lib().mc_llm_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        """Accepts the reference key grammar: base llama tensors, lora_{A,B}.{adapter}, prefix/suffix tokens,
+        model.modal_projectors.*, model.modal_encoders.* .  Call finalize() afterwards (load_pretrained_model does)."""
+        enc_sd: Dict[str, Dict[str, torch.Tensor]] = {}
+        proj_sd: Dict[str, Dict[str, torch.Tensor]] = {}
+        for k, v in sd.items():
+            if k.startswith("base_model.model."):
+                k = k[len("base_model.model."):]
+            if k.startswith("model.modal_encoders."):
+                m, rest = k[len("model.modal_encoders."):].split(".", 1)
+                enc_sd.setdefault(m, {})[rest] = v
+            elif k.startswith("model.modal_projectors."):
+                m, rest = k[len("model.modal_projectors."):].split(".", 1)
+                proj_sd.setdefault(m, {})[rest] = v
+            elif k.startswith("prefix_tokens.") or k.startswith("suffix_tokens."):
+                which, m = k.split(".", 1)
+                d = getattr(self, which) or {}
+                d[m] = v.to(self.device, BF16).reshape(-1, v.shape[-1]).contiguous()
+                setattr(self, which, d)
+            else:
+                self._raw[k] = v
+        for m, d in proj_sd.items():
+            if m in self.model.modal_projectors:
+                self.model.modal_projectors[m].load_state_dict(d)
+        for m, d in enc_sd.items():
+            if m in self.model.modal_encoders:
+                d = {k[len("vision_tower."):] if k.startswith("vision_tower.") else k: v for k, v in d.items()}
+                self.model.modal_encoders[m].load_state_dict(d)
+        self._dirty = True
+        return self
+
+    def _has_lora(self, prefix, key):
+        return f"{prefix}.lora_A.{key}.weight" in self._raw and f"{prefix}.lora_B.{key}.weight" in self._raw
+
+    def _compose_linear(self, prefix: str, adapter: str, out: torch.Tensor, N: int, K: int):
+        """dense weight of `adapter` for one LocalLoRA linear -> packed slice `out`."""
+        dev = self.device
+        w = self._raw[f"{prefix}.weight"].to(dev, BF16)
+        terms = composition_terms(self.config, adapter, lambda key: self._has_lora(prefix, key))
+        tl = []
+        for key, scale in terms:
+            if not self._has_lora(prefix, key):
+                continue                                             # e.g. 'default-point' never trained: contributes B=0
+            a = self._raw[f"{prefix}.lora_A.{key}.weight"].to(dev)
+            b = self._raw[f"{prefix}.lora_B.{key}.weight"].to(dev)
+            tl.append((a, b, scale))
+        _compose_into(w, tl, N, K, out)
+
+    def finalize(self):
+        """Compose + pack every weight, create the C runtime handle."""
+        cfg, dev = self.config, self.device
+        Hd, I, Lyr = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        names = self.modal_names
+        nA = len(names)
+        raw = self._raw
+        if "model.embed_tokens.weight" not in raw:
+            raise ValueError("state dict lacks model.embed_tokens.weight")
+        self.model.embed_tokens = raw["model.embed_tokens.weight"].to(dev, BF16).contiguous()
+        qkv_n, Kp_h, Kp_i = (H + 2 * Hkv) * D, ops.ceil_to(Hd, 64), ops.ceil_to(I, 64)
+        keep = []
+        layer_ptrs = []
+        # adapters whose dense weights equal another adapter's (no LoRA terms at all) share storage with the base
+        for l in range(Lyr):
+            base_cache = {}
+            for ai, ad in enumerate(names):
+                p = f"model.layers.{l}"
+                has_any = any(composition_terms(cfg, ad, lambda key, pp=f"{p}.{blk}.{lin}": self._has_lora(pp, key))
+                              for blk, lins in LINEARS for lin in lins)
+                if not has_any and "base" in base_cache:
+                    layer_ptrs.extend(base_cache["base"])
+                    continue
+                qkv = torch.empty(ops.packed_elems(qkv_n, Hd), dtype=BF16, device=dev)
+                off = 0
+                for lin, n in (("q_proj", H * D), ("k_proj", Hkv * D), ("v_proj", Hkv * D)):
+                    self._compose_linear(f"{p}.self_attn.{lin}", ad, qkv[off * Kp_h:(off + n) * Kp_h], n, Hd)
+                    off += n
+                o = torch.empty(ops.packed_elems(Hd, H * D), dtype=BF16, device=dev)
+                self._compose_linear(f"{p}.self_attn.o_proj", ad, o, Hd, H * D)
+                gu = torch.empty(ops.packed_elems(2 * I, Hd), dtype=BF16, device=dev)
+                self._compose_linear(f"{p}.mlp.gate_proj", ad, gu[:I * Kp_h], I, Hd)
+                self._compose_linear(f"{p}.mlp.up_proj", ad, gu[I * Kp_h:], I, Hd)
+                dn = torch.empty(ops.packed_elems(Hd, I), dtype=BF16, device=dev)
+                self._compose_linear(f"{p}.mlp.down_proj", ad, dn, Hd, I)
+                ptrs = [qkv.data_ptr(), o.data_ptr(), gu.data_ptr(), dn.data_ptr()]
+                keep.extend([qkv, o, gu, dn])
+                if not has_any:
+                    base_cache["base"] = ptrs
+                layer_ptrs.extend(ptrs)
+        in_norms = [raw[f"model.layers.{l}.input_layernorm.weight"].to(dev, BF16).contiguous() for l in range(Lyr)]
+        post_norms = [raw[f"model.layers.{l}.post_attention_layernorm.weight"].to(dev, BF16).contiguous() for l in range(Lyr)]
+        final_norm = raw["model.norm.weight"].to(dev, BF16).contiguous()
+        self.lm_head = ops.pack_weight(raw["lm_head.weight"].to(dev))
+        # rotary tables, fp32 (LlamaRotaryEmbedding 4.31: inv_freq and angles in fp32)
+        n_pos = cfg.max_position_embeddings
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+        ang = torch.outer(torch.arange(n_pos, dtype=torch.float32), inv)
+        self._cos, self._sin = ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous()
+        keep.extend(in_norms + post_norms + [final_norm, self.lm_head.data, self._cos, self._sin, self.model.embed_tokens])
+        L = _lib.lib()
+        if self._handle:
+            L.mc_llm_destroy(self._handle)
+            self._handle = C.c_void_p(0)
+        cc = _LlmConfigC(Hd, I, Lyr, H, Hkv, D, cfg.vocab_size, nA, n_pos, cfg.rms_norm_eps)
+        h = C.c_void_p(0)
+        _lib.check(L.mc_llm_create(C.byref(cc), C.byref(h)), "mc_llm_create")
+        self._handle = h
+        arr = (C.c_void_p * len(layer_ptrs))(*layer_ptrs)
+        inn = (C.c_void_p * Lyr)(*[t.data_ptr() for t in in_norms])
+        pon = (C.c_void_p * Lyr)(*[t.data_ptr() for t in post_norms])
+        _lib.check(L.mc_llm_set_weights(h, arr, inn, pon, _ptr(final_norm), _ptr(self.lm_head.data), _ptr(self.model.embed_tokens),
+                                        _ptr(self._cos), _ptr(self._sin)), "mc_llm_set_weights")
+        _lib.check(L.mc_llm_set_option(h, b"use_graph", 1 if self.use_graph else 0), "mc_llm_set_option")
+        self._keep = keep
+        self._final_norm = final_norm
+        self._dirty = False
+        torch.cuda.synchronize()
+        return self
+
+    # ------------------------------------------------------------------ encode / splice (multimodal_arch.py:197-459)
+    def encode_modal_inputs(self, inputs, prefix_tokens=None, suffix_tokens=None):
+        """Per modality: encoder -> projector -> cat(prefix, feat, suffix) (multimodal_arch.py:197-268).  Absent
+        modalities are skipped: the reference runs their encoder on zeros only as a ZeRO-3 workaround (:203-206)
+        and never uses the result."""
+        feats, masks = {}, {}
+        for modal in [m for m in self.modal_names if m != "default"]:
+            if modal not in inputs:
+                continue
+            encoder, projector = self.model.get_modal_encoder(modal), self.model.get_modal_projector(modal)
+            x = inputs[modal]
+            if type(x) is list:
+                if modal == "audio":
+                    x = torch.stack(x, dim=0)                          # :215
+                else:
+                    raise ValueError("list-of-tensors inputs are only defined for audio in the reference (:224-230 raises)")
+            if modal == "audio" and isinstance(x, dict):
+                f = encoder(**x)
+                f = f[0] if isinstance(f, tuple) else f                # :233-235
+                f = projector(f)
+            elif modal == "video":
+                f = encoder(x)                                         # b t n d
+                b, t, n, d = f.shape
+                f = projector(f.reshape(b, t * n, d))                  # :236-240
+            else:
+                f = projector(encoder(x))
+            f = f.to(BF16)
+            b = f.shape[0]
+            parts = []
+            if prefix_tokens is not None and modal in prefix_tokens:
+                parts.append(prefix_tokens[modal].view(1, -1, f.shape[-1]).expand(b, -1, -1))
+            parts.append(f)
+            if suffix_tokens is not None and modal in suffix_tokens:
+                parts.append(suffix_tokens[modal].view(1, -1, f.shape[-1]).expand(b, -1, -1))
+            if len(parts) > 1:
+                f = _cat_rows(parts)
+            feats[modal] = f.contiguous()
+            masks[modal] = torch.ones(b, f.shape[1], device=f.device)
+        return feats, masks
+
+    def _plan(self, input_ids, attention_mask, labels, modal_inputs, feats) -> SplicePlan:
+        ids = input_ids.detach().cpu().numpy()
+        am = None if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool)
+        lb = None if labels is None else labels.detach().cpu().numpy()
+        keys = list(modal_inputs.keys())
+        return plan_splice(ids, am, lb, keys, {m: feats[m].shape[1] for m in feats}, {m: feats[m].shape[0] for m in feats})
+
+    def _gather_rows(self, plan: SplicePlan, feats, order_b, order_t, out: torch.Tensor):
+        """Fill out[r] for r in range(len(order_b)) with the embedding / feature row of token (order_b[r], order_t[r])."""
+        dev = self.device
+        tok = plan.tok_id[order_b, order_t]
+        sm = plan.src_modal[order_b, order_t]
+        sr = plan.src_row[order_b, order_t]
+        text = np.nonzero(sm < 0)[0]
+        if len(text):
+            ids = torch.from_numpy(tok[text]).to(dev)
+            ops.embed_rows(self.model.embed_tokens, ids, out, torch.from_numpy(text.astype(np.int32)).to(dev))
+        for i, m in enumerate(plan.modal_order):
+            sel = np.nonzero(sm == i)[0]
+            if len(sel) == 0:
+                continue
+            f = feats[m].view(-1, feats[m].shape[-1])
+            ops.copy_rows(f, out, len(sel), torch.from_numpy(sr[sel].astype(np.int32)).to(dev),
+                          torch.from_numpy(sel.astype(np.int32)).to(dev))
+        return out
+
+    def prepare_inputs_labels_for_multimodal(self, input_ids, attention_mask, past_key_values, labels, modal_inputs,
+                                             prefix_tokens, suffix_tokens):
+        """Reference-shaped splice (multimodal_arch.py:287-459): returns
+        (None, attention_mask, past_key_values, inputs_embeds (B, L, hidden), labels, modal_attention_mask)."""
+        if modal_inputs is None or input_ids.shape[1] == 1:                                 # :290-293
+            if past_key_values is not None and modal_inputs is not None and input_ids.shape[1] == 1:
+                attention_mask = torch.ones((attention_mask.shape[0], _past_len(past_key_values) + 1), dtype=attention_mask.dtype,
+                                            device=attention_mask.device)
+            return input_ids, attention_mask, past_key_values, None, labels, None
+        feats, _ = self.encode_modal_inputs(modal_inputs, prefix_tokens, suffix_tokens)
+        plan = self._plan(input_ids, attention_mask, labels, modal_inputs, feats)
+        B, Lmax = plan.tok_id.shape
+        emb = torch.zeros(B * Lmax, self.config.hidden_size, dtype=BF16, device=self.device)
+        bb, tt = np.nonzero(np.arange(Lmax)[None, :] < plan.lens[:, None])
+        rows = torch.empty(len(bb), self.config.hidden_size, dtype=BF16, device=self.device)
+        self._gather_rows(plan, feats, bb, tt, rows)
+        ops.copy_rows(rows, emb, len(bb), None, torch.from_numpy((bb * Lmax + tt).astype(np.int32)).to(self.device))
+        dev = input_ids.device
+        am = torch.from_numpy(plan.attention_mask).to(dev) if attention_mask is not None else None
+        lab = torch.from_numpy(plan.labels).to(dev) if labels is not None else None
+        mam = {k: torch.from_numpy(v).to(dev) for k, v in plan.modal_masks.items()} or None
+        return None, am, past_key_values, emb.view(B, Lmax, -1), lab, mam
+
+    # ------------------------------------------------------------------ device forward
+    def _buffers(self, B, Smax, M, Lq):
+        cfg, dev = self.config, self.device
+        key = ("kv", B, Smax)
+        if key not in self._cache:
+            for k in [k for k in self._cache if k[0] == "kv"]:
+                del self._cache[k]
+            shape = (cfg.num_hidden_layers, B, cfg.num_key_value_heads, Smax, cfg.head_dim)
+            self._cache[key] = (torch.zeros(shape, dtype=BF16, device=dev), torch.zeros(shape, dtype=BF16, device=dev))
+        nbytes = C.c_int64(0)
+        _lib.check(_lib.lib().mc_llm_workspace_bytes(self._handle, M, B, Lq, C.byref(nbytes)), "mc_llm_workspace_bytes")
+        ws = self._cache.get(("ws",))
+        if ws is None or ws.numel() < nbytes.value:
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            self._cache[("ws",)] = ws
+        return self._cache[key], ws
+
+    def _prefill(self, plan: SplicePlan, feats, max_new_tokens: int, want_hidden=False, want_logits=True):
+        if getattr(self, "_dirty", True):
+            self.finalize()
+        cfg, dev = self.config, self.device
+        routed = cfg.lora_strategy in ("modal", "modal+language") and bool(plan.modal_masks)     # :703-704
+        lay = routed_layout(plan, {m: self.modal_names.index(m) for m in plan.modal_order}, routed)
+        B, Lmax, M = plan.B, plan.Lmax, lay.M
+        if Lmax + max_new_tokens > cfg.max_position_embeddings:
+            raise ValueError(f"sequence length {Lmax}+{max_new_tokens} exceeds max_position_embeddings {cfg.max_position_embeddings}")
+        Smax = ops.ceil_to(Lmax + max_new_tokens, 64)
+        (kc, vc), ws = self._buffers(B, Smax, M, Lmax)
+        x = torch.empty(M, cfg.hidden_size, dtype=BF16, device=dev)
+        self._gather_rows(plan, feats, lay.order_b, lay.order_t, x)
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        row_b, row_t = i32(lay.order_b), i32(lay.order_t)
+        out_map, kv_lens, last_rows = i32(lay.out_map), i32(plan.lens), i32(lay.last_rows)
+        hidden = torch.empty(M, cfg.hidden_size, dtype=BF16, device=dev) if want_hidden else None
+        logits = torch.empty(B, cfg.vocab_size, dtype=torch.float32, device=dev) if want_logits else None
+        next_ids = torch.empty(B, dtype=torch.int64, device=dev)
+        gs = np.ascontiguousarray(lay.group_start, dtype=np.int32)
+        ga = np.ascontiguousarray(lay.group_adapter, dtype=np.int32)
+        _lib.check(_lib.lib().mc_llm_prefill(self._handle, _ptr(x), M, len(ga), gs.ctypes.data_as(C.c_void_p), ga.ctypes.data_as(C.c_void_p),
+                                             _ptr(row_b), _ptr(row_t), _ptr(row_t), _ptr(out_map), _ptr(kv_lens), _ptr(last_rows), B, Lmax,
+                                             _ptr(kc), _ptr(vc), Smax, _ptr(ws), _ptr(hidden), _ptr(logits), _ptr(next_ids), _stream()),
+                   "mc_llm_prefill")
+        return dict(plan=plan, layout=lay, kc=kc, vc=vc, ws=ws, Smax=Smax, logits=logits, next_ids=next_ids, hidden=hidden,
+                    kv_lens=kv_lens, out_map=out_map)
+
+    def _decode(self, st, n_steps: int, out_ids: torch.Tensor, step0: int, want_logits=False):
+        B = st["plan"].B
+        dev = self.device
+        state = self._cache.get(("state", B))
+        if state is None:
+            state = torch.zeros(4 * B + 4, dtype=torch.int32, device=dev)
+            self._cache[("state", B)] = state
+        L = _lib.lib()
+        _lib.check(L.mc_decode_state_init(_ptr(state), _ptr(st["kv_lens"]), B, step0, _stream()), "mc_decode_state_init")
+        logits = torch.empty(n_steps, B, self.config.vocab_size, dtype=torch.float32, device=dev) if want_logits else None
+        # the workspace of the prefill is at least as large as the decode one (M >= B)
+        _lib.check(L.mc_llm_decode(self._handle, B, n_steps, _ptr(st["next_ids"]), _ptr(out_ids), out_ids.stride(0), _ptr(state),
+                                   _ptr(st["kc"]), _ptr(st["vc"]), st["Smax"], _ptr(st["ws"]), _ptr(logits), _stream()), "mc_llm_decode")
+        return logits
+
+    # ------------------------------------------------------------------ public API
+    def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, modal_inputs=None, return_dict=None):
+        """Prefill forward with logits for every position (multimodal_llama.py:676-745).  Incremental calls with
+        past_key_values are served by generate(); forward() is the full-sequence entry point."""
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention maps / per-layer hidden states are never materialised on the HIP path")
+        if past_key_values is not None or inputs_embeds is not None:
+            raise NotImplementedError("forward() takes input_ids; cached decoding is driven by generate()")
+        if input_ids is None:
+            raise ValueError("You have to specify either decoder_input_ids or decoder_inputs_embeds")
+        modal_inputs = modal_inputs or {}
+        feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
+        plan = self._plan(input_ids, attention_mask, labels, modal_inputs, feats)
+        st = self._prefill(plan, feats, 0, want_hidden=True, want_logits=False)
+        B, Lmax, V = plan.B, plan.Lmax, self.config.vocab_size
+        lg_r = ops.linear(st["hidden"], self.lm_head, out_f32=True)                          # lm_head (:720), routed order
+        logits = torch.zeros(B * Lmax, V, dtype=torch.float32, device=self.device)
+        valid = st["out_map"] >= 0
+        logits[valid] = lg_r[st["out_map"][valid].long()]
+        logits = logits.view(B, Lmax, V)
+        loss = None
+        if labels is not None:                                                                # :722-733 (torch CE on device logits)
+            lab = torch.from_numpy(plan.labels).to(self.device)
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, V), lab[:, 1:].reshape(-1), ignore_index=IGNORE_INDEX)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None)
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, modal_inputs=None, do_sample=False, temperature=None, top_p=None, num_beams=1,
+                 max_new_tokens=128, use_cache=True, attention_mask=None, ignore_eos=False, return_step_logits=False, **kw):
+        """Greedy generation (model_multimodal_qa_loader.py:94-102).  Returns LongTensor (B, L_text + n_new): the text-length
+        prompt followed by the new ids, rows that hit EOS are padded with pad_token_id (transformers greedy_search)."""
+        if do_sample or (temperature not in (None, 0, 0.0) and do_sample) or (num_beams not in (None, 1)):
+            raise NotImplementedError("only greedy decoding (do_sample=False, num_beams=1) is implemented on the HIP path")
+        if input_ids is None:
+            raise ValueError("generate() needs input_ids")
+        modal_inputs = modal_inputs or {}
+        feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
+        plan = self._plan(input_ids, attention_mask, None, modal_inputs, feats)
+        st = self._prefill(plan, feats, max_new_tokens, want_logits=return_step_logits)
+        B = plan.B
+        out = torch.zeros(B, max_new_tokens, dtype=torch.int64, device=self.device)
+        out[:, 0] = st["next_ids"]
+        step_logits = [st["logits"][None]] if return_step_logits else None
+        eos, pad = self.config.eos_token_id, self.config.pad_token_id
+        pad = eos if pad is None else pad
+        done_at = max_new_tokens
+        if max_new_tokens > 1:
+            if ignore_eos:
+                lg = self._decode(st, max_new_tokens - 1, out[:, 1:], 0, want_logits=return_step_logits)
+                if return_step_logits:
+                    step_logits.append(lg)
+            else:
+                chunk, s = 16, 0
+                while s < max_new_tokens - 1:
+                    n = min(chunk, max_new_tokens - 1 - s)
+                    lg = self._decode(st, n, out[:, 1:], s, want_logits=return_step_logits)
+                    if return_step_logits:
+                        step_logits.append(lg)
+                    s += n
+                    if bool(((out[:, :1 + s] == eos).any(dim=1)).all()):            # host sync once per chunk
+                        break
+        new = out
+        if not ignore_eos:
+            is_eos = new == eos
+            after = (is_eos.cumsum(1) - is_eos.long()) > 0                           # strictly after the first EOS
+            new = torch.where(after, torch.full_like(new, pad), new)
+            fin = is_eos.any(1)
+            if bool(fin.all()):
+                done_at = int((is_eos.float().argmax(1) + 1).max().item())
+            new = new[:, :done_at]
+        res = torch.cat([input_ids.to(self.device), new], dim=1)
+        if return_step_logits:
+            return res, torch.cat(step_logits, 0).transpose(0, 1)[:, :new.shape[1]]
+        return res
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):
+        """multimodal_llama.py:747-767 (kept for API parity; generate() does not call it)."""
+        if past_key_values:
+            input_ids = input_ids[:, -1:]
+        model_inputs = {"inputs_embeds": inputs_embeds} if inputs_embeds is not None and past_key_values is None else {"input_ids": input_ids}
+        model_inputs.update({"past_key_values": past_key_values, "use_cache": kwargs.get("use_cache"), "attention_mask": attention_mask,
+                             "modal_inputs": kwargs.get("modal_inputs", None)})
+        return model_inputs
+
+
+# alias kept by the reference's package __init__ (model/__init__.py:1-3); the legacy single-image class is out of scope
+LlavaLlamaForCausalLM = MultimodalLlamaForCausalLM
+
+
+def _past_len(pkv):
+    return pkv[-1][-1].shape[-2]
+
+
+def _cat_rows(parts: List[torch.Tensor]) -> torch.Tensor:
+    """cat along dim 1 of (b, T_i, H) bf16 tensors with the device copy kernel."""
+    b, Hd = parts[0].shape[0], parts[0].shape[-1]
+    T = sum(p.shape[1] for p in parts)
+    out = torch.empty(b, T, Hd, dtype=BF16, device=parts[0].device)
+    off = 0
+    for p in parts:
+        t = p.shape[1]
+        pc = p if p.is_contiguous() else None
+        for i in range(b):
+            src = (pc[i] if pc is not None else p[i].contiguous())
+            ops.copy_rows(src, out[i, off:off + t], t)
+        off += t
+    return out
+
+
+def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor):
+    """W' = W + Σ scale·B·A packed into the preallocated slice `out`."""
+    n = len(terms)
+    ats, bs, r = [], [], 0
+    for (a, b, s) in terms:
+        r0 = a.shape[0]
+        rp = ops.ceil_to(r0, 32)
+        at = a.to(BF16).t().contiguous()
+        bb = b.to(BF16).contiguous()
+        if rp != r0:
+            at = torch.nn.functional.pad(at, (0, rp - r0))
+            bb = torch.nn.functional.pad(bb, (0, rp - r0))
+        r = rp
+        ats.append(at)
+        bs.append(bb)
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    at_arr = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in ats])
+    b_arr = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in bs])
+    sc = (C.c_float * max(n, 1))(*[float(t[2]) for t in terms])
+    if out.numel() != ops.packed_elems(N, K):
+        raise ValueError("packed slice has the wrong size")
+    _lib.check(_lib.lib().mc_compose_weight_bf16(_ptr(w), w.stride(0), at_arr, b_arr, sc, n, r, _ptr(out), None, 0, N, K, _stream()),
+               "mc_compose_weight_bf16")
+    # keep operands alive until the kernel has been enqueued on the stream (stream-ordered allocator semantics)
+    return out

@@ -277,9 +277,11 @@ def g4():
     ce = refshim.import_ref("modelcompose.model.multimodal_encoder.clip_encoder")
     pb = refshim.import_ref("modelcompose.model.multimodal_projector.builder")
     with tempfile.TemporaryDirectory() as tmp:
-        clip_dir, ccfg = _tiny_clip_dir(tmp)
+        # dims the HIP path supports: head_dim 64, hidden % 64 == 0, vocab % 4 == 0
+        clip_dir, ccfg = _tiny_clip_dir(tmp, hidden=128, layers=3, heads=2, inter=256)
         torch.manual_seed(14)
-        cfg = tiny_llm_config(ml, modal=("vision",), reset="default-vision=0.5", layers=2, prefix_tokens=2)
+        cfg = tiny_llm_config(ml, modal=("vision",), reset="default-vision=0.5", layers=2, prefix_tokens=2,
+                              hidden=128, heads=2, inter=192, vocab=128)
         cfg.mm_vision_encoder = clip_dir
         cfg.mm_vision_select_layer = -2
         cfg.mm_vision_select_feature = "patch"
@@ -400,7 +402,7 @@ def g7():
 def g5_clip():
     ce = refshim.import_ref("modelcompose.model.multimodal_encoder.clip_encoder")
     with tempfile.TemporaryDirectory() as tmp:
-        clip_dir, ccfg = _tiny_clip_dir(tmp, hidden=64, layers=3, heads=4, inter=128, image=42, patch=14, seed=31)
+        clip_dir, ccfg = _tiny_clip_dir(tmp, hidden=128, layers=3, heads=2, inter=256, image=42, patch=14, seed=31)
         args = types.SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature="patch")
         tower = ce.CLIPVisionTower(clip_dir, args, delay_load=False).eval()
         torch.manual_seed(5)
@@ -412,7 +414,7 @@ def g5_clip():
             f_last = tower(px)
         arrays = dict(pixels=px, features=f, features_last_cls=f_last, hs0=hs[0], hs1=hs[1])
         arrays.update(_sd(tower.vision_tower, clip_prefix=""))
-        meta = {"hidden_size": 64, "intermediate_size": 128, "num_hidden_layers": 3, "num_attention_heads": 4,
+        meta = {"hidden_size": 128, "intermediate_size": 256, "num_hidden_layers": 3, "num_attention_heads": 2,
                 "image_size": 42, "patch_size": 14, "layer_norm_eps": ccfg.layer_norm_eps, "hidden_act": ccfg.hidden_act}
         _save("g5_clip", meta=np.array(json.dumps(meta)), **arrays)
 

@@ -1,0 +1,73 @@
+"""Micro-benchmarks of the hot kernels at Vicuna-7B shapes (run on the GPU box)."""
+import sys, os, time, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from modelcompose_amd import ops
+
+BF = torch.bfloat16
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def gemm_case(M, N, K, rot=4):
+    # rotate over several weight copies so decode shapes are not served from the 256 MiB Infinity Cache
+    ws = [ops.pack_weight(torch.randn(N, K, device="cuda").to(BF) * K ** -0.5) for _ in range(rot)]
+    x = torch.randn(M, K, device="cuda").to(BF)
+    out = torch.empty(M, N, dtype=BF, device="cuda")
+    i = [0]
+    def f():
+        ops.linear(x, ws[i[0] % rot], out=out)
+        i[0] += 1
+    t = timeit(f)
+    fl = 2.0 * M * N * K
+    by = N * K * 2 + M * K * 2 + M * N * 2
+    print(f"gemm M={M:6d} N={N:6d} K={K:6d}: {t*1e6:9.1f} us  {fl/t/1e12:8.1f} TFLOP/s  {by/t/1e12:6.2f} TB/s")
+
+
+def main():
+    which = sys.argv[1:] or ["prefill", "decode", "attn"]
+    if "prefill" in which:
+        for M in (1536, 9376, 10912):
+            for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)):
+                gemm_case(M, N, K, rot=1)
+        gemm_case(9232, 1024, 1024, rot=1); gemm_case(9232, 4096, 1024, rot=1); gemm_case(9232, 1024, 4096, rot=1)
+    if "decode" in which:
+        for M in (1, 16, 32, 64):
+            for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008), (32000, 4096)):
+                gemm_case(M, N, K, rot=6)
+    if "attn" in which:
+        B, H, D, L = 16, 32, 128, 682
+        q = torch.randn(B, L, H, D, device="cuda").to(BF)
+        k = torch.randn(B, H, 1024, D, device="cuda").to(BF)
+        v = torch.randn(B, H, 1024, D, device="cuda").to(BF)
+        out = torch.empty(B * L, H * D, dtype=BF, device="cuda")
+        t = timeit(lambda: ops.attn_prefill(q, k, v, out, B, H, H, L, L, D, (L*H*D, H*D, D), (H*1024*D, D, 1024*D), (H*1024*D, D, 1024*D), H*D, True))
+        fl = 4.0 * L * L * D * H * B / 2
+        print(f"attn prefill B={B} L={L}: {t*1e6:9.1f} us {fl/t/1e12:7.1f} TFLOP/s (causal-counted)")
+        for S in (700, 3400):
+            Smax = S + 128
+            kc = torch.randn(B, H, Smax, D, device="cuda").to(BF)
+            vc = torch.randn(B, H, Smax, D, device="cuda").to(BF)
+            q1 = torch.randn(B, H, D, device="cuda").to(BF)
+            o1 = torch.empty(B, H * D, dtype=BF, device="cuda")
+            lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+            for ns in (1, 2, 4, 8):
+                ws = torch.empty(B * H * ns * (D + 2), dtype=torch.float32, device="cuda")
+                t = timeit(lambda: ops.attn_decode(q1, kc, vc, o1, B, H, H, Smax, D, (H*D, D), (H*Smax*D, D, Smax*D), (H*Smax*D, D, Smax*D), H*D, nsplit=ns, workspace=ws, kv_lens=lens))
+                by = 2.0 * B * H * S * D * 2
+                print(f"attn decode B={B} S={S} nsplit={ns}: {t*1e6:9.1f} us {by/t/1e12:6.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()
