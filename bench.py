@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Headline benchmark: samples/s of composed-Vicuna-7B greedy generation (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch of synthetic input on every rank:
+  CLIP-ViT-L/14-336 encode -> mlp2x_gelu projector -> splice -> LocalLoRA-composed Vicuna-7B prefill ->
+  32 greedy tokens (device-resident loop) -> all-gather of the generated ids (N > 1).
+Workload at every N = BASELINE.json configs[1]: vision-only Vicuna-7B bf16, batch 16 synthetic 336 px images per GPU
+(weak scaling: per-GPU work fixed).  Inputs and weights are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
+  roofline     – the dominant kernel (gemm_tile_kernel, MFMA-bound): algorithmic FLOPs per launch / average launch
+                 duration measured live with HIP events on the launch stream during the timed steps
+  cpu_baseline – the oracle (CPU port of the reference algorithm, torch fp32, all host cores) on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0                      # spec HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--new-tokens", type=int, default=32)
+    ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers (invalidates the number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(new_tokens: int):
+    """Oracle = CPU port of the reference algorithm (branch-form LocalLoRA on all tokens, mask-sum routing), torch fp32.
+    Bounded sample: BASELINE config 1 (1 image, ~683-token prompt, `new_tokens` greedy tokens) with 2 and with 4 of the 32
+    decoder layers; the per-layer cost from the difference is scaled to 32 layers, fixed costs (CLIP-L, projector, lm_head,
+    splice) are measured in full."""
+    from modelcompose_amd import synthetic
+    from oracle import pipeline
+    # torch's intra-op pool degrades badly far beyond ~32 threads on these op sizes (256 threads measured 70x slower)
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    times = {}
+    gen_dev = "cuda" if torch.cuda.is_available() else "cpu"      # weights are only GENERATED on the GPU, then moved to host fp32
+    for nl in (2, 4):
+        meta = synthetic.vicuna7b_meta(("vision",), None, layers=nl)
+        sd = synthetic.synthetic_state_dict(meta, device=gen_dev, seed=7, dtype=torch.float32)
+        sd = {k: v.cpu() for k, v in sd.items()}
+        om = pipeline.OracleModel.from_state_dict(sd, meta)
+        ids = synthetic.synthetic_prompt(1, [-200])
+        px = torch.randn(1, 3, 336, 336)
+        with torch.no_grad():
+            om.generate(ids, {"vision": px}, max_new_tokens=2, ignore_eos=True)      # untimed warm-up (thread pool, allocator)
+            t0 = time.perf_counter()
+            om.generate(ids, {"vision": px}, max_new_tokens=new_tokens, ignore_eos=True)
+            times[nl] = time.perf_counter() - t0
+        del sd, om
+    per_layer = max((times[4] - times[2]) / 2.0, 1e-9)
+    fixed = max(times[2] - 2 * per_layer, 0.0)
+    full = fixed + 32 * per_layer
+    return {"value": 1.0 / full, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch fp32 CPU port of the reference path) on BASELINE config 1: 1x336px image, 683-token prompt, "
+                      f"{new_tokens} greedy tokens; timed with 2 and 4 of 32 decoder layers ({times[2]:.2f}s, {times[4]:.2f}s), "
+                      f"per-layer cost x32 + measured fixed cost (CLIP-L/14-336, projector, lm_head) = {full:.1f}s per sample"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    from modelcompose_amd import _lib, synthetic
+    from modelcompose_amd.dist import gather_ids
+    from modelcompose_amd.model.builder import build_from_state_dict
+    import ctypes as C
+
+    dev = torch.device("cuda", local)
+    meta = synthetic.vicuna7b_meta(("vision",), None, layers=args.layers)
+    sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
+    model = build_from_state_dict(meta, sd, device=dev)
+    model.use_graph = not args.no_graph
+    _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"use_graph", 0 if args.no_graph else 1), "set_option")
+    del sd
+    model._raw = {}
+    torch.cuda.empty_cache()
+
+    B = args.batch
+    ids = synthetic.synthetic_prompt(B, [-200], seed=rank).to(dev)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    pixels = torch.randn(B, 3, 336, 336, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    modal_inputs = {"vision": pixels}
+
+    def step():
+        out = model.generate(ids, modal_inputs=modal_inputs, max_new_tokens=args.new_tokens, ignore_eos=True)
+        return gather_ids(out[:, ids.shape[1]:], world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    L = _lib.lib()
+    barrier()
+    L.mc_gemm_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    L.mc_gemm_profile_enable(0)
+    ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+    L.mc_gemm_profile_read(C.byref(ms), C.byref(fl), C.byref(n))
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    value = world * B * args.steps / dt
+    achieved = (fl.value / max(ms.value, 1e-9)) / 1e9          # flops/ms -> TFLOP/s
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")     # HBM bytes per launch from the rocprofv3 PMC passes (see profiles/)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("gemm_tile_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "samples/sec (whole node) composed-Vicuna-7B greedy gen",
+        "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[1]: vision-only composed Vicuna-7B (LocalLoRA r128: default+vision adapters), "
+                               f"batch {B} synthetic 336px images per GPU, 683-token spliced prompt, {args.new_tokens} greedy tokens",
+                   "per_gpu_batch": B, "new_tokens": args.new_tokens, "layers": args.layers, "parallelism": f"dp{world}",
+                   "decode_graph": not args.no_graph},
+        "roofline": {"bound": "mfma", "kernel": "gemm_tile_kernel", "achieved": round(achieved, 2),
+                     "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                     "traffic": traffic, "launches": int(n.value),
+                     "avg_launch_us": round(ms.value / max(n.value, 1) * 1e3, 2),
+                     "avg_flops_per_launch": fl.value / max(n.value, 1)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.new_tokens)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,6 +50,10 @@ int mc_compose_weight_bf16(const void* w_rowmajor, int64_t ldw, const void* cons
 int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* bias, const void* residual, int64_t ldr,
                  void* out, int64_t ldo, int M, int N, int K, int act, int out_f32, float alpha, void* stream);
 
+/* live HIP-event timing of the large-M GEMM kernel on its launch stream (bench.py roofline) */
+int mc_gemm_profile_enable(int on);
+int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches);
+
 /* ---- norms: LlamaRMSNorm (multimodal_llama.py:405-406, :482) / nn.LayerNorm (CLIP blocks) -------------- */
 int mc_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* out, int64_t ldo, int M, int D, float eps, void* stream);
 int mc_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, void* out, int64_t ldo, int M, int D,

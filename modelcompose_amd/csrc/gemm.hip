@@ -295,6 +295,40 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
+#include <vector>
+// Optional live timing of the tile kernel: HIP events recorded on the launch stream around every launch while
+// enabled (bench.py's roofline object).  Not graph-capturable; leave disabled in normal operation.
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+extern "C" int mc_gemm_profile_enable(int on) {
+    if (on && !g_prof_on) {
+        for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        g_prof.clear();
+    }
+    g_prof_on = on != 0;
+    return 0;
+}
+
+// total elapsed (ms), total algorithmic flops and launch count of the tile kernel since the last enable
+extern "C" int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches) {
+    double ms = 0.0, fl = 0.0;
+    for (auto& r : g_prof) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) { mc_set_error("mc_gemm_profile_read: %s", hipGetErrorString(e)); return 2; }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        ms += t; fl += r.flops;
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = (int64_t)g_prof.size();
+    return 0;
+}
+
 extern "C" int mc_packed_weight_elems(int N, int K, int64_t* out_elems) {
     const int64_t Np = (N + 15) / 16 * 16, Kp = (K + 63) / 64 * 64;
     *out_elems = Np * Kp;
@@ -353,8 +387,15 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
             (void)hipFuncSetAttribute((const void*)gemm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_set = true;
         }
+        ProfRec rec{};
+        if (g_prof_on) {
+            (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);
+            rec.flops = 2.0 * M * (double)N * K;
+            (void)hipEventRecord(rec.a, s);
+        }
         gemm_tile_kernel<<<tiles_m * tiles_n, 256, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep,
                                                              tiles_m, tiles_n);
+        if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     }
     MC_CHECK_LAUNCH();
     return 0;

@@ -1,0 +1,79 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/mc_hip.h declares (no compute calls without a GPU), and argument validation reports through mc_last_error."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mc_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from modelcompose_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    return _lib
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    L = lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(L, s), f"libmc_hip.so lacks {s}"
+    bound = set(lib.exported_symbols())
+    missing = [s for s in syms if s not in bound]
+    assert not missing, f"ctypes signatures missing for {missing}"
+    assert L.mc_abi_version() == lib.ABI_VERSION
+
+
+def test_argument_errors_do_not_touch_the_gpu(lib):
+    L = lib.lib()
+    # null pointers / bad shapes are rejected before any HIP call
+    rc = L.mc_gemm_bf16(None, 0, None, None, None, 0, None, 0, 1, 1, 1, 0, 0, 1.0, None)
+    assert rc == 1 and b"null pointer" in L.mc_last_error()
+    with pytest.raises(ValueError):
+        lib.check(rc, "mc_gemm_bf16")
+    n = C.c_int64(0)
+    assert L.mc_packed_weight_elems(4096, 588, C.byref(n)) == 0 and n.value == 4096 * 640
+    cfg = lib.LlmConfigC(100, 64, 1, 3, 3, 33, 97, 1, 128, 1e-5)
+    h = C.c_void_p(0)
+    assert L.mc_llm_create(C.byref(cfg), C.byref(h)) == 1 and b"unsupported geometry" in L.mc_last_error()
+    cfg = lib.LlmConfigC(128, 192, 2, 2, 2, 64, 128, 2, 256, 1e-5)
+    assert L.mc_llm_create(C.byref(cfg), C.byref(h)) == 0 and h.value
+    assert L.mc_llm_prefill(h, None, 1, 1, None, None, None, None, None, None, None, None, 1, 1, None, None, 1, None, None,
+                            None, None, None) == 1
+    assert b"mc_llm_set_weights has not been called" in L.mc_last_error()
+    assert L.mc_llm_destroy(h) == 0
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from modelcompose_amd import _lib, ops
+    from modelcompose_amd.model import MultimodalConfig, MultimodalLlamaForCausalLM
+    with pytest.raises(_lib.MCError):
+        MultimodalLlamaForCausalLM(MultimodalConfig())
+    with pytest.raises(ValueError):
+        ops.rmsnorm(torch.zeros(2, 64, dtype=torch.bfloat16), torch.ones(64, dtype=torch.bfloat16), 1e-5)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under modelcompose_amd/ may import it except smoke.py's checker."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "modelcompose_amd")):
+        for f in fs:
+            if f.endswith(".py") and f != "smoke.py":
+                if re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dp, f)).read(), flags=re.M):
+                    bad.append(f)
+    assert not bad, bad

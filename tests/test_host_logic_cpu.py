@@ -1,0 +1,116 @@
+"""Host-side integer logic of the product (no GPU): splice planner bit-exact against the reference's golden masks /
+labels / attention masks, adapter plan, routing layout, partition rule, merge CLI."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from modelcompose_amd.model import config as mcfg
+from modelcompose_amd.model.splice import plan_splice, routed_layout
+
+
+def _plan_case(a, tag, keys, block_len, n_items):
+    ids = a[f"{tag}::input_ids"].numpy()
+    am = a[f"{tag}::attention_mask_in"].numpy()
+    lab = a[f"{tag}::labels_in"].numpy() if f"{tag}::labels_in" in a else None
+    return plan_splice(ids, am, lab, keys, block_len, n_items)
+
+
+def test_plan_splice_matches_reference_masks_labels():
+    a, _, _ = load_golden("g3_splice")
+    cases = [("eq", ["vision", "audio"], {"vision": 4 + 3, "audio": 3 + 3}, {"vision": 2, "audio": 2}),
+             ("ragged", ["vision", "video"], {"vision": 4 + 3, "video": 6 + 3}, {"vision": 2, "video": 1}),
+             ("edge", ["vision", "video"], {"vision": 4, "video": 6}, {"vision": 2, "video": 2})]
+    for tag, keys, bl, ni in cases:
+        p = _plan_case(a, tag, keys, bl, ni)
+        assert np.array_equal(p.attention_mask, a[f"{tag}::attention_mask"].numpy()), tag
+        if p.labels is not None:
+            assert np.array_equal(p.labels, a[f"{tag}::labels"].numpy()), tag
+        exp = {k.split("::")[-1]: v.numpy() for k, v in a.items() if k.startswith(f"{tag}::mask::")}
+        assert set(p.modal_masks) == set(exp)
+        for k in exp:
+            assert np.array_equal(p.modal_masks[k], exp[k]), (tag, k)
+        # text rows index the embedding table
+        emb = a[f"{tag}::embeds"]
+        table = a["embed_tokens"]
+        B, Lmax = p.tok_id.shape
+        for b in range(B):
+            for t in range(int(p.lens[b])):
+                if p.src_modal[b, t] < 0:
+                    assert torch.equal(emb[b, t], table[p.tok_id[b, t]])
+
+
+def test_plan_splice_errors():
+    ids = np.array([[1, -200, 5]])
+    with pytest.raises(ValueError):
+        plan_splice(ids, None, None, [], {}, {})                       # sentinel without a modal_inputs entry
+    with pytest.raises(ValueError):
+        plan_splice(np.array([[1, -200, -200]]), None, None, ["vision"], {"vision": 3}, {"vision": 1})   # not enough items
+
+
+def test_routed_layout_is_a_permutation_grouped_by_adapter():
+    ids = np.array([[1, 7, -200, 13, 8, -203, 9], [1, -203, 13, 7, 8, -200, 9]])
+    p = plan_splice(ids, None, None, ["vision", "audio"], {"vision": 5, "audio": 2}, {"vision": 2, "audio": 2})
+    lay = routed_layout(p, {"vision": 2, "audio": 1}, routed=True)
+    assert lay.M == int(p.lens.sum())
+    assert sorted(lay.out_map[lay.out_map >= 0].tolist()) == list(range(lay.M))
+    assert lay.group_adapter.tolist() == [0, 1, 2]
+    for g, (s, e) in enumerate(zip(lay.group_start[:-1], lay.group_start[1:])):
+        for r in range(s, e):
+            b, t = lay.order_b[r], lay.order_t[r]
+            exp = {-1: 0, p.modal_order.index("vision"): 2, p.modal_order.index("audio"): 1}[int(p.src_modal[b, t])]
+            assert exp == lay.group_adapter[g]
+    for b in range(2):
+        r = lay.last_rows[b]
+        assert lay.order_b[r] == b and lay.order_t[r] == p.lens[b] - 1
+    un = routed_layout(p, {"vision": 2, "audio": 1}, routed=False)
+    assert un.group_adapter.tolist() == [0] and un.M == lay.M
+
+
+def test_adapter_plan_matches_reference_fixture():
+    _, meta, _ = load_golden("g1_lora_linear")
+    cfg = mcfg.MultimodalConfig(lora_r=meta["lora_r"], lora_alpha=meta["lora_alpha"], mm_audio_encoder="a", mm_vision_encoder="v",
+                                mm_video_encoder="d", reset_scaling_weights=meta["reset_scaling_weights"])
+    names, scaling, dn, merge = mcfg.adapter_plan(cfg)
+    assert names == meta["adapters"] and dn == meta["default_adapter_names"] and merge == meta["merge_default_weights"]
+    for k, v in meta["scaling"].items():
+        assert abs(scaling[k] - v) < 1e-12
+    terms = mcfg.composition_terms(cfg, "default", lambda k: True)
+    assert [t[0] for t in terms] == dn
+    assert mcfg.composition_terms(cfg, "point", lambda k: True) == []
+    assert mcfg.composition_terms(cfg, "vision", lambda k: k != "vision") == []
+    with pytest.raises(ValueError):
+        mcfg.extract_params("default-vision")                             # malformed strategy string
+    with pytest.raises(ValueError):
+        mcfg.MultimodalConfig(rope_scaling={"type": "linear", "factor": 2})
+
+
+def test_partition_rule_matches_reference():
+    from modelcompose_amd.dist import get_chunk, split_list
+    lst = list(range(10))
+    assert split_list(lst, 4) == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]
+    assert get_chunk(lst, 8, 1) == [2, 3]
+    assert sum(split_list(lst, 3), []) == lst
+
+
+def test_merge_cli_matches_reference_golden(tmp_path):
+    from modelcompose_amd import compose
+    a, meta, _ = load_golden("g6_merge")
+    paths = []
+    for modal in meta["order"]:
+        d = tmp_path / f"ckpt-{modal}"
+        d.mkdir()
+        torch.save({k.split("::", 2)[2]: v for k, v in a.items() if k.startswith(f"in::{modal}::")}, d / "adapter_model.bin")
+        json.dump(meta["in_configs"][modal], open(d / "config.json", "w"))
+        paths.append(str(d))
+    out = tmp_path / "merged"
+    compose.main(paths + ["-o", str(out), "--strategy", meta["strategy"]])
+    got = torch.load(out / "adapter_model.bin")
+    exp = {k[5:]: v for k, v in a.items() if k.startswith("out::")}
+    assert sorted(got) == sorted(exp) and all(torch.equal(got[k], exp[k]) for k in exp)
+    assert json.load(open(out / "config.json")) == meta["out_config"]
+    assert open(out / "merge_info.txt").read().replace(str(tmp_path), "<TMP>") == meta["merge_info"]
+    with pytest.raises(NotImplementedError):
+        compose.merge_checkpoints(paths, str(out), "ties-sum")
