@@ -99,7 +99,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const bf16_t* __restrict__ x, int64_t ldx,
                                                            const bf16_t* __restrict__ wp, int M, int N, int K,
-                                                           Epilogue ep, int tiles_m, int tiles_n) {
+                                                           Epilogue ep, int tiles_m, int tiles_n, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [stage][W 16K | X 16K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const bf16_t* __restr
     const int gsz = min(tiles_m - first_m, GROUP);
     const int tm = first_m + (bid % per_group) % gsz;
     const int tn = (bid % per_group) / gsz;
-    const int m0 = tm * TM, n0 = tn * TN;
+    const int m0 = (dbg & 1) ? 0 : tm * TM, n0 = (dbg & 1) ? 0 : tn * TN;
 
     const int kblocks = K >> 5;           // 32-wide k blocks in the packed weight
     const int nblocks = (N + 15) >> 4;
@@ -184,23 +184,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const bf16_t* __restr
         if (t + 1 < nt) stage(t + 1, buf ^ 1);
         const char* wb = smem + buf * (2 * TILE_BYTES);
         const char* xb = wb + TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 wf[4], xf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(wb + woff[i] + kk * 1024);
+        // all 16 fragments of the K-tile are requested up front (one exposed LDS latency per tile instead of
+        // one per 4-MFMA group); the compiler retires them with counted lgkmcnt waits as the MFMAs consume them
+        bf16x8 wf[2][4], xf[2][4];
+        auto ldx = [&](int kk) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = xrow[j];
                 const int ch = (kk * 4 + q4) ^ (row & 7);
-                xf[j] = *(const bf16x8*)(xb + row * 128 + ch * 16);
+                xf[kk][j] = *(const bf16x8*)(xb + row * 128 + ch * 16);
             }
+        };
+        auto ldw = [&](int kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[kk][i] = *(const bf16x8*)(wb + woff[i] + kk * 1024);
+        };
+        auto mm = [&](int kk) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+        };
+        // 12 reads in flight (lgkmcnt is a 4-bit counter), k-step 0 computes while k-step 1's fragments land
+        ldx(0); ldw(0); ldx(1);
+        __builtin_amdgcn_sched_barrier(0);
+        ldw(1);
+        mm(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
         buf ^= 1;
     }
 
@@ -301,8 +313,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t
 namespace {
 struct ProfRec { hipEvent_t a, b; double flops; };
 bool g_prof_on = false;
+int g_gemm_dbg = 0;
 std::vector<ProfRec> g_prof;
 }  // namespace
+
+extern "C" int mc_gemm_debug(int v) { g_gemm_dbg = v; return 0; }
 
 extern "C" int mc_gemm_profile_enable(int on) {
     if (on && !g_prof_on) {
@@ -394,7 +409,7 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
             (void)hipEventRecord(rec.a, s);
         }
         gemm_tile_kernel<<<tiles_m * tiles_n, 256, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep,
-                                                             tiles_m, tiles_n);
+                                                             tiles_m, tiles_n, g_gemm_dbg);
         if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     }
     MC_CHECK_LAUNCH();

@@ -37,6 +37,16 @@ def gemm_case(M, N, K, rot=4):
 
 def main():
     which = sys.argv[1:] or ["prefill", "decode", "attn"]
+    if "dbg" in which:
+        import ctypes
+        from modelcompose_amd import _lib
+        L = _lib.lib()
+        for d in (0, 1):
+            L.mc_gemm_debug(d)
+            print("gemm debug mode", d)
+            for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)):
+                gemm_case(9376, N, K, rot=1)
+        L.mc_gemm_debug(0)
     if "prefill" in which:
         for M in (1536, 9376, 10912):
             for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)):
