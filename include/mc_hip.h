@@ -19,13 +19,14 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 1
+#define MC_ABI_VERSION 2
 
 /* activation codes for mc_gemm_bf16 */
 #define MC_ACT_NONE 0
 #define MC_ACT_GELU 1        /* exact erf GELU: multimodal_projector/builder.py:208-215 (nn.GELU)          */
 #define MC_ACT_QUICK_GELU 2  /* x*sigmoid(1.702x): CLIP MLP (transformers CLIPMLP via clip_encoder.py:53) */
 #define MC_ACT_SILU 3        /* ACT2FN['silu']: model/language_model/multimodal_llama.py:361               */
+#define MC_ACT_RELU 4        /* nn.ReLU of the PointBERT mini-PointNet (multimodal_encoder/pointbert/dvae.py:196-206) */
 
 const char* mc_last_error(void);
 int mc_abi_version(void);
@@ -44,13 +45,14 @@ int mc_compose_weight_bf16(const void* w_rowmajor, int64_t ldw, const void* cons
                            const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
                            int N, int K, void* stream);
 
-/* ---- linear: out[M,N] = act(alpha * x[M,K] W^T + bias) + residual -----------------------------------
+/* ---- linear: out[M,N] = act(alpha * x[M,K] W^T + bias) + beta * residual ----------------------------
  * Replaces F.linear at multimodal_llama.py:122 (LocalLoRA base GEMM), :720 (lm_head), the CLIP / projector
  * linears.  K must be a multiple of 64 (zero padded), x rows 16-byte aligned.  out_f32 != 0 -> fp32 out.  */
 int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* bias, const void* residual, int64_t ldr,
-                 void* out, int64_t ldo, int M, int N, int K, int act, int out_f32, float alpha, void* stream);
+                 void* out, int64_t ldo, int M, int N, int K, int act, int out_f32, float alpha, float beta, void* stream);
 
 /* live HIP-event timing of the large-M GEMM kernel on its launch stream (bench.py roofline) */
+int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgroup computes tile (0,0)) */
 int mc_gemm_profile_enable(int on);
 int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches);
 
@@ -69,7 +71,8 @@ int mc_rope_kv_bf16(const void* qkv, int64_t ld, const int32_t* row_b, const int
 int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
                          int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
                          int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B, int H, int Hkv, int Lq,
-                         int S, int D, int causal, int q_offset, float scale, void* stream);
+                         int S, int D, int causal, int q_offset, float scale, const float* rel_table, int rel_stride, int rel_off,
+                         const float* q_gate, void* stream);   /* rel_table/q_gate: gated relative-position bias of BEATs, may be null */
 int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* bytes);
 int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st, int64_t k_sh,
                         const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o, int64_t o_sb, void* workspace,
@@ -86,6 +89,21 @@ int mc_im2col_bf16(const void* in, void* out, int B, int C, int Hin, int Win, in
                    void* stream);                                                     /* patch-embed conv */
 int mc_vit_assemble_bf16(const void* patches, const void* cls, const void* pos, void* out, int B, int T, int D, void* stream);
 int mc_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+/* ---- encoder-specific row kernels (csrc/encoders.hip) ------------------------------------------------ */
+int mc_add_rows_bf16(const void* x, int64_t ldx, const void* table, int64_t ldt, const int32_t* idx, void* out, int64_t ldo,
+                     int n_rows, int D, void* stream);       /* out[r] = x[r] + table[idx[r]]  (languagebind/video/modeling_video.py:110-113) */
+int mc_zero_rows_bf16(void* x, int64_t ldx, const int32_t* rows, int n_rows, int D, void* stream);   /* beats/backbone.py:150-151 */
+int mc_im2col_ex_bf16(const void* in, int64_t s_b, int64_t s_c, int64_t s_h, int64_t s_w, void* out, int B, int C, int Hin, int Win,
+                      int c0, int Cg, int kh, int kw, int sh, int sw, int ph, int pw, int oh, int ow, int Kp, void* stream);
+int mc_beats_gate_f32(const float* g8, const float* grep_a, float* gate, int B, int L, int H, void* stream);   /* beats/backbone.py:689-697 */
+int mc_group_max_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, void* bcast, int64_t ldb, int G, int n, int C,
+                      void* stream);                          /* pointbert/dvae.py:216-221 */
+int mc_fps_bf16(const void* pts, int B, int N, int C, const int32_t* start_idx, int npoint, int32_t* out_idx, float* centers,
+                void* stream);                                /* pointbert/misc.py:40-60 */
+int mc_knn_group_bf16(const void* pts, int B, int N, int C, const float* centers, int G, int k, void* out, int Kp, int32_t* out_idx,
+                      void* stream);                          /* pointbert/dvae.py:107-187 */
+int mc_f32_rows_to_bf16(const float* in, int C, void* out, int Kp, int64_t rows, void* stream);
 
 /* ---- device-resident greedy-loop state: [pos(B) | kvlen(B) | iota(B) | zeros(B) | step | pad(3)] int32 ---- */
 int mc_decode_state_init(int32_t* state, const int32_t* prompt_lens, int B, int step0, void* stream);

@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -23,14 +23,14 @@ _SIGS = {
     "mc_pack_weight_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_unpack_weight_bf16": [c_p, c_p, c_i, c_i, c_p],
     "mc_compose_weight_bf16": [c_p, c_l, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_f), c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p],
-    "mc_gemm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "mc_gemm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
     "mc_gemm_profile_enable": [c_i],
     "mc_gemm_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)],
     "mc_rmsnorm_bf16": [c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_layernorm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_rope_kv_bf16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "mc_attn_prefill_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
-                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p, c_p],
     "mc_attn_decode_workspace_bytes": [c_i, c_i, c_i, c_i, C.POINTER(c_l)],
     "mc_attn_decode_bf16": [c_p, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
                             c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
@@ -51,6 +51,15 @@ class LlmConfigC(C.Structure):
 
 
 _SIGS.update({
+    "mc_add_rows_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_p],
+    "mc_zero_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
+    "mc_im2col_ex_bf16": [c_p, c_l, c_l, c_l, c_l, c_p] + [c_i] * 15 + [c_p],
+    "mc_beats_gate_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "mc_group_max_bf16": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    "mc_fps_bf16": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p],
+    "mc_knn_group_bf16": [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p],
+    "mc_f32_rows_to_bf16": [c_p, c_i, c_p, c_i, c_l, c_p],
+    "mc_gemm_debug": [c_i],
     "mc_decode_state_init": [c_p, c_p, c_i, c_i, c_p],
     "mc_decode_state_advance": [c_p, c_i, c_p],
     "mc_argmax_step_f32": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_p],

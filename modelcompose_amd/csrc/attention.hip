@@ -24,6 +24,9 @@ struct AttnParams {
     int B, H, Hkv, Lq, S;
     int causal, q_offset;                          // query t has absolute position t + q_offset
     float scale_log2e;                             // softmax scale * log2(e)
+    // optional gated relative-position bias (BEATs, beats/backbone.py:431-468,689-697):
+    //   score += q_gate[b,h,t] * rel_table[h*rel_stride + (key - t + rel_off)]
+    const float* rel_table; const float* q_gate; int rel_stride, rel_off;
 };
 
 #define NEG_BIG (-1.0e30f)
@@ -54,6 +57,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
     }
     const int q_abs = q0 + c + p.q_offset;   // absolute position of this lane's query
+    const float* relrow = nullptr;
+    float gate = 0.f;
+    if (p.rel_table) {
+        const int tq_ = min(q0 + c, p.Lq - 1);
+        relrow = p.rel_table + (int64_t)h * p.rel_stride + (p.rel_off - tq_);
+        gate = (p.q_gate ? p.q_gate[((int64_t)b * p.H + h) * p.Lq + tq_] : 1.0f) * 1.4426950408889634f;
+    }
 
     f32x4 oacc[DB];
 #pragma unroll
@@ -110,7 +120,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                 const int key = kt * 64 + kb * 16 + g * 4 + r;
                 const bool ok = key < kvlen && (!p.causal || key <= q_abs);
                 valid[kb][r] = ok;
-                const float sv = s[kb][r] * p.scale_log2e;
+                float sv = s[kb][r] * p.scale_log2e;
+                if (relrow && ok) sv += gate * relrow[key];
                 s[kb][r] = sv;
                 tmax = ok ? fmaxf(tmax, sv) : tmax;
             }
@@ -302,7 +313,7 @@ extern "C" int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, i
                                     int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
                                     void* o, int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B,
                                     int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
-                                    void* stream) {
+                                    const float* rel_table, int rel_stride, int rel_off, const float* q_gate, void* stream) {
     MC_CHECK_ARG(q && k && v && o, "mc_attn_prefill_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_prefill_bf16: head_dim %d not supported (64 or 128)", D);
     MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Lq > 0 && S > 0, "mc_attn_prefill_bf16: bad shape");
@@ -310,7 +321,7 @@ extern "C" int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, i
                  "mc_attn_prefill_bf16: strides must be multiples of 8 elements");
     AttnParams p{(const bf16_t*)q, q_sb, q_st, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
                  (bf16_t*)o, o_row_stride, out_map, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
-                 scale * 1.4426950408889634f};
+                 scale * 1.4426950408889634f, rel_table, q_gate, rel_stride, rel_off};
     dim3 grid((Lq + 63) / 64, H, B);
     if (D == 128) attn_prefill_kernel<128><<<grid, 256, 0, (hipStream_t)stream>>>(p);
     else attn_prefill_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(p);

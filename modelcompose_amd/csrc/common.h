@@ -15,7 +15,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define MC_WAVE 64
 
 // activation codes shared with include/mc_hip.h
-enum { MC_ACT_NONE = 0, MC_ACT_GELU = 1, MC_ACT_QUICK_GELU = 2, MC_ACT_SILU = 3 };
+enum { MC_ACT_NONE = 0, MC_ACT_GELU = 1, MC_ACT_QUICK_GELU = 2, MC_ACT_SILU = 3, MC_ACT_RELU = 4 };
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
@@ -25,6 +25,7 @@ __device__ __forceinline__ float mc_act(float x, int act) {
         case MC_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
         case MC_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
         case MC_ACT_SILU: return x / (1.0f + __expf(-x));
+        case MC_ACT_RELU: return fmaxf(x, 0.0f);
         default: return x;
     }
 }

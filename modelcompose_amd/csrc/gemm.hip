@@ -59,6 +59,7 @@ struct Epilogue {
     int act;
     int out_f32;
     float alpha;             // scale applied to the accumulator before bias
+    float beta;              // scale applied to the residual
 };
 
 __device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n, f32x4 v) {
@@ -75,7 +76,7 @@ __device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n,
     if (e.residual) {
         bf16x4 b = *(const bf16x4*)(e.residual + (int64_t)m * e.ldr + n);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] += (float)b[i];
+        for (int i = 0; i < 4; ++i) r[i] += e.beta * (float)b[i];
     }
     if (e.out_f32) {
         f32x4 o = {r[0], r[1], r[2], r[3]};
@@ -375,7 +376,7 @@ extern "C" int mc_unpack_weight_bf16(const void* packed, void* w, int N, int K, 
 // N may be any positive value; packed weight has ceil16(N) rows.
 extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* bias, const void* residual,
                             int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int act, int out_f32, float alpha,
-                            void* stream) {
+                            float beta, void* stream) {
     MC_CHECK_ARG(x && w_packed && out, "mc_gemm_bf16: null pointer");
     MC_CHECK_ARG(M > 0 && N > 0 && K > 0, "mc_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
     MC_CHECK_ARG(K % 64 == 0, "mc_gemm_bf16: K=%d must be a multiple of 64 (pad activations/weights)", K);
@@ -383,7 +384,7 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
     MC_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "mc_gemm_bf16: x must be 16-byte aligned rows (ldx=%lld)", (long long)ldx);
     MC_CHECK_ARG(ldo % 4 == 0, "mc_gemm_bf16: ldo=%lld must be a multiple of 4", (long long)ldo);
     MC_CHECK_ARG(!residual || ldr % 4 == 0, "mc_gemm_bf16: ldr must be a multiple of 4");
-    Epilogue ep{(const bf16_t*)bias, (const bf16_t*)residual, ldr, out, ldo, act, out_f32, alpha};
+    Epilogue ep{(const bf16_t*)bias, (const bf16_t*)residual, ldr, out, ldo, act, out_f32, alpha, beta};
     hipStream_t s = (hipStream_t)stream;
     if (M <= 64) {
         const int grid = (N + 15) / 16;

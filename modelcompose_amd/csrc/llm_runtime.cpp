@@ -91,7 +91,7 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
         const int r0 = gstart[g], mg = gstart[g + 1] - r0;
         if (mg <= 0) continue;
         RUN(mc_gemm_bf16(w.n + (size_t)r0 * hd * 2, hd, W(gadapter[g], 0), nullptr, nullptr, 0, w.qkv + (size_t)r0 * qkvd * 2, qkvd, mg,
-                         (int)qkvd, (int)hd, MC_ACT_NONE, 0, 1.0f, stream));
+                         (int)qkvd, (int)hd, MC_ACT_NONE, 0, 1.0f, 1.0f, stream));
     }
     RUN(mc_rope_kv_bf16(w.qkv, qkvd, row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, M, (int)H, (int)Hkv, (int)D, Lq,
                         Smax, stream));
@@ -102,14 +102,14 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     } else {
         RUN(mc_attn_prefill_bf16(w.qseq, (int64_t)Lq * H * D, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
                                  Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, out_map, kv_lens, B, (int)H, (int)Hkv, Lq, Smax,
-                                 (int)D, 1, 0, scale, stream));
+                                 (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, stream));
     }
     for (int g = 0; g < n_groups; ++g) {
         const int r0 = gstart[g], mg = gstart[g + 1] - r0;
         if (mg <= 0) continue;
         char* xr = x + (size_t)r0 * hd * 2;
         RUN(mc_gemm_bf16(w.attn + (size_t)r0 * hd * 2, hd, W(gadapter[g], 1), nullptr, xr, hd, xr, hd, mg, (int)hd, (int)hd, MC_ACT_NONE,
-                         0, 1.0f, stream));
+                         0, 1.0f, 1.0f, stream));
     }
     RUN(mc_rmsnorm_bf16(x, hd, m->post_norm[layer], w.n, hd, M, (int)hd, c.rms_eps, stream));
     const int64_t I = c.inter;
@@ -117,7 +117,7 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
         const int r0 = gstart[g], mg = gstart[g + 1] - r0;
         if (mg <= 0) continue;
         RUN(mc_gemm_bf16(w.n + (size_t)r0 * hd * 2, hd, W(gadapter[g], 2), nullptr, nullptr, 0, w.gu + (size_t)r0 * 2 * I * 2, 2 * I, mg,
-                         (int)(2 * I), (int)hd, MC_ACT_NONE, 0, 1.0f, stream));
+                         (int)(2 * I), (int)hd, MC_ACT_NONE, 0, 1.0f, 1.0f, stream));
     }
     RUN(mc_silu_mul_bf16(w.gu, 2 * I, w.inter, I, M, (int)I, stream));
     for (int g = 0; g < n_groups; ++g) {
@@ -125,7 +125,7 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
         if (mg <= 0) continue;
         char* xr = x + (size_t)r0 * hd * 2;
         RUN(mc_gemm_bf16(w.inter + (size_t)r0 * I * 2, I, W(gadapter[g], 3), nullptr, xr, hd, xr, hd, mg, (int)hd, (int)I, MC_ACT_NONE, 0,
-                         1.0f, stream));
+                         1.0f, 1.0f, stream));
     }
     return 0;
 }
@@ -133,7 +133,7 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
 int head_forward(Llm* m, const char* xl, int B, const Ws& w, float* logits, void* stream) {
     const mc_llm_config& c = m->cfg;
     RUN(mc_rmsnorm_bf16(xl, c.hidden, m->final_norm, w.nl, c.hidden, B, c.hidden, c.rms_eps, stream));
-    RUN(mc_gemm_bf16(w.nl, c.hidden, m->lm_head, nullptr, nullptr, 0, logits, c.vocab, B, c.vocab, c.hidden, MC_ACT_NONE, 1, 1.0f,
+    RUN(mc_gemm_bf16(w.nl, c.hidden, m->lm_head, nullptr, nullptr, 0, logits, c.vocab, B, c.vocab, c.hidden, MC_ACT_NONE, 1, 1.0f, 1.0f,
                      stream));
     return 0;
 }

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3}
+ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3, "relu": 4}
 BF16 = torch.bfloat16
 
 
@@ -106,8 +106,8 @@ def compose_weight(w: Optional[torch.Tensor], terms: Sequence, N: int, K: int, r
 
 
 def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           out_f32: bool = False, alpha: float = 1.0, bias: bool = True) -> torch.Tensor:
-    """out[M,N] = act(alpha * x W^T + b) + residual.  x: [M, Kp] bf16 (Kp = K padded to 64, pad columns zero)."""
+           out_f32: bool = False, alpha: float = 1.0, bias: bool = True, beta: float = 1.0) -> torch.Tensor:
+    """out[M,N] = act(alpha * x W^T + b) + beta * residual.  x: [M, Kp] bf16 (Kp = K padded to 64, pad columns zero)."""
     _req(x, BF16, "x")
     if x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("x must be 2-D with contiguous rows")
@@ -119,7 +119,7 @@ def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.
     b = w.bias if bias else None
     _lib.check(_lib.lib().mc_gemm_bf16(_p(x), x.stride(0), _p(w.data), _p(b), _p(residual),
                                        0 if residual is None else residual.stride(0), _p(out), out.stride(0), M, w.N, w.Kp,
-                                       ACT[act], 1 if out_f32 else 0, alpha, _stream()), "mc_gemm_bf16")
+                                       ACT[act], 1 if out_f32 else 0, alpha, beta, _stream()), "mc_gemm_bf16")
     return out
 
 
@@ -146,11 +146,12 @@ def rope_kv(qkv, row_b, row_pos, row_t, cos, sin, q_out, k_cache, v_cache, H, Hk
 
 
 def attn_prefill(q, k, v, out, B, H, Hkv, Lq, S, D, q_strides, k_strides, v_strides, o_row_stride, causal, q_offset=0,
-                 scale=None, out_map=None, kv_lens=None):
+                 scale=None, out_map=None, kv_lens=None, rel_table=None, rel_off=0, q_gate=None):
     scale = (1.0 / math.sqrt(D)) if scale is None else scale
     _lib.check(_lib.lib().mc_attn_prefill_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_row_stride,
                                                _p(out_map), _p(kv_lens), B, H, Hkv, Lq, S, D, 1 if causal else 0, q_offset,
-                                               scale, _stream()), "mc_attn_prefill_bf16")
+                                               scale, _p(rel_table), 0 if rel_table is None else rel_table.stride(0), rel_off,
+                                               _p(q_gate), _stream()), "mc_attn_prefill_bf16")
     return out
 
 
@@ -214,4 +215,68 @@ def vit_assemble(patches, cls, pos, B, T, D):
 def add(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
     _lib.check(_lib.lib().mc_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "mc_add_bf16")
+    return out
+
+
+# ---- encoder-specific kernels ---------------------------------------------------------------------------
+def add_rows(x, table, idx=None, out=None):
+    """out[r] = x[r] + table[idx[r]] (idx None -> r)."""
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().mc_add_rows_bf16(_p(x), x.stride(0), _p(table), table.stride(0), _p(idx), _p(out), out.stride(0), x.shape[0],
+                                           x.shape[1], _stream()), "mc_add_rows_bf16")
+    return out
+
+
+def zero_rows(x, rows):
+    if rows.numel():
+        _lib.check(_lib.lib().mc_zero_rows_bf16(_p(x), x.stride(0), _p(rows), rows.numel(), x.shape[1], _stream()), "mc_zero_rows_bf16")
+    return x
+
+
+def im2col_ex(x, strides, B, Cc, Hin, Win, c0, Cg, kh, kw, sh, sw, ph, pw, oh, ow, Kp=None):
+    """x: bf16 device tensor addressed as x[b*s_b + c*s_c + y*s_h + x*s_w]."""
+    K = Cg * kh * kw
+    Kp = ceil_to(K, 64) if Kp is None else Kp
+    out = torch.empty(B * oh * ow, Kp, dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().mc_im2col_ex_bf16(_p(x), *strides, _p(out), B, Cc, Hin, Win, c0, Cg, kh, kw, sh, sw, ph, pw, oh, ow, Kp,
+                                            _stream()), "mc_im2col_ex_bf16")
+    return out
+
+
+def beats_gate(g8, grep_a, B, L, H):
+    gate = torch.empty(B, H, L, dtype=torch.float32, device=g8.device)
+    _lib.check(_lib.lib().mc_beats_gate_f32(_p(g8), _p(grep_a), _p(gate), B, L, H, _stream()), "mc_beats_gate_f32")
+    return gate
+
+
+def group_max(x, G, n, out=None, bcast=None):
+    C_ = x.shape[1]
+    if out is None and bcast is None:
+        out = torch.empty(G, C_, dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().mc_group_max_bf16(_p(x), x.stride(0), _p(out), 0 if out is None else out.stride(0), _p(bcast),
+                                            0 if bcast is None else bcast.stride(0), G, n, C_, _stream()), "mc_group_max_bf16")
+    return out
+
+
+def fps(pts, npoint, start_idx=None):
+    B, N, Cc = pts.shape
+    idx = torch.empty(B, npoint, dtype=torch.int32, device=pts.device)
+    centers = torch.empty(B, npoint, 3, dtype=torch.float32, device=pts.device)
+    _lib.check(_lib.lib().mc_fps_bf16(_p(pts), B, N, Cc, _p(start_idx), npoint, _p(idx), _p(centers), _stream()), "mc_fps_bf16")
+    return idx, centers
+
+
+def knn_group(pts, centers, k, Kp=64):
+    B, N, Cc = pts.shape
+    G = centers.shape[1]
+    out = torch.empty(B * G * k, Kp, dtype=BF16, device=pts.device)
+    idx = torch.empty(B, G, k, dtype=torch.int32, device=pts.device)
+    _lib.check(_lib.lib().mc_knn_group_bf16(_p(pts), B, N, Cc, _p(centers), G, k, _p(out), Kp, _p(idx), _stream()), "mc_knn_group_bf16")
+    return out, idx
+
+
+def f32_rows_to_bf16(x, Kp=64):
+    rows, Cc = x.shape
+    out = torch.empty(rows, Kp, dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().mc_f32_rows_to_bf16(_p(x), Cc, _p(out), Kp, rows, _stream()), "mc_f32_rows_to_bf16")
     return out

@@ -419,7 +419,122 @@ def g5_clip():
         _save("g5_clip", meta=np.array(json.dumps(meta)), **arrays)
 
 
-GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g6": g6, "g7": g7}
+def _jitter(module, seed, scale=0.05):
+    """Randomise every parameter/buffer a little so that no term is trivially 0/1."""
+    g = torch.Generator().manual_seed(seed)
+    for n, p_ in list(module.named_parameters()) + [(n, b) for n, b in module.named_buffers() if b.is_floating_point()]:
+        if "running_var" in n:
+            p_.data = 0.5 + torch.rand(p_.shape, generator=g)
+        elif p_.ndim <= 1 and ("norm" in n.lower() or "ln" in n.lower()) and n.endswith("weight"):
+            p_.data = 1.0 + 0.1 * torch.randn(p_.shape, generator=g)
+        else:
+            p_.data = p_.data + scale * torch.randn(p_.shape, generator=g)
+
+
+def g5_beats():
+    bm = refshim.import_ref("modelcompose.model.multimodal_encoder.beats.BEATs")
+    cfgd = dict(input_patch_size=16, embed_dim=64, conv_bias=False, encoder_layers=2, encoder_embed_dim=128,
+                encoder_ffn_embed_dim=256, encoder_attention_heads=2, activation_fn="gelu", layer_norm_first=False, deep_norm=True,
+                dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, dropout_input=0.0,
+                conv_pos=8, conv_pos_groups=2, relative_position_embedding=True, num_buckets=32, max_distance=64, gru_rel_pos=True,
+                finetuned_model=False)
+    torch.manual_seed(41)
+    model = bm.BEATs(bm.BEATsConfig(cfgd)).eval()
+    _jitter(model, 42)
+    fbank = torch.randn(2, 64, 128) * 0.5
+    pad = torch.zeros(2, 64, dtype=torch.bool)
+    pad[1, 40:] = True                      # trailing padding on sample 1 (32 of 64 frames -> tokens 20.. padded)
+    fbank[1, 40:] = 0
+    with torch.no_grad():
+        f, pm = model.extract_features_new(fbank.clone(), pad.clone(), feature_only=True)
+        f_nopad, _ = model.extract_features_new(fbank.clone(), None, feature_only=True)
+    arrays = dict(fbank=fbank, padding_mask=pad, features=f, pooled_mask=pm, features_nopad=f_nopad)
+    arrays.update(_sd(model))
+    _save("g5_beats", meta=np.array(json.dumps(cfgd)), **arrays)
+
+
+def g5_qformer():
+    pb = refshim.import_ref("modelcompose.model.multimodal_projector.builder")
+    real = pb.BertConfig
+    small = dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, vocab_size=64, max_position_embeddings=16)
+    pb.BertConfig = lambda **kw: real(**{**small, **kw})
+    import transformers
+    iw = transformers.PreTrainedModel.init_weights
+    # transformers==4.31 init_weights = apply(_init_weights) (+ tying, nothing is tied once word embeddings are dropped)
+    transformers.PreTrainedModel.init_weights = lambda self: self.apply(self._init_weights)
+    try:
+        torch.manual_seed(43)
+        proj = pb.VideoLlamaAudioQformer(num_query_token=4, vision_width=128, num_hidden_layers=2, num_positions=64).eval()
+    finally:
+        pb.BertConfig = real
+        transformers.PreTrainedModel.init_weights = iw
+    _jitter(proj, 44)
+    x = torch.randn(2, 32, 128)
+    # ModuleUtilsMixin.get_head_mask of transformers==4.31 with head_mask=None: [None] * num_hidden_layers
+    if not hasattr(transformers.PreTrainedModel, "get_head_mask"):
+        transformers.PreTrainedModel.get_head_mask = lambda self, head_mask, n, is_attention_chunked=False: [None] * n
+    with torch.no_grad():
+        y = proj(x)
+    arrays = dict(x=x, y=y)
+    arrays.update(_sd(proj))
+    meta = dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2, layer_norm_eps=1e-12,
+                num_query_token=4, encoder_width=128, out_features=y.shape[-1])
+    _save("g5_qformer", meta=np.array(json.dumps(meta)), **arrays)
+
+
+def g5_video():
+    mv = refshim.import_ref("modelcompose.model.multimodal_encoder.languagebind.video.modeling_video")
+    cv = refshim.import_ref("modelcompose.model.multimodal_encoder.languagebind.video.configuration_video")
+    vc = cv.CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=28,
+                             patch_size=14, num_frames=2, add_time_attn=True, force_patch_dropout=0.0)
+    torch.manual_seed(45)
+    tower = mv.CLIPVisionTransformer(vc).eval()
+    _jitter(tower, 46)
+    video = torch.randn(2, 3, 2, 28, 28)
+    with torch.no_grad():
+        out = tower(video, output_hidden_states=True, return_dict=True)
+    hs = out.hidden_states
+    arrays = dict(video=video, hs_m2=hs[-2], hs0=hs[0], hs1=hs[1])
+    arrays.update(_sd(tower))
+    meta = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=28, patch_size=14,
+                num_frames=2, add_time_attn=True, layer_norm_eps=vc.layer_norm_eps, hidden_act=vc.hidden_act)
+    _save("g5_video", meta=np.array(json.dumps(meta)), **arrays)
+
+
+def g5_point():
+    pe = refshim.import_ref("modelcompose.model.multimodal_encoder.pointbert.point_encoder")
+    from easydict import EasyDict
+    cfgd = dict(trans_dim=128, depth=2, drop_path_rate=0.0, cls_dim=40, num_heads=2, group_size=8, num_group=16, encoder_dims=64,
+                point_dims=6, use_max_pool=False)
+    torch.manual_seed(47)
+    model = pe.PointTransformer(EasyDict(cfgd), use_max_pool=False)
+    # SyncBatchNorm refuses CPU tensors; in eval mode it is the running-stat affine of BatchNorm1d (same state_dict keys)
+    for seq in (model.encoder.first_conv, model.encoder.second_conv):
+        bn = seq[1]
+        nb = nn.BatchNorm1d(bn.num_features)
+        nb.load_state_dict(bn.state_dict())
+        seq[1] = nb
+    model.eval()
+    _jitter(model, 48)
+    B, N = 2, 256
+    g = torch.Generator().manual_seed(49)
+    xyz = torch.randn(B, N, 3, generator=g)
+    xyz = xyz / xyz.norm(dim=-1, keepdim=True).clamp_min(1e-6) * torch.rand(B, N, 1, generator=g) ** (1 / 3)
+    pts = torch.cat([xyz, torch.rand(B, N, 3, generator=g)], -1)
+    torch.manual_seed(50)
+    start = torch.randint(0, N, (B,), dtype=torch.long)        # what misc.fps draws first (pointbert/misc.py:52)
+    torch.manual_seed(50)
+    with torch.no_grad():
+        y = model(pts)
+        torch.manual_seed(50)
+        nbh, center = model.group_divider(pts)
+    arrays = dict(points=pts, fps_start=start, features=y, center=center, neighborhood=nbh)
+    arrays.update(_sd(model))
+    _save("g5_point", meta=np.array(json.dumps(cfgd)), **arrays)
+
+
+GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
+          "g5_point": g5_point, "g6": g6, "g7": g7}
 
 
 def main(argv):

@@ -39,7 +39,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 def test_argument_errors_do_not_touch_the_gpu(lib):
     L = lib.lib()
     # null pointers / bad shapes are rejected before any HIP call
-    rc = L.mc_gemm_bf16(None, 0, None, None, None, 0, None, 0, 1, 1, 1, 0, 0, 1.0, None)
+    rc = L.mc_gemm_bf16(None, 0, None, None, None, 0, None, 0, 1, 1, 1, 0, 0, 1.0, 1.0, None)
     assert rc == 1 and b"null pointer" in L.mc_last_error()
     with pytest.raises(ValueError):
         lib.check(rc, "mc_gemm_bf16")

@@ -172,3 +172,37 @@ def test_g6_merge_checkpoints_file_level(tmp_path):
     assert json.load(open(out / "config.json")) == meta["out_config"]
     info = open(out / "merge_info.txt").read().replace(str(tmp_path), "<TMP>")
     assert info == meta["merge_info"]
+
+
+def test_g5_beats_encoder():
+    from oracle import encoders_extra as ex
+    a, cfg, sd = load_golden("g5_beats")
+    f, pm = ex.beats_encode(a["fbank"], a["padding_mask"], sd, cfg)
+    assert torch.equal(pm, a["pooled_mask"])
+    torch.testing.assert_close(f, a["features"], rtol=2e-4, atol=5e-5)
+    f2, _ = ex.beats_encode(a["fbank"], None, sd, cfg)
+    torch.testing.assert_close(f2, a["features_nopad"], rtol=2e-4, atol=5e-5)
+
+
+def test_g5_qformer_projector():
+    from oracle import encoders_extra as ex
+    a, cfg, sd = load_golden("g5_qformer")
+    y = ex.qformer_project(a["x"], sd, cfg)
+    torch.testing.assert_close(y, a["y"], rtol=2e-4, atol=5e-5)
+
+
+def test_g5_languagebind_video_tower():
+    from oracle import encoders_extra as ex
+    a, cfg, sd = load_golden("g5_video")
+    hs = ex.languagebind_video_hidden_states(a["video"], sd, cfg)
+    torch.testing.assert_close(hs[0], a["hs0"], **TOL)
+    torch.testing.assert_close(hs[1], a["hs1"], rtol=2e-4, atol=5e-5)
+    torch.testing.assert_close(ex.languagebind_video_tower(a["video"], sd, cfg, -2), a["hs_m2"], rtol=2e-4, atol=5e-5)
+
+
+def test_g5_pointbert_encoder():
+    from oracle import encoders_extra as ex
+    a, cfg, sd = load_golden("g5_point")
+    y, cidx, idx, center = ex.pointbert_encode(a["points"], sd, cfg, a["fps_start"], return_aux=True)
+    assert torch.equal(center, a["center"])                      # FPS selection is index work: bit-exact
+    torch.testing.assert_close(y, a["features"], rtol=2e-4, atol=5e-5)
