@@ -231,6 +231,199 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// large-M kernel, 256x256x64 tiles, 8 waves in two groups that alternate LDS->register loads with MFMA work
+// ------------------------------------------------------------------------------------------
+// One workgroup (512 threads) per CU.  LDS = 2 K-tile buffers x (W 32 KiB | X 32 KiB) = 128 KiB, filled by
+// LDS-DMA in 16-KiB "pieces" (2 x 1 KiB per wave):  W piece nh = the 64 weight rows each wave_n uses in output
+// quadrant nh, X piece mh = the 32 tokens each wave_m uses in quadrant mh.
+// A K-tile is 4 phases = the 4 output quadrants (nh,mh) in the order (0,0) (0,1) (1,1) (1,0); each phase is
+//     [ds_read the operand half that changed | issue ONE piece of a later K-tile | counted vmcnt] s_barrier
+//     [16 MFMA 16x16x32] s_barrier
+// Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave feeds the matrix pipe while its partner
+// loads.  Pieces are re-staged two phases after their last read (safe for both groups) and waited for with
+// vmcnt(8): four younger pieces stay in flight across the barriers, nothing drains to zero in the main loop.
+//   staging order per tile t:  P1 X1(t+1)  P2 W1(t+1)  P3 W0(t+2)  P4 X0(t+2)
+//   waits (end of the load half): P1 X1(t)   P2 W1(t)   P4 W0(t+1),X0(t+1)
+#define G2_STAGE 65536
+#define G2_XOFF 32768
+
+template <int N_>
+__device__ __forceinline__ void g2_waitvm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+struct G2Src {
+    const bf16_t* w[2][2];   // [nh][e]  source of this lane's 16 bytes for K-tile 0
+    const bf16_t* x[2][2];   // [mh][e]
+};
+
+// MODE 0: steady state (t <= nt-3), 1: t == nt-2, 2: t == nt-1
+template <int MODE>
+__device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, int xoff, const G2Src& src,
+                                        f32x4 (&acc)[2][4][2][2]) {
+    char* cur = smem + (t & 1) * G2_STAGE;
+    char* nxt = smem + ((t + 1) & 1) * G2_STAGE;
+    bf16x8 wf[4][2], xf[2][2][2];
+    auto stage_w = [&](char* buf, int nh, int tt) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src.w[nh][e] + (int64_t)tt * 1024),
+                                             (lds_void*)(buf + nh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
+    };
+    auto stage_x = [&](char* buf, int mh, int tt) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src.x[mh][e] + (int64_t)tt * 64),
+                                             (lds_void*)(buf + G2_XOFF + mh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
+    };
+    auto read_w = [&](int nh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) wf[i][kk] = *(const bf16x8*)(cur + nh * 16384 + woff + i * 2048 + kk * 1024);
+    };
+    auto read_x = [&](int mh) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                xf[mh][jj][kk] = *(const bf16x8*)(cur + G2_XOFF + mh * 16384 + ((xoff + jj * 2048) ^ (kk * 64)));
+    };
+    auto mma = [&](int nh, int mh) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[nh][i][mh][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][kk], xf[mh][jj][kk], acc[nh][i][mh][jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    // P1 (0,0)
+    read_x(0);
+    read_w(0);
+    if (MODE <= 1) stage_x(nxt, 1, t + 1);
+    if (MODE <= 1) g2_waitvm<8>(); else g2_waitvm<2>();
+    mma(0, 0);
+    // P2 (0,1)
+    read_x(1);
+    if (MODE <= 1) stage_w(nxt, 1, t + 1);
+    if (MODE <= 1) g2_waitvm<8>(); else g2_waitvm<0>();
+    mma(0, 1);
+    // P3 (1,1)
+    read_w(1);
+    if (MODE == 0) stage_w(cur, 0, t + 2);
+    mma(1, 1);
+    // P4 (1,0)
+    if (MODE == 0) stage_x(cur, 0, t + 2);
+    if (MODE == 0) g2_waitvm<8>(); else if (MODE == 1) g2_waitvm<4>();
+    mma(1, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                              const bf16_t* __restrict__ wp, int M, int N, int K,
+                                                              Epilogue ep, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave >> 2, wave_m = wave & 3;
+    const int c16 = lane & 15, q4 = lane >> 4;
+
+    // XCD-aware tile order (same scheme as gemm_tile_kernel): contiguous chunk per XCD, 4 m-tiles per n-tile column
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = bid / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP);
+    const int tm = first_m + (bid % per_group) % gsz;
+    const int tn = (bid % per_group) / gsz;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int kblocks = K >> 5;
+    const int nblocks = (N + 15) >> 4;
+    const int nt = K >> 6;
+
+    G2Src src;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = wave * 2 + e;
+            // W: block c of piece h  ->  (wn, i, kk)
+            const int wn = c >> 3, i = (c >> 1) & 3, kk = c & 1;
+            const int nb = min((n0 >> 4) + wn * 8 + h * 4 + i, nblocks - 1);
+            src.w[h][e] = wp + ((int64_t)nb * kblocks + kk) * 512 + lane * 8;
+            // X: block c of piece h  ->  8 rows of wave_m group wm
+            const int wm = c >> 2, r8 = c & 3;
+            const int row = wm * 64 + h * 32 + r8 * 8 + (lane >> 3);
+            const int gch = (lane & 7) ^ (lane >> 3);
+            src.x[h][e] = x + (int64_t)min(m0 + row, M - 1) * ldx + gch * 8;
+        }
+    const int woff = wave_n * 8192 + lane * 16;
+    const int xoff = wave_m * 4096 + c16 * 128 + ((q4 ^ (c16 & 7)) * 16);
+
+    f32x4 acc[2][4][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: all of K-tile 0, then W0 / X0 of K-tile 1 (the order the steady state would have produced)
+    {
+        auto pw = [&](int buf, int nh, int tt) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src.w[nh][e] + (int64_t)tt * 1024),
+                                                 (lds_void*)(smem + buf * G2_STAGE + nh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
+        };
+        auto px = [&](int buf, int mh, int tt) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src.x[mh][e] + (int64_t)tt * 64),
+                                                 (lds_void*)(smem + buf * G2_STAGE + G2_XOFF + mh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
+        };
+        pw(0, 0, 0); px(0, 0, 0); px(0, 1, 0); pw(0, 1, 0); pw(1, 0, 1); px(1, 0, 1);
+        g2_waitvm<8>();
+        __builtin_amdgcn_s_barrier();
+        if (wave_n == 1) __builtin_amdgcn_s_barrier();
+    }
+    int t = 0;
+    for (; t < nt - 2; ++t) g2_tile<0>(smem, t, wave, woff, xoff, src, acc);
+    g2_tile<1>(smem, t, wave, woff, xoff, src, acc);
+    g2_tile<2>(smem, t + 1, wave, woff, xoff, src, acc);
+    if (wave_n == 0) __builtin_amdgcn_s_barrier();
+
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
+            if (m >= M) continue;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + wave_n * 128 + nh * 64 + i * 16 + q4 * 4;
+                    if (n < N) epilogue_store4(ep, m, n, acc[nh][i][mh][jj]);
+                }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // skinny kernel: M <= 16*MB, one 16-row weight block-row per workgroup, K split over 8 waves
 // ------------------------------------------------------------------------------------------
 #define SK_WAVES 8
@@ -320,6 +513,15 @@ std::vector<ProfRec> g_prof;
 
 extern "C" int mc_gemm_debug(int v) { g_gemm_dbg = v; return 0; }
 
+// 256x256 tiles need enough tiles to fill the 256 CUs; bit 1 of the debug word forces the 128x128 kernel, bit 2 the 256x256 one
+static bool use_tile256(int M, int N, int K) {
+    if (K < 128) return false;
+    if (g_gemm_dbg & 2) return false;
+    if (g_gemm_dbg & 4) return true;
+    const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    return tiles >= 192;
+}
+
 extern "C" int mc_gemm_profile_enable(int on) {
     if (on && !g_prof_on) {
         for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -395,6 +597,23 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
             case 3: gemm_skinny_kernel<3><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
             default: gemm_skinny_kernel<4><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
         }
+    } else if (use_tile256(M, N, K)) {
+        const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+        static bool attr256_set = false;
+        const int lds = 2 * G2_STAGE;
+        if (!attr256_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr256_set = true;
+        }
+        ProfRec rec{};
+        if (g_prof_on) {
+            (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);
+            rec.flops = 2.0 * M * (double)N * K;
+            (void)hipEventRecord(rec.a, s);
+        }
+        gemm_tile256_kernel<<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep,
+                                                                tiles_m, tiles_n);
+        if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     } else {
         const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
         static bool attr_set = false;

@@ -47,11 +47,12 @@ def load_base_state_dict(path: str) -> Dict[str, torch.Tensor]:
 
 
 def build_modal_modules(model: MultimodalLlamaForCausalLM, clip_config: Optional[ClipVisionConfig] = None, delay_load: bool = True,
-                        encoder_hidden: Optional[Dict[str, int]] = None):
+                        encoder_hidden: Optional[Dict[str, int]] = None, encoder_configs: Optional[Dict[str, dict]] = None):
     """multimodal_encoder/builder.py:86-117 (build_modal_encoders) + multimodal_projector/builder.py:246-260."""
     cfg = model.config
     dev = model.device
     encoder_hidden = encoder_hidden or {}
+    encoder_configs = encoder_configs or {}
     for modal in [m for m in infer_modals(cfg) if m != "default"]:
         if modal == "vision":
             path = getattr(cfg, "mm_vision_tower", None) or cfg.mm_vision_encoder
@@ -61,23 +62,23 @@ def build_modal_modules(model: MultimodalLlamaForCausalLM, clip_config: Optional
             hidden = enc.config.hidden_size if enc.config is not None else getattr(cfg, "mm_hidden_size", None)
         else:
             from . import encoders_extra
-            enc, hidden = encoders_extra.build(modal, cfg, dev, delay_load)
+            enc, hidden = encoders_extra.build(modal, cfg, dev, delay_load, config=encoder_configs.get(modal))
         model.model.modal_encoders[modal] = enc
         hidden = encoder_hidden.get(modal, hidden)
         key = "mm_hidden_size" if modal == "vision" else f"mm_{modal}_hidden_size"
         hidden = getattr(cfg, key, None) or hidden
-        model.model.modal_projectors[modal] = _build_modal_projector(cfg, modal, hidden, dev)
+        model.model.modal_projectors[modal] = _build_modal_projector(cfg, modal, hidden, dev, encoder_configs.get("qformer"))
     return model
 
 
-def _build_modal_projector(cfg, modal, hidden, dev):
+def _build_modal_projector(cfg, modal, hidden, dev, qformer_config=None):
     if modal == "audio" and "VideoLLaMA" in str(getattr(cfg, "mm_audio_encoder", "")):
         from . import encoders_extra
-        return encoders_extra.build_audio_qformer(cfg, dev, num_positions=8)
+        return encoders_extra.build_audio_qformer(cfg, dev, num_positions=8, config=qformer_config)   # builder.py:249-251
     ptype = projector_type_for(cfg, modal)
     if ptype.startswith("qformer"):
         from . import encoders_extra
-        return encoders_extra.build_qformer_projector(cfg, ptype, hidden, dev)
+        return encoders_extra.build_qformer_projector(cfg, ptype, hidden, dev, config=qformer_config)
     return build_projector(ptype, hidden, cfg.hidden_size, dev)
 
 
@@ -129,7 +130,11 @@ def build_from_state_dict(meta: dict, sd: Dict[str, torch.Tensor], device="cuda"
     cfg = MultimodalConfig(**{k: v for k, v in meta.items() if k in known or k.startswith("mm_") or k.startswith("local_")})
     model = MultimodalLlamaForCausalLM(cfg, device=device)
     clip_cfg = ClipVisionConfig(**meta["clip"]) if "clip" in meta else None
-    build_modal_modules(model, clip_config=clip_cfg, delay_load=True)
+    enc_cfgs = {m: meta[k] for m, k in (("audio", "beats"), ("audio", "imagebind"), ("video", "video"), ("point", "point"),
+                                        ("qformer", "qformer")) if k in meta}
+    build_modal_modules(model, clip_config=clip_cfg, delay_load=True, encoder_configs=enc_cfgs)
+    if "fps_start" in meta and "point" in model.model.modal_encoders:
+        model.model.modal_encoders["point"].fps_start = torch.as_tensor(meta["fps_start"])
     model.load_state_dict(sd)
     model.finalize()
     return model

@@ -513,34 +513,48 @@ class HipPointEncoder:
 # =========================================================================================================
 # builders used by model/builder.py
 # =========================================================================================================
-def build(modal: str, cfg, dev, delay_load=True):
-    """multimodal_encoder/builder.py:86-117 for audio / video / point."""
+def build(modal: str, cfg, dev, delay_load=True, config=None):
+    """multimodal_encoder/builder.py:86-117 for audio / video / point.  `config` (a dict) replaces the configuration the
+    reference reads from the encoder checkpoint / directory (in-memory construction: tests, synthetic benchmarks)."""
     if modal == "audio":
         path = cfg.mm_audio_encoder
         if "VideoLLaMA" in str(path):
-            raise NotImplementedError("ImageBind-audio (the VideoLLaMA branch, multimodal_encoder/builder.py:91-95) is not built yet")
-        enc = HipBeatsAudioEncoder(path, cfg, delay_load=delay_load, device=dev)
+            from .imagebind_audio import HipImageBindAudioEncoder
+            enc = HipImageBindAudioEncoder(path, cfg, delay_load=delay_load, config=config, device=dev)
+            return enc, enc.hidden_size
+        enc = HipBeatsAudioEncoder(path, cfg, delay_load=delay_load, config=BeatsConfig(config) if config is not None else None, device=dev)
         return enc, (enc.cfg.encoder_embed_dim if enc.cfg is not None else None)
     if modal == "video":
         path = cfg.mm_video_encoder
-        if os.path.isdir(str(path)) is False and not str(path).endswith("LanguageBind_Video_merge") and not str(path).startswith("synthetic"):
+        if config is None and os.path.isdir(str(path)) is False and not str(path).endswith("LanguageBind_Video_merge"):
             raise ValueError(f"Unknown video encoder: {path}")                  # builder.py:97-101
-        enc = HipLanguageBindVideoTower(path if os.path.isdir(str(path)) else None, cfg, delay_load=delay_load, device=dev)
+        enc = HipLanguageBindVideoTower(path if os.path.isdir(str(path)) else None, cfg, delay_load=delay_load,
+                                        config=VideoConfig(**config) if config is not None else None, device=dev)
         return enc, (enc.config.hidden_size if enc.config is not None else None)
     if modal == "point":
-        enc = HipPointEncoder(cfg.mm_point_encoder if os.path.isfile(str(cfg.mm_point_encoder)) else None, cfg, delay_load=delay_load, device=dev)
+        enc = HipPointEncoder(cfg.mm_point_encoder if os.path.isfile(str(cfg.mm_point_encoder)) else None, cfg, delay_load=delay_load,
+                              config=PointConfig(**config) if config is not None else None, device=dev)
         return enc, enc.cfg.trans_dim
     raise ValueError(f"unknown modality {modal}")
 
 
-def build_qformer_projector(cfg, ptype: str, hidden, dev):
-    """'qformer_{N}N_{L}L' (multimodal_projector/builder.py:217-220)."""
+def build_qformer_projector(cfg, ptype: str, hidden, dev, config=None):
+    """'qformer_{N}N_{L}L' (multimodal_projector/builder.py:217-220).  `config` overrides the BERT-base widths."""
     import re
     m = re.match(r"^qformer_(\d+)N_(\d+)L$", ptype)
     if not m:
         raise ValueError(f"Unknown projector type: {ptype}")
-    return HipQformerProjector(int(m.group(1)), hidden, int(m.group(2)), device=dev)
+    kw = {}
+    if config:
+        kw = {k: config[k] for k in ("hidden_size", "num_attention_heads", "intermediate_size", "layer_norm_eps", "num_positions")
+              if k in config}
+    return HipQformerProjector(int(m.group(1)), hidden, int(m.group(2)), device=dev, **kw)
 
 
-def build_audio_qformer(cfg, dev, num_positions=8):
-    return HipQformerProjector(num_positions=num_positions, device=dev)
+def build_audio_qformer(cfg, dev, num_positions=8, config=None):
+    kw = dict(config or {})
+    kw.pop("out_features", None)
+    kw.setdefault("num_positions", num_positions)
+    if "encoder_width" in kw:
+        kw["vision_width"] = kw.pop("encoder_width")
+    return HipQformerProjector(device=dev, **kw)

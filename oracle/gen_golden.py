@@ -16,6 +16,7 @@ Groups:
   g5  encoders / projectors (clip, ...)
   g6  merge script file-level outputs
   g7  dense-merge equivalence
+  g8  tiny 4-modality composed model end to end (all encoders + projectors + routed LLM + greedy ids)
 """
 from __future__ import annotations
 
@@ -533,8 +534,165 @@ def g5_point():
     _save("g5_point", meta=np.array(json.dumps(cfgd)), **arrays)
 
 
+def g8():
+    """Tiny 4-modality composed model end to end through the reference classes (BASELINE configs 3/4 in miniature):
+    CLIP + mlp2x_gelu, BEATs + Q-Former, LanguageBind-Video + mlp2x_gelu, PointBERT + mlp2x_gelu, prefix/suffix tokens,
+    4-way online-merge-reset coefficients, routed LocalLoRA prefill, cached greedy decode.  The encoder wrapper objects
+    are the reference's own classes (their forward() is what runs); only their checkpoint-file loading is bypassed."""
+    ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
+    ce = refshim.import_ref("modelcompose.model.multimodal_encoder.clip_encoder")
+    ae = refshim.import_ref("modelcompose.model.multimodal_encoder.audio_encoder")
+    bm = refshim.import_ref("modelcompose.model.multimodal_encoder.beats.BEATs")
+    lb = refshim.import_ref("modelcompose.model.multimodal_encoder.languagebind")
+    mv = refshim.import_ref("modelcompose.model.multimodal_encoder.languagebind.video.modeling_video")
+    cv = refshim.import_ref("modelcompose.model.multimodal_encoder.languagebind.video.configuration_video")
+    pw = refshim.import_ref("modelcompose.model.multimodal_encoder.point_encoder")
+    pe = refshim.import_ref("modelcompose.model.multimodal_encoder.pointbert.point_encoder")
+    pb = refshim.import_ref("modelcompose.model.multimodal_projector.builder")
+    from easydict import EasyDict
+    import transformers
+    H = 128
+    with tempfile.TemporaryDirectory() as tmp:
+        clip_dir, ccfg = _tiny_clip_dir(tmp, hidden=128, layers=3, heads=2, inter=256)
+        torch.manual_seed(81)
+        reset = "default-vision=0.25,default-audio=0.25,default-video=0.25,default-point=0.25"
+        cfg = tiny_llm_config(ml, modal=("vision", "audio", "video", "point"), reset=reset, layers=2, prefix_tokens=2,
+                              hidden=H, heads=2, inter=192, vocab=128)
+        cfg.mm_vision_encoder = clip_dir
+        cfg.mm_vision_select_layer, cfg.mm_vision_select_feature, cfg.mm_projector_type = -2, "patch", "mlp2x_gelu"
+        model = ml.MultimodalLlamaForCausalLM(cfg).eval()
+        # --- vision
+        args = types.SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature="patch", mm_video_select_layer=-2)
+        vis = ce.CLIPVisionTower(clip_dir, args, delay_load=False)
+        # --- audio: BEATs inside the reference's BeatsAudioEncoder wrapper
+        beats_cfg = dict(input_patch_size=16, embed_dim=64, conv_bias=False, encoder_layers=2, encoder_embed_dim=128,
+                         encoder_ffn_embed_dim=256, encoder_attention_heads=2, activation_fn="gelu", layer_norm_first=False,
+                         deep_norm=True, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0,
+                         dropout_input=0.0, conv_pos=8, conv_pos_groups=2, relative_position_embedding=True, num_buckets=32,
+                         max_distance=64, gru_rel_pos=True, finetuned_model=False)
+        aud = ae.BeatsAudioEncoder.__new__(ae.BeatsAudioEncoder)
+        nn.Module.__init__(aud)
+        aud.cfg_only = bm.BEATsConfig(beats_cfg)
+        aud.audio_encoder = bm.BEATs(aud.cfg_only).eval()
+        aud.is_loaded = True
+        _jitter(aud, 82)
+        # --- video: LanguageBind CLIPVisionTransformer inside LanguageBindVideoTower
+        vcd = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=28, patch_size=14,
+                   num_frames=2, add_time_attn=True, force_patch_dropout=0.0)
+        vc = cv.CLIPVisionConfig(**vcd)
+        vid = lb.LanguageBindVideoTower.__new__(lb.LanguageBindVideoTower)
+        nn.Module.__init__(vid)
+        vid.select_layer, vid.select_feature, vid.is_loaded = -2, "patch", True
+        vid.video_tower = mv.CLIPVisionTransformer(vc).eval()
+        _jitter(vid, 83)
+        # --- point: PointTransformer inside PointEncoder
+        pcd = dict(trans_dim=128, depth=2, drop_path_rate=0.0, cls_dim=40, num_heads=2, group_size=8, num_group=16, encoder_dims=64,
+                   point_dims=6, use_max_pool=False)
+        pnt = pw.PointEncoder.__new__(pw.PointEncoder)
+        nn.Module.__init__(pnt)
+        pnt.cfg_only, pnt.is_loaded = EasyDict(pcd), True
+        ptm = pe.PointTransformer(EasyDict(pcd), use_max_pool=False)
+        for seq in (ptm.encoder.first_conv, ptm.encoder.second_conv):
+            bn = seq[1]
+            nb_ = nn.BatchNorm1d(bn.num_features)
+            nb_.load_state_dict(bn.state_dict())
+            seq[1] = nb_
+        pnt.point_encoder = ptm.eval()
+        _jitter(pnt, 84)
+        # --- projectors (reference builders; the Q-Former's output Linear is hard-wired to 4096 -> resized to the tiny hidden)
+        def mlp(in_f):
+            pc = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=in_f, hidden_size=H)
+            m = pb.build_vision_projector(pc)
+            return m
+        real = pb.BertConfig
+        small = dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, vocab_size=64, max_position_embeddings=16)
+        pb.BertConfig = lambda **kw: real(**{**small, **kw})
+        iw = transformers.PreTrainedModel.init_weights
+        transformers.PreTrainedModel.init_weights = lambda self: self.apply(self._init_weights)
+        try:
+            torch.manual_seed(85)
+            qf = pb.VideoLlamaAudioQformer(num_query_token=4, vision_width=128, num_hidden_layers=2, num_positions=64).eval()
+        finally:
+            pb.BertConfig = real
+            transformers.PreTrainedModel.init_weights = iw
+        qf.audio_llama_proj = nn.Linear(128, H)
+        if not hasattr(transformers.PreTrainedModel, "get_head_mask"):
+            transformers.PreTrainedModel.get_head_mask = lambda self, head_mask, n, is_attention_chunked=False: [None] * n
+        projs = {"vision": mlp(128), "audio": qf, "video": mlp(128), "point": mlp(128)}
+        for i, (k, m) in enumerate(projs.items()):
+            _jitter(m, 86 + i, scale=0.08)
+        model.model.modal_encoders = nn.ModuleDict({"vision": vis, "audio": aud, "video": vid, "point": pnt})
+        model.model.modal_projectors = nn.ModuleDict(projs)
+        _randomize_lora(model, 9)
+        model.eval()
+        # --- inputs: both samples carry all four modalities, in different orders (equal spliced length: the reference's
+        # ragged branch needs labels, multimodal_arch.py:414-431, and its position ids ignore padding, SURVEY App. B)
+        g = torch.Generator().manual_seed(90)
+        V, A, VD, P = -200, -203, -204, -205
+        r = lambda n: torch.randint(3, 97, (n,), generator=g).tolist()
+        s0 = [1] + r(3) + [V, 13] + [A, 13] + [VD, 13] + [P, 13] + r(4)
+        s1 = [1] + r(2) + [P, 13] + r(1) + [VD, 13] + [A, 13] + r(2) + [V, 13] + r(2)
+        assert len(s0) == len(s1)
+        ids = torch.tensor([s0, s1], dtype=torch.long)
+        pixels = torch.randn(2, 3, 28, 28, generator=g)
+        fbank = torch.randn(2, 64, 128, generator=g) * 0.5
+        pad = torch.zeros(2, 64, dtype=torch.bool)
+        video = torch.randn(2, 3, 2, 28, 28, generator=g)
+        N = 256
+        xyz = torch.randn(2, N, 3, generator=g)
+        xyz = xyz / xyz.norm(dim=-1, keepdim=True).clamp_min(1e-6) * torch.rand(2, N, 1, generator=g) ** (1 / 3)
+        pts = torch.cat([xyz, torch.rand(2, N, 3, generator=g)], -1)
+        torch.manual_seed(91)
+        fps_start = torch.randint(0, N, (2,), dtype=torch.long)            # the draw misc.fps makes first (pointbert/misc.py:52)
+        # modal_inputs dict order = collator order of first appearance (multimodal_dataset.py:171-173)
+        mi = {"vision": pixels, "audio": {"audio_inputs": fbank, "audio_padding_mask": pad}, "video": video, "point": pts}
+        n_new = 8
+
+        def fwd(**kw):
+            torch.manual_seed(91)                                          # FPS start is redrawn at every encode
+            return model(modal_inputs=mi, use_cache=True, **kw)
+
+        with torch.no_grad():
+            torch.manual_seed(91)
+            feats, _ = model.encode_modal_inputs(mi, model.prefix_tokens, model.suffix_tokens)
+            out = fwd(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool))
+            logits0 = out.logits
+            kv = out.past_key_values
+            nxt = logits0[:, -1].argmax(-1)
+            gen, steps_logits = [nxt], [logits0[:, -1]]
+            am = torch.ones(2, logits0.shape[1], dtype=torch.bool)
+            for _ in range(n_new - 1):
+                am = torch.cat([am, torch.ones(2, 1, dtype=torch.bool)], dim=1)
+                o = fwd(input_ids=nxt[:, None], attention_mask=am, past_key_values=kv)
+                kv = o.past_key_values
+                steps_logits.append(o.logits[:, -1])
+                nxt = o.logits[:, -1].argmax(-1)
+                gen.append(nxt)
+        arrays = dict(input_ids=ids, pixels=pixels, fbank=fbank, padding_mask=pad, video=video, points=pts, fps_start=fps_start,
+                      logits_prefill=logits0, gen_ids=torch.stack(gen, 1), step_logits=torch.stack(steps_logits, 1))
+        for m_, f_ in feats.items():
+            arrays[f"feat_{m_}"] = f_
+        arrays.update(_sd(model, clip_prefix="model.modal_encoders.vision.vision_tower."))
+        extra = {"modal_names": model.modal_names, "mm_projector_type": "mlp2x_gelu", "mm_vision_select_layer": -2,
+                 "mm_audio_projector_type": "qformer_4N_2L", "mm_video_projector_type": "mlp2x_gelu",
+                 "mm_point_projector_type": "mlp2x_gelu", "mm_video_select_layer": -2, "fps_start": fps_start.tolist(),
+                 "mm_audio_hidden_size": 128, "mm_video_hidden_size": 128, "mm_point_hidden_size": 128, "mm_hidden_size": 128,
+                 "clip": {"hidden_size": ccfg.hidden_size, "intermediate_size": ccfg.intermediate_size,
+                          "num_hidden_layers": ccfg.num_hidden_layers, "num_attention_heads": ccfg.num_attention_heads,
+                          "image_size": ccfg.image_size, "patch_size": ccfg.patch_size,
+                          "layer_norm_eps": ccfg.layer_norm_eps, "hidden_act": ccfg.hidden_act},
+                 "beats": beats_cfg,
+                 "video": dict(vcd, layer_norm_eps=vc.layer_norm_eps, hidden_act=vc.hidden_act),
+                 "point": pcd,
+                 "qformer": dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2,
+                                 layer_norm_eps=1e-12, num_query_token=4, encoder_width=128, out_features=H, num_positions=64)}
+        d = json.loads(cfg_json(cfg, extra))
+        d["mm_vision_encoder"] = "clip-tiny"
+        _save("g8_e2e_4modal", meta=np.array(json.dumps(d)), **arrays)
+
+
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
-          "g5_point": g5_point, "g6": g6, "g7": g7}
+          "g5_point": g5_point, "g6": g6, "g7": g7, "g8": g8}
 
 
 def main(argv):

@@ -128,3 +128,36 @@ def test_splice_api_matches_golden_g3():
         for k in exp:
             assert torch.equal(mam[k], exp[k]), (tag, k)
         assert torch.equal(emb.cpu(), a[f"{tag}::embeds"].to(torch.bfloat16))
+
+
+def test_g8_four_modality_composed_model_matches_reference():
+    """BASELINE configs 3/4 in miniature: CLIP + BEATs/Q-Former + LanguageBind-Video + PointBERT feature blocks spliced in two
+    different orders, 4-way online-merge-reset coefficients, routed prefill, device-resident greedy decode — against the
+    reference's own outputs (tests/golden/g8_e2e_4modal.npz)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from modelcompose_amd.model.builder import build_from_state_dict
+    a, meta, sd = load_golden("g8_e2e_4modal")
+    model = build_from_state_dict(meta, sd)
+    assert model.modal_names == ["default", "audio", "vision", "video", "point"]
+    mi = {"vision": a["pixels"].cuda(), "audio": {"audio_inputs": a["fbank"].cuda(), "audio_padding_mask": a["padding_mask"].cuda()},
+          "video": a["video"].cuda(), "point": a["points"].cuda()}
+    feats, masks = model.encode_modal_inputs(mi, model.prefix_tokens, model.suffix_tokens)
+    for m in ("vision", "audio", "video", "point"):
+        assert feats[m].shape == a[f"feat_{m}"].shape
+        # bf16 encoders (2-3 layers) + projector vs the fp32 reference; point: bf16 rounding of the coordinates on top
+        assert rel_err(feats[m], a[f"feat_{m}"]) < (2 ** -4 if m == "point" else 2 ** -5), m
+    ids = a["input_ids"].cuda()
+    out = model.forward(input_ids=ids, modal_inputs=mi)
+    assert out.logits.shape == a["logits_prefill"].shape
+    assert rel_err(out.logits, a["logits_prefill"]) < 3e-2
+    n_new = a["gen_ids"].shape[1]
+    res, step_logits = model.generate(ids, modal_inputs=mi, max_new_tokens=n_new, ignore_eos=True, return_step_logits=True)
+    assert rel_err(step_logits, a["step_logits"]) < 4e-2
+    ref_l = a["step_logits"]
+    top2 = ref_l.topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 8e-2 * ref_l.abs().max()
+    got = res[:, ids.shape[1]:].cpu()
+    for b in range(got.shape[0]):
+        n = n_new if bool(safe[b].all()) else int((~safe[b]).float().argmax())
+        assert torch.equal(got[b, :n], a["gen_ids"][b, :n]), (b, got[b], a["gen_ids"][b])

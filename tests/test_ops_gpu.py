@@ -60,6 +60,31 @@ def test_gemm_matches_fp32_matmul(ops, M, N, K):
     close_bf16(got, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 192), (257, 4096, 1024), (2000, 1028, 4096), (3000, 4096, 11008)])
+def test_gemm_tile256_kernel_bit_identical_to_tile128(ops, M, N, K):
+    """The 256x256 ping-pong kernel (forced through the debug word) accumulates every output in the same k order as the 128x128
+    kernel: outputs must be bit-identical, and both within bf16 rounding of the fp32 matmul (edge tiles in M and N, K tails)."""
+    from modelcompose_amd import _lib
+    L = _lib.lib()
+    x = dev(rand_bf(M, K, seed=5))
+    w = dev(rand_bf(N, K, scale=K ** -0.5, seed=6))
+    b = dev(rand_bf(N, seed=7))
+    r = dev(rand_bf(M, N, seed=8))
+    pw = ops.pack_weight(w, b)
+    try:
+        L.mc_gemm_debug(2)
+        small = ops.linear(x, pw, act="gelu", residual=r)
+        L.mc_gemm_debug(4)
+        big = ops.linear(x, pw, act="gelu", residual=r)
+        big32 = ops.linear(x, pw, out_f32=True)
+    finally:
+        L.mc_gemm_debug(0)
+    assert torch.equal(small, big)
+    close_bf16(big, F.gelu(x.float() @ w.float().t() + b.float()) + r.float())
+    ref = x.float() @ w.float().t() + b.float()
+    assert (big32.cpu() - ref.cpu()).abs().max().item() <= 1e-3 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M", [8, 300])
 @pytest.mark.parametrize("act", ["none", "gelu", "quick_gelu", "silu"])
 def test_gemm_epilogue_bias_act_residual(ops, M, act):

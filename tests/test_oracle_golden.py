@@ -150,6 +150,29 @@ def test_g4_end_to_end_vision_greedy_ids():
     torch.testing.assert_close(step_logits, a["step_logits"], rtol=2e-4, atol=5e-5)
 
 
+def _g8_inputs(a):
+    return {"vision": a["pixels"], "audio": {"audio_inputs": a["fbank"], "audio_padding_mask": a["padding_mask"]},
+            "video": a["video"], "point": a["points"]}
+
+
+def test_g8_end_to_end_four_modalities_greedy_ids():
+    """Composed 4-modality model (CLIP, BEATs+Q-Former, LanguageBind-Video, PointBERT; 4-way reset coefficients) against the
+    reference's own outputs: per-modality feature blocks, routed prefill logits, cached greedy ids."""
+    from oracle import pipeline
+    a, meta, sd = load_golden("g8_e2e_4modal")
+    model = pipeline.OracleModel.from_state_dict(sd, meta)
+    mi = _g8_inputs(a)
+    for m in ("vision", "audio", "video", "point"):
+        f = model.encode_modal(m, mi[m])
+        ref = a[f"feat_{m}"][:, 2:-2]                      # reference block = [prefix(2) | features | suffix(2)]
+        torch.testing.assert_close(f, ref, rtol=5e-4, atol=5e-5)
+    logits, kv, _ = model.prefill(a["input_ids"], mi)
+    torch.testing.assert_close(logits, a["logits_prefill"], rtol=5e-4, atol=1e-4)
+    ids, step_logits = model.generate(a["input_ids"], mi, max_new_tokens=a["gen_ids"].shape[1], ignore_eos=True, return_logits=True)
+    assert torch.equal(ids, a["gen_ids"])
+    torch.testing.assert_close(step_logits, a["step_logits"], rtol=5e-4, atol=1e-4)
+
+
 def test_g6_merge_checkpoints_file_level(tmp_path):
     import os
     from oracle import merge as omerge

@@ -47,6 +47,36 @@ def main():
             for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)):
                 gemm_case(9376, N, K, rot=1)
         L.mc_gemm_debug(0)
+    if "g256" in which:
+        from modelcompose_amd import _lib
+        L = _lib.lib()
+        # correctness of the 256x256 kernel (edge tiles, small K, epilogue variants) against an fp32 matmul of the bf16 values
+        for (M, N, K) in ((256, 256, 128), (300, 520, 192), (1000, 4096, 1024), (10928, 4096, 4096), (513, 1028, 11008)):
+            w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
+            x = torch.randn(M, K, device="cuda").to(BF)
+            res = torch.randn(M, N, device="cuda").to(BF)
+            bias = torch.randn(N, device="cuda").to(BF)
+            pw = ops.pack_weight(w, bias)
+            ref = x.float() @ w.float().t() + bias.float() + res.float()
+            outs = {}
+            for d in (2, 4):
+                L.mc_gemm_debug(d)
+                outs[d] = ops.linear(x, pw, residual=res)
+            L.mc_gemm_debug(0)
+            torch.cuda.synchronize()
+            e2 = (outs[2].float() - ref).abs().max().item() / ref.abs().max().item()
+            e4 = (outs[4].float() - ref).abs().max().item() / ref.abs().max().item()
+            same = torch.equal(outs[2], outs[4])
+            print(f"check M={M} N={N} K={K}: rel err 128-kernel {e2:.2e}  256-kernel {e4:.2e}  bit-identical={same}")
+        for rep in range(2):
+            for d in (2, 4):
+                L.mc_gemm_debug(d)
+                print("gemm debug mode", d, "(2 = 128x128 kernel, 4 = 256x256 kernel)")
+                for M in (10928,):
+                    for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)):
+                        gemm_case(M, N, K, rot=1)
+                gemm_case(9232, 4096, 1024, rot=1); gemm_case(9232, 1024, 4096, rot=1); gemm_case(8192, 8192, 8192, rot=1)
+        L.mc_gemm_debug(0)
     if "prefill" in which:
         for M in (1536, 9376, 10912):
             for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)):
