@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 2
+#define MC_ABI_VERSION 3
 
 /* activation codes for mc_gemm_bf16 */
 #define MC_ACT_NONE 0
@@ -45,11 +45,32 @@ int mc_compose_weight_bf16(const void* w_rowmajor, int64_t ldw, const void* cons
                            const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
                            int N, int K, void* stream);
 
+/* As above with (a) col_scale fp32 [K] multiplied into the columns before the single bf16 rounding — folds the weight of the
+ * LlamaRMSNorm that precedes the linear (multimodal_llama.py:405-406, :443, :462) into it — and (b) block interleaving: packed
+ * 16-row block nb is written at block index nb*nb_stride + nb_offset (gate_proj / up_proj interleaved for the fused SwiGLU
+ * epilogue of mc_gemm_ex_bf16).                                                                                           */
+int mc_compose_weight_ex_bf16(const void* w_rowmajor, int64_t ldw, const void* const* at_list, const void* const* b_list,
+                              const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
+                              int N, int K, const float* col_scale, int nb_stride, int nb_offset, void* stream);
+
 /* ---- linear: out[M,N] = act(alpha * x[M,K] W^T + bias) + beta * residual ----------------------------
  * Replaces F.linear at multimodal_llama.py:122 (LocalLoRA base GEMM), :720 (lm_head), the CLIP / projector
  * linears.  K must be a multiple of 64 (zero padded), x rows 16-byte aligned.  out_f32 != 0 -> fp32 out.  */
 int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* bias, const void* residual, int64_t ldr,
                  void* out, int64_t ldo, int M, int N, int K, int act, int out_f32, float alpha, float beta, void* stream);
+
+/* Extended form.  row_scale: fp32 [M] multiplied into accumulator row m before bias/act (the 1/rms factor of LlamaRMSNorm,
+ * multimodal_llama.py:405-406, when the norm weight has been folded into W by mc_compose_weight_ex_bf16).
+ * swiglu: the packed weight interleaves gate_proj / up_proj per 16-row block (block 2j = gate rows 16j.., block 2j+1 = up rows
+ * 16j..); out is [M, N/2] bf16 = silu(gate) * up (LocalLoraMLP.forward, multimodal_llama.py:381-388).
+ * split_k > 1 (M <= 64 only): K is split over workgroups; slice s stores its fp32 partial sums (x row_scale x alpha) in slab s
+ * of out = fp32 [split_k][M][ldo]; mc_residual_rms_bf16 adds the slabs in order into the hidden state (no atomics).      */
+typedef struct mc_gemm_args {
+    const void* x; int64_t ldx; const void* w_packed; const void* bias; const void* residual; int64_t ldr;
+    void* out; int64_t ldo; int M, N, K; int act; int out_f32; float alpha, beta;
+    const float* row_scale; int swiglu; int split_k;
+} mc_gemm_args;
+int mc_gemm_ex_bf16(const mc_gemm_args* args, void* stream);
 
 /* live HIP-event timing of the large-M GEMM kernel on its launch stream (bench.py roofline) */
 int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgroup computes tile (0,0)) */
@@ -60,6 +81,12 @@ int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launche
 int mc_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* out, int64_t ldo, int M, int D, float eps, void* stream);
 int mc_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, void* out, int64_t ldo, int M, int D,
                       float eps, void* stream);
+/* RMSNorm's per-row factor only (its weight is folded into the next linear): row_scale[m] = rsqrt(mean(x[m]^2) + eps)        */
+int mc_rms_scale_bf16(const void* x, int64_t ldx, float* row_scale, int M, int D, float eps, void* stream);
+/* h[m] = bf16(h[m] + sum_s part[s][m]); row_scale[m] = rsqrt(mean(h[m]^2) + eps) (may be NULL): residual add of the decoder
+ * layer (multimodal_llama.py:447, :466) over the fp32 split-K slabs [n_slabs][M][ldp] of mc_gemm_ex_bf16, plus the next norm's factor */
+int mc_residual_rms_bf16(void* h, int64_t ldh, const float* part, int64_t ldp, int n_slabs, float* row_scale, int M, int D,
+                         float eps, void* stream);
 
 /* ---- RoPE + KV-cache append (multimodal_llama.py:281-289; apply_rotary_pos_emb of transformers 4.31) ----
  * qkv rows are in routed order; row_b / row_pos / row_t give batch entry, absolute position and query index. */
@@ -122,11 +149,13 @@ typedef struct mc_llm_config {
 
 int mc_llm_create(const mc_llm_config* cfg, void** handle);
 int mc_llm_destroy(void* handle);
-/* layer_w[(layer*n_adapters + adapter)*4 + {0:qkv,1:o,2:gate_up,3:down}] = packed weights (fused q|k|v rows, gate|up rows);
- * cos/sin tables [max_pos, head_dim/2] fp32 (LlamaRotaryEmbedding of transformers 4.31, computed in fp32).        */
-int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* const* in_norms, const void* const* post_norms,
-                       const void* final_norm, const void* lm_head_packed, const void* embed_table, const float* cos_table,
-                       const float* sin_table);
+/* layer_w[(layer*n_adapters + adapter)*4 + {0:qkv,1:o,2:gate_up,3:down}] = packed weights composed by
+ * mc_compose_weight_ex_bf16: q|k|v rows fused with input_layernorm's weight folded into the columns; gate|up rows interleaved
+ * per 16-row block (gate even, up odd) with post_attention_layernorm's weight folded in; o_proj / down_proj plain.
+ * final_norm: bf16 [hidden] (model.norm, applied unfolded before lm_head); cos/sin tables [max_pos, head_dim/2] fp32
+ * (LlamaRotaryEmbedding of transformers 4.31, computed in fp32).                                                        */
+int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* final_norm, const void* lm_head_packed,
+                       const void* embed_table, const float* cos_table, const float* sin_table);
 int mc_llm_set_option(void* handle, const char* name, int value);        /* "use_graph" */
 int mc_llm_workspace_bytes(void* handle, int M, int B, int Lq, int64_t* bytes);
 /* Prefill over M rows in routed order.  group_start / group_adapter are HOST arrays (n_groups+1 / n_groups); the other

@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -24,6 +24,9 @@ _SIGS = {
     "mc_unpack_weight_bf16": [c_p, c_p, c_i, c_i, c_p],
     "mc_compose_weight_bf16": [c_p, c_l, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_f), c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p],
     "mc_gemm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
+    "mc_compose_weight_ex_bf16": [c_p, c_l, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_f), c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_i, c_p],
+    "mc_rms_scale_bf16": [c_p, c_l, c_p, c_i, c_i, c_f, c_p],
+    "mc_residual_rms_bf16": [c_p, c_l, c_p, c_l, c_i, c_p, c_i, c_i, c_f, c_p],
     "mc_gemm_profile_enable": [c_i],
     "mc_gemm_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)],
     "mc_rmsnorm_bf16": [c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
@@ -44,6 +47,13 @@ _SIGS = {
 }
 
 
+class GemmArgsC(C.Structure):
+    """struct mc_gemm_args (include/mc_hip.h)."""
+    _fields_ = [("x", c_p), ("ldx", c_l), ("w_packed", c_p), ("bias", c_p), ("residual", c_p), ("ldr", c_l), ("out", c_p), ("ldo", c_l),
+                ("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i), ("out_f32", c_i), ("alpha", c_f), ("beta", c_f),
+                ("row_scale", c_p), ("swiglu", c_i), ("split_k", c_i)]
+
+
 class LlmConfigC(C.Structure):
     """struct mc_llm_config (include/mc_hip.h)."""
     _fields_ = [(n, C.c_int) for n in ("hidden", "inter", "n_layers", "n_heads", "n_kv_heads", "head_dim", "vocab", "n_adapters",
@@ -51,6 +61,7 @@ class LlmConfigC(C.Structure):
 
 
 _SIGS.update({
+    "mc_gemm_ex_bf16": [C.POINTER(GemmArgsC), c_p],
     "mc_add_rows_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_p],
     "mc_zero_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_im2col_ex_bf16": [c_p, c_l, c_l, c_l, c_l, c_p] + [c_i] * 15 + [c_p],
@@ -65,7 +76,7 @@ _SIGS.update({
     "mc_argmax_step_f32": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_llm_create": [C.POINTER(LlmConfigC), C.POINTER(c_p)],
     "mc_llm_destroy": [c_p],
-    "mc_llm_set_weights": [c_p, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_p), c_p, c_p, c_p, c_p, c_p],
+    "mc_llm_set_weights": [c_p, C.POINTER(c_p), c_p, c_p, c_p, c_p, c_p],
     "mc_llm_set_option": [c_p, C.c_char_p, c_i],
     "mc_llm_workspace_bytes": [c_p, c_i, c_i, c_i, C.POINTER(c_l)],
     "mc_llm_prefill": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],

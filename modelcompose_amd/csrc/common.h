@@ -14,8 +14,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define MC_WAVE 64
 
-// activation codes shared with include/mc_hip.h
-enum { MC_ACT_NONE = 0, MC_ACT_GELU = 1, MC_ACT_QUICK_GELU = 2, MC_ACT_SILU = 3, MC_ACT_RELU = 4 };
+#include "../../include/mc_hip.h"   // activation codes, argument blocks
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }

@@ -23,6 +23,8 @@ struct ComposeParams {
     bf16_t* out_packed;                      // [ceil16(N)/16][Kp/32][64][8]
     bf16_t* out_rowmajor; int64_t ldo;       // optional row-major copy (debug / parity), may be null
     int N, K, Kp;
+    const float* col_scale;                  // [K] fp32 or null: W'[n][k] *= col_scale[k] before the single bf16 rounding
+    int nb_stride, nb_offset;                // packed 16-row block nb is written at block index nb*nb_stride + nb_offset
 };
 
 // workgroup = 4 waves; tile = 32 rows (n) x 256 cols (k); wave w owns cols [64w, 64w+64)
@@ -94,12 +96,17 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeParams p) {
                         if (k + j < p.K) r4[j] += (float)p.w[(int64_t)n * p.ldw + k + j];
                 }
             }
+            if (p.col_scale) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k + j < p.K) r4[j] *= p.col_scale[k + j];
+            }
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (inb && k + j < p.K) ? (bf16_t)r4[j] : (bf16_t)0.0f;
             const int kb = k >> 5;
             const int q = (k & 31) >> 3;
-            bf16_t* dst = p.out_packed + ((int64_t)nb * kblocks + kb) * 512 + ((q << 4) | (n & 15)) * 8 + (k & 7);
+            bf16_t* dst = p.out_packed + ((int64_t)(nb * p.nb_stride + p.nb_offset) * kblocks + kb) * 512 + ((q << 4) | (n & 15)) * 8 + (k & 7);
             *(bf16x4*)dst = o;
             if (p.out_rowmajor && inb) {
 #pragma unroll
@@ -110,13 +117,15 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeParams p) {
     }
 }
 
-extern "C" int mc_compose_weight_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,
-                                      const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor,
-                                      int64_t ldo, int N, int K, void* stream) {
+extern "C" int mc_compose_weight_ex_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,
+                                         const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor,
+                                         int64_t ldo, int N, int K, const float* col_scale, int nb_stride, int nb_offset,
+                                         void* stream) {
     MC_CHECK_ARG(out_packed && N > 0 && K > 0, "mc_compose_weight_bf16: bad arguments");
     MC_CHECK_ARG(n_terms >= 0 && n_terms <= MC_MAX_TERMS, "mc_compose_weight_bf16: at most %d terms (got %d)", MC_MAX_TERMS, n_terms);
     MC_CHECK_ARG(n_terms == 0 || (r > 0 && r % 32 == 0), "mc_compose_weight_bf16: rank %d must be a multiple of 32 (pad A^T / B)", r);
     MC_CHECK_ARG(!w || ldw % 4 == 0, "mc_compose_weight_bf16: ldw must be a multiple of 4");
+    MC_CHECK_ARG(nb_stride >= 1 && nb_offset >= 0 && nb_offset < nb_stride, "mc_compose_weight_ex_bf16: bad block interleave %d/%d", nb_offset, nb_stride);
     ComposeParams p;
     p.w = (const bf16_t*)w; p.ldw = ldw;
     for (int i = 0; i < n_terms; ++i) {
@@ -126,8 +135,16 @@ extern "C" int mc_compose_weight_bf16(const void* w, int64_t ldw, const void* co
     p.n_terms = n_terms; p.r = r;
     p.out_packed = (bf16_t*)out_packed; p.out_rowmajor = (bf16_t*)out_rowmajor; p.ldo = ldo;
     p.N = N; p.K = K; p.Kp = (K + 63) / 64 * 64;
+    p.col_scale = col_scale; p.nb_stride = nb_stride; p.nb_offset = nb_offset;
     dim3 grid((p.Kp + 255) / 256, (N + 31) / 32);
     compose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
     MC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mc_compose_weight_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,
+                                      const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor,
+                                      int64_t ldo, int N, int K, void* stream) {
+    return mc_compose_weight_ex_bf16(w, ldw, at_list, b_list, scales, n_terms, r, out_packed, out_rowmajor, ldo, N, K, nullptr, 1, 0,
+                                     stream);
 }

@@ -10,8 +10,9 @@
 // Blocks are ordered nb-major, kb-minor.  One 16-byte-per-lane wave load (1 KiB, fully coalesced)
 // is then exactly the A operand of v_mfma_f32_16x16x32_bf16, for both kernels below:
 //   * gemm_tile_kernel   (M > 64, MFMA-bound): 128x128x64 tiles, LDS-DMA (global_load_lds) double buffer.
-//   * gemm_skinny_kernel (M <= 64, HBM-bound): weights streamed straight to VGPRs, K split over
-//     the 8 waves of a workgroup, x fragments from L2, one LDS reduction.
+//   * gemm_tile256_kernel (enough 256x256 tiles to fill the chip): two wave groups alternating LDS loads with MFMA work.
+//   * gemm_skinny2_kernel (M <= 64, HBM-bound): weights streamed straight to VGPRs, K split over
+//     the 8 waves of a workgroup, x fragments from L2 reused against R weight block-rows, one LDS reduction.
 // MFMA roles: A = weight fragment (rows = n), B = activation fragment (cols = m) so that a lane
 // ends up with 4 consecutive n for one token m  ->  8-byte packed bf16 stores.
 #include "common.h"
@@ -60,10 +61,14 @@ struct Epilogue {
     int out_f32;
     float alpha;             // scale applied to the accumulator before bias
     float beta;              // scale applied to the residual
+    const float* row_scale;  // [M] fp32 or null: accumulator row m is multiplied by row_scale[m] (RMSNorm 1/rms with the
+                             // norm weight folded into W at compose time: LlamaRMSNorm, multimodal_llama.py:405-406)
+    int swiglu;              // 16-row weight blocks alternate gate/up: out[m][16*(nb/2) + c] = silu(gate) * up (LocalLoraMLP :381-388)
 };
 
 __device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n, f32x4 v) {
-    float r[4] = {v[0] * e.alpha, v[1] * e.alpha, v[2] * e.alpha, v[3] * e.alpha};
+    const float a = e.row_scale ? e.alpha * e.row_scale[m] : e.alpha;
+    float r[4] = {v[0] * a, v[1] * a, v[2] * a, v[3] * a};
     if (e.bias) {
         bf16x4 b = *(const bf16x4*)(e.bias + n);
 #pragma unroll
@@ -85,6 +90,20 @@ __device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n,
         bf16x4 o = {(bf16_t)r[0], (bf16_t)r[1], (bf16_t)r[2], (bf16_t)r[3]};
         *(bf16x4*)((bf16_t*)e.out + (int64_t)m * e.ldo + n) = o;
     }
+}
+
+// gate / up accumulators of the same 4 output columns (n_out = column in the [M, N/2] result)
+__device__ __forceinline__ void epilogue_store4_swiglu(const Epilogue& e, int m, int n_out, f32x4 g, f32x4 u) {
+    const float a = e.row_scale ? e.alpha * e.row_scale[m] : e.alpha;
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // gate and up are rounded to the storage dtype as the unfused path stores them (the reference's projections return
+        // the model dtype, :381-388); act(gate) * up is evaluated in fp32 and rounded once
+        const float gg = (float)(bf16_t)(g[i] * a), uu = (float)(bf16_t)(u[i] * a);
+        o[i] = (bf16_t)(gg / (1.0f + __expf(-gg)) * uu);
+    }
+    *(bf16x4*)((bf16_t*)e.out + (int64_t)m * e.ldo + n_out) = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -222,6 +241,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const bf16_t* __restr
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wave_m * 64 + j * 16 + c16;
         if (m >= M) continue;
+        if (ep.swiglu) {
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const int n = n0 + wave_n * 64 + i * 16;
+                if (n + 16 < N) epilogue_store4_swiglu(ep, m, (n >> 1) + q4 * 4, acc[i][j], acc[i + 1][j]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wave_n * 64 + i * 16 + q4 * 4;
@@ -253,83 +280,139 @@ __device__ __forceinline__ void g2_waitvm() {
 }
 
 struct G2Src {
-    const bf16_t* w[2][2];   // [nh][e]  source of this lane's 16 bytes for K-tile 0
-    const bf16_t* x[2][2];   // [mh][e]
+    const char* wbase;       // wave-uniform bases (SGPRs); the K-tile offset is added to them on the scalar unit
+    const char* xbase;
+    uint32_t w[2][2];        // [nh][e]  byte offset of this lane's 16 bytes in K-tile 0
+    uint32_t x[2][2];        // [mh][e]
 };
 
 // MODE 0: steady state (t <= nt-3), 1: t == nt-2, 2: t == nt-1
-template <int MODE>
+// ABL: timing-only ablations (bit 0 no LDS-DMA, bit 1 no fragment reads, bit 2 DMA always from K-tiles 0/1)
+// GL : where a phase's two LDS-DMA instructions are issued: 0 = in the load half, 1 = inside the MFMA half (after MFMA 4 and 12),
+//      2 = one in each half
+//      3 = as 0, plus X0 of the NEXT K-tile is read during P4's (otherwise empty) load half: fragment reads per phase 8,4,8,4
+template <int MODE, int ABL, int GL>
 __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, int xoff, const G2Src& src,
-                                        f32x4 (&acc)[2][4][2][2]) {
+                                        f32x4 (&acc)[2][4][2][2], bf16x8 (&wf)[4][2], bf16x8 (&xf)[2][2][2], bf16x8 (&xn)[2][2]) {
+    constexpr bool BAL = GL == 3;
     char* cur = smem + (t & 1) * G2_STAGE;
     char* nxt = smem + ((t + 1) & 1) * G2_STAGE;
-    bf16x8 wf[4][2], xf[2][2][2];
-    auto stage_w = [&](char* buf, int nh, int tt) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(src.w[nh][e] + (int64_t)tt * 1024),
-                                             (lds_void*)(buf + nh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
-    };
-    auto stage_x = [&](char* buf, int mh, int tt) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(src.x[mh][e] + (int64_t)tt * 64),
-                                             (lds_void*)(buf + G2_XOFF + mh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
+    // piece ids: 0 = X1(t+1) -> nxt, 1 = W1(t+1) -> nxt, 2 = W0(t+2) -> cur, 3 = X0(t+2) -> cur
+    auto stage1 = [&](int piece, int e) {
+        if (ABL & 1) return;
+        const bool on = (piece < 2) ? (MODE <= 1) : (MODE == 0);
+        if (!on) return;
+        int tt = (piece < 2) ? t + 1 : t + 2;
+        if (ABL & 4) tt &= 1;
+        char* buf = (piece < 2) ? nxt : cur;
+        const bool is_w = (piece == 1 || piece == 2);
+        const int h = (piece < 2) ? 1 : 0;
+        if (is_w)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src.wbase + (int64_t)tt * 2048 + src.w[h][e]),
+                                             (lds_void*)(buf + h * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src.xbase + (int64_t)tt * 128 + src.x[h][e]),
+                                             (lds_void*)(buf + G2_XOFF + h * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
     };
     auto read_w = [&](int nh) {
+        if ((ABL & 2) && t > 0) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) wf[i][kk] = *(const bf16x8*)(cur + nh * 16384 + woff + i * 2048 + kk * 1024);
     };
     auto read_x = [&](int mh) {
+        if ((ABL & 2) && t > 0) return;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
                 xf[mh][jj][kk] = *(const bf16x8*)(cur + G2_XOFF + mh * 16384 + ((xoff + jj * 2048) ^ (kk * 64)));
     };
-    auto mma = [&](int nh, int mh) {
+    // load half: DMA issue (GL 0: both, GL 2: the first) and the counted wait for the pieces the NEXT phase reads.
+    // steady-state count = 2 x (pieces issued after the awaited one, before this point): 4 pieces (GL 0), 3 (GL 1), 3.5 (GL 2)
+    auto load_tail = [&](int piece, int wait_steady, int wait_m1, int wait_m2) {
+        if (GL == 0 || GL == 3) { stage1(piece, 0); stage1(piece, 1); }
+        if (GL == 2) stage1(piece, 0);
+        if (ABL & 1) return;
+        const int w = MODE == 0 ? wait_steady : (MODE == 1 ? wait_m1 : wait_m2);
+        switch (w) {
+            case 0: g2_waitvm<0>(); break;
+            case 1: g2_waitvm<1>(); break;
+            case 2: g2_waitvm<2>(); break;
+            case 3: g2_waitvm<3>(); break;
+            case 4: g2_waitvm<4>(); break;
+            case 5: g2_waitvm<5>(); break;
+            case 6: g2_waitvm<6>(); break;
+            case 7: g2_waitvm<7>(); break;
+            case 8: g2_waitvm<8>(); break;
+            default: break;        // -1: no wait
+        }
+    };
+    auto mma = [&](int nh, int mh, int piece) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
                     acc[nh][i][mh][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][kk], xf[mh][jj][kk], acc[nh][i][mh][jj], 0, 0, 0);
+                if (GL == 1 && i == 1) { __builtin_amdgcn_sched_barrier(0); stage1(piece, kk); __builtin_amdgcn_sched_barrier(0); }
+                if (GL == 2 && i == 1 && kk == 1) { __builtin_amdgcn_sched_barrier(0); stage1(piece, 1); __builtin_amdgcn_sched_barrier(0); }
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
-    // P1 (0,0)
-    read_x(0);
+    // wait counts: {steady, t == nt-2, t == nt-1}; derivation in DESIGN.md (pieces are issued and retired in one fixed order)
+    constexpr int S = (GL == 0 || GL == 3) ? 8 : (GL == 1 ? 6 : 7);
+    // P1 (0,0): reads W0,X0; stages X1(t+1); waits for X1(t)
+    if (BAL) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) xf[0][jj][kk] = xn[jj][kk];
+    } else {
+        read_x(0);
+    }
     read_w(0);
-    if (MODE <= 1) stage_x(nxt, 1, t + 1);
-    if (MODE <= 1) g2_waitvm<8>(); else g2_waitvm<2>();
-    mma(0, 0);
-    // P2 (0,1)
+    load_tail(0, S, S, 2);
+    mma(0, 0, 0);
+    // P2 (0,1): reads X1; stages W1(t+1); waits for W1(t)
     read_x(1);
-    if (MODE <= 1) stage_w(nxt, 1, t + 1);
-    if (MODE <= 1) g2_waitvm<8>(); else g2_waitvm<0>();
-    mma(0, 1);
-    // P3 (1,1)
+    load_tail(1, S, S, 0);
+    mma(0, 1, 1);
+    // P3 (1,1): reads W1; stages W0(t+2); nothing to wait for
     read_w(1);
-    if (MODE == 0) stage_w(cur, 0, t + 2);
-    mma(1, 1);
-    // P4 (1,0)
-    if (MODE == 0) stage_x(cur, 0, t + 2);
-    if (MODE == 0) g2_waitvm<8>(); else if (MODE == 1) g2_waitvm<4>();
-    mma(1, 0);
+    if (BAL) load_tail(2, 6, 4, -1);      // X0(t+1) (and the older W0(t+1)) must have landed before P4 reads it
+    else load_tail(2, -1, -1, -1);
+    mma(1, 1, 2);
+    // P4 (1,0): stages X0(t+2); waits for W0(t+1), X0(t+1)
+    if (BAL) {
+        if (MODE <= 1 && !((ABL & 2) && t > 0)) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    xn[jj][kk] = *(const bf16x8*)(nxt + G2_XOFF + ((xoff + jj * 2048) ^ (kk * 64)));
+        }
+        load_tail(3, -1, -1, -1);
+    } else {
+        load_tail(3, S, 4, -1);
+    }
+    mma(1, 0, 3);
 }
 
+template <int ABL, int GL>
 __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx,
                                                               const bf16_t* __restrict__ wp, int M, int N, int K,
                                                               Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA destinations stay on the scalar unit
     const int wave_n = wave >> 2, wave_m = wave & 3;
     const int c16 = lane & 15, q4 = lane >> 4;
 
@@ -354,6 +437,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
     const int nt = K >> 6;
 
     G2Src src;
+    src.wbase = (const char*)wp;
+    src.xbase = (const char*)x;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -362,12 +447,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
             // W: block c of piece h  ->  (wn, i, kk)
             const int wn = c >> 3, i = (c >> 1) & 3, kk = c & 1;
             const int nb = min((n0 >> 4) + wn * 8 + h * 4 + i, nblocks - 1);
-            src.w[h][e] = wp + ((int64_t)nb * kblocks + kk) * 512 + lane * 8;
+            src.w[h][e] = (uint32_t)((((int64_t)nb * kblocks + kk) * 512 + lane * 8) * 2);
             // X: block c of piece h  ->  8 rows of wave_m group wm
             const int wm = c >> 2, r8 = c & 3;
             const int row = wm * 64 + h * 32 + r8 * 8 + (lane >> 3);
             const int gch = (lane & 7) ^ (lane >> 3);
-            src.x[h][e] = x + (int64_t)min(m0 + row, M - 1) * ldx + gch * 8;
+            src.x[h][e] = (uint32_t)(((int64_t)min(m0 + row, M - 1) * ldx + gch * 8) * 2);
         }
     const int woff = wave_n * 8192 + lane * 16;
     const int xoff = wave_m * 4096 + c16 * 128 + ((q4 ^ (c16 & 7)) * 16);
@@ -387,24 +472,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
         auto pw = [&](int buf, int nh, int tt) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(src.w[nh][e] + (int64_t)tt * 1024),
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src.wbase + (int64_t)tt * 2048 + src.w[nh][e]),
                                                  (lds_void*)(smem + buf * G2_STAGE + nh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
         };
         auto px = [&](int buf, int mh, int tt) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(src.x[mh][e] + (int64_t)tt * 64),
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src.xbase + (int64_t)tt * 128 + src.x[mh][e]),
                                                  (lds_void*)(smem + buf * G2_STAGE + G2_XOFF + mh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
         };
         pw(0, 0, 0); px(0, 0, 0); px(0, 1, 0); pw(0, 1, 0); pw(1, 0, 1); px(1, 0, 1);
         g2_waitvm<8>();
         __builtin_amdgcn_s_barrier();
-        if (wave_n == 1) __builtin_amdgcn_s_barrier();
     }
+    bf16x8 wf[4][2], xf[2][2][2], xn[2][2];
+    if (GL == 3) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) xn[jj][kk] = *(const bf16x8*)(smem + G2_XOFF + ((xoff + jj * 2048) ^ (kk * 64)));
+    }
+    if (wave_n == 1) __builtin_amdgcn_s_barrier();      // second group runs one barrier behind
     int t = 0;
-    for (; t < nt - 2; ++t) g2_tile<0>(smem, t, wave, woff, xoff, src, acc);
-    g2_tile<1>(smem, t, wave, woff, xoff, src, acc);
-    g2_tile<2>(smem, t + 1, wave, woff, xoff, src, acc);
+    for (; t < nt - 2; ++t) g2_tile<0, ABL, GL>(smem, t, wave, woff, xoff, src, acc, wf, xf, xn);
+    g2_tile<1, ABL, GL>(smem, t, wave, woff, xoff, src, acc, wf, xf, xn);
+    g2_tile<2, ABL, GL>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf, xn);
     if (wave_n == 0) __builtin_amdgcn_s_barrier();
 
 #pragma unroll
@@ -413,6 +505,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
         for (int jj = 0; jj < 2; ++jj) {
             const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
             if (m >= M) continue;
+            if (ep.swiglu) {
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        const int n = n0 + wave_n * 128 + nh * 64 + i * 16;
+                        if (n + 16 < N) epilogue_store4_swiglu(ep, m, (n >> 1) + q4 * 4, acc[nh][i][mh][jj], acc[nh][i + 1][mh][jj]);
+                    }
+                continue;
+            }
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -423,77 +525,122 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
         }
 }
 
-// ------------------------------------------------------------------------------------------
-// skinny kernel: M <= 16*MB, one 16-row weight block-row per workgroup, K split over 8 waves
-// ------------------------------------------------------------------------------------------
 #define SK_WAVES 8
-#define SK_UNROLL 8
 
-template <int MB>
-__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ x, int64_t ldx,
-                                                                    const bf16_t* __restrict__ wp, int M, int N, int K,
-                                                                    Epilogue ep) {
-    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][MB][64][4];
+// ------------------------------------------------------------------------------------------
+// skinny kernel (M <= 64, HBM-bound): R weight block-rows per workgroup, K split over the 8 waves, optional K split over workgroups
+// ------------------------------------------------------------------------------------------
+// The activation fragment of a k-step is loaded once and used against R weight fragments, so the L2->CU traffic for x
+// drops to 1/R of the weight stream (with R = 1 it equals the weight bytes at M = 16 and caps the kernel at ~4.4 TB/s).
+// Shapes with few block-rows (N = 4096: 256) keep all CUs streaming by splitting K over `gridDim.y` workgroups; slice s
+// stores its fp32 partial sums (whole 256-byte row segments per wave instruction) in slab s of out[split_k][M][ldo], and
+// the next kernel (mc_residual_rms_bf16) adds the slabs in a fixed order into the hidden state: deterministic, no atomics.
+template <int MB, int R>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                                     const bf16_t* __restrict__ wp, int M, int N, int K,
+                                                                     Epilogue ep, int partial) {
+    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][R][MB][64][4];
+    constexpr int U = (R * MB >= 8) ? 1 : ((R * MB >= 4) ? 2 : (R * MB >= 2 ? 4 : 8));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb = blockIdx.x;
-    const int kblocks = K >> 5;
-    // contiguous K slice per wave
-    const int per = (kblocks + SK_WAVES - 1) / SK_WAVES;
-    const int kb0 = wave * per;
-    const int kb1 = min(kb0 + per, kblocks);
+    const int nb0 = blockIdx.x * R;
+    const int kblocks = K >> 5, nblocks = (N + 15) >> 4;
+    const int per_slice = (kblocks + gridDim.y - 1) / gridDim.y;
+    const int ks0 = blockIdx.y * per_slice, ks1 = min(ks0 + per_slice, kblocks);
+    const int per = (ks1 - ks0 + SK_WAVES - 1) / SK_WAVES;
+    const int kb0 = min(ks0 + wave * per, ks1);
+    const int kb1 = min(kb0 + per, ks1);
     const int c16 = lane & 15, q4 = lane >> 4;
 
-    const bf16_t* wptr = wp + ((int64_t)nb * kblocks + kb0) * 512 + lane * 8;
+    const bf16_t* wptr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wptr[r] = wp + ((int64_t)min(nb0 + r, nblocks - 1) * kblocks + kb0) * 512 + lane * 8;
     const bf16_t* xptr[MB];
 #pragma unroll
-    for (int b = 0; b < MB; ++b) {
-        const int m = min(b * 16 + c16, M - 1);
-        xptr[b] = x + (int64_t)m * ldx + kb0 * 32 + q4 * 8;
-    }
-    f32x4 acc[MB];
+    for (int b = 0; b < MB; ++b) xptr[b] = x + (int64_t)min(b * 16 + c16, M - 1) * ldx + kb0 * 32 + q4 * 8;
+    f32x4 acc[R][MB];
 #pragma unroll
-    for (int b = 0; b < MB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[r][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int kb = kb0;
-    for (; kb + SK_UNROLL <= kb1; kb += SK_UNROLL) {
-        bf16x8 wf[SK_UNROLL];
+    for (; kb + U <= kb1; kb += U) {
+        bf16x8 wf[U][R], xf[U][MB];
 #pragma unroll
-        for (int u = 0; u < SK_UNROLL; ++u) wf[u] = __builtin_nontemporal_load((const bf16x8*)(wptr + u * 512));
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int u = 0; u < SK_UNROLL; ++u) {
+            for (int r = 0; r < R; ++r) wf[u][r] = __builtin_nontemporal_load((const bf16x8*)(wptr[r] + u * 512));
 #pragma unroll
-            for (int b = 0; b < MB; ++b) {
-                bf16x8 xf = *(const bf16x8*)(xptr[b] + u * 32);
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc[b], 0, 0, 0);
-            }
-        }
-        wptr += SK_UNROLL * 512;
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int b = 0; b < MB; ++b) xptr[b] += SK_UNROLL * 32;
+            for (int b = 0; b < MB; ++b) xf[u][b] = *(const bf16x8*)(xptr[b] + u * 32);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int b = 0; b < MB; ++b) acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][r], xf[u][b], acc[r][b], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) wptr[r] += U * 512;
+#pragma unroll
+        for (int b = 0; b < MB; ++b) xptr[b] += U * 32;
     }
     for (; kb < kb1; ++kb) {
-        bf16x8 wf = __builtin_nontemporal_load((const bf16x8*)wptr);
+        bf16x8 xf[MB];
 #pragma unroll
-        for (int b = 0; b < MB; ++b) {
-            bf16x8 xf = *(const bf16x8*)(xptr[b]);
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[b], 0, 0, 0);
-            xptr[b] += 32;
+        for (int b = 0; b < MB; ++b) { xf[b] = *(const bf16x8*)(xptr[b]); xptr[b] += 32; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bf16x8 wf = __builtin_nontemporal_load((const bf16x8*)wptr[r]);
+            wptr[r] += 512;
+#pragma unroll
+            for (int b = 0; b < MB; ++b) acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[b], acc[r][b], 0, 0, 0);
         }
-        wptr += 512;
     }
 #pragma unroll
-    for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave][b][lane][0] = acc[b];
-    __syncthreads();
-    // waves 0..MB-1 each reduce + store one m-block
-    if (wave < MB) {
-        f32x4 s = *(f32x4*)&red[0][wave][lane][0];
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int w = 1; w < SK_WAVES; ++w) {
-            f32x4 t = *(f32x4*)&red[w][wave][lane][0];
-            s += t;
+        for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave][r][b][lane][0] = acc[r][b];
+    __syncthreads();
+    if (partial) {
+        // element (m, nl) of the [16*MB, 16*R] tile lives at red[w][nl>>4][m>>4][lane = (c>>2)<<4 | (m&15)][c&3], c = nl & 15;
+        // consecutive threads take consecutive columns of one row: contiguous 256-byte segments
+        const int cols = R * 16;
+        for (int e = tid; e < MB * 16 * cols; e += SK_WAVES * 64) {
+            const int m = e / cols, nl = e - m * cols;
+            const int n = nb0 * 16 + nl;
+            if (m >= M || n >= N) continue;
+            const int c = nl & 15;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; ++w) v += red[w][nl >> 4][m >> 4][((c >> 2) << 4) | (m & 15)][c & 3];
+            const float a = ep.row_scale ? ep.alpha * ep.row_scale[m] : ep.alpha;
+            ((float*)ep.out)[((int64_t)blockIdx.y * M + m) * ep.ldo + n] = v * a;
         }
-        const int m = wave * 16 + c16;
-        const int n = nb * 16 + q4 * 4;
+        return;
+    }
+    if (ep.swiglu) {
+        for (int p = wave; p < (R / 2) * MB; p += SK_WAVES) {
+            const int rp = p / MB, b = p - rp * MB;
+            f32x4 g = *(f32x4*)&red[0][2 * rp][b][lane][0], u = *(f32x4*)&red[0][2 * rp + 1][b][lane][0];
+#pragma unroll
+            for (int w = 1; w < SK_WAVES; ++w) {
+                g += *(f32x4*)&red[w][2 * rp][b][lane][0];
+                u += *(f32x4*)&red[w][2 * rp + 1][b][lane][0];
+            }
+            const int m = b * 16 + c16;
+            const int nb = nb0 + 2 * rp;
+            if (m < M && (nb + 1) * 16 < N) epilogue_store4_swiglu(ep, m, (nb >> 1) * 16 + q4 * 4, g, u);
+        }
+        return;
+    }
+    for (int p = wave; p < R * MB; p += SK_WAVES) {
+        const int r = p / MB, b = p - r * MB;
+        f32x4 s = *(f32x4*)&red[0][r][b][lane][0];
+#pragma unroll
+        for (int w = 1; w < SK_WAVES; ++w) s += *(f32x4*)&red[w][r][b][lane][0];
+        const int m = b * 16 + c16;
+        const int n = (nb0 + r) * 16 + q4 * 4;
         if (m < M && n < N) epilogue_store4(ep, m, n, s);
     }
 }
@@ -576,33 +723,90 @@ extern "C" int mc_unpack_weight_bf16(const void* packed, void* w, int N, int K, 
 // x: [M, K] bf16 row-major with leading dimension ldx (elements); K here is the PADDED K (multiple of 64,
 // the columns K_real..K-1 of x must be zero or the weight pad rows zero — packed weights are zero padded).
 // N may be any positive value; packed weight has ceil16(N) rows.
-extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* bias, const void* residual,
-                            int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int act, int out_f32, float alpha,
-                            float beta, void* stream) {
-    MC_CHECK_ARG(x && w_packed && out, "mc_gemm_bf16: null pointer");
+template <int MB, int R>
+static void launch_skinny2_r(dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K,
+                             const Epilogue& ep, int partial) {
+    if constexpr (R * MB <= 8) gemm_skinny2_kernel<MB, R><<<grid, SK_WAVES * 64, 0, s>>>(x, ldx, w, M, N, K, ep, partial);
+}
+
+template <int MB>
+static void launch_skinny2(int R, dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K,
+                           const Epilogue& ep, int partial) {
+    switch (R) {
+        case 1: launch_skinny2_r<MB, 1>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
+        case 2: launch_skinny2_r<MB, 2>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
+        case 3: launch_skinny2_r<MB, 3>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
+        case 4: launch_skinny2_r<MB, 4>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
+        case 6: launch_skinny2_r<MB, 6>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
+        default: launch_skinny2_r<MB, 8>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
+    }
+}
+
+// block-rows per workgroup for the skinny kernel: the largest R in {8,6,4,3,2,1} (R * MB <= 8, even for swiglu) whose grid
+// still covers >= ~85 % of the CUs in its last round
+static int skinny_rows(int nblocks, int mb, int split_k, bool swiglu) {
+    static const int cand[6] = {8, 6, 4, 3, 2, 1};
+    int best = swiglu ? 2 : 1;
+    double best_cost = 1e30;
+    for (int i = 0; i < 6; ++i) {
+        const int R = cand[i];
+        if (R * mb > 8) continue;
+        if (swiglu && (R & 1)) continue;
+        const int64_t wgs = (int64_t)((nblocks + R - 1) / R) * split_k;
+        const int64_t rounds = (wgs + 255) / 256;
+        // time ~ rounds * (weight bytes + x bytes per workgroup) ;  x bytes relative to weights = mb*16 / (16*R)
+        const double cost = (double)rounds * R * (1.0 + (double)mb / R);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = R; }
+    }
+    return best;
+}
+
+extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
+    MC_CHECK_ARG(a, "mc_gemm_ex_bf16: null argument block");
+    const void* x = a->x; const int64_t ldx = a->ldx; const void* w_packed = a->w_packed;
+    const int M = a->M, N = a->N, K = a->K;
+    MC_CHECK_ARG(x && w_packed && a->out, "mc_gemm_bf16: null pointer");
     MC_CHECK_ARG(M > 0 && N > 0 && K > 0, "mc_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
     MC_CHECK_ARG(K % 64 == 0, "mc_gemm_bf16: K=%d must be a multiple of 64 (pad activations/weights)", K);
     MC_CHECK_ARG(N % 4 == 0, "mc_gemm_bf16: N=%d must be a multiple of 4", N);
     MC_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "mc_gemm_bf16: x must be 16-byte aligned rows (ldx=%lld)", (long long)ldx);
-    MC_CHECK_ARG(ldo % 4 == 0, "mc_gemm_bf16: ldo=%lld must be a multiple of 4", (long long)ldo);
-    MC_CHECK_ARG(!residual || ldr % 4 == 0, "mc_gemm_bf16: ldr must be a multiple of 4");
-    Epilogue ep{(const bf16_t*)bias, (const bf16_t*)residual, ldr, out, ldo, act, out_f32, alpha, beta};
+    MC_CHECK_ARG(a->ldo % 4 == 0, "mc_gemm_bf16: ldo=%lld must be a multiple of 4", (long long)a->ldo);
+    MC_CHECK_ARG(!a->residual || a->ldr % 4 == 0, "mc_gemm_bf16: ldr must be a multiple of 4");
+    MC_CHECK_ARG(!a->swiglu || (N % 32 == 0 && !a->bias && !a->residual && !a->out_f32 && a->act == MC_ACT_NONE),
+                 "mc_gemm_ex_bf16: swiglu needs N %% 32 == 0 (gate/up interleaved per 16 rows) and a plain bf16 output");
+    const int split_k = a->split_k > 1 ? a->split_k : 1;
+    MC_CHECK_ARG(split_k == 1 || (M <= 64 && a->out_f32 && !a->bias && !a->residual && !a->swiglu && a->act == MC_ACT_NONE),
+                 "mc_gemm_ex_bf16: split_k accumulates raw fp32 partial sums (M <= 64, out_f32, no bias/act/residual)");
+    Epilogue ep{(const bf16_t*)a->bias, (const bf16_t*)a->residual, a->ldr, a->out, a->ldo, a->act, a->out_f32, a->alpha, a->beta,
+                a->row_scale, a->swiglu};
+    void* out = a->out;
+    (void)out;
     hipStream_t s = (hipStream_t)stream;
     if (M <= 64) {
-        const int grid = (N + 15) / 16;
         const int mb = (M + 15) / 16;
+        const int nblocks = (N + 15) / 16;
+        const int R = (g_gemm_dbg & 256) ? (a->swiglu ? 2 : 1) : skinny_rows(nblocks, mb, split_k, a->swiglu != 0);
+        dim3 grid((nblocks + R - 1) / R, split_k);
+        const bf16_t* xb = (const bf16_t*)x; const bf16_t* wb = (const bf16_t*)w_packed;
         switch (mb) {
-            case 1: gemm_skinny_kernel<1><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
-            case 2: gemm_skinny_kernel<2><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
-            case 3: gemm_skinny_kernel<3><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
-            default: gemm_skinny_kernel<4><<<grid, SK_WAVES * 64, 0, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep); break;
+            case 1: launch_skinny2<1>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
+            case 2: launch_skinny2<2>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
+            case 3: launch_skinny2<3>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
+            default: launch_skinny2<4>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
         }
     } else if (use_tile256(M, N, K)) {
         const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
         static bool attr256_set = false;
         const int lds = 2 * G2_STAGE;
         if (!attr256_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr256_set = true;
         }
         ProfRec rec{};
@@ -611,8 +815,19 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
             rec.flops = 2.0 * M * (double)N * K;
             (void)hipEventRecord(rec.a, s);
         }
-        gemm_tile256_kernel<<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep,
-                                                                tiles_m, tiles_n);
+#define G2_LAUNCH(A, G) gemm_tile256_kernel<A, G><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep, tiles_m, tiles_n)
+        // debug word: bits 3-5 timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1;
+        // bits 6-7 DMA placement variant (64 = inside the MFMA half, 128 = one in each half)
+        switch ((g_gemm_dbg >> 3) & 31) {
+            case 1: G2_LAUNCH(1, 0); break;
+            case 2: G2_LAUNCH(2, 0); break;
+            case 3: G2_LAUNCH(3, 0); break;
+            case 4: G2_LAUNCH(4, 0); break;
+            case 8: G2_LAUNCH(0, 1); break;
+            case 16: G2_LAUNCH(0, 2); break;
+            case 24: G2_LAUNCH(0, 3); break;
+            default: G2_LAUNCH(0, 0); break;
+        }
         if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     } else {
         const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
@@ -634,4 +849,14 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
     }
     MC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* bias, const void* residual,
+                            int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int act, int out_f32, float alpha,
+                            float beta, void* stream) {
+    mc_gemm_args a;
+    a.x = x; a.ldx = ldx; a.w_packed = w_packed; a.bias = bias; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
+    a.M = M; a.N = N; a.K = K; a.act = act; a.out_f32 = out_f32; a.alpha = alpha; a.beta = beta;
+    a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1;
+    return mc_gemm_ex_bf16(&a, stream);
 }

@@ -7,8 +7,14 @@
 //   lm_head (:720) + greedy argmax of transformers' greedy_search (model_multimodal_qa_loader.py:94-102)
 // LocalLoRA routing: hidden rows are kept grouped by adapter ("routed order"); every token has exactly one
 // active adapter (multimodal_arch.py:452-453), so each group runs ONE dense GEMM against that adapter's
-// pre-composed weight (mc_compose_weight_bf16) instead of all adapters on all tokens + mask-sum (:262-268).
+// pre-composed weight (mc_compose_weight_ex_bf16) instead of all adapters on all tokens + mask-sum (:262-268).
 // During decode the modal mask is dropped (:435-438): adapter 0 ('default') only.
+// Fusions (results-identical restructuring of MultimodalLlamaDecoderLayer.forward :408-468):
+//   * RMSNorm = (per-row 1/rms) x (per-column weight): the weight is folded into the q|k|v and gate|up columns at compose
+//     time, the 1/rms factor is a GEMM epilogue input (row_scale) -> no normalised copy of the hidden state is written;
+//   * silu(gate) * up is the epilogue of the gate|up GEMM (weights interleaved per 16 rows) -> no [M, 2I] intermediate;
+//   * decode (M <= 64): o_proj / down_proj split K over 4 workgroups per block-row so all CUs stream weights; the residual
+//     add folds their fp32 slabs into the hidden state and produces the next 1/rms in the same kernel.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -22,7 +28,6 @@ namespace {
 struct Llm {
     mc_llm_config cfg;
     std::vector<const void*> layer_w;       // [(layer*n_adapters + adapter)*4 + {qkv,o,gate_up,down}]
-    std::vector<const void*> in_norm, post_norm;
     const void* final_norm = nullptr;
     const void* lm_head = nullptr;
     const void* embed = nullptr;
@@ -38,21 +43,24 @@ struct Llm {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Ws {          // carve-up of the caller-provided workspace
-    char *n, *qkv, *qseq, *attn, *gu, *inter, *xl, *nl, *logits;
+    char *qkv, *qseq, *attn, *inter, *xl, *nl, *logits;
+    float *rs, *part;
     size_t total;
 };
+
+constexpr int kDecodeSplitK = 4;
 
 Ws carve(const mc_llm_config& c, int M, int B, int Lq, char* base) {
     const size_t hd = c.hidden, qkvd = (size_t)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
     Ws w;
-    w.n = take((size_t)M * hd * 2);
     w.qkv = take((size_t)M * qkvd * 2);
     w.qseq = take((size_t)B * Lq * c.n_heads * c.head_dim * 2);
     w.attn = take((size_t)M * hd * 2);
-    w.gu = take((size_t)M * 2 * c.inter * 2);
     w.inter = take((size_t)M * c.inter * 2);
+    w.rs = (float*)take((size_t)M * 4);
+    w.part = (float*)take(M <= 64 ? (size_t)kDecodeSplitK * M * hd * 4 : 0);
     w.xl = take((size_t)B * hd * 2);
     w.nl = take((size_t)B * hd * 2);
     w.logits = take((size_t)B * c.vocab * 4);
@@ -72,26 +80,37 @@ int check_handle(Llm* m, const char* fn) {
     return 0;
 }
 
-// one decoder layer over rows grouped by adapter; x is updated in place
+int gemm_ex(const void* x, int64_t ldx, const void* w, const void* residual, int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
+            int out_f32, const float* row_scale, int swiglu, int split_k, void* stream) {
+    mc_gemm_args a;
+    a.x = x; a.ldx = ldx; a.w_packed = w; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
+    a.M = M; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = out_f32; a.alpha = 1.0f; a.beta = 1.0f;
+    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = split_k;
+    return mc_gemm_ex_bf16(&a, stream);
+}
+
+// one decoder layer over rows grouped by adapter; x is updated in place.  On entry w.rs holds 1/rms of every row of x
+// (input_layernorm's factor); on exit it holds the factor for the next layer's input_layernorm (or the final norm).
 int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t* gstart, const int32_t* gadapter,
                   const Ws& w, const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t, const int32_t* out_map,
                   const int32_t* kv_lens, int B, int Lq, char* kc, char* vc, int Smax, bool decode, int nsplit, void* attn_ws,
                   void* stream) {
     const mc_llm_config& c = m->cfg;
-    const int64_t hd = c.hidden, D = c.head_dim, H = c.n_heads, Hkv = c.n_kv_heads;
+    const int64_t hd = c.hidden, D = c.head_dim, H = c.n_heads, Hkv = c.n_kv_heads, I = c.inter;
     const int64_t qkvd = (H + 2 * Hkv) * D;
     const size_t kv_layer = (size_t)B * Hkv * Smax * D * 2;
     char* kcl = kc + (size_t)layer * kv_layer;
     char* vcl = vc + (size_t)layer * kv_layer;
     const float scale = 1.0f / sqrtf((float)D);
+    const bool split = decode && M <= 64;   // skinny decode shapes: split-K slabs + residual_rms instead of an in-epilogue residual
     auto W = [&](int adapter, int which) { return m->layer_w[((size_t)layer * c.n_adapters + adapter) * 4 + which]; };
 
-    RUN(mc_rmsnorm_bf16(x, hd, m->in_norm[layer], w.n, hd, M, (int)hd, c.rms_eps, stream));
+    // q|k|v = (x / rms) . (W_qkv diag(g_in))^T                                                  (:440-443, :262-268)
     for (int g = 0; g < n_groups; ++g) {
         const int r0 = gstart[g], mg = gstart[g + 1] - r0;
         if (mg <= 0) continue;
-        RUN(mc_gemm_bf16(w.n + (size_t)r0 * hd * 2, hd, W(gadapter[g], 0), nullptr, nullptr, 0, w.qkv + (size_t)r0 * qkvd * 2, qkvd, mg,
-                         (int)qkvd, (int)hd, MC_ACT_NONE, 0, 1.0f, 1.0f, stream));
+        RUN(gemm_ex(x + (size_t)r0 * hd * 2, hd, W(gadapter[g], 0), nullptr, 0, w.qkv + (size_t)r0 * qkvd * 2, qkvd, mg, (int)qkvd,
+                    (int)hd, 0, w.rs + r0, 0, 1, stream));
     }
     RUN(mc_rope_kv_bf16(w.qkv, qkvd, row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, M, (int)H, (int)Hkv, (int)D, Lq,
                         Smax, stream));
@@ -104,28 +123,38 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
                                  Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, out_map, kv_lens, B, (int)H, (int)Hkv, Lq, Smax,
                                  (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, stream));
     }
-    for (int g = 0; g < n_groups; ++g) {
-        const int r0 = gstart[g], mg = gstart[g + 1] - r0;
-        if (mg <= 0) continue;
-        char* xr = x + (size_t)r0 * hd * 2;
-        RUN(mc_gemm_bf16(w.attn + (size_t)r0 * hd * 2, hd, W(gadapter[g], 1), nullptr, xr, hd, xr, hd, mg, (int)hd, (int)hd, MC_ACT_NONE,
-                         0, 1.0f, 1.0f, stream));
+    // x += o_proj(attn)  (:447);  then 1/rms of the new x for post_attention_layernorm (:462)
+    if (split) {
+        RUN(gemm_ex(w.attn, hd, W(gadapter[0], 1), nullptr, 0, w.part, hd, M, (int)hd, (int)hd, 1, nullptr, 0, kDecodeSplitK, stream));
+        RUN(mc_residual_rms_bf16(x, hd, w.part, hd, kDecodeSplitK, w.rs, M, (int)hd, c.rms_eps, stream));
+    } else {
+        for (int g = 0; g < n_groups; ++g) {
+            const int r0 = gstart[g], mg = gstart[g + 1] - r0;
+            if (mg <= 0) continue;
+            char* xr = x + (size_t)r0 * hd * 2;
+            RUN(gemm_ex(w.attn + (size_t)r0 * hd * 2, hd, W(gadapter[g], 1), xr, hd, xr, hd, mg, (int)hd, (int)hd, 0, nullptr, 0, 1, stream));
+        }
+        RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
     }
-    RUN(mc_rmsnorm_bf16(x, hd, m->post_norm[layer], w.n, hd, M, (int)hd, c.rms_eps, stream));
-    const int64_t I = c.inter;
+    // inter = silu(gate) * up with gate|up = (x / rms) . (W_gu diag(g_post))^T                 (:380-390)
     for (int g = 0; g < n_groups; ++g) {
         const int r0 = gstart[g], mg = gstart[g + 1] - r0;
         if (mg <= 0) continue;
-        RUN(mc_gemm_bf16(w.n + (size_t)r0 * hd * 2, hd, W(gadapter[g], 2), nullptr, nullptr, 0, w.gu + (size_t)r0 * 2 * I * 2, 2 * I, mg,
-                         (int)(2 * I), (int)hd, MC_ACT_NONE, 0, 1.0f, 1.0f, stream));
+        RUN(gemm_ex(x + (size_t)r0 * hd * 2, hd, W(gadapter[g], 2), nullptr, 0, w.inter + (size_t)r0 * I * 2, I, mg, (int)(2 * I), (int)hd,
+                    0, w.rs + r0, 1, 1, stream));
     }
-    RUN(mc_silu_mul_bf16(w.gu, 2 * I, w.inter, I, M, (int)I, stream));
-    for (int g = 0; g < n_groups; ++g) {
-        const int r0 = gstart[g], mg = gstart[g + 1] - r0;
-        if (mg <= 0) continue;
-        char* xr = x + (size_t)r0 * hd * 2;
-        RUN(mc_gemm_bf16(w.inter + (size_t)r0 * I * 2, I, W(gadapter[g], 3), nullptr, xr, hd, xr, hd, mg, (int)hd, (int)I, MC_ACT_NONE, 0,
-                         1.0f, 1.0f, stream));
+    // x += down_proj(inter)  (:466);  then 1/rms for the next layer's input_layernorm / the final norm
+    if (split) {
+        RUN(gemm_ex(w.inter, I, W(gadapter[0], 3), nullptr, 0, w.part, hd, M, (int)hd, (int)I, 1, nullptr, 0, kDecodeSplitK, stream));
+        RUN(mc_residual_rms_bf16(x, hd, w.part, hd, kDecodeSplitK, w.rs, M, (int)hd, c.rms_eps, stream));
+    } else {
+        for (int g = 0; g < n_groups; ++g) {
+            const int r0 = gstart[g], mg = gstart[g + 1] - r0;
+            if (mg <= 0) continue;
+            char* xr = x + (size_t)r0 * hd * 2;
+            RUN(gemm_ex(w.inter + (size_t)r0 * I * 2, I, W(gadapter[g], 3), xr, hd, xr, hd, mg, (int)hd, (int)I, 0, nullptr, 0, 1, stream));
+        }
+        RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
     }
     return 0;
 }
@@ -169,11 +198,10 @@ extern "C" int mc_llm_destroy(void* handle) {
     return 0;
 }
 
-extern "C" int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* const* in_norms,
-                                  const void* const* post_norms, const void* final_norm, const void* lm_head_packed,
+extern "C" int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* final_norm, const void* lm_head_packed,
                                   const void* embed_table, const float* cos_table, const float* sin_table) {
     Llm* m = (Llm*)handle;
-    if (!m || !layer_w || !in_norms || !post_norms || !final_norm || !lm_head_packed || !embed_table || !cos_table || !sin_table) {
+    if (!m || !layer_w || !final_norm || !lm_head_packed || !embed_table || !cos_table || !sin_table) {
         mc_set_error("mc_llm_set_weights: null argument");
         return 1;
     }
@@ -181,8 +209,6 @@ extern "C" int mc_llm_set_weights(void* handle, const void* const* layer_w, cons
     m->layer_w.assign(layer_w, layer_w + n);
     for (size_t i = 0; i < n; ++i)
         if (!m->layer_w[i]) { mc_set_error("mc_llm_set_weights: null weight pointer at index %zu", i); return 1; }
-    m->in_norm.assign(in_norms, in_norms + m->cfg.n_layers);
-    m->post_norm.assign(post_norms, post_norms + m->cfg.n_layers);
     m->final_norm = final_norm; m->lm_head = lm_head_packed; m->embed = embed_table;
     m->cos_t = cos_table; m->sin_t = sin_table;
     m->weights_set = true;
@@ -227,6 +253,7 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
         }
     const mc_llm_config& c = m->cfg;
     Ws w = carve(c, M, B, Lq, (char*)workspace);
+    RUN(mc_rms_scale_bf16(x_routed, c.hidden, w.rs, M, c.hidden, c.rms_eps, stream));
     for (int l = 0; l < c.n_layers; ++l)
         RUN(layer_forward(m, l, (char*)x_routed, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
                           Lq, (char*)k_cache, (char*)v_cache, Smax, false, 1, nullptr, stream));
@@ -254,6 +281,7 @@ static int decode_one_step(Llm* m, int B, int64_t* next_ids, int64_t* out_ids, i
     const int32_t* zeros = state + 3 * B;
     const int32_t* step = state + 4 * B;
     RUN(mc_embed_rows_bf16(m->embed, c.hidden, next_ids, w.xl, c.hidden, nullptr, B, c.hidden, stream));
+    RUN(mc_rms_scale_bf16(w.xl, c.hidden, w.rs, B, c.hidden, c.rms_eps, stream));
     for (int l = 0; l < c.n_layers; ++l)
         RUN(layer_forward(m, l, w.xl, B, 1, gs, gad, w, iota, pos, zeros, nullptr, kvlen, B, 1, (char*)k_cache, (char*)v_cache, Smax, true,
                           nsplit, attn_ws, stream));

@@ -158,8 +158,9 @@ class MultimodalLlamaForCausalLM:
     def _has_lora(self, prefix, key):
         return f"{prefix}.lora_A.{key}.weight" in self._raw and f"{prefix}.lora_B.{key}.weight" in self._raw
 
-    def _compose_linear(self, prefix: str, adapter: str, out: torch.Tensor, N: int, K: int):
-        """dense weight of `adapter` for one LocalLoRA linear -> packed slice `out`."""
+    def _compose_linear(self, prefix: str, adapter: str, out: torch.Tensor, N: int, K: int, col_scale=None, nb_stride=1, nb_offset=0):
+        """dense weight of `adapter` for one LocalLoRA linear -> packed buffer `out` (block nb at nb*nb_stride + nb_offset),
+        columns multiplied by col_scale (the preceding RMSNorm's weight) before the single bf16 rounding."""
         dev = self.device
         w = self._raw[f"{prefix}.weight"].to(dev, BF16)
         terms = composition_terms(self.config, adapter, lambda key: self._has_lora(prefix, key))
@@ -170,7 +171,7 @@ class MultimodalLlamaForCausalLM:
             a = self._raw[f"{prefix}.lora_A.{key}.weight"].to(dev)
             b = self._raw[f"{prefix}.lora_B.{key}.weight"].to(dev)
             tl.append((a, b, scale))
-        _compose_into(w, tl, N, K, out)
+        _compose_into(w, tl, N, K, out, col_scale, nb_stride, nb_offset)
 
     def finalize(self):
         """Compose + pack every weight, create the C runtime handle."""
@@ -196,25 +197,28 @@ class MultimodalLlamaForCausalLM:
                 if not has_any and "base" in base_cache:
                     layer_ptrs.extend(base_cache["base"])
                     continue
+                # input_layernorm / post_attention_layernorm weights (fp32) folded into the q|k|v and gate|up columns
+                g_in = raw[f"{p}.input_layernorm.weight"].to(dev, torch.float32).contiguous()
+                g_post = raw[f"{p}.post_attention_layernorm.weight"].to(dev, torch.float32).contiguous()
                 qkv = torch.empty(ops.packed_elems(qkv_n, Hd), dtype=BF16, device=dev)
                 off = 0
                 for lin, n in (("q_proj", H * D), ("k_proj", Hkv * D), ("v_proj", Hkv * D)):
-                    self._compose_linear(f"{p}.self_attn.{lin}", ad, qkv[off * Kp_h:(off + n) * Kp_h], n, Hd)
+                    self._compose_linear(f"{p}.self_attn.{lin}", ad, qkv[off * Kp_h:(off + n) * Kp_h], n, Hd, col_scale=g_in)
                     off += n
                 o = torch.empty(ops.packed_elems(Hd, H * D), dtype=BF16, device=dev)
                 self._compose_linear(f"{p}.self_attn.o_proj", ad, o, Hd, H * D)
+                # gate / up interleaved per 16-row block (gate even, up odd) for the fused SwiGLU epilogue
                 gu = torch.empty(ops.packed_elems(2 * I, Hd), dtype=BF16, device=dev)
-                self._compose_linear(f"{p}.mlp.gate_proj", ad, gu[:I * Kp_h], I, Hd)
-                self._compose_linear(f"{p}.mlp.up_proj", ad, gu[I * Kp_h:], I, Hd)
+                self._compose_linear(f"{p}.mlp.gate_proj", ad, gu, I, Hd, col_scale=g_post, nb_stride=2, nb_offset=0)
+                self._compose_linear(f"{p}.mlp.up_proj", ad, gu, I, Hd, col_scale=g_post, nb_stride=2, nb_offset=1)
                 dn = torch.empty(ops.packed_elems(Hd, I), dtype=BF16, device=dev)
                 self._compose_linear(f"{p}.mlp.down_proj", ad, dn, Hd, I)
+                keep.extend([g_in, g_post])
                 ptrs = [qkv.data_ptr(), o.data_ptr(), gu.data_ptr(), dn.data_ptr()]
                 keep.extend([qkv, o, gu, dn])
                 if not has_any:
                     base_cache["base"] = ptrs
                 layer_ptrs.extend(ptrs)
-        in_norms = [raw[f"model.layers.{l}.input_layernorm.weight"].to(dev, BF16).contiguous() for l in range(Lyr)]
-        post_norms = [raw[f"model.layers.{l}.post_attention_layernorm.weight"].to(dev, BF16).contiguous() for l in range(Lyr)]
         final_norm = raw["model.norm.weight"].to(dev, BF16).contiguous()
         self.lm_head = ops.pack_weight(raw["lm_head.weight"].to(dev))
         # rotary tables, fp32 (LlamaRotaryEmbedding 4.31: inv_freq and angles in fp32)
@@ -222,7 +226,7 @@ class MultimodalLlamaForCausalLM:
         inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
         ang = torch.outer(torch.arange(n_pos, dtype=torch.float32), inv)
         self._cos, self._sin = ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous()
-        keep.extend(in_norms + post_norms + [final_norm, self.lm_head.data, self._cos, self._sin, self.model.embed_tokens])
+        keep.extend([final_norm, self.lm_head.data, self._cos, self._sin, self.model.embed_tokens])
         L = _lib.lib()
         if self._handle:
             L.mc_llm_destroy(self._handle)
@@ -232,9 +236,7 @@ class MultimodalLlamaForCausalLM:
         _lib.check(L.mc_llm_create(C.byref(cc), C.byref(h)), "mc_llm_create")
         self._handle = h
         arr = (C.c_void_p * len(layer_ptrs))(*layer_ptrs)
-        inn = (C.c_void_p * Lyr)(*[t.data_ptr() for t in in_norms])
-        pon = (C.c_void_p * Lyr)(*[t.data_ptr() for t in post_norms])
-        _lib.check(L.mc_llm_set_weights(h, arr, inn, pon, _ptr(final_norm), _ptr(self.lm_head.data), _ptr(self.model.embed_tokens),
+        _lib.check(L.mc_llm_set_weights(h, arr, _ptr(final_norm), _ptr(self.lm_head.data), _ptr(self.model.embed_tokens),
                                         _ptr(self._cos), _ptr(self._sin)), "mc_llm_set_weights")
         _lib.check(L.mc_llm_set_option(h, b"use_graph", 1 if self.use_graph else 0), "mc_llm_set_option")
         self._keep = keep
@@ -504,8 +506,8 @@ def _cat_rows(parts: List[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor):
-    """W' = W + Σ scale·B·A packed into the preallocated slice `out`."""
+def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col_scale=None, nb_stride=1, nb_offset=0):
+    """W' = (W + Σ scale·B·A)·diag(col_scale) packed into the preallocated buffer `out` (16-row block nb at nb*nb_stride + nb_offset)."""
     n = len(terms)
     ats, bs, r = [], [], 0
     for (a, b, s) in terms:
@@ -521,12 +523,14 @@ def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor):
         bs.append(bb)
     if w.stride(1) != 1:
         w = w.contiguous()
+    if N % 16 and nb_stride != 1:
+        raise ValueError("interleaved packing needs N to be a multiple of 16")
     at_arr = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in ats])
     b_arr = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in bs])
     sc = (C.c_float * max(n, 1))(*[float(t[2]) for t in terms])
-    if out.numel() != ops.packed_elems(N, K):
-        raise ValueError("packed slice has the wrong size")
-    _lib.check(_lib.lib().mc_compose_weight_bf16(_ptr(w), w.stride(0), at_arr, b_arr, sc, n, r, _ptr(out), None, 0, N, K, _stream()),
-               "mc_compose_weight_bf16")
+    if out.numel() != ops.packed_elems(N, K) * nb_stride:
+        raise ValueError("packed buffer has the wrong size")
+    _lib.check(_lib.lib().mc_compose_weight_ex_bf16(_ptr(w), w.stride(0), at_arr, b_arr, sc, n, r, _ptr(out), None, 0, N, K,
+                                                    _ptr(col_scale), nb_stride, nb_offset, _stream()), "mc_compose_weight_ex_bf16")
     # keep operands alive until the kernel has been enqueued on the stream (stream-ordered allocator semantics)
     return out

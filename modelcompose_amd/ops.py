@@ -123,6 +123,46 @@ def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.
     return out
 
 
+def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor] = None, swiglu: bool = False, split_k: int = 1,
+              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    """mc_gemm_ex_bf16: row_scale fp32 [M] (1/rms of a folded RMSNorm), swiglu (gate/up interleaved per 16 rows -> [M, N/2]),
+    split_k > 1 (M <= 64): fp32 partial slabs [split_k, M, N]."""
+    _req(x, BF16, "x")
+    M, Kx = x.shape
+    if Kx != w.Kp:
+        raise ValueError(f"x has {Kx} columns, weight expects K padded to {w.Kp}")
+    n_out = w.N // 2 if swiglu else w.N
+    if out is None:
+        if split_k > 1:
+            out = torch.empty(split_k, M, n_out, dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty(M, n_out, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), w.data.data_ptr(), 0, 0 if residual is None else residual.data_ptr(),
+                       0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(-2), M, w.N, w.Kp, 0,
+                       1 if (out_f32 or split_k > 1) else 0, 1.0, 1.0, 0 if row_scale is None else row_scale.data_ptr(),
+                       1 if swiglu else 0, split_k)
+    _lib.check(_lib.lib().mc_gemm_ex_bf16(C.byref(a), _stream()), "mc_gemm_ex_bf16")
+    return out
+
+
+def rms_scale(x, eps):
+    _req(x, BF16, "x")
+    M, D = x.shape
+    rs = torch.empty(M, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mc_rms_scale_bf16(_p(x), x.stride(0), _p(rs), M, D, eps, _stream()), "mc_rms_scale_bf16")
+    return rs
+
+
+def residual_rms(h, part, eps):
+    """h += sum over slabs of part [S, M, D] (in place); returns 1/rms of the new rows."""
+    _req(h, BF16, "h")
+    M, D = h.shape
+    rs = torch.empty(M, dtype=torch.float32, device=h.device)
+    _lib.check(_lib.lib().mc_residual_rms_bf16(_p(h), h.stride(0), _p(part), part.stride(1), part.shape[0], _p(rs), M, D, eps, _stream()),
+               "mc_residual_rms_bf16")
+    return rs
+
+
 def rmsnorm(x, w, eps, out=None):
     _req(x, BF16, "x")
     M, D = x.shape

@@ -292,3 +292,87 @@ def test_compose_weight_dense_merge(ops, N, K, r, nt):
     for a, b, s in terms:
         yb = yb + s * ((x.float() @ a.float().t()) @ b.float().t())
     close_bf16(y, yb, rel=2 ** -6)
+
+
+def _interleave_gate_up(wg, wu):
+    """[I, K] gate / up -> [2I, K] with 16-row blocks alternating gate, up (layout expected by the swiglu epilogue)."""
+    I, K = wg.shape
+    return torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K)
+
+
+@pytest.mark.parametrize("M", [5, 16, 40, 200, 700])
+def test_gemm_ex_row_scale_and_swiglu_epilogue(ops, M):
+    """Folded RMSNorm (row_scale = 1/rms, norm weight in the weight columns) + fused silu(gate)*up against the unfused fp32 math
+    (LlamaRMSNorm + LocalLoraMLP gate/up, multimodal_llama.py:380-390).  Covers the skinny, 128x128 and 256x256 kernels."""
+    from modelcompose_amd import _lib
+    K, I, eps = 256, 640, 1e-5
+    x = dev(rand_bf(M, K, seed=11))
+    g = dev(1.0 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(12)))
+    wg = dev(rand_bf(I, K, scale=K ** -0.5, seed=13))
+    wu = dev(rand_bf(I, K, scale=K ** -0.5, seed=14))
+    fold = lambda w: (w.float() * g[None, :]).to(BF)
+    pw = ops.pack_weight(_interleave_gate_up(fold(wg), fold(wu)))
+    rs = ops.rms_scale(x, eps)
+    ref_rs = torch.rsqrt(x.float().pow(2).mean(-1) + eps)
+    assert torch.allclose(rs, ref_rs, rtol=1e-5, atol=0)
+    xn = x.float() * ref_rs[:, None]
+    gate, up = xn @ fold(wg).float().t(), xn @ fold(wu).float().t()
+    ref = F.silu(gate.to(BF).float()) * up.to(BF).float()
+    for dbg in ((0,) if M <= 64 else (2, 4)):
+        _lib.lib().mc_gemm_debug(dbg)
+        try:
+            got = ops.linear_ex(x, pw, row_scale=rs, swiglu=True)
+        finally:
+            _lib.lib().mc_gemm_debug(0)
+        assert got.shape == (M, I)
+        # gate/up each carry one bf16 rounding before the product: 2^-6 of the output scale
+        close_bf16(got, ref, rel=2 ** -6)
+
+
+@pytest.mark.parametrize("M,N,K,S", [(16, 4096, 4096, 4), (3, 512, 11008, 4), (33, 256, 1024, 2), (64, 4096, 512, 4)])
+def test_gemm_ex_split_k_slabs_and_residual_rms(ops, M, N, K, S):
+    """Decode o_proj / down_proj: K split over S workgroups -> fp32 slabs, folded into the hidden state by residual_rms
+    (h += sum of slabs in slab order; 1/rms of the new rows).  Deterministic: two runs are bit-identical."""
+    x = dev(rand_bf(M, K, seed=21))
+    w = dev(rand_bf(N, K, scale=K ** -0.5, seed=22))
+    h0 = dev(rand_bf(M, N, seed=23))
+    pw = ops.pack_weight(w)
+    part = ops.linear_ex(x, pw, split_k=S)
+    assert part.shape == (S, M, N)
+    ref = x.float() @ w.float().t()
+    assert (part.sum(0) - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    h = h0.clone()
+    rs = ops.residual_rms(h, part, 1e-5)
+    ref_h = (h0.float() + part.sum(0)).to(BF)
+    assert (h.float() - ref_h.float()).abs().max().item() <= 2 ** -7 * ref_h.float().abs().max().item()
+    assert torch.allclose(rs, torch.rsqrt(h.float().pow(2).mean(-1) + 1e-5), rtol=1e-5, atol=0)
+    part2 = ops.linear_ex(x, pw, split_k=S)
+    assert torch.equal(part, part2)
+    # every R (block-rows per workgroup) variant of the skinny kernel gives the same sums as the plain path
+    plain = ops.linear(x, pw, out_f32=True)
+    assert (plain - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_compose_ex_col_scale_and_interleave(ops):
+    """mc_compose_weight_ex_bf16: W' = (W + s B A) diag(g), 16-row blocks written at nb*stride + offset."""
+    import ctypes as C
+    from modelcompose_amd import _lib
+    N, K, r = 64, 128, 32
+    w = dev(rand_bf(N, K, seed=31))
+    a = dev(rand_bf(r, K, seed=32))
+    b = dev(rand_bf(N, r, scale=0.1, seed=33))
+    g = dev(1.0 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(34)))
+    out = torch.zeros(ops.packed_elems(2 * N, K), dtype=BF, device="cuda")
+    at = a.t().contiguous()
+    for off in (0, 1):
+        arr_a = (C.c_void_p * 1)(at.data_ptr())
+        arr_b = (C.c_void_p * 1)(b.data_ptr())
+        sc = (C.c_float * 1)(0.5 + off)
+        _lib.check(_lib.lib().mc_compose_weight_ex_bf16(w.data_ptr(), w.stride(0), arr_a, arr_b, sc, 1, r, out.data_ptr(), None, 0, N, K,
+                                                        g.data_ptr(), 2, off, None), "compose_ex")
+    torch.cuda.synchronize()
+    got = ops.unpack_weight(ops.PackedWeight(out, 2 * N, K))
+    for off in (0, 1):
+        ref = ((w.float() + (0.5 + off) * (b.float() @ a.float())) * g[None, :]).to(BF)
+        blk = got.view(N // 16, 2, 16, K)[:, off].reshape(N, K)
+        assert (blk.float() - ref.float()).abs().max().item() <= 2 ** -7 * ref.float().abs().max().item()

@@ -77,6 +77,34 @@ def main():
                         gemm_case(M, N, K, rot=1)
                 gemm_case(9232, 4096, 1024, rot=1); gemm_case(9232, 1024, 4096, rot=1); gemm_case(8192, 8192, 8192, rot=1)
         L.mc_gemm_debug(0)
+    if "var" in which:
+        from modelcompose_amd import _lib
+        L = _lib.lib()
+        w = (torch.randn(4096, 4096, device="cuda") * 4096 ** -0.5).to(BF)
+        x = torch.randn(3000, 4096, device="cuda").to(BF)
+        pw = ops.pack_weight(w)
+        L.mc_gemm_debug(2); ref = ops.linear(x, pw)
+        for d, nm in ((4, "DMA in load half"), (4 + 192, "balanced reads 8,4,8,4")):
+            L.mc_gemm_debug(d)
+            print(nm, "bit-identical to 128 kernel:", torch.equal(ops.linear(x, pw), ref))
+        for rep in range(3):
+            for d, nm in ((4, "DMA in load half"), (4 + 192, "balanced reads 8,4,8,4")):
+                L.mc_gemm_debug(d)
+                print("256x256 kernel variant:", nm)
+                gemm_case(8192, 8192, 8192, rot=1)
+                gemm_case(10928, 4096, 4096, rot=1)
+                gemm_case(10928, 22016, 4096, rot=1)
+        L.mc_gemm_debug(0)
+    if "abl" in which:
+        from modelcompose_amd import _lib
+        L = _lib.lib()
+        for rep in range(2):
+            for d, nm in ((4, "full"), (4 + 8, "no LDS-DMA"), (4 + 16, "no ds_read"), (4 + 24, "MFMA + barriers only"), (4 + 32, "DMA always from K-tiles 0/1 (cache-hot)")):
+                L.mc_gemm_debug(d)
+                print("256x256 kernel ablation:", nm)
+                gemm_case(8192, 8192, 8192, rot=1)
+                gemm_case(10928, 4096, 4096, rot=1)
+        L.mc_gemm_debug(0)
     if "prefill" in which:
         for M in (1536, 9376, 10912):
             for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)):
