@@ -10,7 +10,7 @@ Workload at every N = BASELINE.json configs[1]: vision-only Vicuna-7B bf16, batc
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
-  roofline     – the dominant kernel (gemm_tile_kernel, MFMA-bound): algorithmic FLOPs per launch / average launch
+  roofline     – the dominant kernel (gemm_tile256_kernel, MFMA-bound): algorithmic FLOPs per launch / average launch
                  duration measured live with HIP events on the launch stream during the timed steps
   cpu_baseline – the oracle (CPU port of the reference algorithm, torch fp32, all host cores) on a bounded sample
 """
@@ -146,7 +146,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")     # HBM bytes per launch from the rocprofv3 PMC passes (see profiles/)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("gemm_tile_kernel_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("gemm_tile256_kernel_bytes_per_launch")
         except Exception:
             traffic = None
     line = {
@@ -158,7 +158,7 @@ def main():
                                f"batch {B} synthetic 336px images per GPU, 683-token spliced prompt, {args.new_tokens} greedy tokens",
                    "per_gpu_batch": B, "new_tokens": args.new_tokens, "layers": args.layers, "parallelism": f"dp{world}",
                    "decode_graph": not args.no_graph},
-        "roofline": {"bound": "mfma", "kernel": "gemm_tile_kernel", "achieved": round(achieved, 2),
+        "roofline": {"bound": "mfma", "kernel": "gemm_tile256_kernel", "achieved": round(achieved, 2),
                      "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                      "traffic": traffic, "launches": int(n.value),
                      "avg_launch_us": round(ms.value / max(n.value, 1) * 1e3, 2),

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
 // host launchers
 // ------------------------------------------------------------------------------------------
 #include <vector>
-// Optional live timing of the tile kernel: HIP events recorded on the launch stream around every launch while
+// Optional live timing of the dominant kernel (gemm_tile256_kernel): HIP events recorded on the launch stream around every launch while
 // enabled (bench.py's roofline object).  Not graph-capturable; leave disabled in normal operation.
 namespace {
 struct ProfRec { hipEvent_t a, b; double flops; };
@@ -678,7 +678,7 @@ extern "C" int mc_gemm_profile_enable(int on) {
     return 0;
 }
 
-// total elapsed (ms), total algorithmic flops and launch count of the tile kernel since the last enable
+// total elapsed (ms), total algorithmic flops and launch count of gemm_tile256_kernel since the last enable
 extern "C" int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches) {
     double ms = 0.0, fl = 0.0;
     for (auto& r : g_prof) {
@@ -837,15 +837,8 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
             (void)hipFuncSetAttribute((const void*)gemm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_set = true;
         }
-        ProfRec rec{};
-        if (g_prof_on) {
-            (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);
-            rec.flops = 2.0 * M * (double)N * K;
-            (void)hipEventRecord(rec.a, s);
-        }
         gemm_tile_kernel<<<tiles_m * tiles_n, 256, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep,
                                                              tiles_m, tiles_n, g_gemm_dbg);
-        if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     }
     MC_CHECK_LAUNCH();
     return 0;
