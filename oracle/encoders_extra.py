@@ -291,10 +291,57 @@ def pointbert_encode(pts, sd, cfg, fps_start, return_aux=False):
 
 
 # =========================================================================================================
+# ImageBind audio branch  (imagebind/imagebind_model.py:186-203, 342-349, 402-406, 436-439, 493-527; imagebind/transformer.py:94-97,
+# 105-173; imagebind/multimodal_preprocessors.py:120-160, 205-316)
+# =========================================================================================================
+def imagebind_audio_encode(x, sd, cfg, return_cls=False):
+    """x (B, S, 1, mel, frames) -> (B, S, out_embed_dim): per clip conv(k, stride, no bias) -> LayerNorm -> [cls | patches] + pos ->
+    pre-LN blocks with nn.MultiheadAttention(add_bias_kv) -> LayerNorm(1e-6) -> token 0 -> Linear(no bias) -> L2 normalise x exp(log_scale).
+    Clips are folded into the batch (:496-503) and unfolded at the end (:522-525)."""
+    B, S = x.shape[:2]
+    v = x.reshape(B * S, *x.shape[2:]).float()
+    pp, tr = "modality_preprocessors.audio.", "modality_trunks.audio."
+    t = F.conv2d(v, sd[pp + "rgbt_stem.proj.weight"], None, stride=cfg["audio_stride"])
+    t = t.flatten(2).transpose(1, 2)                                                    # B (T)HW C   (PatchEmbedGeneric.forward)
+    t = _ln(t, sd, pp + "rgbt_stem.norm_layer", 1e-5)
+    t = torch.cat([sd[pp + "cls_token"].expand(t.shape[0], -1, -1), t], dim=1)
+    pos = sd[pp + "pos_embedding_helper.pos_embed"]
+    assert pos.shape[1] == t.shape[1], "input size differs from the trained grid: position interpolation is not restated"
+    t = t + pos
+    E, H = cfg["audio_embed_dim"], cfg["audio_num_heads"]
+    d = E // H
+    n = t.shape[0]
+    for i in range(cfg["audio_num_blocks"]):
+        p = f"{tr}blocks.{i}."
+        h = _ln(t, sd, p + "norm_1", 1e-6)
+        qkv = F.linear(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"])
+        q, k, vv = qkv.split(E, dim=-1)
+        # add_bias_kv: one learned key / value appended AFTER the input projection (torch MultiheadAttention)
+        k = torch.cat([k, sd[p + "attn.bias_k"].reshape(1, 1, E).expand(n, -1, -1)], dim=1)
+        vv = torch.cat([vv, sd[p + "attn.bias_v"].reshape(1, 1, E).expand(n, -1, -1)], dim=1)
+        sh = lambda z: z.reshape(n, -1, H, d).transpose(1, 2)
+        a = torch.softmax((sh(q) * d ** -0.5) @ sh(k).transpose(-1, -2), dim=-1) @ sh(vv)
+        a = a.transpose(1, 2).reshape(n, -1, E)
+        t = t + F.linear(a, sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"])
+        h = _ln(t, sd, p + "norm_2", 1e-6)
+        h = F.linear(F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+        t = t + h
+    cls = _ln(t, sd, "modality_heads.audio.0", 1e-6)[:, 0]
+    y = F.linear(cls, sd["modality_heads.audio.2.weight"])
+    y = F.normalize(y, dim=-1, p=2) * torch.clip(sd["modality_postprocessors.audio.1.log_logit_scale"].exp(), max=100.0)
+    y = y.reshape(B, S, -1)
+    return (cls.reshape(B, S, -1), y) if return_cls else y
+
+
+# =========================================================================================================
 # dispatch used by oracle.pipeline.OracleModel.encode_modal
 # =========================================================================================================
 def encode(model, modal: str, x):
     sd, meta = model.sd, model.meta
+    if modal == "audio" and "imagebind" in meta:
+        sub = model._sub("model.modal_encoders.audio.")
+        feats = imagebind_audio_encode(x, sub, meta["imagebind"])
+        return qformer_project(feats, sd, meta["qformer"], prefix="model.modal_projectors.audio.")
     if modal == "audio":
         sub = model._sub("model.modal_encoders.audio.audio_encoder.")
         feats, _ = beats_encode(x["audio_inputs"], x.get("audio_padding_mask"), sub, meta["beats"])

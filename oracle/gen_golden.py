@@ -691,8 +691,33 @@ def g8():
         _save("g8_e2e_4modal", meta=np.array(json.dumps(d)), **arrays)
 
 
+def g5_imagebind():
+    """ImageBind audio branch (the 'VideoLLaMA' audio encoder, multimodal_encoder/builder.py:91-95): reference ImageBindModel with
+    tiny widths for every modality, only the audio preprocessor / trunk / head / postprocessor are exercised and stored."""
+    im = refshim.import_ref("modelcompose.model.multimodal_encoder.imagebind.imagebind_model")
+    torch.manual_seed(61)
+    kw = dict(video_frames=2, kernel_size=(2, 14, 14), audio_kernel_size=16, audio_stride=10, out_embed_dim=64,
+              vision_embed_dim=32, vision_num_blocks=1, vision_num_heads=2, audio_embed_dim=128, audio_num_blocks=2, audio_num_heads=2,
+              audio_num_mel_bins=32, audio_target_len=46, audio_drop_path=0.1, text_embed_dim=32, text_num_blocks=1, text_num_heads=2,
+              depth_embed_dim=32, depth_num_blocks=1, depth_num_heads=2, thermal_embed_dim=32, thermal_num_blocks=1,
+              thermal_num_heads=2, imu_embed_dim=32, imu_num_blocks=1, imu_num_heads=2)
+    model = im.ImageBindModel(**kw).eval()
+    _jitter(model, 62)
+    x = torch.randn(2, 3, 1, 32, 46)                       # (B, clips, 1, mel bins, frames)
+    with torch.no_grad():
+        feat, out = model.get_audio_feature(x.clone(), im.ModalityType.AUDIO)
+        fwd = model(x.clone())
+    assert torch.equal(fwd, out)
+    arrays = dict(x=x, cls_feature=feat, out=out)
+    keep = ("modality_preprocessors.audio.", "modality_trunks.audio.", "modality_heads.audio.", "modality_postprocessors.audio.")
+    arrays.update({k: v for k, v in _sd(model).items() if k[4:].startswith(keep)})
+    meta = dict(audio_kernel_size=16, audio_stride=10, audio_embed_dim=128, audio_num_blocks=2, audio_num_heads=2, audio_num_mel_bins=32,
+                audio_target_len=46, out_embed_dim=64)
+    _save("g5_imagebind", meta=np.array(json.dumps(meta)), **arrays)
+
+
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
-          "g5_point": g5_point, "g6": g6, "g7": g7, "g8": g8}
+          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8}
 
 
 def main(argv):

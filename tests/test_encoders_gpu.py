@@ -72,3 +72,14 @@ def test_pointbert_encoder_matches_reference():
     assert rel_err(y, yo) < 2 ** -5
     # and against the reference's own output (fp32 points): only the bf16 rounding of the input coordinates differs
     assert rel_err(y, a["features"]) < 2 ** -4
+
+
+def test_imagebind_audio_branch_matches_reference():
+    from modelcompose_amd.model.imagebind_audio import HipImageBindAudioEncoder
+    a, cfg, sd = load_golden("g5_imagebind")
+    enc = HipImageBindAudioEncoder(None, None, delay_load=True, config=cfg)
+    enc.load_state_dict(sd)
+    cls, y = enc.forward(a["x"].cuda(), return_cls=True)
+    assert y.shape == a["out"].shape
+    assert rel_err(cls, a["cls_feature"]) < 2 ** -5
+    assert rel_err(y, a["out"]) < 2 ** -5

@@ -150,6 +150,14 @@ def test_g4_end_to_end_vision_greedy_ids():
     torch.testing.assert_close(step_logits, a["step_logits"], rtol=2e-4, atol=5e-5)
 
 
+def test_g5_imagebind_audio_branch():
+    from oracle import encoders_extra as ex
+    a, meta, sd = load_golden("g5_imagebind")
+    cls, y = ex.imagebind_audio_encode(a["x"], sd, meta, return_cls=True)
+    torch.testing.assert_close(cls, a["cls_feature"], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(y, a["out"], rtol=2e-4, atol=2e-5)
+
+
 def _g8_inputs(a):
     return {"vision": a["pixels"], "audio": {"audio_inputs": a["fbank"], "audio_padding_mask": a["padding_mask"]},
             "video": a["video"], "point": a["points"]}
