@@ -94,12 +94,47 @@ int mc_rope_kv_bf16(const void* qkv, int64_t ld, const int32_t* row_b, const int
                     const float* cos_table, const float* sin_table, void* q_out, void* k_cache, void* v_cache, int M,
                     int H, int Hkv, int D, int Lq, int Smax, void* stream);
 
+/* ---- training step (BASELINE config 5): element-wise / reduction kernels replacing autograd through the decoder layer
+ * (multimodal_llama.py:408-468), the shifted CrossEntropyLoss (:722-733) and torch.optim.AdamW ---------------------------- */
+int mc_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int Rp, void* stream);   /* out[c][r], cols R..Rp-1 zero */
+int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_adapter, int M, int r, int n_adapters, void* stream);
+int mc_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* g, const void* dy, int64_t ldy, const void* dres, int64_t ldr,
+                        void* dx, int64_t ldd, int M, int D, float eps, void* stream);
+int mc_swiglu_bwd_bf16(const void* gate_up, int64_t ld, const void* dinter, int64_t ldi, void* dgate_up, int64_t ldg, int M, int I,
+                       void* stream);
+int mc_act_bf16(const void* pre, const void* dy, void* out, int64_t n, int act, void* stream);   /* dy NULL: act(pre); else dy*act'(pre) */
+int mc_ce_loss_f32(const float* logits, int64_t ld, const int64_t* labels, float* loss_rows, void* dlogits_bf16, int64_t ldd, int M,
+                   int V, float inv_n, void* stream);
+int mc_colsum_bf16(const void* x, int64_t ld, float* out, int M, int C, void* stream);
+int mc_rope_inplace_bf16(void* x, int64_t ld, const int32_t* row_pos, const float* cos_table, const float* sin_table, int M,
+                         int n_heads, int D, float sign, void* stream);
+int mc_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+int mc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* ---- attention backward (training step; replaces autograd through multimodal_llama.py:295-312 and the flash-attn backward of
+ * train/multimodal_flash_attn_monkey_patch.py:96-106).  MHA only (H == Hkv).  lse from mc_attn_prefill_lse_bf16; delta is
+ * scratch [B, H, Lq] fp32.  Strides in elements, head_dim contiguous.                                                       */
+typedef struct mc_attn_bwd_args {
+    const void* q; int64_t q_sb, q_st, q_sh; const void* k; int64_t k_sb, k_st, k_sh; const void* v; int64_t v_sb, v_st, v_sh;
+    const void* o; const void* d_o; int64_t o_sb, o_st, o_sh; const float* lse; float* delta;
+    void* dq; int64_t dq_sb, dq_st, dq_sh; void* dk; int64_t dk_sb, dk_st, dk_sh; void* dv; int64_t dv_sb, dv_st, dv_sh;
+    const int32_t* kv_lens; int B, H, Lq, S, D, causal, q_offset; float scale;
+} mc_attn_bwd_args;
+int mc_attn_bwd_bf16(const mc_attn_bwd_args* args, void* stream);
+
 /* ---- attention (multimodal_llama.py:295-312; CLIPAttention) ------------------------------------------- */
 int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
                          int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
                          int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B, int H, int Hkv, int Lq,
                          int S, int D, int causal, int q_offset, float scale, const float* rel_table, int rel_stride, int rel_off,
                          const float* q_gate, void* stream);   /* rel_table/q_gate: gated relative-position bias of BEATs, may be null */
+/* as mc_attn_prefill_bf16, plus lse [B, H, Lq] fp32 = log2-sum-exp of the scaled scores (input of mc_attn_bwd_bf16) */
+int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
+                             int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
+                             int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B, int H, int Hkv, int Lq,
+                             int S, int D, int causal, int q_offset, float scale, const float* rel_table, int rel_stride, int rel_off,
+                             const float* q_gate, float* lse, void* stream);
 int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* bytes);
 int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st, int64_t k_sh,
                         const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o, int64_t o_sb, void* workspace,

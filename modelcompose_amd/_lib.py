@@ -54,6 +54,15 @@ class GemmArgsC(C.Structure):
                 ("row_scale", c_p), ("swiglu", c_i), ("split_k", c_i)]
 
 
+class AttnBwdArgsC(C.Structure):
+    """struct mc_attn_bwd_args (include/mc_hip.h)."""
+    _fields_ = ([("q", c_p), ("q_sb", c_l), ("q_st", c_l), ("q_sh", c_l), ("k", c_p), ("k_sb", c_l), ("k_st", c_l), ("k_sh", c_l),
+                 ("v", c_p), ("v_sb", c_l), ("v_st", c_l), ("v_sh", c_l), ("o", c_p), ("d_o", c_p), ("o_sb", c_l), ("o_st", c_l), ("o_sh", c_l),
+                 ("lse", c_p), ("delta", c_p), ("dq", c_p), ("dq_sb", c_l), ("dq_st", c_l), ("dq_sh", c_l),
+                 ("dk", c_p), ("dk_sb", c_l), ("dk_st", c_l), ("dk_sh", c_l), ("dv", c_p), ("dv_sb", c_l), ("dv_st", c_l), ("dv_sh", c_l),
+                 ("kv_lens", c_p)] + [(n, c_i) for n in ("B", "H", "Lq", "S", "D", "causal", "q_offset")] + [("scale", c_f)])
+
+
 class LlmConfigC(C.Structure):
     """struct mc_llm_config (include/mc_hip.h)."""
     _fields_ = [(n, C.c_int) for n in ("hidden", "inter", "n_layers", "n_heads", "n_kv_heads", "head_dim", "vocab", "n_adapters",
@@ -62,6 +71,19 @@ class LlmConfigC(C.Structure):
 
 _SIGS.update({
     "mc_gemm_ex_bf16": [C.POINTER(GemmArgsC), c_p],
+    "mc_attn_bwd_bf16": [C.POINTER(AttnBwdArgsC), c_p],
+    "mc_attn_prefill_lse_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
+                                 c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p, c_p, c_p],
+    "mc_transpose_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    "mc_lora_mask_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
+    "mc_rmsnorm_bwd_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_p],
+    "mc_swiglu_bwd_bf16": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    "mc_act_bf16": [c_p, c_p, c_p, c_l, c_i, c_p],
+    "mc_ce_loss_f32": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
+    "mc_colsum_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
+    "mc_rope_inplace_bf16": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "mc_adamw_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p],
+    "mc_cast_f32_bf16": [c_p, c_p, c_l, c_p],
     "mc_add_rows_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_p],
     "mc_zero_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_im2col_ex_bf16": [c_p, c_l, c_l, c_l, c_l, c_p] + [c_i] * 15 + [c_p],

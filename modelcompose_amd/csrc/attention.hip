@@ -27,6 +27,7 @@ struct AttnParams {
     // optional gated relative-position bias (BEATs, beats/backbone.py:431-468,689-697):
     //   score += q_gate[b,h,t] * rel_table[h*rel_stride + (key - t + rel_off)]
     const float* rel_table; const float* q_gate; int rel_stride, rel_off;
+    float* lse;                                    // optional [B, H, Lq]: log2-sum-exp of the scaled scores (training: backward input)
 };
 
 #define NEG_BIG (-1.0e30f)
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     const int t = q0 + c;
+    if (p.lse && t < p.Lq && g == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + t] = l > 0.f ? m_run + log2f(l) : NEG_BIG;
     if (t < p.Lq) {
         const int64_t row = p.out_map ? p.out_map[b * p.Lq + t] : (int64_t)b * p.Lq + t;
         if (row >= 0) {
@@ -309,11 +311,12 @@ __global__ void attn_decode_combine_kernel(DecodeParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-extern "C" int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb,
-                                    int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
-                                    void* o, int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B,
-                                    int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
-                                    const float* rel_table, int rel_stride, int rel_off, const float* q_gate, void* stream) {
+extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb,
+                                        int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                        void* o, int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B,
+                                        int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
+                                        const float* rel_table, int rel_stride, int rel_off, const float* q_gate, float* lse,
+                                        void* stream) {
     MC_CHECK_ARG(q && k && v && o, "mc_attn_prefill_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_prefill_bf16: head_dim %d not supported (64 or 128)", D);
     MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Lq > 0 && S > 0, "mc_attn_prefill_bf16: bad shape");
@@ -321,12 +324,21 @@ extern "C" int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, i
                  "mc_attn_prefill_bf16: strides must be multiples of 8 elements");
     AttnParams p{(const bf16_t*)q, q_sb, q_st, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
                  (bf16_t*)o, o_row_stride, out_map, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
-                 scale * 1.4426950408889634f, rel_table, q_gate, rel_stride, rel_off};
+                 scale * 1.4426950408889634f, rel_table, q_gate, rel_stride, rel_off, lse};
     dim3 grid((Lq + 63) / 64, H, B);
     if (D == 128) attn_prefill_kernel<128><<<grid, 256, 0, (hipStream_t)stream>>>(p);
     else attn_prefill_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(p);
     MC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb,
+                                    int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                    void* o, int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B,
+                                    int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
+                                    const float* rel_table, int rel_stride, int rel_off, const float* q_gate, void* stream) {
+    return mc_attn_prefill_lse_bf16(q, q_sb, q_st, q_sh, k, k_sb, k_st, k_sh, v, v_sb, v_st, v_sh, o, o_row_stride, out_map, kv_lens, B,
+                                    H, Hkv, Lq, S, D, causal, q_offset, scale, rel_table, rel_stride, rel_off, q_gate, nullptr, stream);
 }
 
 extern "C" int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* bytes) {

@@ -1,0 +1,301 @@
+// Softmax-attention backward for gfx950 (training step, BASELINE config 5).
+//
+// Replaces autograd through LocalLoraAttention.forward's  softmax_fp32(QK^T/sqrt(d) + mask)·V
+// (modelcompose/model/language_model/multimodal_llama.py:295-312) and the flash-attn backward the reference uses in training
+// (modelcompose/train/multimodal_flash_attn_monkey_patch.py:96-106, third-party CUDA kernel).  Flash-style: P is recomputed
+// from Q, K and the forward's log-sum-exp, no LxS matrix in HBM.  With s = scale·q·k, p = softmax(s), dp = dO·V^T,
+// delta = rowsum(dO ⊙ O):   ds = p ⊙ (dp − delta),  dQ = scale·ds·K,  dK = scale·ds^T·Q,  dV = p^T·dO.
+//
+//   attn_delta_kernel : delta[b,h,t] = sum_d dO·O
+//   attn_bwd_dq_kernel  : one workgroup = 4 waves x 16 queries of one (batch, head), loops over key tiles of 64.
+//       Same operand orientation as the forward kernel: S^T = K·Q^T and dP^T = V·dO^T put one query on a lane, so
+//       lse / delta are lane scalars and dS^T feeds  dQ^T += K^T·dS^T  straight from registers.
+//   attn_bwd_dkv_kernel : one workgroup = 4 waves x 16 keys, loops over query tiles.  S = Q·K^T and dP = dO·V^T put one
+//       key on a lane; P and dS feed  dV^T += dO^T·P  and  dK^T += Q^T·dS  from registers.
+// Tiles are staged twice in LDS where both a row read (XOR-swizzled, ds_read_b128) and a transposed read
+// (linear, ds_read_b64_tr_b16) are needed.
+#include "common.h"
+
+#define NEG_BIG (-1.0e30f)
+
+struct AttnBwdParams {
+    const bf16_t* q; int64_t q_sb, q_st, q_sh;      // [B, Lq, H, D]-like strides (elements)
+    const bf16_t* k; int64_t k_sb, k_st, k_sh;
+    const bf16_t* v; int64_t v_sb, v_st, v_sh;
+    const bf16_t* o; const bf16_t* d_o; int64_t o_sb, o_st, o_sh;     // O and dO share strides
+    const float* lse;                               // [B, H, Lq] log2 domain (mc_attn_prefill_lse_bf16)
+    float* delta;                                   // [B, H, Lq]
+    bf16_t* dq; int64_t dq_sb, dq_st, dq_sh;
+    bf16_t* dk; int64_t dk_sb, dk_st, dk_sh;
+    bf16_t* dv; int64_t dv_sb, dv_st, dv_sh;
+    const int32_t* kv_lens;
+    int B, H, Lq, S, causal, q_offset;
+    float scale, scale_log2e;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnBwdParams p) {
+    // one wave per (b, h, t) row; D/8 lanes active
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int total = p.B * p.H * p.Lq;
+    if (row >= total) return;
+    const int t = row % p.Lq, h = (row / p.Lq) % p.H, b = row / (p.Lq * p.H);
+    float s = 0.f;
+    if (lane < D / 8) {
+        const int64_t off = b * p.o_sb + t * p.o_st + h * p.o_sh + lane * 8;
+        const bf16x8 a = *(const bf16x8*)(p.o + off), d = *(const bf16x8*)(p.d_o + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)d[j];
+    }
+    s = wave_sum(s);
+    if (lane == 0) p.delta[row] = s;
+}
+
+template <int D>
+__device__ __forceinline__ int swz(int ch, int row) {
+    return (D == 128) ? (ch ^ (row & 15)) : (ch ^ ((row >> 1) & 7));
+}
+
+// stage 64 rows x D of src (row stride in elements) into a swizzled and/or linear LDS tile; rows >= n_valid are clamped
+template <int D, bool SW, bool LIN>
+__device__ __forceinline__ void stage_tile(const bf16_t* src, int64_t row_stride, int row0, int n_rows_total, char* sw_tile, char* lin_tile,
+                                           int tid) {
+    constexpr int ROWB = D * 2, CH = ROWB / 16;
+#pragma unroll
+    for (int it = 0; it < (64 * CH) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx / CH, ch = idx % CH;
+        const int r = min(row0 + row, n_rows_total - 1);
+        const u32x4 v4 = *(const u32x4*)(src + (int64_t)r * row_stride + ch * 8);
+        if (SW) *(u32x4*)(sw_tile + row * ROWB + swz<D>(ch, row) * 16) = v4;
+        if (LIN) *(u32x4*)(lin_tile + row * ROWB + ch * 16) = v4;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
+    constexpr int ROWB = D * 2, KS = D / 32, DB = D / 16;
+    __shared__ __attribute__((aligned(16))) char lds[3 * 64 * ROWB];
+    char* k_sw = lds;
+    char* k_lin = lds + 64 * ROWB;
+    char* v_sw = lds + 2 * 64 * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
+    const int t = min(q0 + c, p.Lq - 1);
+
+    bf16x8 qf[KS], dof[KS];
+    {
+        const bf16_t* qp = p.q + b * p.q_sb + t * p.q_st + h * p.q_sh + g * 8;
+        const bf16_t* dp_ = p.d_o + b * p.o_sb + t * p.o_st + h * p.o_sh + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { qf[ks] = *(const bf16x8*)(qp + ks * 32); dof[ks] = *(const bf16x8*)(dp_ + ks * 32); }
+    }
+    const int64_t stat = ((int64_t)b * p.H + h) * p.Lq + t;
+    const float lse = p.lse[stat], delta = p.delta[stat];
+    const int q_abs = q0 + c + p.q_offset;
+
+    f32x4 acc[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int last_key = kvlen;
+    if (p.causal) last_key = min(last_key, blockIdx.x * 64 + 63 + p.q_offset + 1);
+    const int ntiles = (last_key + 63) / 64;
+    const bf16_t* kbase = p.k + b * p.k_sb + h * p.k_sh;
+    const bf16_t* vbase = p.v + b * p.v_sb + h * p.v_sh;
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        stage_tile<D, true, true>(kbase, p.k_st, kt * 64, p.S, k_sw, k_lin, tid);
+        stage_tile<D, true, false>(vbase, p.v_st, kt * 64, p.S, v_sw, nullptr, tid);
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = kb * 16 + c;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = row * ROWB + swz<D>(ks * 4 + g, row) * 16;
+                const bf16x8 kf = *(const bf16x8*)(k_sw + off);
+                const bf16x8 vf = *(const bf16x8*)(v_sw + off);
+                s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp[kb], 0, 0, 0);
+            }
+        }
+        bf16x8 dsf[2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 64 + kb * 16 + g * 4 + r;
+                const bool ok = key < kvlen && (!p.causal || key <= q_abs);
+                const float pv = ok ? exp2f(s[kb][r] * p.scale_log2e - lse) : 0.f;
+                dsf[kb >> 1][(kb & 1) * 4 + r] = (bf16_t)(pv * (dp[kb][r] - delta));
+            }
+        // dQ^T[d][query] += K^T · dS^T   (K^T through the transposing LDS read of the linear tile)
+        const int tq = (lane & 15) >> 2, tp = lane & 3;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int key_lo = (2 * pr) * 16 + g * 4 + tq;
+            const int key_hi = (2 * pr + 1) * 16 + g * 4 + tq;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(k_lin + key_lo * ROWB + (db * 16 + tp * 4) * 2));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(k_lin + key_hi * ROWB + (db * 16 + tp * 4) * 2));
+                bf16x8 kf;
+                kf[0] = lo[0]; kf[1] = lo[1]; kf[2] = lo[2]; kf[3] = lo[3];
+                kf[4] = hi[0]; kf[5] = hi[1]; kf[6] = hi[2]; kf[7] = hi[3];
+                acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf[pr], acc[db], 0, 0, 0);
+            }
+        }
+    }
+    if (q0 + c < p.Lq) {
+        bf16_t* op = p.dq + b * p.dq_sb + (int64_t)(q0 + c) * p.dq_st + h * p.dq_sh;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            bf16x4 ov = {(bf16_t)(acc[db][0] * p.scale), (bf16_t)(acc[db][1] * p.scale), (bf16_t)(acc[db][2] * p.scale),
+                         (bf16_t)(acc[db][3] * p.scale)};
+            *(bf16x4*)(op + db * 16 + g * 4) = ov;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+    constexpr int ROWB = D * 2, KS = D / 32, DB = D / 16;
+    __shared__ __attribute__((aligned(16))) char lds[4 * 64 * ROWB + 2 * 64 * 4];
+    char* q_sw = lds;
+    char* q_lin = lds + 64 * ROWB;
+    char* o_sw = lds + 2 * 64 * ROWB;
+    char* o_lin = lds + 3 * 64 * ROWB;
+    float* lse_t = (float*)(lds + 4 * 64 * ROWB);
+    float* del_t = lse_t + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int k0 = blockIdx.x * 64 + wave * 16;
+    const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
+    const int key = k0 + c;                       // this lane's key column
+    const int keyc = min(key, p.S - 1);
+
+    bf16x8 kf[KS], vf[KS];
+    {
+        const bf16_t* kp = p.k + b * p.k_sb + (int64_t)keyc * p.k_st + h * p.k_sh + g * 8;
+        const bf16_t* vp = p.v + b * p.v_sb + (int64_t)keyc * p.v_st + h * p.v_sh + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { kf[ks] = *(const bf16x8*)(kp + ks * 32); vf[ks] = *(const bf16x8*)(vp + ks * 32); }
+    }
+    f32x4 acck[DB], accv[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) { acck[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; accv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // causal: query t (absolute t + q_offset) sees key iff key <= t + q_offset  ->  first query tile that can see this key tile
+    int first_q = 0;
+    if (p.causal) first_q = max(0, blockIdx.x * 64 - p.q_offset) / 64;
+    const int nq = (p.Lq + 63) / 64;
+    const bf16_t* qbase = p.q + b * p.q_sb + h * p.q_sh;
+    const bf16_t* dobase = p.d_o + b * p.o_sb + h * p.o_sh;
+    const int64_t stat0 = ((int64_t)b * p.H + h) * p.Lq;
+
+    for (int qt = first_q; qt < nq; ++qt) {
+        __syncthreads();
+        stage_tile<D, true, true>(qbase, p.q_st, qt * 64, p.Lq, q_sw, q_lin, tid);
+        stage_tile<D, true, true>(dobase, p.o_st, qt * 64, p.Lq, o_sw, o_lin, tid);
+        if (tid < 64) {
+            const int tt = min(qt * 64 + tid, p.Lq - 1);
+            lse_t[tid] = p.lse[stat0 + tt];
+            del_t[tid] = p.delta[stat0 + tt];
+        }
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            s[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = qb * 16 + c;             // A operand row = query
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = row * ROWB + swz<D>(ks * 4 + g, row) * 16;
+                const bf16x8 qf = *(const bf16x8*)(q_sw + off);
+                const bf16x8 of = *(const bf16x8*)(o_sw + off);
+                s[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], s[qb], 0, 0, 0);
+                dp[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, vf[ks], dp[qb], 0, 0, 0);
+            }
+        }
+        // lane owns key column c, queries 16qb + 4g + r
+        bf16x8 pf[2], dsf[2];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = qb * 16 + g * 4 + r;
+                const int tq_ = qt * 64 + ql;
+                const bool ok = tq_ < p.Lq && key < kvlen && (!p.causal || key <= tq_ + p.q_offset);
+                const float pv = ok ? exp2f(s[qb][r] * p.scale_log2e - lse_t[ql]) : 0.f;
+                pf[qb >> 1][(qb & 1) * 4 + r] = (bf16_t)pv;
+                dsf[qb >> 1][(qb & 1) * 4 + r] = (bf16_t)(pv * (dp[qb][r] - del_t[ql]));
+            }
+        const int tq = (lane & 15) >> 2, tp = lane & 3;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int r_lo = (2 * pr) * 16 + g * 4 + tq;
+            const int r_hi = (2 * pr + 1) * 16 + g * 4 + tq;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int coff = (db * 16 + tp * 4) * 2;
+                const bf16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(o_lin + r_lo * ROWB + coff));
+                const bf16x4 ohi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(o_lin + r_hi * ROWB + coff));
+                const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(q_lin + r_lo * ROWB + coff));
+                const bf16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(q_lin + r_hi * ROWB + coff));
+                bf16x8 of, qf;
+                of[0] = olo[0]; of[1] = olo[1]; of[2] = olo[2]; of[3] = olo[3]; of[4] = ohi[0]; of[5] = ohi[1]; of[6] = ohi[2]; of[7] = ohi[3];
+                qf[0] = qlo[0]; qf[1] = qlo[1]; qf[2] = qlo[2]; qf[3] = qlo[3]; qf[4] = qhi[0]; qf[5] = qhi[1]; qf[6] = qhi[2]; qf[7] = qhi[3];
+                accv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, pf[pr], accv[db], 0, 0, 0);
+                acck[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf[pr], acck[db], 0, 0, 0);
+            }
+        }
+    }
+    if (key < p.S) {
+        bf16_t* kp = p.dk + b * p.dk_sb + (int64_t)key * p.dk_st + h * p.dk_sh;
+        bf16_t* vp = p.dv + b * p.dv_sb + (int64_t)key * p.dv_st + h * p.dv_sh;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            bf16x4 ok_ = {(bf16_t)(acck[db][0] * p.scale), (bf16_t)(acck[db][1] * p.scale), (bf16_t)(acck[db][2] * p.scale),
+                          (bf16_t)(acck[db][3] * p.scale)};
+            bf16x4 ov = {(bf16_t)accv[db][0], (bf16_t)accv[db][1], (bf16_t)accv[db][2], (bf16_t)accv[db][3]};
+            *(bf16x4*)(kp + db * 16 + g * 4) = ok_;
+            *(bf16x4*)(vp + db * 16 + g * 4) = ov;
+        }
+    }
+}
+
+extern "C" int mc_attn_bwd_bf16(const mc_attn_bwd_args* a, void* stream) {
+    MC_CHECK_ARG(a && a->q && a->k && a->v && a->o && a->d_o && a->lse && a->delta && a->dq && a->dk && a->dv, "mc_attn_bwd_bf16: null pointer");
+    MC_CHECK_ARG(a->D == 64 || a->D == 128, "mc_attn_bwd_bf16: head_dim %d not supported (64 or 128)", a->D);
+    MC_CHECK_ARG(a->B > 0 && a->H > 0 && a->Lq > 0 && a->S > 0, "mc_attn_bwd_bf16: bad shape");
+    AttnBwdParams p{(const bf16_t*)a->q, a->q_sb, a->q_st, a->q_sh, (const bf16_t*)a->k, a->k_sb, a->k_st, a->k_sh,
+                    (const bf16_t*)a->v, a->v_sb, a->v_st, a->v_sh, (const bf16_t*)a->o, (const bf16_t*)a->d_o, a->o_sb, a->o_st, a->o_sh,
+                    a->lse, a->delta, (bf16_t*)a->dq, a->dq_sb, a->dq_st, a->dq_sh, (bf16_t*)a->dk, a->dk_sb, a->dk_st, a->dk_sh,
+                    (bf16_t*)a->dv, a->dv_sb, a->dv_st, a->dv_sh, a->kv_lens, a->B, a->H, a->Lq, a->S, a->causal, a->q_offset,
+                    a->scale, a->scale * 1.4426950408889634f};
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = a->B * a->H * a->Lq;
+    dim3 gq((a->Lq + 63) / 64, a->H, a->B), gk((a->S + 63) / 64, a->H, a->B);
+    if (a->D == 128) {
+        attn_delta_kernel<128><<<(rows + 3) / 4, 256, 0, s>>>(p);
+        attn_bwd_dq_kernel<128><<<gq, 256, 0, s>>>(p);
+        attn_bwd_dkv_kernel<128><<<gk, 256, 0, s>>>(p);
+    } else {
+        attn_delta_kernel<64><<<(rows + 3) / 4, 256, 0, s>>>(p);
+        attn_bwd_dq_kernel<64><<<gq, 256, 0, s>>>(p);
+        attn_bwd_dkv_kernel<64><<<gk, 256, 0, s>>>(p);
+    }
+    MC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,325 @@
+// Element-wise / reduction kernels of the training step (BASELINE config 5: stage-2 finetune forward + backward).
+// They replace autograd through the pieces of MultimodalLlamaDecoderLayer.forward (multimodal_llama.py:408-468) that are not
+// GEMMs or attention, the shifted CrossEntropyLoss (:722-733) and the optimiser update; all HBM-bound, 16-byte vector access.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// out[c][r] = in[r][c]  (r < R, c < C), columns R..Rp-1 of out zero.  64x64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, int64_t ldi, bf16_t* __restrict__ out, int64_t ldo,
+                                                        int R, int C, int Rp) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(int64_t)r * ldi + c] : (bf16_t)0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < Rp) out[(int64_t)c * ldo + r] = tile[tx][i];
+    }
+}
+
+extern "C" int mc_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int Rp, void* stream) {
+    MC_CHECK_ARG(in && out && R > 0 && C > 0 && Rp >= R, "mc_transpose_bf16: bad arguments");
+    dim3 grid((C + 63) / 64, (Rp + 63) / 64);
+    transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)in, ldi, (bf16_t*)out, ldo, R, C, Rp);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// LocalLoRA routing of the low-rank activations: t is [M, n_adapters*r]; row m keeps the r columns of its adapter
+// (row_adapter[m]) and is zeroed elsewhere — the per-token mask-sum of multimodal_llama.py:262-268 applied where it is cheap.
+__global__ __launch_bounds__(256) void lora_mask_kernel(bf16_t* __restrict__ t, int64_t ld, const int32_t* __restrict__ row_adapter, int M, int r,
+                                                        int n_adapters) {
+    const int nv = (n_adapters * r) >> 3;
+    const int64_t total = (int64_t)M * nv;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / nv), cv = (int)(i % nv);
+        if ((cv * 8) / r != row_adapter[m]) *(u32x4*)(t + (int64_t)m * ld + cv * 8) = (u32x4){0u, 0u, 0u, 0u};
+    }
+}
+
+extern "C" int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_adapter, int M, int r, int n_adapters, void* stream) {
+    MC_CHECK_ARG(t && row_adapter && M > 0 && r > 0 && r % 8 == 0 && n_adapters > 0 && ld % 8 == 0, "mc_lora_mask_rows_bf16: bad arguments");
+    const int64_t total = (int64_t)M * ((n_adapters * r) >> 3);
+    lora_mask_kernel<<<(int)min((int64_t)8192, (total + 255) / 256), 256, 0, (hipStream_t)stream>>>((bf16_t*)t, ld, row_adapter, M, r, n_adapters);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm backward (LlamaRMSNorm: y = g * x * rs, rs = rsqrt(mean(x^2) + eps)):
+//   dx = rs * (g*dy) - x * rs^3 * mean(x * g*dy)   (+ dres: the residual branch's gradient)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ g,
+                                                          const bf16_t* __restrict__ dy, int64_t ldy, const bf16_t* __restrict__ dres,
+                                                          int64_t ldr, bf16_t* __restrict__ dx, int64_t ldd, int D, float eps) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const bf16_t* xr = x + (int64_t)row * ldx;
+    const bf16_t* dyr = dy + (int64_t)row * ldy;
+    const int nv = D >> 3;
+    float s2 = 0.f, sxg = 0.f;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        const bf16x8 xv = *(const bf16x8*)(xr + i * 8), gv = *(const bf16x8*)(g + i * 8), dv = *(const bf16x8*)(dyr + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xf = (float)xv[j];
+            s2 += xf * xf;
+            sxg += xf * (float)gv[j] * (float)dv[j];
+        }
+    }
+    s2 = block_sum(s2, red);
+    sxg = block_sum(sxg, red);
+    const float rs = rsqrtf(s2 / D + eps);
+    const float coef = rs * rs * rs * sxg / D;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        const bf16x8 xv = *(const bf16x8*)(xr + i * 8), gv = *(const bf16x8*)(g + i * 8), dv = *(const bf16x8*)(dyr + i * 8);
+        bf16x8 rv;
+        if (dres) rv = *(const bf16x8*)(dres + (int64_t)row * ldr + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = rs * (float)gv[j] * (float)dv[j] - (float)xv[j] * coef;
+            if (dres) v += (float)rv[j];
+            o[j] = (bf16_t)v;
+        }
+        *(bf16x8*)(dx + (int64_t)row * ldd + i * 8) = o;
+    }
+}
+
+extern "C" int mc_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* g, const void* dy, int64_t ldy, const void* dres, int64_t ldr,
+                                   void* dx, int64_t ldd, int M, int D, float eps, void* stream) {
+    MC_CHECK_ARG(x && g && dy && dx && M > 0 && D > 0 && D % 8 == 0 && (ldx | ldy | ldd | ldr) % 8 == 0, "mc_rmsnorm_bwd_bf16: bad arguments");
+    rmsnorm_bwd_kernel<<<M, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, (const bf16_t*)g, (const bf16_t*)dy, ldy, (const bf16_t*)dres,
+                                                           ldr, (bf16_t*)dx, ldd, D, eps);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// SwiGLU backward: inter = silu(gate) * up  ->  dgate = dinter * up * silu'(gate), dup = dinter * silu(gate)
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, int64_t ld, const bf16_t* __restrict__ dinter, int64_t ldi,
+                                                         bf16_t* __restrict__ dgu, int64_t ldg, int M, int I) {
+    const int nv = I >> 3;
+    const int64_t total = (int64_t)M * nv;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / nv), c = (int)(i % nv);
+        const bf16x8 g = *(const bf16x8*)(gu + (int64_t)m * ld + c * 8), u = *(const bf16x8*)(gu + (int64_t)m * ld + I + c * 8);
+        const bf16x8 d = *(const bf16x8*)(dinter + (int64_t)m * ldi + c * 8);
+        bf16x8 og, ou;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gf = (float)g[j], sg = 1.0f / (1.0f + __expf(-gf)), df = (float)d[j];
+            ou[j] = (bf16_t)(df * gf * sg);
+            og[j] = (bf16_t)(df * (float)u[j] * sg * (1.0f + gf * (1.0f - sg)));
+        }
+        *(bf16x8*)(dgu + (int64_t)m * ldg + c * 8) = og;
+        *(bf16x8*)(dgu + (int64_t)m * ldg + I + c * 8) = ou;
+    }
+}
+
+extern "C" int mc_swiglu_bwd_bf16(const void* gate_up, int64_t ld, const void* dinter, int64_t ldi, void* dgate_up, int64_t ldg, int M, int I,
+                                  void* stream) {
+    MC_CHECK_ARG(gate_up && dinter && dgate_up && M > 0 && I > 0 && I % 8 == 0 && (ld | ldi | ldg) % 8 == 0, "mc_swiglu_bwd_bf16: bad arguments");
+    const int64_t total = (int64_t)M * (I >> 3);
+    swiglu_bwd_kernel<<<(int)min((int64_t)8192, (total + 255) / 256), 256, 0, (hipStream_t)stream>>>((const bf16_t*)gate_up, ld, (const bf16_t*)dinter,
+                                                                                                    ldi, (bf16_t*)dgate_up, ldg, M, I);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// activation forward / backward on a saved pre-activation (mm_projector's nn.GELU, multimodal_projector/builder.py:208-215)
+__device__ __forceinline__ float act_grad(float x, int act) {
+    switch (act) {
+        case MC_ACT_GELU: {
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+            return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+        }
+        case MC_ACT_QUICK_GELU: { const float s = 1.0f / (1.0f + __expf(-1.702f * x)); return s * (1.0f + 1.702f * x * (1.0f - s)); }
+        case MC_ACT_SILU: { const float s = 1.0f / (1.0f + __expf(-x)); return s * (1.0f + x * (1.0f - s)); }
+        case MC_ACT_RELU: return x > 0.f ? 1.0f : 0.f;
+        default: return 1.0f;
+    }
+}
+
+// dy == null: out = act(pre);  else out = dy * act'(pre)
+__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ pre, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, int64_t n8,
+                                                  int act) {
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 p = *(const bf16x8*)(pre + i * 8);
+        bf16x8 o;
+        if (dy) {
+            const bf16x8 d = *(const bf16x8*)(dy + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)d[j] * act_grad((float)p[j], act));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)mc_act((float)p[j], act);
+        }
+        *(bf16x8*)(out + i * 8) = o;
+    }
+}
+
+extern "C" int mc_act_bf16(const void* pre, const void* dy, void* out, int64_t n, int act, void* stream) {
+    MC_CHECK_ARG(pre && out && n > 0 && n % 8 == 0, "mc_act_bf16: n must be a positive multiple of 8");
+    act_kernel<<<(int)min((int64_t)8192, (n / 8 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const bf16_t*)pre, (const bf16_t*)dy, (bf16_t*)out, n / 8, act);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// shifted cross-entropy (multimodal_llama.py:722-733): per row m with target label[m] (already shifted; < 0 = ignored)
+//   loss_rows[m] = logsumexp(logits[m]) - logits[m][label];  dlogits[m] = (softmax - onehot) * inv_n   (bf16, zero for ignored rows)
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                      float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits, int64_t ldd, int V, float inv_n) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const float* lr = logits + (int64_t)row * ld;
+    bf16_t* dr = dlogits + (int64_t)row * ldd;
+    const int64_t lab = labels[row];
+    const int nv = V >> 2;
+    if (lab < 0) {
+        loss_rows[row] = 0.f;
+        for (int i = threadIdx.x; i < nv; i += 256) *(bf16x4*)(dr + i * 4) = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        return;
+    }
+    float mx = -3.0e38f;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        const f32x4 v = *(const f32x4*)(lr + i * 4);
+        mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float se = 0.f;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        const f32x4 v = *(const f32x4*)(lr + i * 4);
+        se += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+    }
+    se = block_sum(se, red);
+    const float inv = 1.0f / se;
+    if (threadIdx.x == 0) loss_rows[row] = logf(se) + mx - lr[lab];
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        const f32x4 v = *(const f32x4*)(lr + i * 4);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pj = __expf(v[j] - mx) * inv;
+            if (i * 4 + j == lab) pj -= 1.0f;
+            o[j] = (bf16_t)(pj * inv_n);
+        }
+        *(bf16x4*)(dr + i * 4) = o;
+    }
+}
+
+extern "C" int mc_ce_loss_f32(const float* logits, int64_t ld, const int64_t* labels, float* loss_rows, void* dlogits_bf16, int64_t ldd, int M,
+                              int V, float inv_n, void* stream) {
+    MC_CHECK_ARG(logits && labels && loss_rows && dlogits_bf16 && M > 0 && V > 0 && V % 4 == 0 && ld % 4 == 0 && ldd % 4 == 0, "mc_ce_loss_f32: bad arguments");
+    ce_loss_kernel<<<M, 256, 0, (hipStream_t)stream>>>(logits, ld, labels, loss_rows, (bf16_t*)dlogits_bf16, ldd, V, inv_n);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// out[c] = sum_m x[m][c]   (bias gradients, prefix/suffix token gradients); fp32 result.  One workgroup per 64 columns.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int64_t ld, float* __restrict__ out, int M, int C) {
+    __shared__ float part[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+    float s = 0.f;
+    if (col < C)
+        for (int m = ty; m < M; m += 4) s += (float)x[(int64_t)m * ld + col];
+    part[ty][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ty == 0 && col < C) out[col] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+extern "C" int mc_colsum_bf16(const void* x, int64_t ld, float* out, int M, int C, void* stream) {
+    MC_CHECK_ARG(x && out && M > 0 && C > 0, "mc_colsum_bf16: bad arguments");
+    colsum_kernel<<<(C + 63) / 64, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, ld, out, M, C);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// in-place rotate-half RoPE on the first n_heads heads of every row (transformers 4.31 apply_rotary_pos_emb via
+// multimodal_llama.py:281-282); sign = -1 applies the inverse rotation = the backward of the forward rotation.
+__global__ __launch_bounds__(256) void rope_inplace_kernel(bf16_t* __restrict__ x, int64_t ld, const int32_t* __restrict__ row_pos,
+                                                           const float* __restrict__ cosT, const float* __restrict__ sinT, int n_heads, int D,
+                                                           float sign) {
+    const int r = blockIdx.x;
+    const int pos = row_pos[r];
+    const int half = D >> 1, cpd = half >> 3;
+    bf16_t* xr = x + (int64_t)r * ld;
+    const float* cr = cosT + (int64_t)pos * half;
+    const float* sr = sinT + (int64_t)pos * half;
+    for (int it = threadIdx.x; it < n_heads * cpd; it += 256) {
+        const int hh = it / cpd, ch = it % cpd;
+        bf16_t* s0 = xr + hh * D + ch * 8;
+        const bf16x8 x1 = *(const bf16x8*)s0, x2 = *(const bf16x8*)(s0 + half);
+        bf16x8 o1, o2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float c = cr[ch * 8 + j], s = sign * sr[ch * 8 + j];
+            const float a = (float)x1[j], b = (float)x2[j];
+            o1[j] = (bf16_t)(a * c - b * s);
+            o2[j] = (bf16_t)(b * c + a * s);
+        }
+        *(bf16x8*)s0 = o1;
+        *(bf16x8*)(s0 + half) = o2;
+    }
+}
+
+extern "C" int mc_rope_inplace_bf16(void* x, int64_t ld, const int32_t* row_pos, const float* cos_table, const float* sin_table, int M,
+                                    int n_heads, int D, float sign, void* stream) {
+    MC_CHECK_ARG(x && row_pos && cos_table && sin_table && M > 0 && n_heads > 0 && D % 16 == 0 && ld % 8 == 0, "mc_rope_inplace_bf16: bad arguments");
+    rope_inplace_kernel<<<M, 256, 0, (hipStream_t)stream>>>((bf16_t*)x, ld, row_pos, cos_table, sin_table, n_heads, D, sign);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW semantics, the optimiser HF Trainer builds in llava_trainer.py:210-288) on fp32 master weights,
+// refreshing the bf16 working copy in the same pass.  grad is scaled by grad_scale first (1/world_size after the all-reduce sum).
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ p16, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                                                    float bc1, float bc2, float grad_scale) {
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        p[i] = pi;
+        if (p16) p16[i] = (bf16_t)pi;
+    }
+}
+
+extern "C" int mc_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, int64_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    MC_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "mc_adamw_f32: bad arguments");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    adamw_kernel<<<(int)min((int64_t)8192, (n + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, (bf16_t*)param_bf16, n, lr,
+                                                                                            beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 -> bf16 cast of a flat buffer (working copies of the trainable parameters)
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (bf16_t)x[i];
+}
+
+extern "C" int mc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
+    MC_CHECK_ARG(x && y && n > 0, "mc_cast_f32_bf16: bad arguments");
+    cast_f32_bf16_kernel<<<(int)min((int64_t)8192, (n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)y, n);
+    MC_CHECK_LAUNCH();
+    return 0;
+}

@@ -320,3 +320,94 @@ def f32_rows_to_bf16(x, Kp=64):
     out = torch.empty(rows, Kp, dtype=BF16, device=x.device)
     _lib.check(_lib.lib().mc_f32_rows_to_bf16(_p(x), Cc, _p(out), Kp, rows, _stream()), "mc_f32_rows_to_bf16")
     return out
+
+
+# ---- training step (csrc/train.hip, csrc/attention_bwd.hip) ---------------------------------------------
+def transpose(x, Rp=None, out=None):
+    """[R, C] bf16 (row stride free) -> [C, Rp] with zero padded columns R..Rp-1."""
+    R, Cc = x.shape
+    Rp = R if Rp is None else Rp
+    out = torch.empty(Cc, Rp, dtype=BF16, device=x.device) if out is None else out
+    _lib.check(_lib.lib().mc_transpose_bf16(_p(x), x.stride(0), _p(out), out.stride(0), R, Cc, Rp, _stream()), "mc_transpose_bf16")
+    return out
+
+
+def lora_mask_rows(t, row_adapter, r, n_adapters):
+    _lib.check(_lib.lib().mc_lora_mask_rows_bf16(_p(t), t.stride(0), _p(row_adapter), t.shape[0], r, n_adapters, _stream()),
+               "mc_lora_mask_rows_bf16")
+    return t
+
+
+def rmsnorm_bwd(x, g, dy, eps, dres=None, out=None):
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=BF16, device=x.device) if out is None else out
+    _lib.check(_lib.lib().mc_rmsnorm_bwd_bf16(_p(x), x.stride(0), _p(g), _p(dy), dy.stride(0), _p(dres), 0 if dres is None else dres.stride(0),
+                                              _p(out), out.stride(0), M, D, eps, _stream()), "mc_rmsnorm_bwd_bf16")
+    return out
+
+
+def swiglu_bwd(gu, dinter, out=None):
+    M, I2 = gu.shape
+    out = torch.empty(M, I2, dtype=BF16, device=gu.device) if out is None else out
+    _lib.check(_lib.lib().mc_swiglu_bwd_bf16(_p(gu), gu.stride(0), _p(dinter), dinter.stride(0), _p(out), out.stride(0), M, I2 // 2, _stream()),
+               "mc_swiglu_bwd_bf16")
+    return out
+
+
+def act(pre, kind, dy=None):
+    """dy None: act(pre); else dy * act'(pre).  Contiguous tensors."""
+    out = torch.empty_like(pre)
+    _lib.check(_lib.lib().mc_act_bf16(_p(pre), _p(dy), _p(out), pre.numel(), ACT[kind], _stream()), "mc_act_bf16")
+    return out
+
+
+def ce_loss(logits_f32, labels, inv_n):
+    """labels int64 [M] (already shifted, < 0 ignored) -> (loss_rows fp32 [M], dlogits bf16 [M, V] = (softmax - onehot) * inv_n)."""
+    M, V = logits_f32.shape
+    loss_rows = torch.empty(M, dtype=torch.float32, device=logits_f32.device)
+    dl = torch.empty(M, V, dtype=BF16, device=logits_f32.device)
+    _lib.check(_lib.lib().mc_ce_loss_f32(_p(logits_f32), logits_f32.stride(0), _p(labels), _p(loss_rows), _p(dl), dl.stride(0), M, V, inv_n,
+                                         _stream()), "mc_ce_loss_f32")
+    return loss_rows, dl
+
+
+def colsum(x, out=None):
+    M, Cc = x.shape
+    out = torch.empty(Cc, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.check(_lib.lib().mc_colsum_bf16(_p(x), x.stride(0), _p(out), M, Cc, _stream()), "mc_colsum_bf16")
+    return out
+
+
+def rope_inplace(x, row_pos, cos, sin, n_heads, D, sign):
+    _lib.check(_lib.lib().mc_rope_inplace_bf16(_p(x), x.stride(0), _p(row_pos), _p(cos), _p(sin), x.shape[0], n_heads, D, sign, _stream()),
+               "mc_rope_inplace_bf16")
+    return x
+
+
+def attn_prefill_lse(q, k, v, out, lse, B, H, Lq, S, D, q_strides, k_strides, v_strides, o_row_stride, causal, scale=None, kv_lens=None):
+    sc = (1.0 / math.sqrt(D)) if scale is None else scale
+    _lib.check(_lib.lib().mc_attn_prefill_lse_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_row_stride, None,
+                                                   _p(kv_lens), B, H, H, Lq, S, D, 1 if causal else 0, 0, sc, None, 0, 0, None, _p(lse),
+                                                   _stream()), "mc_attn_prefill_lse_bf16")
+    return out
+
+
+def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, S, D, q_strides, k_strides, v_strides, o_strides, dq_strides, dk_strides, dv_strides,
+             causal, scale=None, kv_lens=None):
+    delta = torch.empty(B * H * Lq, dtype=torch.float32, device=q.device)
+    a = _lib.AttnBwdArgsC(q.data_ptr(), *q_strides, k.data_ptr(), *k_strides, v.data_ptr(), *v_strides, o.data_ptr(), d_o.data_ptr(), *o_strides,
+                          lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), *dq_strides, dk.data_ptr(), *dk_strides, dv.data_ptr(), *dv_strides,
+                          0 if kv_lens is None else kv_lens.data_ptr(), B, H, Lq, S, D, 1 if causal else 0, 0,
+                          (1.0 / math.sqrt(D)) if scale is None else scale)
+    _lib.check(_lib.lib().mc_attn_bwd_bf16(C.byref(a), _stream()), "mc_attn_bwd_bf16")
+
+
+def adamw(p32, g32, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    _lib.check(_lib.lib().mc_adamw_f32(_p(p32), _p(g32), _p(m), _p(v), _p(p16), p32.numel(), lr, beta1, beta2, eps, wd, step, grad_scale, _stream()),
+               "mc_adamw_f32")
+
+
+def cast_bf16(x32, out=None):
+    out = torch.empty(x32.shape, dtype=BF16, device=x32.device) if out is None else out
+    _lib.check(_lib.lib().mc_cast_f32_bf16(_p(x32), _p(out), x32.numel(), _stream()), "mc_cast_f32_bf16")
+    return out

@@ -17,6 +17,7 @@ Groups:
   g6  merge script file-level outputs
   g7  dense-merge equivalence
   g8  tiny 4-modality composed model end to end (all encoders + projectors + routed LLM + greedy ids)
+  g9  stage-2 finetune step: loss + gradients of the trainable set
 """
 from __future__ import annotations
 
@@ -716,8 +717,67 @@ def g5_imagebind():
     _save("g5_imagebind", meta=np.array(json.dumps(meta)), **arrays)
 
 
+def g9():
+    """Stage-2 finetune step in miniature (BASELINE config 5): vision-only LocalLoRA model (adapters default + vision, no reset
+    string), labels with IGNORE_INDEX over the prompt, loss = shifted cross-entropy (multimodal_llama.py:722-733) and its gradients
+    w.r.t. the trainable set of train_multimodal.py:436-465 with lora_strategy='modal+language': every lora_A/lora_B, the
+    mm_projector, prefix/suffix tokens.  lora_dropout = 0 so the step is deterministic."""
+    ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
+    ce = refshim.import_ref("modelcompose.model.multimodal_encoder.clip_encoder")
+    pb = refshim.import_ref("modelcompose.model.multimodal_projector.builder")
+    with tempfile.TemporaryDirectory() as tmp:
+        clip_dir, ccfg = _tiny_clip_dir(tmp, hidden=128, layers=3, heads=2, inter=256)
+        torch.manual_seed(94)
+        cfg = tiny_llm_config(ml, modal=("vision",), reset=None, layers=2, prefix_tokens=2, hidden=128, heads=2, inter=192, vocab=128,
+                              r=32, alpha=64)
+        cfg.mm_vision_encoder = clip_dir
+        cfg.mm_vision_select_layer, cfg.mm_vision_select_feature, cfg.mm_projector_type = -2, "patch", "mlp2x_gelu"
+        model = ml.MultimodalLlamaForCausalLM(cfg).eval()
+        args = types.SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature="patch")
+        tower = ce.CLIPVisionTower(clip_dir, args, delay_load=False)
+        pcfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=ccfg.hidden_size, hidden_size=cfg.hidden_size)
+        proj = pb.build_vision_projector(pcfg)
+        for p_ in proj.parameters():
+            p_.data = torch.randn_like(p_) * 0.1
+        model.model.modal_encoders = nn.ModuleDict({"vision": tower})
+        model.model.modal_projectors = nn.ModuleDict({"vision": proj})
+        _randomize_lora(model, 11)
+        # trainable set (train_multimodal.py:436-465, lora_strategy='modal+language')
+        model.requires_grad_(False)
+        train = {}
+        for n, p_ in model.named_parameters():
+            if "prefix_tokens" in n or "suffix_tokens" in n or "lora" in n or n.startswith("model.modal_projectors."):
+                p_.requires_grad = True
+                train[n] = p_
+        B, V = 3, -200
+        g = torch.Generator().manual_seed(95)
+        ids = torch.cat([torch.ones(B, 1, dtype=torch.long), torch.randint(3, 97, (B, 3), generator=g), torch.full((B, 1), V),
+                         torch.full((B, 1), 13), torch.randint(3, 97, (B, 9), generator=g)], dim=1)
+        labels = ids.clone()
+        labels[:, :8] = -100                      # prompt (incl. the image sentinel) is not a target
+        labels[1, 12:] = -100                     # ragged answer lengths
+        pixels = torch.randn(B, 3, 28, 28, generator=g)
+        out = model(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool), labels=labels, modal_inputs={"vision": pixels})
+        out.loss.backward()
+        arrays = dict(input_ids=ids, labels=labels, pixels=pixels, loss=out.loss.detach(), logits=out.logits.detach())
+        for n, p_ in train.items():
+            if p_.grad is None:                  # e.g. prefix_tokens.default: no text-modality block is ever spliced
+                assert n.endswith("_tokens.default"), n
+                continue
+            arrays["grad::" + n] = p_.grad
+        arrays.update(_sd(model, clip_prefix="model.modal_encoders.vision.vision_tower."))
+        extra = {"modal_names": model.modal_names, "mm_projector_type": "mlp2x_gelu", "mm_vision_select_layer": -2,
+                 "clip": {"hidden_size": ccfg.hidden_size, "intermediate_size": ccfg.intermediate_size,
+                          "num_hidden_layers": ccfg.num_hidden_layers, "num_attention_heads": ccfg.num_attention_heads,
+                          "image_size": ccfg.image_size, "patch_size": ccfg.patch_size,
+                          "layer_norm_eps": ccfg.layer_norm_eps, "hidden_act": ccfg.hidden_act}}
+        d = json.loads(cfg_json(cfg, extra))
+        d["mm_vision_encoder"] = "clip-tiny"
+        _save("g9_train_step", meta=np.array(json.dumps(d)), **arrays)
+
+
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
-          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8}
+          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9}
 
 
 def main(argv):

@@ -237,3 +237,18 @@ def test_g5_pointbert_encoder():
     y, cidx, idx, center = ex.pointbert_encode(a["points"], sd, cfg, a["fps_start"], return_aux=True)
     assert torch.equal(center, a["center"])                      # FPS selection is index work: bit-exact
     torch.testing.assert_close(y, a["features"], rtol=2e-4, atol=5e-5)
+
+
+def test_g9_training_step_loss_and_gradients():
+    """Stage-2 finetune step (BASELINE config 5 in miniature): the oracle's autograd loss / gradients against the reference's
+    own loss.backward() on the same weights and batch."""
+    from oracle import train
+    a, meta, sd = load_golden("g9_train_step")
+    loss, logits, grads = train.loss_and_grads(sd, meta, a["input_ids"], a["labels"], {"vision": a["pixels"]})
+    torch.testing.assert_close(loss, a["loss"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(logits, a["logits"], rtol=2e-4, atol=5e-5)
+    ref = {k[6:]: v for k, v in a.items() if k.startswith("grad::")}
+    assert sorted(grads) == sorted(ref)
+    for k, g in ref.items():
+        scale = g.abs().max().item()
+        assert (grads[k] - g).abs().max().item() <= 2e-4 * scale + 1e-8, k
