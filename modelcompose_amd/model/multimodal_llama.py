@@ -138,6 +138,7 @@ class MultimodalLlamaForCausalLM:
             elif k.startswith("model.modal_projectors."):
                 m, rest = k[len("model.modal_projectors."):].split(".", 1)
                 proj_sd.setdefault(m, {})[rest] = v
+                self._raw[k] = v                                      # trainable in stage 2: the training step needs the master copy
             elif k.startswith("prefix_tokens.") or k.startswith("suffix_tokens."):
                 which, m = k.split(".", 1)
                 d = getattr(self, which) or {}

@@ -1,0 +1,398 @@
+"""One stage-2 finetune step (forward + backward + gradient all-reduce + AdamW) of the LocalLoRA model on the HIP path.
+
+Host-side mirror of what `modelcompose/train/train_multimodal.py` asks HF Trainer / DeepSpeed / autograd to do for one batch:
+  forward   MultimodalLlamaForCausalLM.forward with labels (multimodal_llama.py:676-745): splice -> 32 x decoder layer in the
+            branch form y = x W^T + s_a B_a (A_a x) with the adapter chosen per token (:120-160, :262-268) -> lm_head ->
+            shifted CrossEntropyLoss (:722-733)
+  backward  gradients of the trainable set of train_multimodal.py:436-465 (lora_strategy 'modal+language': every lora_A/lora_B,
+            the modal projectors, prefix/suffix tokens); base weights, norms, embeddings, lm_head and encoders are frozen
+  exchange  data-parallel gradient all-reduce (the reference: DeepSpeed ZeRO-2/3 over NCCL; here torch.distributed = RCCL over
+            xGMI, bucketed and overlapped with the backward pass), then AdamW on fp32 master weights.
+Every tensor op is a kernel of libmc_hip.so; torch provides memory, streams and the collective.
+
+Restructuring that keeps the function:
+  * rows stay in sequence order (row = b*L + t); the per-token adapter mask-sum (:262-268) is applied to the rank-r activations:
+    T = x [A_0; A_1; ..]^T  ([M, n_adapters*r]), row m keeps the r columns of its adapter (zero elsewhere), y += s T [B_0 | B_1 | ..]^T.
+    One pair of skinny GEMMs serves all adapters, and the same mask routes the gradients.
+  * nothing is recomputed: activations of all layers stay resident (≈0.4 GB per layer at B=4, L=682 — the reference checkpoints
+    per layer, multimodal_llama.py:567-583, because it targets 80 GB parts).
+Limits of this version (raise, never fall back): equal-length samples without padding, MLP / linear projectors only,
+lora_dropout must be 0 (the reference applies nn.Dropout(0.05) to the LoRA input in training, multimodal_llama.py:133)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..constants import IGNORE_INDEX
+from ..model.config import MultimodalConfig, adapter_plan, infer_modals
+from ..model.multimodal_llama import MultimodalLlamaForCausalLM
+from ..model.projector import HipMlpProjector
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+LINS = (("self_attn", "q_proj"), ("self_attn", "k_proj"), ("self_attn", "v_proj"), ("self_attn", "o_proj"),
+        ("mlp", "gate_proj"), ("mlp", "up_proj"), ("mlp", "down_proj"))
+
+
+class _Param:
+    __slots__ = ("name", "off", "shape", "n")
+
+    def __init__(self, name, off, shape):
+        self.name, self.off, self.shape, self.n = name, off, tuple(shape), int(np.prod(shape))
+
+
+class MultimodalTrainStep:
+    def __init__(self, model: MultimodalLlamaForCausalLM, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 bucket_layers: int = 4, process_group=None):
+        cfg = model.config
+        if float(getattr(cfg, "lora_dropout", 0.0) or 0.0) != 0.0:
+            raise NotImplementedError("lora_dropout > 0 (nn.Dropout on the LoRA input, multimodal_llama.py:133) is not implemented; set it to 0")
+        if cfg.reset_scaling_weights is not None:
+            raise NotImplementedError("training a composed (reset_scaling_weights) checkpoint is not what the reference's stage-2 scripts do")
+        if cfg.num_key_value_heads != cfg.num_attention_heads:
+            raise NotImplementedError("attention backward is MHA only (Vicuna)")
+        self.model, self.cfg, self.dev = model, cfg, model.device
+        self.names, scaling, _, _ = adapter_plan(cfg)                       # ['default', <modal>...]
+        self.nA, self.r = len(self.names), cfg.lora_r
+        self.scale = float(scaling["default"])
+        if any(abs(scaling[n] - self.scale) > 0 for n in self.names):
+            raise NotImplementedError("per-adapter scaling differs")
+        self.R = self.nA * self.r
+        if self.R % 64:
+            raise ValueError(f"n_adapters * lora_r = {self.R} must be a multiple of 64 for the MFMA GEMMs")
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.bucket_layers, self.pg = bucket_layers, process_group
+        self.step_count = 0
+        self._build_frozen()
+        self._build_trainable()
+
+    # ------------------------------------------------------------------ weights
+    def _build_frozen(self):
+        cfg, dev, raw = self.cfg, self.dev, self.model._raw
+        Hd, I, Ln = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        t = lambda k: raw[k].to(dev, BF16)
+        self.layers = []
+        for l in range(Ln):
+            p = f"model.layers.{l}"
+            wqkv = torch.cat([t(f"{p}.self_attn.{n}_proj.weight") for n in "qkv"], 0)
+            wgu = torch.cat([t(f"{p}.mlp.gate_proj.weight"), t(f"{p}.mlp.up_proj.weight")], 0)
+            wo, wd = t(f"{p}.self_attn.o_proj.weight"), t(f"{p}.mlp.down_proj.weight")
+            L = dict(qkv=ops.pack_weight(wqkv), qkvT=ops.pack_weight(wqkv.t().contiguous()), o=ops.pack_weight(wo),
+                     oT=ops.pack_weight(wo.t().contiguous()), gu=ops.pack_weight(wgu), guT=ops.pack_weight(wgu.t().contiguous()),
+                     down=ops.pack_weight(wd), downT=ops.pack_weight(wd.t().contiguous()),
+                     g_in=t(f"{p}.input_layernorm.weight").contiguous(), g_post=t(f"{p}.post_attention_layernorm.weight").contiguous())
+            self.layers.append(L)
+        self.g_final = t("model.norm.weight").contiguous()
+        lm = t("lm_head.weight")
+        self.lm_head, self.lm_headT = ops.pack_weight(lm), ops.pack_weight(lm.t().contiguous())
+        self.embed = self.model.model.embed_tokens if self.model.model.embed_tokens is not None else t("model.embed_tokens.weight").contiguous()
+        D = cfg.head_dim
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=F32) / D))
+        ang = torch.outer(torch.arange(cfg.max_position_embeddings, dtype=F32), inv)
+        self.cos, self.sin = ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous()
+
+    def _build_trainable(self):
+        """Flat fp32 master buffer in backward order (last layer first) so gradient buckets complete early."""
+        cfg, raw = self.cfg, self.model._raw
+        Hd, I, Ln = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        dims = {"q_proj": (Hd, Hd), "k_proj": (Hd, Hd), "v_proj": (Hd, Hd), "o_proj": (Hd, Hd), "gate_proj": (I, Hd), "up_proj": (I, Hd),
+                "down_proj": (Hd, I)}
+        params: List[_Param] = []
+        init: List[torch.Tensor] = []
+        off = 0
+        self.layer_end = {}                                       # layer -> end offset of its block in the flat buffer
+
+        def add(name, tensor):
+            nonlocal off
+            params.append(_Param(name, off, tensor.shape))
+            init.append(tensor.reshape(-1).to(self.dev, F32))
+            off += tensor.numel()
+
+        for l in reversed(range(Ln)):
+            for blk, lin in reversed(LINS):
+                N, K = dims[lin]
+                pre = f"model.layers.{l}.{blk}.{lin}"
+                a = [raw.get(f"{pre}.lora_A.{n}.weight") for n in self.names]
+                b = [raw.get(f"{pre}.lora_B.{n}.weight") for n in self.names]
+                if any(x is None for x in a + b):
+                    raise ValueError(f"{pre}: lora_A/lora_B missing for one of the adapters {self.names}")
+                add(pre + ".A_cat", torch.cat([x.float() for x in a], 0))            # [nA*r, K]
+                add(pre + ".B_cat", torch.cat([x.float() for x in b], 1))            # [N, nA*r]
+            self.layer_end[l] = off
+        self.proj_modals = []
+        for m, proj in self.model.model.modal_projectors.items():
+            if not isinstance(proj, HipMlpProjector):
+                raise NotImplementedError(f"projector of modality '{m}' is not an MLP/linear projector: its backward is not implemented")
+            self.proj_modals.append(m)
+            keys = ["weight"] if proj.depth == 0 else [f"{2 * i}.weight" for i in range(proj.depth)]
+            for k in keys:
+                add(f"model.modal_projectors.{m}.{k}", raw_or_fail(raw, f"model.modal_projectors.{m}.{k}"))
+                add(f"model.modal_projectors.{m}.{k.replace('weight', 'bias')}", raw_or_fail(raw, f"model.modal_projectors.{m}.{k.replace('weight', 'bias')}"))
+        for which in ("prefix_tokens", "suffix_tokens"):
+            d = getattr(self.model, which) or {}
+            for m in d:
+                if m == "default":
+                    continue                                       # never spliced: no gradient (reference: grad None)
+                add(f"{which}.{m}", d[m].float())
+        self.params = {p.name: p for p in params}
+        self.n_params = off
+        dev = self.dev
+        self.P = torch.cat(init)
+        self.G = torch.zeros(off, dtype=F32, device=dev)
+        self.m1, self.m2 = torch.zeros_like(self.G), torch.zeros_like(self.G)
+        self.P16 = ops.cast_bf16(self.P)
+
+    def view(self, buf, name):
+        p = self.params[name]
+        return buf[p.off:p.off + p.n].view(*p.shape)
+
+    def named_gradients(self) -> Dict[str, torch.Tensor]:
+        """Gradients under the reference's parameter names (lora_A.{adapter}.weight ...)."""
+        out = {}
+        for name, p in self.params.items():
+            g = self.view(self.G, name)
+            if name.endswith(".A_cat"):
+                for i, n in enumerate(self.names):
+                    out[name[:-6] + f".lora_A.{n}.weight"] = g[i * self.r:(i + 1) * self.r]
+            elif name.endswith(".B_cat"):
+                for i, n in enumerate(self.names):
+                    out[name[:-6] + f".lora_B.{n}.weight"] = g[:, i * self.r:(i + 1) * self.r]
+            elif name.startswith("prefix_tokens.") or name.startswith("suffix_tokens."):
+                out[name] = g.view(1, *g.shape)
+            else:
+                out[name] = g
+        return out
+
+    # ------------------------------------------------------------------ helpers
+    def _lora_fwd(self, x, y, lname, row_adapter, saved):
+        """y += s * mask(x A_cat^T) B_cat^T   (in place on the view y [M, N])."""
+        A16, B16 = self.view(self.P16, lname + ".A_cat"), self.view(self.P16, lname + ".B_cat")
+        T = ops.linear(x, ops.pack_weight(A16))
+        ops.lora_mask_rows(T, row_adapter, self.r, self.nA)
+        ops.linear(T, ops.pack_weight(B16), residual=y, out=y, alpha=self.scale)
+        saved[lname + ".T"] = T
+
+    def _lora_bwd(self, dy, x, xT_packed, dx, lname, row_adapter, saved, Mp):
+        """dx += s * mask(dy B_cat) A_cat;  dB = s dy^T T;  dA = s mask(dy B_cat)^T x."""
+        A16, B16 = self.view(self.P16, lname + ".A_cat"), self.view(self.P16, lname + ".B_cat")
+        T = saved[lname + ".T"]
+        dT = ops.linear(dy, ops.pack_weight(ops.transpose(B16)))                      # [M, R] = dy . B_cat
+        ops.lora_mask_rows(dT, row_adapter, self.r, self.nA)
+        ops.linear(dT, ops.pack_weight(ops.transpose(A16)), residual=dx, out=dx, alpha=self.scale)
+        dyT = ops.transpose(dy, Rp=Mp)                                                # [N, Mp]
+        ops.linear(dyT, ops.pack_weight(ops.transpose(T, Rp=Mp)), out=self.view(self.G, lname + ".B_cat"), out_f32=True, alpha=self.scale)
+        ops.linear(ops.transpose(dT, Rp=Mp), xT_packed, out=self.view(self.G, lname + ".A_cat"), out_f32=True, alpha=self.scale)
+
+    # ------------------------------------------------------------------ one step
+    def forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
+        """Returns the loss (fp32 scalar tensor); gradients of this rank's batch are left in self.G."""
+        model, cfg, dev = self.model, self.cfg, self.dev
+        Hd, I, Hh, D, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
+        HD = Hh * D
+        eps = cfg.rms_norm_eps
+        if attention_mask is not None and not bool(torch.as_tensor(attention_mask).all()):
+            raise NotImplementedError("padded batches are not implemented in the training step (equal-length samples only)")
+        # ---- encoders (frozen, no gradient) + trainable projector forward with saved pre-activations
+        saved: Dict[str, torch.Tensor] = {}
+        feats = self._encode(modal_inputs, saved)
+        plan = model._plan(input_ids, None, labels, modal_inputs, feats)
+        if not (plan.lens == plan.Lmax).all():
+            raise NotImplementedError("ragged spliced lengths are not implemented in the training step")
+        B, L = plan.B, plan.Lmax
+        M = B * L
+        Mp = ops.ceil_to(M, 64)
+        bb, tt = np.divmod(np.arange(M), L)
+        x = torch.empty(M, Hd, dtype=BF16, device=dev)
+        model._gather_rows(plan, feats, bb, tt, x)
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        row_b, row_t = i32(bb), i32(tt)
+        adapter = np.zeros(M, dtype=np.int32)
+        if cfg.lora_strategy in ("modal", "modal+language"):
+            for i, m in enumerate(plan.modal_order):
+                adapter[(plan.src_modal == i).reshape(-1)] = self.names.index(m)
+        row_adapter = i32(adapter)
+        st_q = (L * HD, HD, D)
+        st_kv = (Hh * L * D, D, L * D)                              # cache layout [B][H][L][D]: (batch, token, head) strides
+        acts = []
+        # ---- forward
+        for l, W in enumerate(self.layers):
+            p = f"model.layers.{l}"
+            a = {"x": x}
+            n1 = ops.rmsnorm(x, W["g_in"], eps)
+            qkv = ops.linear(n1, W["qkv"])
+            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                self._lora_fwd(n1, qkv[:, j * HD:(j + 1) * HD], f"{p}.self_attn.{nm}", row_adapter, saved)
+            q_seq = torch.empty(M, HD, dtype=BF16, device=dev)
+            kc, vc = (torch.empty(B, Hh, L, D, dtype=BF16, device=dev) for _ in range(2))
+            ops.rope_kv(qkv, row_b, row_t, row_t, self.cos, self.sin, q_seq, kc, vc, Hh, Hh, D, L, L)
+            attn = torch.empty(M, HD, dtype=BF16, device=dev)
+            lse = torch.empty(B * Hh * L, dtype=F32, device=dev)
+            ops.attn_prefill_lse(q_seq, kc, vc, attn, lse, B, Hh, L, L, D, st_q, st_kv, st_kv, HD, True)
+            x1 = ops.linear(attn, W["o"], residual=x)
+            self._lora_fwd(attn, x1, f"{p}.self_attn.o_proj", row_adapter, saved)
+            n2 = ops.rmsnorm(x1, W["g_post"], eps)
+            gu = ops.linear(n2, W["gu"])
+            self._lora_fwd(n2, gu[:, :I], f"{p}.mlp.gate_proj", row_adapter, saved)
+            self._lora_fwd(n2, gu[:, I:], f"{p}.mlp.up_proj", row_adapter, saved)
+            inter = ops.silu_mul(gu, I)
+            x2 = ops.linear(inter, W["down"], residual=x1)
+            self._lora_fwd(inter, x2, f"{p}.mlp.down_proj", row_adapter, saved)
+            a.update(n1=n1, q=q_seq, kc=kc, vc=vc, attn=attn, lse=lse, x1=x1, n2=n2, gu=gu, inter=inter)
+            acts.append(a)
+            x = x2
+        nf = ops.rmsnorm(x, self.g_final, eps)
+        logits = ops.linear(nf, self.lm_head, out_f32=True)
+        # ---- shifted cross-entropy (:722-733): row (b, t) predicts labels[b, t + 1]
+        lab = np.full((B, L), IGNORE_INDEX, dtype=np.int64)
+        lab[:, :-1] = plan.labels[:, 1:]
+        n_valid = int((lab != IGNORE_INDEX).sum())
+        if n_valid == 0:
+            raise ValueError("no target token in the batch (all labels are IGNORE_INDEX)")
+        loss_rows, dlogits = ops.ce_loss(logits, torch.from_numpy(lab.reshape(-1)).to(dev), 1.0 / n_valid)
+        loss = loss_rows.sum() / n_valid
+        # ---- backward
+        dnf = ops.linear(dlogits, self.lm_headT)
+        dx = ops.rmsnorm_bwd(x, self.g_final, dnf, eps)
+        handles = []
+        for l in reversed(range(len(self.layers))):
+            W, a, p = self.layers[l], acts[l], f"model.layers.{l}"
+            packT = lambda t_: ops.pack_weight(ops.transpose(t_, Rp=Mp))               # activation^T as the wgrad "weight" operand
+            # down_proj
+            d_inter = ops.linear(dx, W["downT"])
+            self._lora_bwd(dx, a["inter"], packT(a["inter"]), d_inter, f"{p}.mlp.down_proj", row_adapter, saved, Mp)
+            dgu = ops.swiglu_bwd(a["gu"], d_inter)
+            dn2 = ops.linear(dgu, W["guT"])
+            n2T = packT(a["n2"])
+            self._lora_bwd(dgu[:, I:], a["n2"], n2T, dn2, f"{p}.mlp.up_proj", row_adapter, saved, Mp)
+            self._lora_bwd(dgu[:, :I], a["n2"], n2T, dn2, f"{p}.mlp.gate_proj", row_adapter, saved, Mp)
+            dx1 = ops.rmsnorm_bwd(a["x1"], W["g_post"], dn2, eps, dres=dx)
+            # o_proj
+            d_attn = ops.linear(dx1, W["oT"])
+            self._lora_bwd(dx1, a["attn"], packT(a["attn"]), d_attn, f"{p}.self_attn.o_proj", row_adapter, saved, Mp)
+            # attention + RoPE
+            dqkv = torch.empty(M, 3 * HD, dtype=BF16, device=dev)
+            st3 = (L * 3 * HD, 3 * HD, D)
+            ops.attn_bwd(a["q"], a["kc"], a["vc"], a["attn"], d_attn, a["lse"], dqkv, dqkv[:, HD:], dqkv[:, 2 * HD:], B, Hh, L, L, D,
+                         st_q, st_kv, st_kv, st_q, st3, st3, st3, True)
+            ops.rope_inplace(dqkv, row_t, self.cos, self.sin, 2 * Hh, D, -1.0)
+            dn1 = ops.linear(dqkv, W["qkvT"])
+            n1T = packT(a["n1"])
+            for j, nm in reversed(list(enumerate(("q_proj", "k_proj", "v_proj")))):
+                self._lora_bwd(dqkv[:, j * HD:(j + 1) * HD], a["n1"], n1T, dn1, f"{p}.self_attn.{nm}", row_adapter, saved, Mp)
+            dx = ops.rmsnorm_bwd(a["x"], W["g_in"], dn1, eps, dres=dx1)
+            acts[l] = None
+            if self.pg is not None and (l % self.bucket_layers == 0):
+                # layers l .. l+k-1 occupy [end of layer l+k, end of layer l) of the flat buffer (last layer first)
+                lo = 0 if l + self.bucket_layers >= len(self.layers) else self.layer_end[l + self.bucket_layers]
+                handles.append(self._allreduce_async(lo, self.layer_end[l]))
+        # ---- spliced feature blocks -> prefix / suffix tokens and the projectors
+        self._backward_features(dx, plan, feats, saved)
+        if self.pg is not None:
+            handles.append(self._allreduce_async(self.layer_end[0], self.n_params))
+            for h in handles:
+                h.wait()
+        return loss
+
+    # ------------------------------------------------------------------ encoders / projectors
+    def _encode(self, modal_inputs, saved):
+        model, dev = self.model, self.dev
+        feats = {}
+        for modal in [m for m in model.modal_names if m != "default"]:
+            if modal not in modal_inputs:
+                continue
+            enc = model.model.get_modal_encoder(modal)
+            f = enc(modal_inputs[modal])
+            if modal == "video":
+                b, t, n, d = f.shape
+                f = f.reshape(b, t * n, d)
+            f = f.to(BF16).contiguous()
+            nI, T, Dm = f.shape
+            proj = model.model.modal_projectors[modal]
+            h = f.view(nI * T, Dm)
+            saved[f"proj.{modal}.in"] = h
+            keys = ["weight"] if proj.depth == 0 else [f"{2 * i}.weight" for i in range(proj.depth)]
+            for i, k in enumerate(keys):
+                w16 = self.view(self.P16, f"model.modal_projectors.{modal}.{k}")
+                b16 = self.view(self.P16, f"model.modal_projectors.{modal}.{k.replace('weight', 'bias')}")
+                if i > 0:
+                    saved[f"proj.{modal}.pre{i}"] = h
+                    h = ops.act(h, "gelu")
+                    saved[f"proj.{modal}.h{i}"] = h
+                hin = h if h.shape[1] % 64 == 0 else torch.nn.functional.pad(h, (0, ops.ceil_to(h.shape[1], 64) - h.shape[1]))
+                h = ops.linear(hin, ops.pack_weight(w16, b16))
+            out = h.view(nI, T, -1)
+            parts = []
+            pre = self.params.get(f"prefix_tokens.{modal}")
+            suf = self.params.get(f"suffix_tokens.{modal}")
+            if pre is not None:
+                parts.append(self.view(self.P16, pre.name).view(1, -1, out.shape[-1]).expand(nI, -1, -1))
+            parts.append(out)
+            if suf is not None:
+                parts.append(self.view(self.P16, suf.name).view(1, -1, out.shape[-1]).expand(nI, -1, -1))
+            from ..model.multimodal_llama import _cat_rows
+            feats[modal] = _cat_rows(parts).contiguous() if len(parts) > 1 else out.contiguous()
+            saved[f"proj.{modal}.nI"], saved[f"proj.{modal}.T"] = nI, T
+        return feats
+
+    def _backward_features(self, dx, plan, feats, saved):
+        dev, Hd = self.dev, self.cfg.hidden_size
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        sm, sr = plan.src_modal.reshape(-1), plan.src_row.reshape(-1)
+        for i, modal in enumerate(plan.modal_order):
+            rows = np.nonzero(sm == i)[0]
+            nI, T = saved[f"proj.{modal}.nI"], saved[f"proj.{modal}.T"]
+            Tb = feats[modal].shape[1]
+            dblk = torch.zeros(nI * Tb, Hd, dtype=BF16, device=dev)                  # items that were not spliced keep zero gradient
+            if len(rows):
+                ops.copy_rows(dx, dblk, len(rows), i32(rows), i32(sr[rows]))
+            pre, suf = self.params.get(f"prefix_tokens.{modal}"), self.params.get(f"suffix_tokens.{modal}")
+            n_pre = pre.shape[0] if pre is not None else 0
+            n_suf = suf.shape[0] if suf is not None else 0
+            if n_pre or n_suf:
+                tok = ops.colsum(dblk.view(nI, Tb * Hd)).view(Tb, Hd)                  # sum over items (tokens are shared: .expand)
+                if n_pre:
+                    self.view(self.G, pre.name).copy_(tok[:n_pre])
+                if n_suf:
+                    self.view(self.G, suf.name).copy_(tok[Tb - n_suf:])
+            dout = dblk.view(nI, Tb, Hd)[:, n_pre:Tb - n_suf].reshape(nI * T, Hd).contiguous() if (n_pre or n_suf) else dblk
+            proj = self.model.model.modal_projectors[modal]
+            keys = ["weight"] if proj.depth == 0 else [f"{2 * k}.weight" for k in range(proj.depth)]
+            Mf = nI * T
+            Mfp = ops.ceil_to(Mf, 64)
+            d = dout
+            for k_i in reversed(range(len(keys))):
+                k = keys[k_i]
+                wname = f"model.modal_projectors.{modal}.{k}"
+                hin = saved[f"proj.{modal}.h{k_i}"] if k_i > 0 else saved[f"proj.{modal}.in"]
+                # dW[o][i] = sum_m d[m][o] hin[m][i];  db = colsum(d)
+                ops.linear(ops.transpose(d, Rp=Mfp), ops.pack_weight(ops.transpose(hin, Rp=Mfp)), out=self.view(self.G, wname), out_f32=True)
+                ops.colsum(d, out=self.view(self.G, wname.replace("weight", "bias")))
+                if k_i > 0:
+                    w16 = self.view(self.P16, wname)
+                    dh = ops.linear(d, ops.pack_weight(ops.transpose(w16)))
+                    d = ops.act(saved[f"proj.{modal}.pre{k_i}"], "gelu", dy=dh)
+
+    # ------------------------------------------------------------------ exchange + update
+    def _allreduce_async(self, lo, hi):
+        import torch.distributed as dist
+        return dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def optimizer_step(self, world_size: int = 1):
+        self.step_count += 1
+        ops.adamw(self.P, self.G, self.m1, self.m2, self.P16, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
+                  grad_scale=1.0 / world_size)
+
+    def step(self, input_ids, labels, modal_inputs, world_size: int = 1) -> torch.Tensor:
+        loss = self.forward_backward(input_ids, labels, modal_inputs)
+        self.optimizer_step(world_size)
+        return loss
+
+
+def raw_or_fail(raw, key):
+    if key not in raw:
+        raise ValueError(f"state dict lacks {key}")
+    return raw[key]
