@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--workload", default="generate", choices=["generate", "train"],
+                    help="generate = BASELINE configs[1] (the headline metric); train = configs[4], the stage-2 finetune step "
+                         "(forward + backward + gradient all-reduce + AdamW), per-GPU batch 4")
     return ap.parse_args()
 
 
@@ -78,6 +81,60 @@ def cpu_baseline(new_tokens: int):
                       f"per-layer cost x32 + measured fixed cost (CLIP-L/14-336, projector, lm_head) = {full:.1f}s per sample"}
 
 
+def train_main(args, world, rank, local):
+    """BASELINE configs[4]: stage-2 finetune step of the vision LocalLoRA model (adapters default + vision, r=128), per-GPU batch 4
+    synthetic image-text pairs (683-token spliced sequence, the last 60 tokens are targets), bf16 compute, fp32 master weights;
+    a step = forward + backward + bucketed RCCL gradient all-reduce + AdamW.  value = samples/s over all ranks."""
+    from modelcompose_amd import synthetic
+    from modelcompose_amd.model.builder import build_from_state_dict
+    from modelcompose_amd.train import MultimodalTrainStep
+    dev = torch.device("cuda", local)
+    meta = synthetic.vicuna7b_meta(("vision",), None, layers=args.layers)
+    meta["lora_dropout"] = 0.0
+    sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
+    model = build_from_state_dict(meta, sd, device=dev)
+    st = MultimodalTrainStep(model, lr=2e-4)
+    del sd
+    model._raw = {}
+    torch.cuda.empty_cache()
+    B = 4 if args.batch == 16 else args.batch
+    ids = synthetic.synthetic_prompt(B, [-200], seed=rank).to(dev)
+    labels = ids.clone()
+    labels[:, :-60] = -100
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    pixels = torch.randn(B, 3, 336, 336, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = st.step(ids, labels, {"vision": pixels})
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = st.step(ids, labels, {"vision": pixels})
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "samples/sec (whole node) stage-2 finetune step, composed Vicuna-7B", "value": round(world * B * args.steps / dt, 4),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[4]: stage-2 finetune step, vision LocalLoRA Vicuna-7B (r128, default+vision adapters), "
+                                   f"batch {B} per GPU, 683-token sequences, fwd+bwd+all-reduce+AdamW", "per_gpu_batch": B,
+                       "layers": args.layers, "parallelism": f"ddp{world}", "trainable_params": int(st.n_params),
+                       "final_loss": float(loss.item())}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,6 +146,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if args.workload == "train":
+        return train_main(args, world, rank, local)
     from modelcompose_amd import _lib, synthetic
     from modelcompose_amd.dist import gather_ids
     from modelcompose_amd.model.builder import build_from_state_dict

@@ -31,6 +31,7 @@ from ..constants import IGNORE_INDEX
 from ..model.config import MultimodalConfig, adapter_plan, infer_modals
 from ..model.multimodal_llama import MultimodalLlamaForCausalLM
 from ..model.projector import HipMlpProjector
+from .buckets import bucket_ranges
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -66,9 +67,17 @@ class MultimodalTrainStep:
             raise ValueError(f"n_adapters * lora_r = {self.R} must be a multiple of 64 for the MFMA GEMMs")
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.bucket_layers, self.pg = bucket_layers, process_group
+        self.world = 1
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.world = dist.get_world_size(process_group)
+        except Exception:
+            self.world = 1
         self.step_count = 0
         self._build_frozen()
         self._build_trainable()
+        self._buckets = bucket_ranges(self.layer_end, cfg.num_hidden_layers, bucket_layers, self.n_params)
 
     # ------------------------------------------------------------------ weights
     def _build_frozen(self):
@@ -285,14 +294,16 @@ class MultimodalTrainStep:
                 self._lora_bwd(dqkv[:, j * HD:(j + 1) * HD], a["n1"], n1T, dn1, f"{p}.self_attn.{nm}", row_adapter, saved, Mp)
             dx = ops.rmsnorm_bwd(a["x"], W["g_in"], dn1, eps, dres=dx1)
             acts[l] = None
-            if self.pg is not None and (l % self.bucket_layers == 0):
-                # layers l .. l+k-1 occupy [end of layer l+k, end of layer l) of the flat buffer (last layer first)
-                lo = 0 if l + self.bucket_layers >= len(self.layers) else self.layer_end[l + self.bucket_layers]
-                handles.append(self._allreduce_async(lo, self.layer_end[l]))
+            if self.world > 1:
+                for (ready, lo, hi) in self._buckets:
+                    if ready == l:
+                        handles.append(self._allreduce_async(lo, hi))
         # ---- spliced feature blocks -> prefix / suffix tokens and the projectors
         self._backward_features(dx, plan, feats, saved)
-        if self.pg is not None:
-            handles.append(self._allreduce_async(self.layer_end[0], self.n_params))
+        if self.world > 1:
+            for (ready, lo, hi) in self._buckets:
+                if ready == -1:
+                    handles.append(self._allreduce_async(lo, hi))
             for h in handles:
                 h.wait()
         return loss
@@ -381,14 +392,15 @@ class MultimodalTrainStep:
         import torch.distributed as dist
         return dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
-    def optimizer_step(self, world_size: int = 1):
+    def optimizer_step(self):
+        """AdamW on the mean gradient over ranks (DDP semantics: all-reduce SUM, then 1 / world_size)."""
         self.step_count += 1
         ops.adamw(self.P, self.G, self.m1, self.m2, self.P16, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
-                  grad_scale=1.0 / world_size)
+                  grad_scale=1.0 / self.world)
 
-    def step(self, input_ids, labels, modal_inputs, world_size: int = 1) -> torch.Tensor:
+    def step(self, input_ids, labels, modal_inputs) -> torch.Tensor:
         loss = self.forward_backward(input_ids, labels, modal_inputs)
-        self.optimizer_step(world_size)
+        self.optimizer_step()
         return loss
 
 
