@@ -191,6 +191,8 @@ def main():
     L.mc_gemm_profile_enable(0)
     ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
     L.mc_gemm_profile_read(C.byref(ms), C.byref(fl), C.byref(n))
+    alg_bytes = C.c_double(0)
+    L.mc_gemm_profile_read_bytes(C.byref(alg_bytes))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -221,7 +223,8 @@ def main():
                      "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                      "traffic": traffic, "launches": int(n.value),
                      "avg_launch_us": round(ms.value / max(n.value, 1) * 1e3, 2),
-                     "avg_flops_per_launch": fl.value / max(n.value, 1)},
+                     "avg_flops_per_launch": fl.value / max(n.value, 1),
+                     "avg_algorithmic_bytes_per_launch": alg_bytes.value / max(n.value, 1)},
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.new_tokens)

@@ -76,6 +76,7 @@ int mc_gemm_ex_bf16(const mc_gemm_args* args, void* stream);
 int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgroup computes tile (0,0)) */
 int mc_gemm_profile_enable(int on);
 int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches);
+int mc_gemm_profile_read_bytes(double* total_bytes);   /* algorithmic HBM bytes (operands read once, output written once) of the same launches */
 
 /* ---- norms: LlamaRMSNorm (multimodal_llama.py:405-406, :482) / nn.LayerNorm (CLIP blocks) -------------- */
 int mc_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* out, int64_t ldo, int M, int D, float eps, void* stream);

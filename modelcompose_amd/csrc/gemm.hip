@@ -652,7 +652,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
 // Optional live timing of the dominant kernel (gemm_tile256_kernel): HIP events recorded on the launch stream around every launch while
 // enabled (bench.py's roofline object).  Not graph-capturable; leave disabled in normal operation.
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; };
 bool g_prof_on = false;
 int g_gemm_dbg = 0;
 std::vector<ProfRec> g_prof;
@@ -691,6 +691,13 @@ extern "C" int mc_gemm_profile_read(double* total_ms, double* total_flops, int64
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
     if (launches) *launches = (int64_t)g_prof.size();
+    return 0;
+}
+
+extern "C" int mc_gemm_profile_read_bytes(double* total_bytes) {
+    double by = 0.0;
+    for (auto& r : g_prof) by += r.bytes;
+    if (total_bytes) *total_bytes = by;
     return 0;
 }
 
@@ -813,6 +820,9 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
         if (g_prof_on) {
             (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);
             rec.flops = 2.0 * M * (double)N * K;
+            // algorithmic HBM bytes: x and W read once, the output written once (half as wide with the fused SwiGLU), residual read once
+            rec.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (a->swiglu ? N / 2 : N) * (a->out_f32 ? 2 : 1) +
+                               (a->residual ? (double)M * N : 0.0));
             (void)hipEventRecord(rec.a, s);
         }
 #define G2_LAUNCH(A, G) gemm_tile256_kernel<A, G><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep, tiles_m, tiles_n)
