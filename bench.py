@@ -41,9 +41,10 @@ def parse():
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--workload", default="generate", choices=["generate", "train"],
+    ap.add_argument("--workload", default="generate", choices=["generate", "train", "mcub4"],
                     help="generate = BASELINE configs[1] (the headline metric); train = configs[4], the stage-2 finetune step "
-                         "(forward + backward + gradient all-reduce + AdamW), per-GPU batch 4")
+                         "(forward + backward + gradient all-reduce + AdamW), per-GPU batch 4; mcub4 = configs[3], the 4-modality "
+                         "composed model on MCUB-4-shaped inputs (image + 10 s audio + 8-frame video + 8192-point cloud), per-GPU batch 2")
     return ap.parse_args()
 
 
@@ -135,6 +136,71 @@ def train_main(args, world, rank, local):
         torch.distributed.destroy_process_group()
 
 
+def mcub4_main(args, world, rank, local):
+    """BASELINE configs[3]: vision + audio + video + point composed Vicuna-7B (online-merge-reset, 4 x 0.25), MCUB-4-shaped synthetic
+    inputs: 336 px image, 1024x128 fbank (10 s), 8 x 224 px frames, 8192 x 6 point cloud; spliced length 3337; greedy decode."""
+    from modelcompose_amd import synthetic
+    from modelcompose_amd.dist import gather_ids
+    from modelcompose_amd.model.builder import build_from_state_dict
+    dev = torch.device("cuda", local)
+    modals = ("vision", "audio", "video", "point")
+    reset = ",".join(f"default-{m}=0.25" for m in modals)
+    meta = synthetic.vicuna7b_meta(modals, reset, layers=args.layers)
+    sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
+    model = build_from_state_dict(meta, sd, device=dev)
+    del sd
+    model._raw = {}
+    torch.cuda.empty_cache()
+    B = 2 if args.batch == 16 else args.batch
+    ids = synthetic.synthetic_prompt(B, [-200, -203, -204, -205], seed=rank).to(dev)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
+    fbank = rnd(B, 1024, 128) * 0.5
+    fbank[:, 998:] = 0
+    xyz = rnd(B, 8192, 3)
+    xyz = xyz / xyz.norm(dim=-1, keepdim=True).clamp_min(1e-6) * torch.rand(B, 8192, 1, generator=g, device=dev) ** (1 / 3)
+    mi = {"vision": rnd(B, 3, 336, 336).to(torch.bfloat16),
+          "audio": {"audio_inputs": fbank.to(torch.bfloat16), "audio_padding_mask": torch.zeros(B, 1024, dtype=torch.bool, device=dev)},
+          "video": rnd(B, 3, 8, 224, 224).to(torch.bfloat16),
+          "point": torch.cat([xyz, torch.rand(B, 8192, 3, generator=g, device=dev)], -1).to(torch.bfloat16)}
+    model.model.modal_encoders["point"].fps_start = torch.zeros(B, dtype=torch.long)
+
+    def step():
+        out = model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True)
+        return gather_ids(out[:, ids.shape[1]:], world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        feats, _ = model.encode_modal_inputs(mi, model.prefix_tokens, model.suffix_tokens)
+        print(json.dumps({
+            "metric": "samples/sec (whole node) composed-Vicuna-7B greedy gen, img+audio+video+point", "value": round(world * B * args.steps / dt, 4),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[3]: 4-modality composed Vicuna-7B (online-merge-reset 4 x 0.25; 9 adapters), MCUB-4-shaped inputs, "
+                                   f"batch {B} per GPU, {args.new_tokens} greedy tokens", "per_gpu_batch": B, "new_tokens": args.new_tokens,
+                       "layers": args.layers, "parallelism": f"dp{world}",
+                       "spliced_length": int(ids.shape[1] - 4 + sum(f.shape[1] for f in feats.values())),
+                       "block_tokens": {m: int(f.shape[1]) for m, f in feats.items()}, "ids_shape": list(out.shape)}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,6 +214,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if args.workload == "train":
         return train_main(args, world, rank, local)
+    if args.workload == "mcub4":
+        return mcub4_main(args, world, rank, local)
     from modelcompose_amd import _lib, synthetic
     from modelcompose_amd.dist import gather_ids
     from modelcompose_amd.model.builder import build_from_state_dict

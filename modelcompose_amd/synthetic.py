@@ -20,6 +20,22 @@ def vicuna7b_meta(modals: Sequence[str] = ("vision",), reset: Optional[str] = No
     if "vision" in modals:
         meta["clip"] = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336,
                             patch_size=14, layer_norm_eps=1e-5, hidden_act="quick_gelu")
+    if "audio" in modals:      # BEATs_iter3+ (beats/BEATs.py:25-65 + checkpoint cfg) and the 32-query, 2-layer Q-Former (run_finetune_audio_damc.sh:37-38)
+        meta["beats"] = dict(input_patch_size=16, embed_dim=512, conv_bias=False, encoder_layers=12, encoder_embed_dim=768,
+                             encoder_ffn_embed_dim=3072, encoder_attention_heads=12, activation_fn="gelu", layer_norm_first=False,
+                             deep_norm=True, conv_pos=128, conv_pos_groups=16, relative_position_embedding=True, num_buckets=320,
+                             max_distance=800, gru_rel_pos=True)
+        meta["qformer"] = dict(hidden_size=768, num_attention_heads=12, intermediate_size=3072, num_hidden_layers=2, layer_norm_eps=1e-12,
+                               num_query_token=32, encoder_width=768, num_positions=1024)
+        meta["mm_audio_projector_type"], meta["mm_audio_hidden_size"] = "qformer_32N_2L", 768
+    if "video" in modals:      # LanguageBind_Video_merge: ViT-L/14 at 224 px, 8 frames, temporal attention in every layer
+        meta["video"] = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224,
+                             patch_size=14, num_frames=8, add_time_attn=True, layer_norm_eps=1e-5, hidden_act="quick_gelu")
+        meta["mm_video_projector_type"], meta["mm_video_hidden_size"], meta["mm_video_select_layer"] = "mlp2x_gelu", 1024, -2
+    if "point" in modals:      # pointbert/PointTransformer_8192point_2layer.yaml
+        meta["point"] = dict(trans_dim=384, depth=12, num_heads=6, group_size=32, num_group=512, encoder_dims=256, point_dims=6,
+                             use_max_pool=False)
+        meta["mm_point_projector_type"], meta["mm_point_hidden_size"] = "mlp2x_gelu", 384
     order = ["default"] + [m for m in ("audio", "vision", "video", "point") if m in modals]
     meta["modal_names"] = order
     return meta
@@ -85,6 +101,84 @@ def synthetic_state_dict(meta: dict, device="cuda", seed: int = 1234, dtype=torc
             sd[q + "mlp.fc2.weight"] = nrm(Dm, Im); sd[q + "mlp.fc2.bias"] = nrm(Dm)
         sd["model.modal_projectors.vision.0.weight"] = nrm(Hd, Dm); sd["model.modal_projectors.vision.0.bias"] = nrm(Hd)
         sd["model.modal_projectors.vision.2.weight"] = nrm(Hd, Hd); sd["model.modal_projectors.vision.2.bias"] = nrm(Hd)
+    ones = lambda n: torch.ones(n, device=device, dtype=dtype)
+    zeros = lambda n: torch.zeros(n, device=device, dtype=dtype)
+
+    def ln(prefix, n):
+        sd[prefix + ".weight"], sd[prefix + ".bias"] = ones(n), zeros(n)
+
+    def lin(prefix, out_f, in_f, bias=True):
+        sd[prefix + ".weight"] = nrm(out_f, in_f)
+        if bias:
+            sd[prefix + ".bias"] = nrm(out_f)
+
+    def mlp2x(modal, in_f):
+        lin(f"model.modal_projectors.{modal}.0", Hd, in_f)
+        lin(f"model.modal_projectors.{modal}.2", Hd, Hd)
+
+    if "beats" in meta:
+        c, pre = meta["beats"], "model.modal_encoders.audio.audio_encoder."
+        E, C, Fd, Hh = c["embed_dim"], c["encoder_embed_dim"], c["encoder_ffn_embed_dim"], c["encoder_attention_heads"]
+        lin(pre + "post_extract_proj", C, E)
+        sd[pre + "patch_embedding.weight"] = nrm(E, 1, c["input_patch_size"], c["input_patch_size"])
+        sd[pre + "encoder.pos_conv.0.bias"] = nrm(C)
+        sd[pre + "encoder.pos_conv.0.parametrizations.weight.original0"] = torch.ones(1, 1, c["conv_pos"], device=device, dtype=dtype)
+        sd[pre + "encoder.pos_conv.0.parametrizations.weight.original1"] = nrm(C, C // c["conv_pos_groups"], c["conv_pos"])
+        for i in range(c["encoder_layers"]):
+            q = f"{pre}encoder.layers.{i}."
+            sd[q + "self_attn.grep_a"] = torch.ones(1, Hh, 1, 1, device=device, dtype=dtype)
+            sd[q + "self_attn.relative_attention_bias.weight"] = nrm(c["num_buckets"], Hh, std=0.2)
+            for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                lin(q + "self_attn." + nm, C, C)
+            lin(q + "self_attn.grep_linear", 8, C // Hh)
+            ln(q + "self_attn_layer_norm", C); ln(q + "final_layer_norm", C)
+            lin(q + "fc1", Fd, C); lin(q + "fc2", C, Fd)
+        ln(pre + "encoder.layer_norm", C); ln(pre + "layer_norm", E)
+        qc, pp = meta["qformer"], "model.modal_projectors.audio."
+        Q, QI = qc["hidden_size"], qc["intermediate_size"]
+        sd[pp + "audio_query_tokens"] = nrm(1, qc["num_query_token"], Q)
+        ln(pp + "audio_Qformer.bert.embeddings.LayerNorm", Q)
+        for i in range(qc["num_hidden_layers"]):
+            q = f"{pp}audio_Qformer.bert.encoder.layer.{i}."
+            for att, kvw in (("attention", Q), ("crossattention", qc["encoder_width"])):
+                lin(q + att + ".self.query", Q, Q); lin(q + att + ".self.key", Q, kvw); lin(q + att + ".self.value", Q, kvw)
+                lin(q + att + ".output.dense", Q, Q); ln(q + att + ".output.LayerNorm", Q)
+            lin(q + "intermediate_query.dense", QI, Q); lin(q + "output_query.dense", Q, QI); ln(q + "output_query.LayerNorm", Q)
+        lin(pp + "audio_llama_proj", Hd, Q)
+        sd[pp + "audio_position_embedding.weight"] = nrm(qc["num_positions"], qc["encoder_width"])
+    if "video" in meta:
+        c, pre = meta["video"], "model.modal_encoders.video.video_tower."
+        Dm, Im, T = c["hidden_size"], c["intermediate_size"], (c["image_size"] // c["patch_size"]) ** 2 + 1
+        sd[pre + "embeddings.class_embedding"] = nrm(Dm)
+        sd[pre + "embeddings.patch_embedding.weight"] = nrm(Dm, 3, c["patch_size"], c["patch_size"])
+        sd[pre + "embeddings.position_embedding.weight"] = nrm(T, Dm)
+        ln(pre + "pre_layrnorm", Dm); ln(pre + "post_layernorm", Dm)
+        for i in range(c["num_hidden_layers"]):
+            q = f"{pre}encoder.layers.{i}."
+            sd[q + "temporal_embedding"] = nrm(1, c["num_frames"], Dm)
+            for att in ("self_attn", "temporal_attn"):
+                for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                    lin(q + att + "." + nm, Dm, Dm)
+            ln(q + "layer_norm1", Dm); ln(q + "layer_norm2", Dm); ln(q + "temporal_layer_norm1", Dm)
+            lin(q + "mlp.fc1", Im, Dm); lin(q + "mlp.fc2", Dm, Im)
+        mlp2x("video", Dm)
+    if "point" in meta:
+        c, pre = meta["point"], "model.modal_encoders.point.point_encoder."
+        Tm, Ed = c["trans_dim"], c["encoder_dims"]
+        sd[pre + "cls_token"], sd[pre + "cls_pos"] = nrm(1, 1, Tm), nrm(1, 1, Tm)
+        for nm, o, i_ in (("first_conv.0", 128, c["point_dims"]), ("first_conv.3", 256, 128), ("second_conv.0", 512, 512), ("second_conv.3", Ed, 512)):
+            sd[pre + f"encoder.{nm}.weight"] = nrm(o, i_, 1, std=0.1); sd[pre + f"encoder.{nm}.bias"] = nrm(o)
+        for nm, n in (("first_conv.1", 128), ("second_conv.1", 512)):
+            ln(pre + "encoder." + nm, n)
+            sd[pre + f"encoder.{nm}.running_mean"] = zeros(n); sd[pre + f"encoder.{nm}.running_var"] = ones(n)
+        lin(pre + "reduce_dim", Tm, Ed); lin(pre + "pos_embed.0", 128, 3); lin(pre + "pos_embed.2", Tm, 128)
+        for i in range(c["depth"]):
+            q = f"{pre}blocks.blocks.{i}."
+            ln(q + "norm1", Tm); ln(q + "norm2", Tm)
+            lin(q + "mlp.fc1", 4 * Tm, Tm); lin(q + "mlp.fc2", Tm, 4 * Tm)
+            lin(q + "attn.qkv", 3 * Tm, Tm, bias=False); lin(q + "attn.proj", Tm, Tm)
+        ln(pre + "norm", Tm)
+        mlp2x("point", Tm)
     return sd
 
 
