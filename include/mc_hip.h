@@ -72,6 +72,12 @@ typedef struct mc_gemm_args {
 } mc_gemm_args;
 int mc_gemm_ex_bf16(const mc_gemm_args* args, void* stream);
 
+/* The same linear over rows grouped by routed adapter (multimodal_llama.py:262-268 made dense): rows
+ * [group_start[g], group_start[g+1]) use w_packed[g]; x / out / residual / row_scale are indexed by absolute row.  group_start
+ * (n_groups+1) and w_packed (n_groups) are HOST arrays; args->w_packed and args->M are ignored.  One launch when the problem
+ * fills the chip with 256x256 tiles, one mc_gemm_ex_bf16 per group otherwise.                                            */
+int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, const int32_t* group_start, const void* const* w_packed, void* stream);
+
 /* live HIP-event timing of the large-M GEMM kernel on its launch stream (bench.py roofline) */
 int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgroup computes tile (0,0)) */
 int mc_gemm_profile_enable(int on);

@@ -288,13 +288,11 @@ struct G2Src {
 
 // MODE 0: steady state (t <= nt-3), 1: t == nt-2, 2: t == nt-1
 // ABL: timing-only ablations (bit 0 no LDS-DMA, bit 1 no fragment reads, bit 2 DMA always from K-tiles 0/1)
-// GL : where a phase's two LDS-DMA instructions are issued: 0 = in the load half, 1 = inside the MFMA half (after MFMA 4 and 12),
-//      2 = one in each half
-//      3 = as 0, plus X0 of the NEXT K-tile is read during P4's (otherwise empty) load half: fragment reads per phase 8,4,8,4
-template <int MODE, int ABL, int GL>
+// Rejected placements of the two DMA instructions of a phase (measured): inside the MFMA half (-5 %), one in each
+// half (-5 %); reading X0 of the next K-tile during P4 to balance the fragment reads 8/4/8/4 (+-0).
+template <int MODE, int ABL>
 __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, int xoff, const G2Src& src,
-                                        f32x4 (&acc)[2][4][2][2], bf16x8 (&wf)[4][2], bf16x8 (&xf)[2][2][2], bf16x8 (&xn)[2][2]) {
-    constexpr bool BAL = GL == 3;
+                                        f32x4 (&acc)[2][4][2][2], bf16x8 (&wf)[4][2], bf16x8 (&xf)[2][2][2]) {
     char* cur = smem + (t & 1) * G2_STAGE;
     char* nxt = smem + ((t + 1) & 1) * G2_STAGE;
     // piece ids: 0 = X1(t+1) -> nxt, 1 = W1(t+1) -> nxt, 2 = W0(t+2) -> cur, 3 = X0(t+2) -> cur
@@ -329,86 +327,67 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
             for (int kk = 0; kk < 2; ++kk)
                 xf[mh][jj][kk] = *(const bf16x8*)(cur + G2_XOFF + mh * 16384 + ((xoff + jj * 2048) ^ (kk * 64)));
     };
-    // load half: DMA issue (GL 0: both, GL 2: the first) and the counted wait for the pieces the NEXT phase reads.
-    // steady-state count = 2 x (pieces issued after the awaited one, before this point): 4 pieces (GL 0), 3 (GL 1), 3.5 (GL 2)
+    // load half: the phase's two DMA instructions, then the counted wait for the pieces the NEXT phase reads.
+    // count = 2 x (pieces issued after the awaited one, before this point) = 8 in the steady state
     auto load_tail = [&](int piece, int wait_steady, int wait_m1, int wait_m2) {
-        if (GL == 0 || GL == 3) { stage1(piece, 0); stage1(piece, 1); }
-        if (GL == 2) stage1(piece, 0);
+        stage1(piece, 0);
+        stage1(piece, 1);
         if (ABL & 1) return;
         const int w = MODE == 0 ? wait_steady : (MODE == 1 ? wait_m1 : wait_m2);
         switch (w) {
             case 0: g2_waitvm<0>(); break;
-            case 1: g2_waitvm<1>(); break;
             case 2: g2_waitvm<2>(); break;
-            case 3: g2_waitvm<3>(); break;
             case 4: g2_waitvm<4>(); break;
-            case 5: g2_waitvm<5>(); break;
-            case 6: g2_waitvm<6>(); break;
-            case 7: g2_waitvm<7>(); break;
             case 8: g2_waitvm<8>(); break;
             default: break;        // -1: no wait
         }
     };
-    auto mma = [&](int nh, int mh, int piece) {
+    auto mma = [&](int nh, int mh) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
                     acc[nh][i][mh][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][kk], xf[mh][jj][kk], acc[nh][i][mh][jj], 0, 0, 0);
-                if (GL == 1 && i == 1) { __builtin_amdgcn_sched_barrier(0); stage1(piece, kk); __builtin_amdgcn_sched_barrier(0); }
-                if (GL == 2 && i == 1 && kk == 1) { __builtin_amdgcn_sched_barrier(0); stage1(piece, 1); __builtin_amdgcn_sched_barrier(0); }
-            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
-    // wait counts: {steady, t == nt-2, t == nt-1}; derivation in DESIGN.md (pieces are issued and retired in one fixed order)
-    constexpr int S = (GL == 0 || GL == 3) ? 8 : (GL == 1 ? 6 : 7);
+    // wait counts {steady, t == nt-2, t == nt-1}: pieces are issued and retired in one fixed order, so "all but the N youngest
+    // DMA instructions of this wave have landed" identifies the piece.
     // P1 (0,0): reads W0,X0; stages X1(t+1); waits for X1(t)
-    if (BAL) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) xf[0][jj][kk] = xn[jj][kk];
-    } else {
-        read_x(0);
-    }
+    read_x(0);
     read_w(0);
-    load_tail(0, S, S, 2);
-    mma(0, 0, 0);
+    load_tail(0, 8, 8, 2);
+    mma(0, 0);
     // P2 (0,1): reads X1; stages W1(t+1); waits for W1(t)
     read_x(1);
-    load_tail(1, S, S, 0);
-    mma(0, 1, 1);
+    load_tail(1, 8, 8, 0);
+    mma(0, 1);
     // P3 (1,1): reads W1; stages W0(t+2); nothing to wait for
     read_w(1);
-    if (BAL) load_tail(2, 6, 4, -1);      // X0(t+1) (and the older W0(t+1)) must have landed before P4 reads it
-    else load_tail(2, -1, -1, -1);
-    mma(1, 1, 2);
+    load_tail(2, -1, -1, -1);
+    mma(1, 1);
     // P4 (1,0): stages X0(t+2); waits for W0(t+1), X0(t+1)
-    if (BAL) {
-        if (MODE <= 1 && !((ABL & 2) && t > 0)) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    xn[jj][kk] = *(const bf16x8*)(nxt + G2_XOFF + ((xoff + jj * 2048) ^ (kk * 64)));
-        }
-        load_tail(3, -1, -1, -1);
-    } else {
-        load_tail(3, S, 4, -1);
-    }
-    mma(1, 0, 3);
+    load_tail(3, 8, 4, -1);
+    mma(1, 0);
 }
 
-template <int ABL, int GL>
-__global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx,
-                                                              const bf16_t* __restrict__ wp, int M, int N, int K,
+// rows of one launch may belong to several adapter groups (routed LocalLoRA order): group g owns rows [row_start[g], row_start[g+1])
+// = m-tiles [tile_start[g], tile_start[g+1]) and multiplies against its own composed weight
+struct G2Groups {
+    int n;
+    int tile_start[9];
+    int row_start[9];
+    const bf16_t* wp[8];
+};
+
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx, G2Groups grp, int N, int K,
                                                               Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -430,7 +409,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
     const int gsz = min(tiles_m - first_m, GROUP);
     const int tm = first_m + (bid % per_group) % gsz;
     const int tn = (bid % per_group) / gsz;
-    const int m0 = tm * 256, n0 = tn * 256;
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < grp.n && tm >= grp.tile_start[i]) gi = i;
+    const int m0 = grp.row_start[gi] + (tm - grp.tile_start[gi]) * 256, n0 = tn * 256;
+    const int M = grp.row_start[gi + 1];          // rows of this tile beyond the group's end are clamped on load and not stored
+    const bf16_t* wp = grp.wp[gi];
 
     const int kblocks = K >> 5;
     const int nblocks = (N + 15) >> 4;
@@ -485,18 +470,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
         g2_waitvm<8>();
         __builtin_amdgcn_s_barrier();
     }
-    bf16x8 wf[4][2], xf[2][2][2], xn[2][2];
-    if (GL == 3) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) xn[jj][kk] = *(const bf16x8*)(smem + G2_XOFF + ((xoff + jj * 2048) ^ (kk * 64)));
-    }
+    bf16x8 wf[4][2], xf[2][2][2];
     if (wave_n == 1) __builtin_amdgcn_s_barrier();      // second group runs one barrier behind
     int t = 0;
-    for (; t < nt - 2; ++t) g2_tile<0, ABL, GL>(smem, t, wave, woff, xoff, src, acc, wf, xf, xn);
-    g2_tile<1, ABL, GL>(smem, t, wave, woff, xoff, src, acc, wf, xf, xn);
-    g2_tile<2, ABL, GL>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf, xn);
+    for (; t < nt - 2; ++t) g2_tile<0, ABL>(smem, t, wave, woff, xoff, src, acc, wf, xf);
+    g2_tile<1, ABL>(smem, t, wave, woff, xoff, src, acc, wf, xf);
+    g2_tile<2, ABL>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf);
     if (wave_n == 0) __builtin_amdgcn_s_barrier();
 
 #pragma unroll
@@ -768,6 +747,42 @@ static int skinny_rows(int nblocks, int mb, int split_k, bool swiglu) {
     return best;
 }
 
+// one launch of the 256x256 kernel over the m-tiles of all groups (M_total = rows over all groups, for the live profile)
+static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_total, const Epilogue& ep, hipStream_t s) {
+    const int N = a->N, K = a->K;
+    const int tiles_m = grp.tile_start[grp.n], tiles_n = (N + 255) / 256;
+    static bool attr256_set = false;
+    const int lds = 2 * G2_STAGE;
+    if (!attr256_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr256_set = true;
+    }
+    ProfRec rec{};
+    if (g_prof_on) {
+        (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);
+        rec.flops = 2.0 * M_total * (double)N * K;
+        // algorithmic HBM bytes: x and every group's W read once, the output written once (half as wide with the fused SwiGLU),
+        // the residual read once
+        rec.bytes = 2.0 * ((double)M_total * K + (double)grp.n * N * K + (double)M_total * (a->swiglu ? N / 2 : N) * (a->out_f32 ? 2 : 1) +
+                           (a->residual ? (double)M_total * N : 0.0));
+        (void)hipEventRecord(rec.a, s);
+    }
+#define G2_LAUNCH(A) gemm_tile256_kernel<A><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n)
+    // debug word bits 3-5: timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1
+    switch ((g_gemm_dbg >> 3) & 7) {
+        case 1: G2_LAUNCH(1); break;
+        case 2: G2_LAUNCH(2); break;
+        case 3: G2_LAUNCH(3); break;
+        case 4: G2_LAUNCH(4); break;
+        default: G2_LAUNCH(0); break;
+    }
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+}
+
 extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
     MC_CHECK_ARG(a, "mc_gemm_ex_bf16: null argument block");
     const void* x = a->x; const int64_t ldx = a->ldx; const void* w_packed = a->w_packed;
@@ -802,43 +817,10 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
             default: launch_skinny2<4>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
         }
     } else if (use_tile256(M, N, K)) {
-        const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
-        static bool attr256_set = false;
-        const int lds = 2 * G2_STAGE;
-        if (!attr256_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr256_set = true;
-        }
-        ProfRec rec{};
-        if (g_prof_on) {
-            (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);
-            rec.flops = 2.0 * M * (double)N * K;
-            // algorithmic HBM bytes: x and W read once, the output written once (half as wide with the fused SwiGLU), residual read once
-            rec.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (a->swiglu ? N / 2 : N) * (a->out_f32 ? 2 : 1) +
-                               (a->residual ? (double)M * N : 0.0));
-            (void)hipEventRecord(rec.a, s);
-        }
-#define G2_LAUNCH(A, G) gemm_tile256_kernel<A, G><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep, tiles_m, tiles_n)
-        // debug word: bits 3-5 timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1;
-        // bits 6-7 DMA placement variant (64 = inside the MFMA half, 128 = one in each half)
-        switch ((g_gemm_dbg >> 3) & 31) {
-            case 1: G2_LAUNCH(1, 0); break;
-            case 2: G2_LAUNCH(2, 0); break;
-            case 3: G2_LAUNCH(3, 0); break;
-            case 4: G2_LAUNCH(4, 0); break;
-            case 8: G2_LAUNCH(0, 1); break;
-            case 16: G2_LAUNCH(0, 2); break;
-            case 24: G2_LAUNCH(0, 3); break;
-            default: G2_LAUNCH(0, 0); break;
-        }
-        if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+        G2Groups grp{};
+        grp.n = 1; grp.tile_start[0] = 0; grp.tile_start[1] = (M + 255) / 256; grp.row_start[0] = 0; grp.row_start[1] = M;
+        grp.wp[0] = (const bf16_t*)w_packed;
+        launch_tile256(a, grp, M, ep, s);
     } else {
         const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
         static bool attr_set = false;
@@ -862,4 +844,67 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
     a.M = M; a.N = N; a.K = K; a.act = act; a.out_f32 = out_f32; a.alpha = alpha; a.beta = beta;
     a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1;
     return mc_gemm_ex_bf16(&a, stream);
+}
+
+// Routed LocalLoRA linear over adapter-grouped rows: rows [group_start[g], group_start[g+1]) of x / out / residual / row_scale use
+// w_packed[g] (group_start: n_groups+1 host ints, w_packed: n_groups host pointers).  Large problems run as ONE launch of the 256x256
+// kernel (each group padded to whole m-tiles), so small groups no longer pay their own launch and partial last round; otherwise every
+// group is a separate mc_gemm_ex_bf16 call.  args->w_packed / args->M are ignored.
+extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, const int32_t* group_start, const void* const* w_packed,
+                                    void* stream) {
+    MC_CHECK_ARG(args && group_start && w_packed && n_groups >= 1, "mc_gemm_grouped_bf16: bad arguments");
+    const int M_total = group_start[n_groups] - group_start[0];
+    int64_t tiles = 0;
+    int ng = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const int mg = group_start[g + 1] - group_start[g];
+        MC_CHECK_ARG(mg >= 0 && w_packed[g], "mc_gemm_grouped_bf16: bad group %d", g);
+        if (mg > 0) { tiles += (mg + 255) / 256; ++ng; }
+    }
+    const int N = args->N, K = args->K;
+    const bool one_launch = ng >= 1 && ng <= 8 && M_total > 64 && K >= 128 && K % 64 == 0 && !(g_gemm_dbg & 2) && args->split_k <= 1 &&
+                            ((g_gemm_dbg & 4) || tiles * ((N + 255) / 256) >= 192);
+    if (!one_launch) {
+        for (int g = 0; g < n_groups; ++g) {
+            const int r0 = group_start[g], mg = group_start[g + 1] - r0;
+            if (mg <= 0) continue;
+            mc_gemm_args a = *args;
+            const int esz_o = a.out_f32 ? 4 : 2;
+            a.x = (const char*)args->x + (int64_t)r0 * args->ldx * 2;
+            a.out = (char*)args->out + (int64_t)r0 * args->ldo * esz_o;
+            if (args->residual) a.residual = (const char*)args->residual + (int64_t)r0 * args->ldr * 2;
+            if (args->row_scale) a.row_scale = args->row_scale + r0;
+            a.w_packed = w_packed[g]; a.M = mg;
+            const int rc = mc_gemm_ex_bf16(&a, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    MC_CHECK_ARG(args->x && args->out && N > 0 && N % 4 == 0, "mc_gemm_grouped_bf16: bad arguments");
+    MC_CHECK_ARG(args->ldx % 8 == 0 && ((uintptr_t)args->x % 16) == 0 && args->ldo % 4 == 0 && (!args->residual || args->ldr % 4 == 0),
+                 "mc_gemm_grouped_bf16: alignment");
+    MC_CHECK_ARG(!args->swiglu || (N % 32 == 0 && !args->bias && !args->residual && !args->out_f32 && args->act == MC_ACT_NONE),
+                 "mc_gemm_grouped_bf16: swiglu needs N %% 32 == 0 and a plain bf16 output");
+    // the kernel indexes rows from the base pointers: shift them to row group_start[0] once
+    const int base = group_start[0];
+    mc_gemm_args a = *args;
+    a.x = (const char*)args->x + (int64_t)base * args->ldx * 2;
+    a.out = (char*)args->out + (int64_t)base * args->ldo * (args->out_f32 ? 4 : 2);
+    if (args->residual) a.residual = (const char*)args->residual + (int64_t)base * args->ldr * 2;
+    if (args->row_scale) a.row_scale = args->row_scale + base;
+    Epilogue ep{(const bf16_t*)a.bias, (const bf16_t*)a.residual, a.ldr, a.out, a.ldo, a.act, a.out_f32, a.alpha, a.beta, a.row_scale, a.swiglu};
+    G2Groups grp{};
+    int t = 0, k = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const int mg = group_start[g + 1] - group_start[g];
+        if (mg <= 0) continue;
+        grp.tile_start[k] = t; grp.row_start[k] = group_start[g] - base; grp.wp[k] = (const bf16_t*)w_packed[g];
+        t += (mg + 255) / 256;
+        ++k;
+        grp.row_start[k] = group_start[g + 1] - base;     // end of this group (= start of the next non-empty one: groups are contiguous)
+    }
+    grp.n = k; grp.tile_start[k] = t;
+    launch_tile256(&a, grp, M_total, ep, (hipStream_t)stream);
+    MC_CHECK_LAUNCH();
+    return 0;
 }

@@ -89,6 +89,15 @@ int gemm_ex(const void* x, int64_t ldx, const void* w, const void* residual, int
     return mc_gemm_ex_bf16(&a, stream);
 }
 
+int gemm_grouped(const void* x, int64_t ldx, const void* residual, int64_t ldr, void* out, int64_t ldo, int N, int K, const float* row_scale,
+                 int swiglu, int n_groups, const int32_t* gstart, const void* const* weights, void* stream) {
+    mc_gemm_args a;
+    a.x = x; a.ldx = ldx; a.w_packed = nullptr; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
+    a.M = 0; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = 0; a.alpha = 1.0f; a.beta = 1.0f;
+    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = 1;
+    return mc_gemm_grouped_bf16(&a, n_groups, gstart, weights, stream);
+}
+
 // one decoder layer over rows grouped by adapter; x is updated in place.  On entry w.rs holds 1/rms of every row of x
 // (input_layernorm's factor); on exit it holds the factor for the next layer's input_layernorm (or the final norm).
 int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t* gstart, const int32_t* gadapter,
@@ -105,13 +114,14 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     const bool split = decode && M <= 64;   // skinny decode shapes: split-K slabs + residual_rms instead of an in-epilogue residual
     auto W = [&](int adapter, int which) { return m->layer_w[((size_t)layer * c.n_adapters + adapter) * 4 + which]; };
 
+    // weights of every group for linear `which`
+    const void* wg[64];
+    auto W_all = [&](int which) {
+        for (int g = 0; g < n_groups; ++g) wg[g] = W(gadapter[g], which);
+        return (const void* const*)wg;
+    };
     // q|k|v = (x / rms) . (W_qkv diag(g_in))^T                                                  (:440-443, :262-268)
-    for (int g = 0; g < n_groups; ++g) {
-        const int r0 = gstart[g], mg = gstart[g + 1] - r0;
-        if (mg <= 0) continue;
-        RUN(gemm_ex(x + (size_t)r0 * hd * 2, hd, W(gadapter[g], 0), nullptr, 0, w.qkv + (size_t)r0 * qkvd * 2, qkvd, mg, (int)qkvd,
-                    (int)hd, 0, w.rs + r0, 0, 1, stream));
-    }
+    RUN(gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, w.rs, 0, n_groups, gstart, W_all(0), stream));
     RUN(mc_rope_kv_bf16(w.qkv, qkvd, row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, M, (int)H, (int)Hkv, (int)D, Lq,
                         Smax, stream));
     if (decode) {
@@ -128,32 +138,17 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
         RUN(gemm_ex(w.attn, hd, W(gadapter[0], 1), nullptr, 0, w.part, hd, M, (int)hd, (int)hd, 1, nullptr, 0, kDecodeSplitK, stream));
         RUN(mc_residual_rms_bf16(x, hd, w.part, hd, kDecodeSplitK, w.rs, M, (int)hd, c.rms_eps, stream));
     } else {
-        for (int g = 0; g < n_groups; ++g) {
-            const int r0 = gstart[g], mg = gstart[g + 1] - r0;
-            if (mg <= 0) continue;
-            char* xr = x + (size_t)r0 * hd * 2;
-            RUN(gemm_ex(w.attn + (size_t)r0 * hd * 2, hd, W(gadapter[g], 1), xr, hd, xr, hd, mg, (int)hd, (int)hd, 0, nullptr, 0, 1, stream));
-        }
+        RUN(gemm_grouped(w.attn, hd, x, hd, x, hd, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream));
         RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
     }
     // inter = silu(gate) * up with gate|up = (x / rms) . (W_gu diag(g_post))^T                 (:380-390)
-    for (int g = 0; g < n_groups; ++g) {
-        const int r0 = gstart[g], mg = gstart[g + 1] - r0;
-        if (mg <= 0) continue;
-        RUN(gemm_ex(x + (size_t)r0 * hd * 2, hd, W(gadapter[g], 2), nullptr, 0, w.inter + (size_t)r0 * I * 2, I, mg, (int)(2 * I), (int)hd,
-                    0, w.rs + r0, 1, 1, stream));
-    }
+    RUN(gemm_grouped(x, hd, nullptr, 0, w.inter, I, (int)(2 * I), (int)hd, w.rs, 1, n_groups, gstart, W_all(2), stream));
     // x += down_proj(inter)  (:466);  then 1/rms for the next layer's input_layernorm / the final norm
     if (split) {
         RUN(gemm_ex(w.inter, I, W(gadapter[0], 3), nullptr, 0, w.part, hd, M, (int)hd, (int)I, 1, nullptr, 0, kDecodeSplitK, stream));
         RUN(mc_residual_rms_bf16(x, hd, w.part, hd, kDecodeSplitK, w.rs, M, (int)hd, c.rms_eps, stream));
     } else {
-        for (int g = 0; g < n_groups; ++g) {
-            const int r0 = gstart[g], mg = gstart[g + 1] - r0;
-            if (mg <= 0) continue;
-            char* xr = x + (size_t)r0 * hd * 2;
-            RUN(gemm_ex(w.inter + (size_t)r0 * I * 2, I, W(gadapter[g], 3), xr, hd, xr, hd, mg, (int)hd, (int)I, 0, nullptr, 0, 1, stream));
-        }
+        RUN(gemm_grouped(w.inter, I, x, hd, x, hd, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream));
         RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
     }
     return 0;

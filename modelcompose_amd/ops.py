@@ -145,6 +145,24 @@ def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor
     return out
 
 
+def linear_grouped(x: torch.Tensor, weights: Sequence[PackedWeight], group_start: Sequence[int], row_scale: Optional[torch.Tensor] = None,
+                   swiglu: bool = False, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mc_gemm_grouped_bf16: rows [group_start[g], group_start[g+1]) of x use weights[g] (routed LocalLoRA linear)."""
+    _req(x, BF16, "x")
+    w0 = weights[0]
+    M = x.shape[0]
+    n_out = w0.N // 2 if swiglu else w0.N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=BF16, device=x.device)
+    a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), 0, 0, 0 if residual is None else residual.data_ptr(),
+                       0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), 0, w0.N, w0.Kp, 0, 0, 1.0, 1.0,
+                       0 if row_scale is None else row_scale.data_ptr(), 1 if swiglu else 0, 1)
+    gs = (C.c_int32 * len(group_start))(*group_start)
+    wp = (C.c_void_p * len(weights))(*[w.data.data_ptr() for w in weights])
+    _lib.check(_lib.lib().mc_gemm_grouped_bf16(C.byref(a), len(weights), gs, wp, _stream()), "mc_gemm_grouped_bf16")
+    return out
+
+
 def rms_scale(x, eps):
     _req(x, BF16, "x")
     M, D = x.shape
