@@ -146,6 +146,13 @@ int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* byt
 int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st, int64_t k_sh,
                         const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o, int64_t o_sb, void* workspace,
                         const int32_t* kv_lens, int B, int H, int Hkv, int S, int D, int nsplit, float scale, void* stream);
+/* decode attention with RoPE + KV-cache append fused in (multimodal_llama.py:281-312 for a one-token step): qkv [B, (H + 2 Hkv) * D]
+ * is the pre-rotary q|k|v row of the token at position kv_lens[b] - 1; its rotated key / value are attended from registers and
+ * written to the caches by the same launch.                                                                                */
+int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const float* cos_table, const float* sin_table, void* k_cache,
+                             int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                             void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
+                             int nsplit, float scale, void* stream);
 
 /* ---- row kernels ---------------------------------------------------------------------------------- */
 int mc_silu_mul_bf16(const void* gate_up, int64_t ld, void* out, int64_t ldo, int M, int I, void* stream);   /* :392-394 */

@@ -198,6 +198,12 @@ struct DecodeParams {
     const int32_t* kv_lens;
     int B, H, Hkv, S, nsplit;
     float scale_log2e;
+    // fused RoPE + KV append (decode step of LocalLoraAttention.forward, multimodal_llama.py:281-289): when qkv is set, q / k_new / v_new
+    // are row b of qkv [B, (H + 2 Hkv) * D] (pre-rotary); the key at position kv_lens[b]-1 is this token: it is rotated in registers,
+    // attended from registers and appended to the caches by this kernel (MHA only: H == Hkv)
+    const bf16_t* qkv; int64_t qkv_ld;
+    const float* cosT; const float* sinT;
+    bf16_t* k_out; bf16_t* v_out;
 };
 
 template <int D>
@@ -210,21 +216,62 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
     const int hk = h / (p.H / p.Hkv);
     const int split = blockIdx.y;
     const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
-    const int per = (kvlen + p.nsplit - 1) / p.nsplit;
-    const int j0 = split * per, j1 = min(j0 + per, kvlen);
     const int slot = lane / LPK, dl = (lane % LPK) * 8;
 
     float qv[8];
-    {
+    float knew[8], vnew[8];
+    const bool fused = p.qkv != nullptr;
+    int cache_len = kvlen;                    // keys read from the cache
+    if (fused) {
+        cache_len = kvlen - 1;
+        const int pos = kvlen - 1;
+        const bf16_t* row = p.qkv + (int64_t)b * p.qkv_ld;
+        const bf16x8 q8 = *(const bf16x8*)(row + h * D + dl);
+        const bf16x8 k8 = *(const bf16x8*)(row + (p.H + hk) * D + dl);
+        const bf16x8 v8 = *(const bf16x8*)(row + (p.H + p.Hkv + hk) * D + dl);
+        // rotate-half: lanes dl < D/2 pair with lane + LPK/2 (dl + D/2)
+        const bool lo = dl < D / 2;
+        const float* cr = p.cosT + (int64_t)pos * (D / 2) + (lo ? dl : dl - D / 2);
+        const float* sr = p.sinT + (int64_t)pos * (D / 2) + (lo ? dl : dl - D / 2);
+        bf16x8 kr;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float qa = (float)q8[i], ka = (float)k8[i];
+            const float qb = __shfl_xor(qa, LPK / 2, 64), kb_ = __shfl_xor(ka, LPK / 2, 64);
+            const float c = cr[i], sn = lo ? -sr[i] : sr[i];
+            // lo: x*c - partner*s ; hi: x*c + partner*s.  Rounded to bf16 like the stored q / cached k of the unfused path
+            qv[i] = (float)(bf16_t)(qa * c + qb * sn) * p.scale_log2e;
+            kr[i] = (bf16_t)(ka * c + kb_ * sn);
+            knew[i] = (float)kr[i];
+            vnew[i] = (float)v8[i];
+        }
+        if (split == 0 && wave == 0 && slot == 0 && h % (p.H / p.Hkv) == 0) {
+            *(bf16x8*)(p.k_out + b * p.k_sb + hk * p.k_sh + (int64_t)pos * p.k_st + dl) = kr;
+            *(bf16x8*)(p.v_out + b * p.v_sb + hk * p.v_sh + (int64_t)pos * p.v_st + dl) = v8;
+        }
+    } else {
         const bf16x8 q8 = *(const bf16x8*)(p.q + b * p.q_sb + h * p.q_sh + dl);
 #pragma unroll
         for (int i = 0; i < 8; ++i) qv[i] = (float)q8[i] * p.scale_log2e;
     }
+    const int per = (cache_len + p.nsplit - 1) / p.nsplit;
+    const int j0 = split * per, j1 = min(j0 + per, cache_len);
     const bf16_t* kb = p.k + b * p.k_sb + hk * p.k_sh + dl;
     const bf16_t* vb = p.v + b * p.v_sb + hk * p.v_sh + dl;
     float m = NEG_BIG, l = 0.f, acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    if (fused && split == p.nsplit - 1 && wave == 0 && slot == 0) {
+        // this token's own key / value, from registers
+        float sdot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sdot += qv[i] * knew[i];
+#pragma unroll
+        for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
+        m = sdot; l = 1.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = vnew[i];
+    }
 
     constexpr int UN = 4;
     for (int j = j0 + wave * KPW; j < j1; j += 4 * KPW * UN) {
@@ -355,7 +402,35 @@ extern "C" int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, co
     MC_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || workspace), "mc_attn_decode_bf16: nsplit>1 needs a workspace");
     MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && S > 0, "mc_attn_decode_bf16: bad shape");
     DecodeParams p{(const bf16_t*)q, q_sb, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
-                   (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f};
+                   (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
+                   nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    dim3 grid(B * H, nsplit);
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 128) {
+        attn_decode_kernel<128><<<grid, 256, 0, s>>>(p);
+        if (nsplit > 1) attn_decode_combine_kernel<128><<<B * H, 128, 0, s>>>(p);
+    } else {
+        attn_decode_kernel<64><<<grid, 256, 0, s>>>(p);
+        if (nsplit > 1) attn_decode_combine_kernel<64><<<B * H, 64, 0, s>>>(p);
+    }
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// Decode attention with RoPE and the KV-cache append fused in: qkv [B, (H + 2 Hkv) * D] is the pre-rotary output of the q|k|v linear
+// for the token at position kv_lens[b] - 1 of every sequence (kv_lens counts this token).  Replaces mc_rope_kv_bf16 +
+// mc_attn_decode_bf16 for one-token steps (multimodal_llama.py:281-312): one launch less per layer and no q round trip.
+extern "C" int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const float* cos_table, const float* sin_table, void* k_cache,
+                                        int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                        void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
+                                        int nsplit, float scale, void* stream) {
+    MC_CHECK_ARG(qkv && cos_table && sin_table && k_cache && v_cache && o && kv_lens, "mc_attn_decode_rope_bf16: null pointer");
+    MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_decode_rope_bf16: head_dim %d not supported (64 or 128)", D);
+    MC_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || workspace), "mc_attn_decode_rope_bf16: nsplit>1 needs a workspace");
+    MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && S > 0 && qkv_ld % 8 == 0, "mc_attn_decode_rope_bf16: bad shape");
+    DecodeParams p{nullptr, 0, 0, (const bf16_t*)k_cache, k_sb, k_st, k_sh, (const bf16_t*)v_cache, v_sb, v_st, v_sh,
+                   (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
+                   (const bf16_t*)qkv, qkv_ld, cos_table, sin_table, (bf16_t*)k_cache, (bf16_t*)v_cache};
     dim3 grid(B * H, nsplit);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) {

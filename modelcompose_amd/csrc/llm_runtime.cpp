@@ -122,13 +122,14 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     };
     // q|k|v = (x / rms) . (W_qkv diag(g_in))^T                                                  (:440-443, :262-268)
     RUN(gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, w.rs, 0, n_groups, gstart, W_all(0), stream));
-    RUN(mc_rope_kv_bf16(w.qkv, qkvd, row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, M, (int)H, (int)Hkv, (int)D, Lq,
-                        Smax, stream));
     if (decode) {
-        RUN(mc_attn_decode_bf16(w.qseq, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl, Hkv * Smax * D, D,
-                                (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit, scale,
-                                stream));
+        // one token per sequence (row b = sequence b): RoPE, the cache append and the attention are one launch (:281-312)
+        RUN(mc_attn_decode_rope_bf16(w.qkv, qkvd, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl, Hkv * Smax * D, D,
+                                     (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit, scale,
+                                     stream));
     } else {
+        RUN(mc_rope_kv_bf16(w.qkv, qkvd, row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, M, (int)H, (int)Hkv, (int)D, Lq,
+                            Smax, stream));
         RUN(mc_attn_prefill_bf16(w.qseq, (int64_t)Lq * H * D, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
                                  Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, out_map, kv_lens, B, (int)H, (int)Hkv, Lq, Smax,
                                  (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, stream));

@@ -429,3 +429,13 @@ def cast_bf16(x32, out=None):
     out = torch.empty(x32.shape, dtype=BF16, device=x32.device) if out is None else out
     _lib.check(_lib.lib().mc_cast_f32_bf16(_p(x32), _p(out), x32.numel(), _stream()), "mc_cast_f32_bf16")
     return out
+
+
+def attn_decode_rope(qkv, cos, sin, k_cache, v_cache, out, kv_lens, B, H, Hkv, Smax, D, nsplit=1, workspace=None, scale=None):
+    """Decode attention with RoPE + KV append fused (caches [B, Hkv, Smax, D]); kv_lens counts the token being decoded."""
+    sc = (1.0 / math.sqrt(D)) if scale is None else scale
+    st = (Hkv * Smax * D, D, Smax * D)
+    _lib.check(_lib.lib().mc_attn_decode_rope_bf16(_p(qkv), qkv.stride(0), _p(cos), _p(sin), _p(k_cache), *st, _p(v_cache), *st, _p(out),
+                                                   out.stride(0), _p(workspace), _p(kv_lens), B, H, Hkv, Smax, D, nsplit, sc, _stream()),
+               "mc_attn_decode_rope_bf16")
+    return out

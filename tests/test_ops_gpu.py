@@ -411,3 +411,33 @@ def test_gemm_grouped_one_launch_equals_per_group(ops, sizes):
     full = torch.cat([(x[gs[g]:gs[g + 1]].float() * rs[gs[g]:gs[g + 1], None]) @ ops.unpack_weight(w).float().t()
                       for g, w in enumerate(ws)], 0) + res.float()
     close_bf16(got, full)
+
+
+@pytest.mark.parametrize("D,H,nsplit", [(128, 4, 1), (64, 2, 1), (128, 2, 4)])
+def test_attn_decode_with_fused_rope_and_kv_append(ops, D, H, nsplit):
+    """One-token decode step: fused RoPE + cache append + attention equals rope_kv followed by attn_decode, bit for bit in the
+    caches and within bf16 rounding in the output (the new key is attended from registers in a different order)."""
+    B, Smax = 3, 96
+    lens = torch.tensor([5, 40, 1], dtype=torch.int32)          # keys visible incl. the token being decoded
+    qkv = dev(rand_bf(B, 3 * H * D, seed=61))
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.outer(torch.arange(128).float(), inv)
+    cos, sin = dev(ang.cos().contiguous()), dev(ang.sin().contiguous())
+    kc0, vc0 = dev(rand_bf(B, H, Smax, D, seed=62)), dev(rand_bf(B, H, Smax, D, seed=63))
+    lens_d = dev(lens)
+    pos = dev(lens - 1)
+    iota, zeros = dev(torch.arange(B, dtype=torch.int32)), dev(torch.zeros(B, dtype=torch.int32))
+    # unfused reference path
+    kc1, vc1 = kc0.clone(), vc0.clone()
+    q1 = torch.empty(B, H * D, dtype=BF, device="cuda")
+    ops.rope_kv(qkv, iota, pos, zeros, cos, sin, q1, kc1, vc1, H, H, D, 1, Smax)
+    o1 = torch.empty(B, H * D, dtype=BF, device="cuda")
+    ws = torch.empty(B * H * nsplit * (D + 2), dtype=torch.float32, device="cuda")
+    st = (H * Smax * D, D, Smax * D)
+    ops.attn_decode(q1, kc1, vc1, o1, B, H, H, Smax, D, (H * D, D), st, st, H * D, nsplit=nsplit, workspace=ws, kv_lens=lens_d)
+    # fused path
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    o2 = torch.empty(B, H * D, dtype=BF, device="cuda")
+    ops.attn_decode_rope(qkv, cos, sin, kc2, vc2, o2, lens_d, B, H, H, Smax, D, nsplit=nsplit, workspace=ws)
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+    close_bf16(o2, o1.float(), rel=2 ** -7)
