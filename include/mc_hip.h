@@ -53,6 +53,18 @@ int mc_compose_weight_ex_bf16(const void* w_rowmajor, int64_t ldw, const void* c
                               const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
                               int N, int K, const float* col_scale, int nb_stride, int nb_offset, void* stream);
 
+/* ---- TIES merging of checkpoints (scripts/model_composition/ties_merging.py:88-221, --strategy ties-{mean,sum,max}) ------------
+ * x: n flattened task vectors [n, d] (row stride ld elements) of dtype MC_DTYPE_*.  mc_ties_hist is one pass of the exact radix
+ * select of each row's k-th smallest magnitude (host reads the 2048-bin histograms and picks the bin: 3 passes of 11/11/10 bits);
+ * mc_ties_merge elects the signs (zero sums take the majority sign) and aggregates the agreeing trimmed entries.                 */
+#define MC_DTYPE_F32 0
+#define MC_DTYPE_BF16 1
+#define MC_DTYPE_F16 2
+int mc_ties_hist(const void* x, int dtype, int64_t ld, int64_t d, int n, int shift, int nbins, const uint32_t* prefix, int prefix_shift,
+                 uint32_t* hist, void* stream);
+int mc_ties_merge(const void* x, int dtype, int64_t ld, int64_t d, int n, const float* thr, int8_t* sign, long long* sign_sum, int func,
+                  void* out, void* stream);
+
 /* ---- linear: out[M,N] = act(alpha * x[M,K] W^T + bias) + beta * residual ----------------------------
  * Replaces F.linear at multimodal_llama.py:122 (LocalLoRA base GEMM), :720 (lm_head), the CLIP / projector
  * linears.  K must be a multiple of 64 (zero padded), x rows 16-byte aligned.  out_f32 != 0 -> fp32 out.  */

@@ -12,7 +12,13 @@ Drop-in for `scripts/model_composition/merge_unimodal_modelcompose.py filepaths.
 The config union keeps the first truthy value per key (`a or b`, :117-123) and records
 {modal}_lora_alpha / {modal}_lora_r (:131-136).  For online-merge no arithmetic happens on disk — exactly as in the
 reference; the arithmetic consequence (W + sum_m coefficient*alpha/r * B_m A_m) is applied once at load time on the
-GPU by csrc/compose.hip.  TIES / convert / drop strategies are outside the hot path and raise."""
+GPU by csrc/compose.hip.
+
+  ties-mean / ties-sum / ties-max   TIES merging of the tensors shared by every checkpoint (ties_merging.py:88-221 through
+                                 merge_unimodal_modelcompose.py:78-93): trim each flattened checkpoint to its top-K % magnitudes,
+                                 elect a sign per parameter, aggregate the agreeing entries — on the GPU (csrc/merge.hip: exact
+                                 radix select + two streaming passes); needs a HIP device, there is no CPU fallback.
+convert-* / drop-* strategies raise."""
 from __future__ import annotations
 
 import argparse
@@ -71,13 +77,108 @@ def _elementwise(per_ckpt: Sequence[Dict[str, torch.Tensor]], mean: bool) -> Dic
     return {n: (sum(ts) / len(ts) if mean else sum(ts)) for n, ts in groups.items()}
 
 
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def ties_merge_vectors(flat: torch.Tensor, K, merge_func: str) -> torch.Tensor:
+    """flat [n, d] device tensor (fp32 / bf16 / fp16) -> merged [d] in the same dtype (ties_merging.py:160-179).
+    The k-th smallest magnitude of every row is found exactly by a 3-pass radix select over the float bits of |x| (11 + 11 + 10
+    bits; the 2048-bin histograms come back to the host between passes), then mc_ties_merge elects signs and aggregates."""
+    import ctypes as C
+    from . import _lib
+    if not flat.is_cuda:
+        raise ValueError("ties_merge_vectors needs device (HIP) tensors; this path has no CPU fallback")
+    if flat.dtype not in _DTYPE_CODE:
+        raise ValueError(f"unsupported checkpoint dtype {flat.dtype}")
+    if merge_func not in ("mean", "sum", "max"):
+        raise ValueError(f"Merge method {merge_func} is not defined.")                     # ties_merging.py:155
+    if K >= 1:
+        K = K / 100                                                                         # :89-90
+    flat = flat.contiguous()
+    n, d = flat.shape
+    k = d - int(d * K)                                                                      # :97-98: k-th smallest, 1-indexed
+    if not 1 <= k <= d:
+        raise RuntimeError(f"kthvalue(): selected number k out of range for dimension {d}")
+    L = _lib.lib()
+    code = _DTYPE_CODE[flat.dtype]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = flat.device
+    prefix = torch.zeros(n, dtype=torch.int32, device=dev)
+    remaining = [k] * n
+    pre_host = [0] * n
+    for (shift, nbits, pshift) in ((21, 11, 32), (10, 11, 21), (0, 10, 10)):
+        hist = torch.zeros(n, 2048, dtype=torch.int32, device=dev)
+        _lib.check(L.mc_ties_hist(flat.data_ptr(), code, flat.stride(0), d, n, shift, 1 << nbits, prefix.data_ptr(), pshift, hist.data_ptr(), st),
+                   "mc_ties_hist")
+        h = hist.cpu().numpy().astype("int64") & 0xFFFFFFFF
+        for r in range(n):
+            cum = 0
+            for b in range(1 << nbits):
+                if cum + h[r, b] >= remaining[r]:
+                    remaining[r] -= cum
+                    pre_host[r] = (pre_host[r] << nbits) | b
+                    break
+                cum += h[r, b]
+            else:
+                raise RuntimeError("radix select ran past the histogram (NaN in the checkpoint?)")
+        prefix = torch.tensor([p - (1 << 32) if p >= (1 << 31) else p for p in pre_host], dtype=torch.int32, device=dev)
+    import numpy as np
+    thr = torch.from_numpy(np.array(pre_host, dtype=np.uint32).view(np.float32).copy()).to(dev)     # k-th smallest |x| per row
+    sign = torch.empty(d, dtype=torch.int8, device=dev)
+    sign_sum = torch.zeros(1, dtype=torch.int64, device=dev)
+    out = torch.empty(d, dtype=flat.dtype, device=dev)
+    _lib.check(L.mc_ties_merge(flat.data_ptr(), code, flat.stride(0), d, n, thr.data_ptr(), sign.data_ptr(), sign_sum.data_ptr(),
+                               {"mean": 0, "sum": 1, "max": 2}[merge_func], out.data_ptr(), st), "mc_ties_merge")
+    return out
+
+
+def ties_merge_state_dicts(checks: Sequence[Dict[str, torch.Tensor]], K=20, merge_func: str = "mean", device="cuda") -> Dict[str, torch.Tensor]:
+    """do_merging (ties_merging.py:182-221): flatten in sorted key order, merge on the GPU, un-flatten (host tensors out).
+    mean divides a half-precision sum by an fp32 count, which torch promotes to fp32 before the copy back into the
+    checkpoint dtype (:145-148, :217-219); the kernel applies the same roundings."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("TIES merging runs on the HIP device; no CPU fallback")
+    keys = sorted(checks[0])
+    for c in checks[1:]:
+        if set(c) != set(keys):
+            raise ValueError("Differing parameter names in models.")                        # :61-72
+    flat = torch.stack([torch.cat([c[k].reshape(-1) for k in keys]).to(device) for c in checks])
+    merged = ties_merge_vectors(flat, K, merge_func).cpu()
+    out, off = {}, 0
+    for k in keys:
+        t = checks[0][k]
+        out[k] = merged[off:off + t.numel()].view(t.shape).clone()
+        off += t.numel()
+    return out
+
+
+def _ties(per_ckpt: Sequence[Dict[str, torch.Tensor]], func: str, K) -> Dict[str, torch.Tensor]:
+    """convert_delta_to_ft (ties_merging.py:224-250) + do_merging: tensors present in every checkpoint are merged, tensors present
+    in exactly one are kept."""
+    groups: Dict[str, List[torch.Tensor]] = {}
+    for tensors in per_ckpt:
+        for name, t in tensors.items():
+            groups.setdefault(name, []).append(t)
+    n = max(len(v) for v in groups.values())
+    out = {}
+    shared = [dict() for _ in range(n)]
+    for name, ts in groups.items():
+        if len(ts) == n:
+            for i in range(n):
+                shared[i][name] = ts[i]
+        else:
+            assert len(ts) == 1, f"tensor '{name}' appears in {len(ts)} of {n} checkpoints"   # :246
+            out[name] = ts[0]
+    out.update(ties_merge_state_dicts(shared, K, func))
+    return out
+
+
 def merge_checkpoints(filepaths: Sequence[str], output_path: str, strategy: str = "sum", K: int = 20):
     loaded = [_read_checkpoint(p) for p in filepaths]
     tensors = [t for t, _ in loaded]
     configs = [c for _, c in loaded]
-    if strategy.startswith(("ties-", "convert-", "drop-")):
-        raise NotImplementedError(f"Merge strategy [{strategy}] (TIES / convert / drop) is not on the hot path; "
-                                  f"use the reference script for it.")
+    if strategy.startswith(("convert-", "drop-")):
+        raise NotImplementedError(f"Merge strategy [{strategy}] (convert / drop) is not implemented; use the reference script for it.")
     label = strategy
     extra_cfg = {}
     if strategy.startswith("online-merge-"):
@@ -87,6 +188,11 @@ def merge_checkpoints(filepaths: Sequence[str], output_path: str, strategy: str 
             extra_cfg["reset_scaling_weights"] = label[len("reset-"):]
         else:
             extra_cfg["merge_default_weights"] = label
+    elif strategy.startswith("ties-"):
+        func = strategy[len("ties-"):]
+        assert func in ("sum", "mean", "max")                                               # merge_unimodal_modelcompose.py:80
+        merged = _ties(tensors, func, K)
+        label = f"dis-{func}-{K}"                                                           # :89
     elif strategy in ("sum", "mean"):
         merged = _elementwise(tensors, mean=strategy == "mean")
     else:

@@ -18,6 +18,7 @@ Groups:
   g7  dense-merge equivalence
   g8  tiny 4-modality composed model end to end (all encoders + projectors + routed LLM + greedy ids)
   g9  stage-2 finetune step: loss + gradients of the trainable set
+  g10 TIES merging (ties-mean / sum / max) tensor- and file-level
 """
 from __future__ import annotations
 
@@ -776,8 +777,75 @@ def g9():
         _save("g9_train_step", meta=np.array(json.dumps(d)), **arrays)
 
 
+def g10():
+    """TIES merging (scripts/model_composition/ties_merging.py:88-221, reached through merge_unimodal_modelcompose.py:78-93 with
+    --strategy ties-{mean,sum,max}): the reference's own do_merging on three small fp32 checkpoints whose shared tensors contain
+    magnitude ties at the trim threshold, columns whose trimmed sum is exactly zero (resolve_zero_signs) and exact zeros; plus
+    the reference's demo() inputs (:253-256) and one file-level merge_checkpoints run."""
+    refshim.install()
+    import importlib
+    mm = importlib.import_module("merge_unimodal_modelcompose")
+    tm = importlib.import_module("ties_merging")
+    g = torch.Generator().manual_seed(101)
+    shapes = {"model.layers.0.self_attn.q_proj.lora_A.default.weight": (4, 24), "model.layers.0.self_attn.q_proj.lora_B.default.weight": (24, 4),
+              "model.layers.1.mlp.down_proj.lora_A.default.weight": (4, 40), "model.layers.1.mlp.down_proj.lora_B.default.weight": (24, 4)}
+    cks = []
+    for i in range(3):
+        w = {k: torch.randn(shp, generator=g) for k, shp in shapes.items()}
+        cks.append(w)
+    # engineered cases inside the first tensor (96 values): ties, cancelling columns, zeros
+    k0 = "model.layers.0.self_attn.q_proj.lora_A.default.weight"
+    for i in range(3):
+        f = cks[i][k0].view(-1)
+        f[0:4] = torch.tensor([2.5, -2.5, 2.5, 0.0])          # equal magnitudes (ties at / near the threshold)
+        f[10] = 0.0
+    cks[0][k0].view(-1)[5], cks[1][k0].view(-1)[5], cks[2][k0].view(-1)[5] = 3.0, -3.0, 0.0        # trimmed sum exactly 0
+    cks[0][k0].view(-1)[6], cks[1][k0].view(-1)[6], cks[2][k0].view(-1)[6] = -4.0, 4.0, 0.0
+    arrays = {}
+    for i, w in enumerate(cks):
+        for k, v in w.items():
+            arrays[f"in::{i}::{k}"] = v
+    import io, contextlib
+    for func in ("mean", "sum", "max"):
+        for K in (20, 50):
+            with contextlib.redirect_stdout(io.StringIO()):
+                out = tm.do_merging([dict(c) for c in cks], K=K, merge_func=f"dis-{func}")
+            for k, v in out.items():
+                arrays[f"out::{func}::{K}::{k}"] = v
+    with contextlib.redirect_stdout(io.StringIO()):
+        demo = tm.do_merging([{"x": torch.Tensor([1, 2, 3]), "y": torch.Tensor([4, 5, 6])},
+                              {"x": torch.Tensor([-1, 2, 3]), "y": torch.Tensor([0, 0, 0])}], K=0.9)
+    arrays["demo::x"], arrays["demo::y"] = demo["x"], demo["y"]
+    # file level: three unimodal checkpoints (shared default keys + unique modal keys)
+    with tempfile.TemporaryDirectory() as tmp:
+        paths, in_cfg = [], {}
+        for i, (modal, enc_key) in enumerate((("vision", "mm_vision_encoder"), ("audio", "mm_audio_encoder"), ("video", "mm_video_encoder"))):
+            d = os.path.join(tmp, f"ckpt-{modal}")
+            os.makedirs(d)
+            w = dict(cks[i])
+            w[f"model.layers.0.self_attn.q_proj.lora_A.{modal}.weight"] = torch.randn(4, 24, generator=g)
+            w[f"model.modal_projectors.{modal}.0.weight"] = torch.randn(8, 6, generator=g)
+            torch.save(w, os.path.join(d, "adapter_model.bin"))
+            c = {"model_type": "multimodal", enc_key: f"/ckpts/{modal}", "lora_r": 4, "lora_alpha": 8, "lora_strategy": "modal+language"}
+            json.dump(c, open(os.path.join(d, "config.json"), "w"))
+            paths.append(d)
+            in_cfg[modal] = c
+            for k, v in w.items():
+                if k not in cks[i]:
+                    arrays[f"fin::{modal}::{k}"] = v
+        outp = os.path.join(tmp, "merged")
+        with contextlib.redirect_stdout(io.StringIO()):
+            mm.merge_checkpoints(paths, outp, "ties-mean", K=20)
+        merged = torch.load(os.path.join(outp, "adapter_model.bin"))
+        for k, v in merged.items():
+            arrays[f"fout::{k}"] = v
+        meta = {"order": ["vision", "audio", "video"], "in_configs": in_cfg, "out_config": json.load(open(os.path.join(outp, "config.json"))),
+                "merge_info": open(os.path.join(outp, "merge_info.txt")).read().replace(tmp, "<TMP>"), "shared_keys": sorted(shapes)}
+    _save("g10_ties", meta=np.array(json.dumps(meta)), **arrays)
+
+
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
-          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9}
+          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
 
 
 def main(argv):

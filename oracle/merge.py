@@ -1,7 +1,8 @@
 """Oracle (TEST INFRASTRUCTURE): checkpoint composition, restating
 scripts/model_composition/merge_unimodal_modelcompose.py:28-145 for the
 'online-merge-*' strategies (key rename + config union; no arithmetic) and the
-plain 'sum' / 'mean' strategies.  Byte-exact tensors."""
+plain 'sum' / 'mean' strategies, and scripts/model_composition/ties_merging.py:88-221 for 'ties-{mean,sum,max}'
+(trim to the top-K % magnitudes per checkpoint, elect a sign per parameter, merge the agreeing entries).  Byte-exact tensors."""
 from __future__ import annotations
 
 import json
@@ -24,6 +25,43 @@ def get_modal_from_config(config):
     raise AssertionError("No modality is recognized, please check the config.")
 
 
+def ties_merge_vectors(flat: torch.Tensor, K, merge_func: str) -> torch.Tensor:
+    """flat [n_checkpoints, d] -> merged [d]  (ties_merging.py:88-179; `merge_func` in {'mean', 'sum', 'max'}).
+    topk_values_mask :88-109: K >= 1 is a percentage; keep |x| >= (d - int(d*K))-th smallest magnitude of the row (ties kept);
+    resolve_sign :122-125 with zero sums taking the majority sign :112-119; disjoint_merge :128-157."""
+    if K >= 1:
+        K = K / 100
+    n, d = flat.shape
+    k = d - int(d * K)
+    kth = flat.abs().kthvalue(k, dim=1, keepdim=True).values
+    upd = flat * (flat.abs() >= kth)
+    sign = torch.sign(upd.sum(dim=0))
+    majority = torch.sign(sign.sum())
+    sign[sign == 0] = majority
+    keep = torch.where(sign.unsqueeze(0) > 0, upd > 0, upd < 0)
+    sel = upd * keep
+    if merge_func == "mean":
+        return sel.sum(dim=0) / torch.clamp((sel != 0).sum(dim=0).float(), min=1)
+    if merge_func == "sum":
+        return sel.sum(dim=0)
+    if merge_func == "max":
+        return sel.abs().max(dim=0)[0] * sign
+    raise ValueError(f"Merge method {merge_func} is not defined.")
+
+
+def ties_merge_state_dicts(checks, K=20, merge_func="mean"):
+    """do_merging :182-221: flatten in sorted key order (state_dict_to_vector :22-31), merge, un-flatten."""
+    keys = sorted(checks[0])
+    flat = torch.vstack([torch.cat([c[k].reshape(-1) for k in keys]) for c in checks])
+    merged = ties_merge_vectors(flat, K, merge_func)
+    out, off = {}, 0
+    for k in keys:
+        n = checks[0][k].numel()
+        out[k] = merged[off:off + n].view_as(checks[0][k]).clone()
+        off += n
+    return out
+
+
 def merge_checkpoints(filepaths, output_path, strategy="sum", K=20):
     configs, weights = [], defaultdict(list)
     for fp in filepaths:                                                     # :31-40
@@ -34,7 +72,16 @@ def merge_checkpoints(filepaths, output_path, strategy="sum", K=20):
         configs.append(json.load(open(os.path.join(fp, "config.json"))))
         for k in w:
             weights[k].append(w[k])
-    if strategy.startswith("online-merge-"):                                 # :94-103
+    if strategy.startswith("ties-"):                                         # :78-93 (convert_delta_to_ft: ties_merging.py:224-250)
+        func = strategy.replace("ties-", "")
+        assert func in ("sum", "mean", "max")
+        n = max(len(v) for v in weights.values())
+        shared = {k: v for k, v in weights.items() if len(v) == n}
+        merged = {k: v[0] for k, v in weights.items() if len(v) != n}
+        assert all(len(v) == 1 for k, v in weights.items() if len(v) != n)
+        merged.update(ties_merge_state_dicts([{k: v[i] for k, v in shared.items()} for i in range(n)], K, func))
+        strategy = f"dis-{func}-{K}"
+    elif strategy.startswith("online-merge-"):                               # :94-103
         merged = {}
         names = [get_modal_from_config(c) for c in configs]
         for k in weights:

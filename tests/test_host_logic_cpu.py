@@ -113,4 +113,7 @@ def test_merge_cli_matches_reference_golden(tmp_path):
     assert json.load(open(out / "config.json")) == meta["out_config"]
     assert open(out / "merge_info.txt").read().replace(str(tmp_path), "<TMP>") == meta["merge_info"]
     with pytest.raises(NotImplementedError):
-        compose.merge_checkpoints(paths, str(out), "ties-sum")
+        compose.merge_checkpoints(paths, str(out), "convert-ties-sum")
+    if not torch.cuda.is_available():             # TIES runs on the HIP device and fails loudly without one (no CPU fallback)
+        with pytest.raises(RuntimeError):
+            compose.merge_checkpoints(paths, str(out), "ties-sum")

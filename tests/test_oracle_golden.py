@@ -252,3 +252,39 @@ def test_g9_training_step_loss_and_gradients():
     for k, g in ref.items():
         scale = g.abs().max().item()
         assert (grads[k] - g).abs().max().item() <= 2e-4 * scale + 1e-8, k
+
+
+def test_g10_ties_merging_tensor_and_file_level(tmp_path):
+    """TIES merging against the reference's do_merging / merge_checkpoints outputs (bit-exact fp32), incl. magnitude ties at the
+    trim threshold, zero-sum columns taking the majority sign, and the reference's demo() inputs."""
+    import os
+    from oracle import merge as omerge
+    a, meta, _ = load_golden("g10_ties")
+    keys = meta["shared_keys"]
+    cks = [{k: a[f"in::{i}::{k}"] for k in keys} for i in range(3)]
+    for func in ("mean", "sum", "max"):
+        for K in (20, 50):
+            got = omerge.ties_merge_state_dicts(cks, K, func)
+            for k in keys:
+                assert torch.equal(got[k], a[f"out::{func}::{K}::{k}"]), (func, K, k)
+    demo = omerge.ties_merge_state_dicts([{"x": torch.Tensor([1, 2, 3]), "y": torch.Tensor([4, 5, 6])},
+                                          {"x": torch.Tensor([-1, 2, 3]), "y": torch.Tensor([0, 0, 0])}], 0.9, "mean")
+    assert torch.equal(demo["x"], a["demo::x"]) and torch.equal(demo["y"], a["demo::y"])
+    paths = []
+    for i, modal in enumerate(meta["order"]):
+        d = tmp_path / f"ckpt-{modal}"
+        d.mkdir()
+        w = dict(cks[i])
+        w.update({k.split("::", 2)[2]: v for k, v in a.items() if k.startswith(f"fin::{modal}::")})
+        torch.save(w, d / "adapter_model.bin")
+        json.dump(meta["in_configs"][modal], open(d / "config.json", "w"))
+        paths.append(str(d))
+    out = tmp_path / "merged"
+    omerge.merge_checkpoints(paths, str(out), "ties-mean", K=20)
+    got = torch.load(out / "adapter_model.bin")
+    exp = {k[6:]: v for k, v in a.items() if k.startswith("fout::")}
+    assert sorted(got) == sorted(exp)
+    for k in exp:
+        assert torch.equal(got[k], exp[k]), k
+    assert json.load(open(out / "config.json")) == meta["out_config"]
+    assert open(out / "merge_info.txt").read().replace(str(tmp_path), "<TMP>") == meta["merge_info"]

@@ -105,6 +105,22 @@ def main():
                 gemm_case(8192, 8192, 8192, rot=1)
                 gemm_case(10928, 4096, 4096, rot=1)
         L.mc_gemm_debug(0)
+    if "ties" in which:
+        from modelcompose_amd import compose
+        n, d = 3, 327_155_712                  # the rank-128 default adapter of Vicuna-7B: 0.33 G elements per checkpoint
+        for dt in (torch.bfloat16, torch.float32):
+            flat = (torch.randn(n, d, device="cuda", dtype=torch.float32) * 0.02).to(dt)
+            compose.ties_merge_vectors(flat, 20, "mean")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            compose.ties_merge_vectors(flat, 20, "mean")
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            by = flat.numel() * flat.element_size()
+            # 3 histogram passes + sign election + merge read the task vectors 5 times; sign [d] int8 written + read, out [d] written
+            alg = 5 * by + 2 * d + d * flat.element_size()
+            print(f"ties-mean n={n} d={d} {dt}: {t*1e3:8.2f} ms  {alg/t/1e12:5.2f} TB/s over {alg/1e9:.1f} GB (5 streaming passes)")
+            del flat
     if "prefill" in which:
         for M in (1536, 9376, 10912):
             for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)):
