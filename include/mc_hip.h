@@ -53,6 +53,13 @@ int mc_compose_weight_ex_bf16(const void* w_rowmajor, int64_t ldw, const void* c
                               const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
                               int N, int K, const float* col_scale, int nb_stride, int nb_offset, void* stream);
 
+/* ---- audio front-end: Kaldi log-mel filterbank + BEATs normalisation + zero padding (beats/audio_processor.py:143-170; replaces
+ * torchaudio.compliance.kaldi.fbank, a third-party CPU dependency of the reference).  wav [B, wav_stride] fp32 at 16 kHz,
+ * n_samples [B] (device), out [B, frames_out, 128] bf16 and / or fp32; window [400], mel [128, 257], mel_lo / mel_hi [128].    */
+int mc_fbank_f32(const float* wav, const int32_t* n_samples, int64_t wav_stride, int B, const float* window, const float* mel,
+                 const int32_t* mel_lo, const int32_t* mel_hi, float in_scale, float mean, float std, void* out_bf16, float* out_f32,
+                 int frames_out, void* stream);
+
 /* ---- TIES merging of checkpoints (scripts/model_composition/ties_merging.py:88-221, --strategy ties-{mean,sum,max}) ------------
  * x: n flattened task vectors [n, d] (row stride ld elements) of dtype MC_DTYPE_*.  mc_ties_hist is one pass of the exact radix
  * select of each row's k-th smallest magnitude (host reads the 2048-bin histograms and picks the bin: 3 passes of 11/11/10 bits);

@@ -63,6 +63,11 @@ class HipBeatsAudioEncoder:
     def __init__(self, audio_encoder: Optional[str], args=None, delay_load=False, config: Optional[BeatsConfig] = None, device="cuda"):
         self.audio_encoder_name, self.device, self.dtype = audio_encoder, torch.device(device), BF16
         self.is_loaded, self.cfg, self.audio_processor = False, config, None
+        try:
+            from .audio_processor import HipBeatsAudioProcessor
+            self.audio_processor = HipBeatsAudioProcessor(device=device)          # audio_encoder.py:33 (BeatsAudioProcessor())
+        except Exception:
+            self.audio_processor = None
         if audio_encoder is not None and os.path.isfile(str(audio_encoder)):
             ck = torch.load(audio_encoder, map_location="cpu")
             self.cfg = BeatsConfig(ck["cfg"])

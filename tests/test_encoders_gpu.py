@@ -83,3 +83,30 @@ def test_imagebind_audio_branch_matches_reference():
     assert y.shape == a["out"].shape
     assert rel_err(cls, a["cls_feature"]) < 2 ** -5
     assert rel_err(y, a["out"]) < 2 ** -5
+
+
+def test_beats_audio_processor_fbank_matches_oracle():
+    """Kaldi log-mel front-end + BEATs normalisation + padding on the GPU against the oracle restatement (itself cross-checked with
+    an independent implementation; torchaudio, the reference's dependency, is absent -> parity unpinned by the reference).
+    Tolerance: fp32 FFT / summation order on values of magnitude ~1 after normalisation."""
+    import numpy as np
+    from modelcompose_amd.model.audio_processor import HipBeatsAudioProcessor
+    from oracle import fbank
+    rng = np.random.default_rng(5)
+    proc = HipBeatsAudioProcessor()
+    for T in (16000 * 10, 16000 * 3 + 77, 399, 400):
+        wav = (rng.standard_normal(T) * 0.1 + 0.01).astype(np.float32)
+        ref, mask_ref = fbank.beats_process_waveform(wav)
+        got, mask = proc(torch.from_numpy(wav))
+        assert got.shape == ref.shape == (1024, 128) and mask.shape == (1024,) and not bool(mask.any())
+        m = 1 + (T - 400) // 160 if T >= 400 else 0
+        assert torch.count_nonzero(got[m:]) == 0
+        f32 = proc.fbank(torch.from_numpy(wav).cuda().view(1, -1), torch.tensor([T], dtype=torch.int32), 1024, out_dtype=torch.float32)[0]
+        assert np.abs(f32.cpu().numpy() - ref).max() < 2e-3
+        assert (got.float().cpu() - torch.from_numpy(ref)).abs().max().item() < 2 ** -6        # bf16 storage of values within ~[-2, 2]
+    pe = HipBeatsAudioProcessor(is_eval=True)
+    wav = (rng.standard_normal(16000 * 7) * 0.1).astype(np.float32)
+    ref, _ = fbank.beats_process_waveform(wav, is_eval=True)
+    got, _ = pe(torch.from_numpy(wav))
+    assert got.shape == ref.shape
+    assert (got.float().cpu() - torch.from_numpy(ref)).abs().max().item() < 2 ** -6

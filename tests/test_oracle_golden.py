@@ -288,3 +288,25 @@ def test_g10_ties_merging_tensor_and_file_level(tmp_path):
         assert torch.equal(got[k], exp[k]), k
     assert json.load(open(out / "config.json")) == meta["out_config"]
     assert open(out / "merge_info.txt").read().replace(str(tmp_path), "<TMP>") == meta["merge_info"]
+
+
+def test_fbank_oracle_against_independent_kaldi_implementation():
+    """torchaudio (the reference's fbank) is absent: the oracle's restatement of kaldi.fbank is cross-checked against the
+    independent numpy implementation in transformers.audio_utils configured for Kaldi compatibility."""
+    import numpy as np
+    from transformers import audio_utils as au
+    from oracle import fbank
+    rng = np.random.default_rng(3)
+    wav = (rng.standard_normal(16000 * 2 + 123) * 0.1).astype(np.float32) * np.float32(2 ** 15)
+    got = fbank.kaldi_fbank(wav)
+    window = au.window_function(400, "povey", periodic=False)
+    mel = au.mel_filter_bank(num_frequency_bins=257, num_mel_filters=128, min_frequency=20, max_frequency=8000, sampling_rate=16000,
+                             norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    ref = au.spectrogram(wav, window, frame_length=400, hop_length=160, fft_length=512, power=2.0, center=False, preemphasis=0.97,
+                         mel_filters=mel, mel_floor=1.192092955078125e-07, log_mel="log", remove_dc_offset=True).T
+    assert got.shape == ref.shape == (1 + (len(wav) - 400) // 160, 128)
+    assert np.abs(got - ref).max() < 2e-3                      # float32 FFT / accumulation order; values are ~10-25
+    fb, mask = fbank.beats_process_waveform(wav / np.float32(2 ** 15))
+    assert fb.shape == (1024, 128) and not mask.any()
+    assert np.all(fb[got.shape[0]:] == 0)
+    np.testing.assert_allclose(fb[:got.shape[0]], (got - 15.41663) / (2 * 6.55582), rtol=1e-5, atol=1e-5)
