@@ -60,6 +60,15 @@ int mc_fbank_f32(const float* wav, const int32_t* n_samples, int64_t wav_stride,
                  const int32_t* mel_lo, const int32_t* mel_hi, float in_scale, float mean, float std, void* out_bf16, float* out_f32,
                  int frames_out, void* stream);
 
+/* ---- image front-end: expand2square (mm_utils.py:14-26) + CLIPImageProcessor (PIL 8-bit bicubic resize, centre crop, /255,
+ * normalise) as integer-exact device kernels.  img [h, w, 3] uint8 (device) pasted at (off_y, off_x) of a canvas of colour bg
+ * (host int[3]); bounds / kk = Pillow's precompute_coeffs tables in 22-bit fixed point (device int32; NULL = axis not resized);
+ * mean / stdv host float[3]; tmp = canvas_h * res_w * 3 bytes of scratch; out [3, size_h, size_w].                          */
+int mc_image_preprocess_u8(const void* img, int h, int w, int canvas_h, int canvas_w, int off_y, int off_x, const int32_t* bg,
+                           const int32_t* bounds_h, const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v,
+                           int ksize_v, int res_h, int res_w, int top, int left, int size_h, int size_w, const float* mean,
+                           const float* stdv, void* tmp, void* out_bf16, float* out_f32, void* out_u8, void* stream);
+
 /* ---- TIES merging of checkpoints (scripts/model_composition/ties_merging.py:88-221, --strategy ties-{mean,sum,max}) ------------
  * x: n flattened task vectors [n, d] (row stride ld elements) of dtype MC_DTYPE_*.  mc_ties_hist is one pass of the exact radix
  * select of each row's k-th smallest magnitude (host reads the 2048-bin histograms and picks the bin: 3 passes of 11/11/10 bits);

@@ -102,3 +102,110 @@ extern "C" int mc_fbank_f32(const float* wav, const int32_t* n_samples, int64_t 
     MC_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Image front-end of the vision branch: expand2square (modelcompose/mm_utils.py:14-26) + the CLIPImageProcessor steps
+// (resize with PIL's 8-bit bicubic resampling, centre crop, rescale 1/255, normalise) that the reference runs on the CPU through
+// PIL / transformers.  Integer work restated exactly: 22-bit fixed-point weights (computed on the host in double precision, as
+// Pillow's precompute_coeffs / normalize_coeffs_8bpc do), rounding bias, clamp to 0..255 after EACH pass (horizontal, then vertical).
+#define RS_PRECISION_BITS 22
+
+struct ResampleSrc {
+    const uint8_t* img;       // [h, w, 3] uint8 (HWC)
+    int h, w;                 // real image
+    int off_y, off_x;         // paste offset inside the virtual (padded) canvas
+    int bg[3];                // canvas colour outside the image
+};
+
+__device__ __forceinline__ int rs_get(const ResampleSrc& s, int y, int x, int c) {
+    const int yy = y - s.off_y, xx = x - s.off_x;
+    if (yy < 0 || yy >= s.h || xx < 0 || xx >= s.w) return s.bg[c];
+    return s.img[((int64_t)yy * s.w + xx) * 3 + c];
+}
+
+__device__ __forceinline__ int rs_clip8(int acc) {
+    const int v = acc >> RS_PRECISION_BITS;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// horizontal pass over canvas rows [row0, row0 + rows): tmp[r][xx][c]; with_resize == 0 copies the canvas column xx
+__global__ __launch_bounds__(256) void resample_h_kernel(ResampleSrc s, const int32_t* __restrict__ bounds, const int32_t* __restrict__ kk, int ksize,
+                                                         int row0, int rows, int out_w, int with_resize, uint8_t* __restrict__ tmp) {
+    const int64_t total = (int64_t)rows * out_w;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / out_w), xx = (int)(i % out_w);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int v;
+            if (with_resize) {
+                const int x0 = bounds[2 * xx], n = bounds[2 * xx + 1];
+                int acc = 1 << (RS_PRECISION_BITS - 1);
+                for (int k = 0; k < n; ++k) acc += kk[xx * ksize + k] * rs_get(s, row0 + r, x0 + k, c);
+                v = rs_clip8(acc);
+            } else {
+                v = rs_get(s, row0 + r, xx, c);
+            }
+            tmp[i * 3 + c] = (uint8_t)v;
+        }
+    }
+}
+
+// vertical pass over the crop window + rescale + normalise: out[c][y][x] (CHW), tmp rows are relative to row0
+__global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* __restrict__ tmp, int tmp_w, int row0, const int32_t* __restrict__ bounds,
+                                                              const int32_t* __restrict__ kk, int ksize, int with_resize, int top, int left, int size_h,
+                                                              int size_w, float m0, float m1, float m2, float s0, float s1, float s2,
+                                                              bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32, uint8_t* __restrict__ out_u8) {
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    const int64_t total = (int64_t)size_h * size_w;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i / size_w), x = (int)(i % size_w);
+        const int yy = top + y, xx = left + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int v;
+            if (with_resize) {
+                const int y0 = bounds[2 * yy], n = bounds[2 * yy + 1];
+                int acc = 1 << (RS_PRECISION_BITS - 1);
+                for (int k = 0; k < n; ++k) acc += kk[yy * ksize + k] * (int)tmp[((int64_t)(y0 + k - row0) * tmp_w + xx) * 3 + c];
+                v = rs_clip8(acc);
+            } else {
+                v = tmp[((int64_t)(yy - row0) * tmp_w + xx) * 3 + c];
+            }
+            if (out_u8) out_u8[i * 3 + c] = (uint8_t)v;
+            // transformers: float32(float64(v) * (1 / 255)), then (x - mean) / std in float32
+            const float f = (float)((double)v * (1.0 / 255.0));
+            const float o = (f - mean[c]) / stdv[c];
+            const int64_t oi = (int64_t)c * total + i;
+            if (out_bf16) out_bf16[oi] = (bf16_t)o;
+            if (out_f32) out_f32[oi] = o;
+        }
+    }
+}
+
+// img [h, w, 3] uint8 on the device is pasted at (off_y, off_x) of a canvas_h x canvas_w canvas of colour bg (expand2square; pass the
+// image size and zero offsets for no padding), resized to res_h x res_w with PIL's bicubic (coefficient tables from the host:
+// bounds_* [out, 2], kk_* [out, ksize_*]; a null table = that axis keeps its size), centre-cropped at (top, left) to size_h x size_w,
+// rescaled and normalised to out [3, size_h, size_w] (bf16 and / or fp32; out_u8 optionally receives the cropped uint8 HWC image).
+// tmp: scratch of canvas_h * res_w * 3 bytes.
+extern "C" int mc_image_preprocess_u8(const void* img, int h, int w, int canvas_h, int canvas_w, int off_y, int off_x, const int32_t* bg,
+                                      const int32_t* bounds_h, const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v,
+                                      int ksize_v, int res_h, int res_w, int top, int left, int size_h, int size_w, const float* mean,
+                                      const float* stdv, void* tmp, void* out_bf16, float* out_f32, void* out_u8, void* stream) {
+    MC_CHECK_ARG(img && bg && mean && stdv && tmp && (out_bf16 || out_f32 || out_u8) && h > 0 && w > 0, "mc_image_preprocess_u8: null / empty argument");
+    MC_CHECK_ARG(canvas_h >= h && canvas_w >= w && off_y >= 0 && off_x >= 0 && off_y + h <= canvas_h && off_x + w <= canvas_w,
+                 "mc_image_preprocess_u8: image does not fit the canvas");
+    MC_CHECK_ARG((bounds_h ? res_w > 0 : res_w == canvas_w) && (bounds_v ? res_h > 0 : res_h == canvas_h), "mc_image_preprocess_u8: bad resize");
+    MC_CHECK_ARG(top >= 0 && left >= 0 && top + size_h <= res_h && left + size_w <= res_w && size_h > 0 && size_w > 0, "mc_image_preprocess_u8: bad crop");
+    hipStream_t s = (hipStream_t)stream;
+    ResampleSrc src{(const uint8_t*)img, h, w, off_y, off_x, {bg[0], bg[1], bg[2]}};
+    const int64_t t1 = (int64_t)canvas_h * res_w;
+    resample_h_kernel<<<(int)min((int64_t)4096, (t1 + 255) / 256), 256, 0, s>>>(src, bounds_h, kk_h, ksize_h, 0, canvas_h, res_w, bounds_h != nullptr,
+                                                                                (uint8_t*)tmp);
+    const int64_t t2 = (int64_t)size_h * size_w;
+    resample_v_norm_kernel<<<(int)min((int64_t)4096, (t2 + 255) / 256), 256, 0, s>>>((const uint8_t*)tmp, res_w, 0, bounds_v, kk_v, ksize_v,
+                                                                                     bounds_v != nullptr, top, left, size_h, size_w, mean[0], mean[1],
+                                                                                     mean[2], stdv[0], stdv[1], stdv[2], (bf16_t*)out_bf16, out_f32,
+                                                                                     (uint8_t*)out_u8);
+    MC_CHECK_LAUNCH();
+    return 0;
+}

@@ -74,6 +74,9 @@ class HipClipVisionTower:
 
     @property
     def modal_processor(self):
+        if self.image_processor is None and self.config is not None:
+            from .image_processor import HipCLIPImageProcessor
+            self.image_processor = HipCLIPImageProcessor(self.config.image_size, device=self.device)
         return self.image_processor
 
     def load_model(self):
@@ -93,11 +96,12 @@ class HipClipVisionTower:
         if sd is None:
             raise FileNotFoundError(f"no CLIP weights (model.safetensors / pytorch_model.bin) under {path}")
         self.load_state_dict(sd)
+        # clip_encoder.py:53 loads transformers' CLIPImageProcessor (PIL on the CPU); here the same steps run on the device
+        from .image_processor import HipCLIPImageProcessor
         try:
-            from transformers import CLIPImageProcessor
-            self.image_processor = CLIPImageProcessor.from_pretrained(path)
-        except Exception:            # processor is CPU-side preprocessing, out of the device path
-            self.image_processor = None
+            self.image_processor = HipCLIPImageProcessor.from_pretrained(path, device=self.device)
+        except Exception:
+            self.image_processor = HipCLIPImageProcessor(self.config.image_size, device=self.device)
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         """Accepts HF CLIPVisionModel keys ('vision_model.…', as in 4.31 checkpoints) or the un-prefixed 5.x grammar."""

@@ -110,3 +110,31 @@ def test_beats_audio_processor_fbank_matches_oracle():
     got, _ = pe(torch.from_numpy(wav))
     assert got.shape == ref.shape
     assert (got.float().cpu() - torch.from_numpy(ref)).abs().max().item() < 2 ** -6
+
+
+def test_clip_image_processor_bit_exact_vs_oracle():
+    """expand2square + PIL bicubic resize + centre crop on the GPU: the uint8 image is bit-identical to the oracle (= PIL), the
+    normalised float32 output equals the oracle's (= transformers CLIPImageProcessor) exactly."""
+    import numpy as np
+    from modelcompose_amd.model.image_processor import HipCLIPImageProcessor
+    from modelcompose_amd.mm_utils import process_images
+    from oracle import image as oi
+    rng = np.random.default_rng(2)
+    proc = HipCLIPImageProcessor(336)
+    for (h, w) in ((480, 640), (700, 500), (336, 336), (90, 200), (1200, 1600)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for pad in (True, False):
+            ref = oi.clip_preprocess(img, 336, pad)
+            bg = tuple(int(x * 255) for x in proc.image_mean) if pad else None
+            got, u8 = proc._one(img, bg, out_u8=True)
+            sq = oi.expand2square(img, bg) if pad else img
+            hh, ww = sq.shape[:2]
+            short, long_ = (ww, hh) if ww <= hh else (hh, ww)
+            oh, ow = (int(336 * long_ / short), 336) if ww <= hh else (336, int(336 * long_ / short))
+            r8 = oi.resize_bicubic_u8(sq, oh, ow)
+            r8 = r8[(oh - 336) // 2:(oh - 336) // 2 + 336, (ow - 336) // 2:(ow - 336) // 2 + 336]
+            assert np.array_equal(u8.cpu().numpy(), r8), (h, w, pad)
+            assert np.array_equal(got.cpu().numpy(), ref), (h, w, pad)
+    cfg = type("C", (), {"image_aspect_ratio": "pad"})()
+    batch = process_images([rng.integers(0, 256, (300, 400, 3), dtype=np.uint8) for _ in range(2)], proc, cfg)
+    assert batch.shape == (2, 3, 336, 336)

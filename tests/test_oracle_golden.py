@@ -310,3 +310,24 @@ def test_fbank_oracle_against_independent_kaldi_implementation():
     assert fb.shape == (1024, 128) and not mask.any()
     assert np.all(fb[got.shape[0]:] == 0)
     np.testing.assert_allclose(fb[:got.shape[0]], (got - 15.41663) / (2 * 6.55582), rtol=1e-5, atol=1e-5)
+
+
+def test_image_preprocess_oracle_against_pil_and_clip_image_processor():
+    """The oracle's integer restatement of Pillow's bicubic resampling is bit-identical to PIL.Image.resize, and the whole
+    expand2square + CLIPImageProcessor chain equals transformers' own processor (both third-party, installed here)."""
+    import numpy as np
+    from PIL import Image
+    from oracle import image as oi
+    rng = np.random.default_rng(0)
+    for (h, w, oh, ow) in ((480, 640, 336, 448), (500, 500, 336, 336), (100, 130, 336, 436), (1000, 700, 224, 224), (337, 900, 336, 336)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), resample=Image.BICUBIC))
+        assert np.array_equal(oi.resize_bicubic_u8(img, oh, ow), ref), (h, w, oh, ow)
+    from transformers import CLIPImageProcessor
+    proc = CLIPImageProcessor(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336})
+    for (h, w) in ((480, 640), (700, 500), (336, 336)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for pad in (True, False):
+            pil = Image.fromarray(oi.expand2square(img, tuple(int(x * 255) for x in proc.image_mean)) if pad else img)
+            ref = proc.preprocess(pil, return_tensors="pt")["pixel_values"][0].numpy()
+            assert np.array_equal(oi.clip_preprocess(img, 336, pad), ref), (h, w, pad)
