@@ -69,6 +69,12 @@ int mc_image_preprocess_u8(const void* img, int h, int w, int canvas_h, int canv
                            int ksize_v, int res_h, int res_w, int top, int left, int size_h, int size_w, const float* mean,
                            const float* stdv, void* tmp, void* out_bf16, float* out_f32, void* out_u8, void* stream);
 
+/* ---- video front-end after decoding (languagebind/video/processing_video.py:24-68): frames [T, H, W, 3] uint8 (device) -> /255 ->
+ * normalise -> bilinear resize to res_h x res_w (torch interpolate semantics, align_corners False) -> crop (top, left, size) ->
+ * optional horizontal flip -> out [3, T, size, size] bf16 and / or fp32.  mean / stdv: host float[3].                        */
+int mc_video_preprocess_u8(const void* frames, int T, int H, int W, int res_h, int res_w, int top, int left, int size, int flip,
+                           const float* mean, const float* stdv, void* out_bf16, float* out_f32, void* stream);
+
 /* ---- TIES merging of checkpoints (scripts/model_composition/ties_merging.py:88-221, --strategy ties-{mean,sum,max}) ------------
  * x: n flattened task vectors [n, d] (row stride ld elements) of dtype MC_DTYPE_*.  mc_ties_hist is one pass of the exact radix
  * select of each row's k-th smallest magnitude (host reads the 2048-bin histograms and picks the bin: 3 passes of 11/11/10 bits);

@@ -75,6 +75,7 @@ _SIGS.update({
     "mc_fbank_f32": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_p],
     "mc_image_preprocess_u8": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(C.c_int32), c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                C.POINTER(c_f), C.POINTER(c_f), c_p, c_p, c_p, c_p, c_p],
+    "mc_video_preprocess_u8": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_f), C.POINTER(c_f), c_p, c_p, c_p],
     "mc_ties_hist": [c_p, c_i, c_l, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
     "mc_ties_merge": [c_p, c_i, c_l, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
     "mc_gemm_grouped_bf16": [C.POINTER(GemmArgsC), c_i, C.POINTER(C.c_int32), C.POINTER(c_p), c_p],

@@ -209,3 +209,47 @@ extern "C" int mc_image_preprocess_u8(const void* img, int h, int w, int canvas_
     MC_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// LanguageBind video front-end after decoding (languagebind/video/processing_video.py:24-68): frames [T, H, W, 3] uint8 ->
+// x / 255 -> (x - mean) / std -> bilinear resize (align_corners = False, no antialiasing: torch.nn.functional.interpolate as called by
+// pytorchvideo's ShortSideScale) -> centre crop -> optional horizontal flip -> out [3, T, size, size].  Source index and
+// interpolation formula follow ATen's upsample_bilinear2d (area_pixel_compute_source_index, h0*(w0*p00 + w1*p01) + h1*(...)).
+__global__ __launch_bounds__(256) void video_preprocess_kernel(const uint8_t* __restrict__ frames, int T, int H, int W, int res_h, int res_w, int top,
+                                                               int left, int size, int flip, float m0, float m1, float m2, float s0, float s1,
+                                                               float s2, bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32) {
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    const float sh = (float)H / (float)res_h, sw = (float)W / (float)res_w;
+    const int64_t per_frame = (int64_t)size * size, total = (int64_t)T * per_frame;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int t = (int)(i / per_frame);
+        const int y = (int)((i % per_frame) / size), x = (int)(i % size);
+        const int oy = top + y, ox = left + (flip ? size - 1 - x : x);
+        const float fy = fmaxf(sh * ((float)oy + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)ox + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float h1 = fy - (float)y0, h0 = 1.f - h1, w1 = fx - (float)x0, w0 = 1.f - w1;
+        const uint8_t* f = frames + (int64_t)t * H * W * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            auto px = [&](int yy, int xx) { return ((float)f[((int64_t)yy * W + xx) * 3 + c] / 255.0f - mean[c]) / stdv[c]; };
+            const float v = h0 * (w0 * px(y0, x0) + w1 * px(y0, x1)) + h1 * (w0 * px(y1, x0) + w1 * px(y1, x1));
+            const int64_t oi = ((int64_t)c * T + t) * per_frame + (int64_t)y * size + x;
+            if (out_bf16) out_bf16[oi] = (bf16_t)v;
+            if (out_f32) out_f32[oi] = v;
+        }
+    }
+}
+
+extern "C" int mc_video_preprocess_u8(const void* frames, int T, int H, int W, int res_h, int res_w, int top, int left, int size, int flip,
+                                      const float* mean, const float* stdv, void* out_bf16, float* out_f32, void* stream) {
+    MC_CHECK_ARG(frames && mean && stdv && (out_bf16 || out_f32) && T > 0 && H > 0 && W > 0 && res_h >= size && res_w >= size && size > 0,
+                 "mc_video_preprocess_u8: bad arguments");
+    MC_CHECK_ARG(top >= 0 && left >= 0 && top + size <= res_h && left + size <= res_w, "mc_video_preprocess_u8: bad crop");
+    const int64_t total = (int64_t)T * size * size;
+    video_preprocess_kernel<<<(int)min((int64_t)8192, (total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        (const uint8_t*)frames, T, H, W, res_h, res_w, top, left, size, flip, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2],
+        (bf16_t*)out_bf16, out_f32);
+    MC_CHECK_LAUNCH();
+    return 0;
+}

@@ -295,6 +295,9 @@ class HipLanguageBindVideoTower:
         self.config, self.is_loaded, self.video_processor = config, False, None
         if config is None and video_tower is not None and os.path.isdir(str(video_tower)):
             self.config = VideoConfig.from_pretrained(video_tower)
+        if self.config is not None:                      # languagebind/__init__.py:205 (LanguageBindVideoProcessor(model.config))
+            from .video_processor import HipLanguageBindVideoProcessor
+            self.video_processor = HipLanguageBindVideoProcessor(self.config.num_frames, self.config.image_size, device=device)
         if not delay_load and video_tower is not None:
             self.load_model()
 

@@ -138,3 +138,23 @@ def test_clip_image_processor_bit_exact_vs_oracle():
     cfg = type("C", (), {"image_aspect_ratio": "pad"})()
     batch = process_images([rng.integers(0, 256, (300, 400, 3), dtype=np.uint8) for _ in range(2)], proc, cfg)
     assert batch.shape == (2, 3, 336, 336)
+
+
+def test_languagebind_video_processor_matches_torch_transform():
+    """/255 + normalise + bilinear short-side resize + centre crop (+ flip) on the GPU against the oracle, which applies the same torch
+    primitives the reference's torchvision / pytorchvideo transforms call.  fp32 within 2e-6 of the value scale (FMA contraction)."""
+    from modelcompose_amd.model.video_processor import HipLanguageBindVideoProcessor, sample_frame_ids
+    from oracle import video as ov
+    import numpy as np
+    assert np.array_equal(sample_frame_ids(100, 8), ov.sample_frame_ids(100, 8))
+    g = torch.Generator().manual_seed(8)
+    proc = HipLanguageBindVideoProcessor(out_dtype=torch.float32)
+    for (T, H, W) in ((8, 240, 320), (8, 360, 202), (2, 224, 224), (3, 100, 500)):
+        fr = torch.randint(0, 256, (T, H, W, 3), generator=g, dtype=torch.uint8)
+        for flip in (False, True):
+            ref = ov.video_transform(fr, 224, flip)
+            got = proc.transform(fr, flip).cpu()
+            assert got.shape == ref.shape == (3, T, 224, 224)
+            assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item(), (T, H, W, flip)
+    out = HipLanguageBindVideoProcessor()(images=[torch.randint(0, 256, (8, 120, 160, 3), generator=g, dtype=torch.uint8)] * 2)
+    assert out["pixel_values"].shape == (2, 3, 8, 224, 224) and out["pixel_values"].dtype == torch.bfloat16
