@@ -161,3 +161,91 @@ def test_g8_four_modality_composed_model_matches_reference():
     for b in range(got.shape[0]):
         n = n_new if bool(safe[b].all()) else int((~safe[b]).float().argmax())
         assert torch.equal(got[b, :n], a["gen_ids"][b, :n]), (b, got[b], a["gen_ids"][b])
+
+
+def _margin_ok(ref_logits, frac):
+    top2 = ref_logits.topk(2, dim=-1).values
+    return (top2[..., 0] - top2[..., 1]) > frac * ref_logits.abs().max()
+
+
+def test_ragged_and_text_only_batch_equals_per_sample_oracle(g4_model):
+    """Edge cases of the splice / decode path: a batch whose samples have different spliced lengths (one of them text only, no image
+    block).  Positions are per sample on the HIP path, so every sample must reproduce the oracle run on that sample alone
+    (the reference's batched position ids ignore padding, SURVEY App. B, so batch-1 is the meaningful reference)."""
+    from oracle import pipeline
+    model, a, meta, sd = g4_model
+    om = pipeline.OracleModel.from_state_dict(sd, meta)
+    V = -200
+    g = torch.Generator().manual_seed(77)
+    r = lambda n: torch.randint(3, 97, (n,), generator=g).tolist()
+    s0 = [1] + r(4) + [V, 13] + r(3)                 # image, length 10 -> spliced 9 + block
+    s1 = [1] + r(9)                                  # text only, same text length, no block
+    ids = torch.tensor([s0, s1], dtype=torch.long)
+    px = a["pixels"][:1]
+    n_new = 5
+    res, lg = model.generate(ids.cuda(), modal_inputs={"vision": px.cuda()}, max_new_tokens=n_new, ignore_eos=True, return_step_logits=True)
+    got = res[:, ids.shape[1]:].cpu()
+    for b, (row, mi) in enumerate(((s0, {"vision": px}), (s1, {}))):
+        ids_o, lg_o = om.generate(torch.tensor([row]), mi, max_new_tokens=n_new, ignore_eos=True, return_logits=True)
+        assert rel_err(lg[b:b + 1], lg_o) < 4e-2, b
+        safe = _margin_ok(lg_o, 8e-2)[0]
+        n = n_new if bool(safe.all()) else int((~safe).float().argmax())
+        assert torch.equal(got[b, :n], ids_o[0, :n]), (b, got[b], ids_o[0])
+    # text-only batch: no modal inputs at all (modal_inputs={} -> no routing, multimodal_llama.py:703-704)
+    res2, lg2 = model.generate(torch.tensor([s1]).cuda(), modal_inputs={}, max_new_tokens=3, ignore_eos=True, return_step_logits=True)
+    _, lg_o2 = om.generate(torch.tensor([s1]), {}, max_new_tokens=3, ignore_eos=True, return_logits=True)
+    assert rel_err(lg2, lg_o2) < 4e-2
+
+
+def test_limits_raise_like_the_reference(g4_model):
+    model, a, meta, sd = g4_model
+    ids = a["input_ids"].cuda()
+    with pytest.raises(ValueError):                   # sentinel without an input for that modality
+        model.generate(ids, modal_inputs={}, max_new_tokens=2)
+    with pytest.raises(ValueError):                   # longer than the rotary table (max_position_embeddings)
+        model.generate(ids, modal_inputs={"vision": a["pixels"].cuda()}, max_new_tokens=meta["max_position_embeddings"])
+    with pytest.raises(NotImplementedError):
+        model.forward(input_ids=ids, modal_inputs={"vision": a["pixels"].cuda()}, output_attentions=True)
+
+
+def test_load_pretrained_model_from_checkpoint_directories(tmp_path):
+    """A15: the loader reads the same files as builder.py:138-185 — base shards (sharded .bin with index), adapter_model.bin,
+    non_lora_trainables.bin, config.json, the CLIP directory — and the loaded model reproduces the in-memory build bit for bit."""
+    import json
+    import os
+    from modelcompose_amd.model.builder import build_from_state_dict, load_pretrained_model
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    a, meta, sd = load_golden("g4_e2e_vision")
+    clip_dir = tmp_path / "clip-tiny"
+    clip_dir.mkdir()
+    pre = "model.modal_encoders.vision.vision_tower."
+    torch.save({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, clip_dir / "pytorch_model.bin")
+    json.dump(dict(meta["clip"], model_type="clip_vision_model"), open(clip_dir / "config.json", "w"))
+    json.dump({"crop_size": 28, "size": 28, "image_mean": [0.48145466, 0.4578275, 0.40821073], "image_std": [0.26862954, 0.26130258, 0.27577711]},
+              open(clip_dir / "preprocessor_config.json", "w"))
+    base, ckpt = tmp_path / "vicuna-tiny", tmp_path / "multimodal-tiny-lora"
+    base.mkdir(); ckpt.mkdir()
+    is_adapter = lambda k: ".lora_" in k or k.startswith("prefix_tokens") or k.startswith("suffix_tokens")
+    is_nonlora = lambda k: k.startswith("model.modal_projectors.")
+    base_sd = {k: v for k, v in sd.items() if not (is_adapter(k) or is_nonlora(k) or k.startswith(pre))}
+    keys = sorted(base_sd)
+    half = len(keys) // 2
+    shards = {"pytorch_model-00001-of-00002.bin": keys[:half], "pytorch_model-00002-of-00002.bin": keys[half:]}
+    for fn, ks in shards.items():
+        torch.save({k: base_sd[k] for k in ks}, base / fn)
+    json.dump({"weight_map": {k: fn for fn, ks in shards.items() for k in ks}}, open(base / "pytorch_model.bin.index.json", "w"))
+    torch.save({"base_model.model." + k: v for k, v in sd.items() if is_adapter(k)}, ckpt / "adapter_model.bin")
+    torch.save({k: v for k, v in sd.items() if is_nonlora(k)}, ckpt / "non_lora_trainables.bin")
+    cfg = {k: v for k, v in meta.items() if k not in ("clip", "modal_names")}
+    cfg["mm_vision_encoder"] = str(clip_dir)
+    json.dump(cfg, open(ckpt / "config.json", "w"))
+    tok, model, procs, ctx = load_pretrained_model(str(ckpt), str(base), "multimodal-tiny-lora")
+    assert ctx == 2048 and set(procs) == {"vision"} and procs["vision"] is not None
+    ref = build_from_state_dict(meta, sd)
+    ids, px = a["input_ids"].cuda(), a["pixels"].cuda()
+    out1 = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=6, ignore_eos=True)
+    out2 = ref.generate(ids, modal_inputs={"vision": px}, max_new_tokens=6, ignore_eos=True)
+    assert torch.equal(out1, out2)
+    with pytest.raises(ValueError):
+        load_pretrained_model(str(ckpt), str(base), "llava-v1.5")            # only the 'multimodal' branch (builder.py:138)
