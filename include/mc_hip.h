@@ -138,7 +138,7 @@ int mc_rope_kv_bf16(const void* qkv, int64_t ld, const int32_t* row_b, const int
 /* ---- training step (BASELINE config 5): element-wise / reduction kernels replacing autograd through the decoder layer
  * (multimodal_llama.py:408-468), the shifted CrossEntropyLoss (:722-733) and torch.optim.AdamW ---------------------------- */
 int mc_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int Rp, void* stream);   /* out[c][r], cols R..Rp-1 zero */
-int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_adapter, int M, int r, int n_adapters, void* stream);
+int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_adapter, int M, int r, int n_adapters, int n_cols, void* stream);
 int mc_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* g, const void* dy, int64_t ldy, const void* dres, int64_t ldr,
                         void* dx, int64_t ldd, int M, int D, float eps, void* stream);
 int mc_swiglu_bwd_bf16(const void* gate_up, int64_t ld, const void* dinter, int64_t ldi, void* dgate_up, int64_t ldg, int M, int I,

@@ -85,7 +85,7 @@ _SIGS.update({
     "mc_attn_prefill_lse_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
                                  c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p, c_p, c_p],
     "mc_transpose_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
-    "mc_lora_mask_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
+    "mc_lora_mask_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
     "mc_rmsnorm_bwd_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_swiglu_bwd_bf16": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "mc_act_bf16": [c_p, c_p, c_p, c_l, c_i, c_p],

@@ -30,22 +30,24 @@ extern "C" int mc_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t
 }
 
 // ------------------------------------------------------------------------------------------
-// LocalLoRA routing of the low-rank activations: t is [M, n_adapters*r]; row m keeps the r columns of its adapter
-// (row_adapter[m]) and is zeroed elsewhere — the per-token mask-sum of multimodal_llama.py:262-268 applied where it is cheap.
+// LocalLoRA routing of the low-rank activations: t is [M, n_cols] = one r-wide block per (linear, adapter), adapters fastest
+// (n_cols = n_linears * n_adapters * r); row m keeps the blocks of its adapter (row_adapter[m]) and is zeroed elsewhere — the
+// per-token mask-sum of multimodal_llama.py:262-268 applied where it is cheap.
 __global__ __launch_bounds__(256) void lora_mask_kernel(bf16_t* __restrict__ t, int64_t ld, const int32_t* __restrict__ row_adapter, int M, int r,
-                                                        int n_adapters) {
-    const int nv = (n_adapters * r) >> 3;
+                                                        int n_adapters, int n_cols) {
+    const int nv = n_cols >> 3;
     const int64_t total = (int64_t)M * nv;
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int m = (int)(i / nv), cv = (int)(i % nv);
-        if ((cv * 8) / r != row_adapter[m]) *(u32x4*)(t + (int64_t)m * ld + cv * 8) = (u32x4){0u, 0u, 0u, 0u};
+        if (((cv * 8) / r) % n_adapters != row_adapter[m]) *(u32x4*)(t + (int64_t)m * ld + cv * 8) = (u32x4){0u, 0u, 0u, 0u};
     }
 }
 
-extern "C" int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_adapter, int M, int r, int n_adapters, void* stream) {
-    MC_CHECK_ARG(t && row_adapter && M > 0 && r > 0 && r % 8 == 0 && n_adapters > 0 && ld % 8 == 0, "mc_lora_mask_rows_bf16: bad arguments");
-    const int64_t total = (int64_t)M * ((n_adapters * r) >> 3);
-    lora_mask_kernel<<<(int)min((int64_t)8192, (total + 255) / 256), 256, 0, (hipStream_t)stream>>>((bf16_t*)t, ld, row_adapter, M, r, n_adapters);
+extern "C" int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_adapter, int M, int r, int n_adapters, int n_cols, void* stream) {
+    MC_CHECK_ARG(t && row_adapter && M > 0 && r > 0 && r % 8 == 0 && n_adapters > 0 && ld % 8 == 0 && n_cols > 0 && n_cols % (n_adapters * r) == 0,
+                 "mc_lora_mask_rows_bf16: bad arguments");
+    const int64_t total = (int64_t)M * (n_cols >> 3);
+    lora_mask_kernel<<<(int)min((int64_t)8192, (total + 255) / 256), 256, 0, (hipStream_t)stream>>>((bf16_t*)t, ld, row_adapter, M, r, n_adapters, n_cols);
     MC_CHECK_LAUNCH();
     return 0;
 }

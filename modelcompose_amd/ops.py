@@ -351,7 +351,8 @@ def transpose(x, Rp=None, out=None):
 
 
 def lora_mask_rows(t, row_adapter, r, n_adapters):
-    _lib.check(_lib.lib().mc_lora_mask_rows_bf16(_p(t), t.stride(0), _p(row_adapter), t.shape[0], r, n_adapters, _stream()),
+    """t [M, n_linears * n_adapters * r]: zero every r-wide block that does not belong to the row's adapter."""
+    _lib.check(_lib.lib().mc_lora_mask_rows_bf16(_p(t), t.stride(0), _p(row_adapter), t.shape[0], r, n_adapters, t.shape[1], _stream()),
                "mc_lora_mask_rows_bf16")
     return t
 

@@ -35,8 +35,11 @@ from .buckets import bucket_ranges
 
 BF16 = torch.bfloat16
 F32 = torch.float32
-LINS = (("self_attn", "q_proj"), ("self_attn", "k_proj"), ("self_attn", "v_proj"), ("self_attn", "o_proj"),
-        ("mlp", "gate_proj"), ("mlp", "up_proj"), ("mlp", "down_proj"))
+# linears that read the same activation share one rank-projection GEMM: their A matrices are stored stacked ("A_in")
+GROUPS = (("attn_in", (("self_attn", "q_proj"), ("self_attn", "k_proj"), ("self_attn", "v_proj"))),
+          ("attn_out", (("self_attn", "o_proj"),)),
+          ("mlp_in", (("mlp", "gate_proj"), ("mlp", "up_proj"))),
+          ("mlp_out", (("mlp", "down_proj"),)))
 
 
 class _Param:
@@ -122,15 +125,17 @@ class MultimodalTrainStep:
             off += tensor.numel()
 
         for l in reversed(range(Ln)):
-            for blk, lin in reversed(LINS):
-                N, K = dims[lin]
-                pre = f"model.layers.{l}.{blk}.{lin}"
-                a = [raw.get(f"{pre}.lora_A.{n}.weight") for n in self.names]
-                b = [raw.get(f"{pre}.lora_B.{n}.weight") for n in self.names]
-                if any(x is None for x in a + b):
-                    raise ValueError(f"{pre}: lora_A/lora_B missing for one of the adapters {self.names}")
-                add(pre + ".A_cat", torch.cat([x.float() for x in a], 0))            # [nA*r, K]
-                add(pre + ".B_cat", torch.cat([x.float() for x in b], 1))            # [N, nA*r]
+            for gname, lins in reversed(GROUPS):
+                a_rows = []
+                for blk, lin in lins:
+                    pre = f"model.layers.{l}.{blk}.{lin}"
+                    a = [raw.get(f"{pre}.lora_A.{n}.weight") for n in self.names]
+                    b = [raw.get(f"{pre}.lora_B.{n}.weight") for n in self.names]
+                    if any(x is None for x in a + b):
+                        raise ValueError(f"{pre}: lora_A/lora_B missing for one of the adapters {self.names}")
+                    a_rows += [x.float() for x in a]
+                    add(pre + ".B_cat", torch.cat([x.float() for x in b], 1))        # [N, nA*r]
+                add(f"model.layers.{l}.{gname}.A_in", torch.cat(a_rows, 0))           # [n_linears*nA*r, K], linear-major, adapter, rank
             self.layer_end[l] = off
         self.proj_modals = []
         for m, proj in self.model.model.modal_projectors.items():
@@ -164,9 +169,12 @@ class MultimodalTrainStep:
         out = {}
         for name, p in self.params.items():
             g = self.view(self.G, name)
-            if name.endswith(".A_cat"):
-                for i, n in enumerate(self.names):
-                    out[name[:-6] + f".lora_A.{n}.weight"] = g[i * self.r:(i + 1) * self.r]
+            if name.endswith(".A_in"):
+                l, gname = name.split(".")[2], name.split(".")[3]
+                lins = dict(GROUPS)[gname]
+                for j, (blk, lin) in enumerate(lins):
+                    for i, n in enumerate(self.names):
+                        out[f"model.layers.{l}.{blk}.{lin}.lora_A.{n}.weight"] = g[j * self.R + i * self.r:j * self.R + (i + 1) * self.r]
             elif name.endswith(".B_cat"):
                 for i, n in enumerate(self.names):
                     out[name[:-6] + f".lora_B.{n}.weight"] = g[:, i * self.r:(i + 1) * self.r]
@@ -177,24 +185,37 @@ class MultimodalTrainStep:
         return out
 
     # ------------------------------------------------------------------ helpers
-    def _lora_fwd(self, x, y, lname, row_adapter, saved):
-        """y += s * mask(x A_cat^T) B_cat^T   (in place on the view y [M, N])."""
-        A16, B16 = self.view(self.P16, lname + ".A_cat"), self.view(self.P16, lname + ".B_cat")
-        T = ops.linear(x, ops.pack_weight(A16))
+    def _lora_fwd(self, x, ys, layer, gname, row_adapter, saved):
+        """For the linears of a group (same input x): y_j += s * mask(x A_j^T) B_j^T, in place on the views ys[j] ([M, N_j]).
+        One GEMM projects x onto all stacked A matrices; the routing mask zeroes, per row, the rank blocks of the other adapters."""
+        lins = dict(GROUPS)[gname]
+        A16 = self.view(self.P16, f"model.layers.{layer}.{gname}.A_in")
+        T = ops.linear(x, ops.pack_weight(A16))                                      # [M, n_linears * R]
         ops.lora_mask_rows(T, row_adapter, self.r, self.nA)
-        ops.linear(T, ops.pack_weight(B16), residual=y, out=y, alpha=self.scale)
-        saved[lname + ".T"] = T
+        for j, (blk, lin) in enumerate(lins):
+            B16 = self.view(self.P16, f"model.layers.{layer}.{blk}.{lin}.B_cat")
+            ops.linear(T[:, j * self.R:(j + 1) * self.R], ops.pack_weight(B16), residual=ys[j], out=ys[j], alpha=self.scale)
+        saved[f"{layer}.{gname}.T"] = T
 
-    def _lora_bwd(self, dy, x, xT_packed, dx, lname, row_adapter, saved, Mp):
-        """dx += s * mask(dy B_cat) A_cat;  dB = s dy^T T;  dA = s mask(dy B_cat)^T x."""
-        A16, B16 = self.view(self.P16, lname + ".A_cat"), self.view(self.P16, lname + ".B_cat")
-        T = saved[lname + ".T"]
-        dT = ops.linear(dy, ops.pack_weight(ops.transpose(B16)))                      # [M, R] = dy . B_cat
+    def _lora_bwd(self, dys, x, dx, layer, gname, row_adapter, saved, Mp):
+        """dx += s * mask(dT) A_in with dT_j = dy_j B_j;  dB_j = s dy_j^T T_j;  dA_in = s mask(dT)^T x."""
+        lins = dict(GROUPS)[gname]
+        aname = f"model.layers.{layer}.{gname}.A_in"
+        A16 = self.view(self.P16, aname)
+        T = saved[f"{layer}.{gname}.T"]
+        M = T.shape[0]
+        dT = torch.empty(M, len(lins) * self.R, dtype=BF16, device=self.dev)
+        for j, (blk, lin) in enumerate(lins):
+            B16 = self.view(self.P16, f"model.layers.{layer}.{blk}.{lin}.B_cat")
+            ops.linear(dys[j], ops.pack_weight(ops.transpose(B16)), out=dT[:, j * self.R:(j + 1) * self.R])   # dy_j . B_j
         ops.lora_mask_rows(dT, row_adapter, self.r, self.nA)
         ops.linear(dT, ops.pack_weight(ops.transpose(A16)), residual=dx, out=dx, alpha=self.scale)
-        dyT = ops.transpose(dy, Rp=Mp)                                                # [N, Mp]
-        ops.linear(dyT, ops.pack_weight(ops.transpose(T, Rp=Mp)), out=self.view(self.G, lname + ".B_cat"), out_f32=True, alpha=self.scale)
-        ops.linear(ops.transpose(dT, Rp=Mp), xT_packed, out=self.view(self.G, lname + ".A_cat"), out_f32=True, alpha=self.scale)
+        for j, (blk, lin) in enumerate(lins):
+            Tj = T[:, j * self.R:(j + 1) * self.R]
+            ops.linear(ops.transpose(dys[j], Rp=Mp), ops.pack_weight(ops.transpose(Tj, Rp=Mp)),
+                       out=self.view(self.G, f"model.layers.{layer}.{blk}.{lin}.B_cat"), out_f32=True, alpha=self.scale)
+        ops.linear(ops.transpose(dT, Rp=Mp), ops.pack_weight(ops.transpose(x, Rp=Mp)), out=self.view(self.G, aname), out_f32=True,
+                   alpha=self.scale)
 
     # ------------------------------------------------------------------ one step
     def forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
@@ -233,8 +254,7 @@ class MultimodalTrainStep:
             a = {"x": x}
             n1 = ops.rmsnorm(x, W["g_in"], eps)
             qkv = ops.linear(n1, W["qkv"])
-            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
-                self._lora_fwd(n1, qkv[:, j * HD:(j + 1) * HD], f"{p}.self_attn.{nm}", row_adapter, saved)
+            self._lora_fwd(n1, [qkv[:, j * HD:(j + 1) * HD] for j in range(3)], l, "attn_in", row_adapter, saved)
             q_seq = torch.empty(M, HD, dtype=BF16, device=dev)
             kc, vc = (torch.empty(B, Hh, L, D, dtype=BF16, device=dev) for _ in range(2))
             ops.rope_kv(qkv, row_b, row_t, row_t, self.cos, self.sin, q_seq, kc, vc, Hh, Hh, D, L, L)
@@ -242,14 +262,13 @@ class MultimodalTrainStep:
             lse = torch.empty(B * Hh * L, dtype=F32, device=dev)
             ops.attn_prefill_lse(q_seq, kc, vc, attn, lse, B, Hh, L, L, D, st_q, st_kv, st_kv, HD, True)
             x1 = ops.linear(attn, W["o"], residual=x)
-            self._lora_fwd(attn, x1, f"{p}.self_attn.o_proj", row_adapter, saved)
+            self._lora_fwd(attn, [x1], l, "attn_out", row_adapter, saved)
             n2 = ops.rmsnorm(x1, W["g_post"], eps)
             gu = ops.linear(n2, W["gu"])
-            self._lora_fwd(n2, gu[:, :I], f"{p}.mlp.gate_proj", row_adapter, saved)
-            self._lora_fwd(n2, gu[:, I:], f"{p}.mlp.up_proj", row_adapter, saved)
+            self._lora_fwd(n2, [gu[:, :I], gu[:, I:]], l, "mlp_in", row_adapter, saved)
             inter = ops.silu_mul(gu, I)
             x2 = ops.linear(inter, W["down"], residual=x1)
-            self._lora_fwd(inter, x2, f"{p}.mlp.down_proj", row_adapter, saved)
+            self._lora_fwd(inter, [x2], l, "mlp_out", row_adapter, saved)
             a.update(n1=n1, q=q_seq, kc=kc, vc=vc, attn=attn, lse=lse, x1=x1, n2=n2, gu=gu, inter=inter)
             acts.append(a)
             x = x2
@@ -269,19 +288,16 @@ class MultimodalTrainStep:
         handles = []
         for l in reversed(range(len(self.layers))):
             W, a, p = self.layers[l], acts[l], f"model.layers.{l}"
-            packT = lambda t_: ops.pack_weight(ops.transpose(t_, Rp=Mp))               # activation^T as the wgrad "weight" operand
             # down_proj
             d_inter = ops.linear(dx, W["downT"])
-            self._lora_bwd(dx, a["inter"], packT(a["inter"]), d_inter, f"{p}.mlp.down_proj", row_adapter, saved, Mp)
+            self._lora_bwd([dx], a["inter"], d_inter, l, "mlp_out", row_adapter, saved, Mp)
             dgu = ops.swiglu_bwd(a["gu"], d_inter)
             dn2 = ops.linear(dgu, W["guT"])
-            n2T = packT(a["n2"])
-            self._lora_bwd(dgu[:, I:], a["n2"], n2T, dn2, f"{p}.mlp.up_proj", row_adapter, saved, Mp)
-            self._lora_bwd(dgu[:, :I], a["n2"], n2T, dn2, f"{p}.mlp.gate_proj", row_adapter, saved, Mp)
+            self._lora_bwd([dgu[:, :I], dgu[:, I:]], a["n2"], dn2, l, "mlp_in", row_adapter, saved, Mp)
             dx1 = ops.rmsnorm_bwd(a["x1"], W["g_post"], dn2, eps, dres=dx)
             # o_proj
             d_attn = ops.linear(dx1, W["oT"])
-            self._lora_bwd(dx1, a["attn"], packT(a["attn"]), d_attn, f"{p}.self_attn.o_proj", row_adapter, saved, Mp)
+            self._lora_bwd([dx1], a["attn"], d_attn, l, "attn_out", row_adapter, saved, Mp)
             # attention + RoPE
             dqkv = torch.empty(M, 3 * HD, dtype=BF16, device=dev)
             st3 = (L * 3 * HD, 3 * HD, D)
@@ -289,9 +305,7 @@ class MultimodalTrainStep:
                          st_q, st_kv, st_kv, st_q, st3, st3, st3, True)
             ops.rope_inplace(dqkv, row_t, self.cos, self.sin, 2 * Hh, D, -1.0)
             dn1 = ops.linear(dqkv, W["qkvT"])
-            n1T = packT(a["n1"])
-            for j, nm in reversed(list(enumerate(("q_proj", "k_proj", "v_proj")))):
-                self._lora_bwd(dqkv[:, j * HD:(j + 1) * HD], a["n1"], n1T, dn1, f"{p}.self_attn.{nm}", row_adapter, saved, Mp)
+            self._lora_bwd([dqkv[:, j * HD:(j + 1) * HD] for j in range(3)], a["n1"], dn1, l, "attn_in", row_adapter, saved, Mp)
             dx = ops.rmsnorm_bwd(a["x"], W["g_in"], dn1, eps, dres=dx1)
             acts[l] = None
             if self.world > 1:
