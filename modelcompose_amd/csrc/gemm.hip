@@ -639,13 +639,15 @@ std::vector<ProfRec> g_prof;
 
 extern "C" int mc_gemm_debug(int v) { g_gemm_dbg = v; return 0; }
 
-// 256x256 tiles need enough tiles to fill the 256 CUs; bit 1 of the debug word forces the 128x128 kernel, bit 2 the 256x256 one
+// 256x256 tiles need enough tiles to fill most of the 256 CUs; bit 1 of the debug word forces the 128x128 kernel, bit 2 the 256x256 one
 static bool use_tile256(int M, int N, int K) {
     if (K < 128) return false;
     if (g_gemm_dbg & 2) return false;
     if (g_gemm_dbg & 4) return true;
+    // measured crossover on MI355X (tools/bench_ops.py mid): 176 tiles (M=2732, N=4096) 1.15-1.4x faster than the 128x128 kernel,
+    // 112 tiles (M=1552) 1.3-1.4x slower
     const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
-    return tiles >= 192;
+    return tiles >= 144;
 }
 
 extern "C" int mc_gemm_profile_enable(int on) {
@@ -863,7 +865,7 @@ extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, cons
     }
     const int N = args->N, K = args->K;
     const bool one_launch = ng >= 1 && ng <= 8 && M_total > 64 && K >= 128 && K % 64 == 0 && !(g_gemm_dbg & 2) && args->split_k <= 1 &&
-                            ((g_gemm_dbg & 4) || tiles * ((N + 255) / 256) >= 192);
+                            ((g_gemm_dbg & 4) || tiles * ((N + 255) / 256) >= 144);
     if (!one_launch) {
         for (int g = 0; g < n_groups; ++g) {
             const int r0 = group_start[g], mg = group_start[g + 1] - r0;

@@ -95,6 +95,17 @@ def main():
                 gemm_case(10928, 4096, 4096, rot=1)
                 gemm_case(10928, 22016, 4096, rot=1)
         L.mc_gemm_debug(0)
+    if "mid" in which:
+        from modelcompose_amd import _lib
+        L = _lib.lib()
+        for rep in range(2):
+            for d in (2, 4):
+                L.mc_gemm_debug(d)
+                print("gemm debug mode", d, "(2 = 128x128 kernel, 4 = 256x256 kernel)")
+                for M in (2732, 1552, 4096):
+                    for (N, K) in ((4096, 4096), (4096, 11008), (4096, 12288), (4096, 22016), (1024, 4096), (768, 4096)):
+                        gemm_case(M, N, K, rot=1)
+        L.mc_gemm_debug(0)
     if "abl" in which:
         from modelcompose_amd import _lib
         L = _lib.lib()
