@@ -803,8 +803,6 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
                  "mc_gemm_ex_bf16: split_k accumulates raw fp32 partial sums (M <= 64, out_f32, no bias/act/residual)");
     Epilogue ep{(const bf16_t*)a->bias, (const bf16_t*)a->residual, a->ldr, a->out, a->ldo, a->act, a->out_f32, a->alpha, a->beta,
                 a->row_scale, a->swiglu};
-    void* out = a->out;
-    (void)out;
     hipStream_t s = (hipStream_t)stream;
     if (M <= 64) {
         const int mb = (M + 15) / 16;

@@ -420,10 +420,24 @@ class PointConfig:
         self.num_group, self.encoder_dims, self.point_dims, self.use_max_pool = num_group, encoder_dims, point_dims, use_max_pool
 
 
+class PointCloudProcessor:
+    """point_encoder.py:87-113: file loading is the whole processor (pc_norm is defined but never applied by __call__)."""
+
+    def __call__(self, pc_files):
+        if isinstance(pc_files, str):
+            pc_files = [pc_files]
+        return torch.from_numpy(np.stack([np.load(f) for f in pc_files], axis=0).astype(np.float32))
+
+    def pc_norm(self, pc):
+        xyz, other = pc[:, :3], pc[:, 3:]
+        xyz = xyz - np.mean(xyz, axis=0)
+        return np.concatenate((xyz / np.max(np.sqrt(np.sum(xyz ** 2, axis=1))), other), axis=1)
+
+
 class HipPointEncoder:
     def __init__(self, point_encoder: Optional[str], args=None, delay_load=False, config: Optional[PointConfig] = None, device="cuda"):
         self.point_encoder_name, self.device, self.dtype = point_encoder, torch.device(device), BF16
-        self.cfg, self.is_loaded, self.point_processor = config or PointConfig(), False, None
+        self.cfg, self.is_loaded, self.point_processor = config or PointConfig(), False, PointCloudProcessor()
         self.fps_start = None            # optional LongTensor (B,): first FPS index; default = torch.randint like misc.py:52
         if self.cfg.use_max_pool:
             raise NotImplementedError("use_max_pool=True is not the released configuration")

@@ -111,8 +111,6 @@ class MultimodalTrainStep:
         """Flat fp32 master buffer in backward order (last layer first) so gradient buckets complete early."""
         cfg, raw = self.cfg, self.model._raw
         Hd, I, Ln = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
-        dims = {"q_proj": (Hd, Hd), "k_proj": (Hd, Hd), "v_proj": (Hd, Hd), "o_proj": (Hd, Hd), "gate_proj": (I, Hd), "up_proj": (I, Hd),
-                "down_proj": (Hd, I)}
         params: List[_Param] = []
         init: List[torch.Tensor] = []
         off = 0
@@ -250,7 +248,6 @@ class MultimodalTrainStep:
         acts = []
         # ---- forward
         for l, W in enumerate(self.layers):
-            p = f"model.layers.{l}"
             a = {"x": x}
             n1 = ops.rmsnorm(x, W["g_in"], eps)
             qkv = ops.linear(n1, W["qkv"])
@@ -287,7 +284,7 @@ class MultimodalTrainStep:
         dx = ops.rmsnorm_bwd(x, self.g_final, dnf, eps)
         handles = []
         for l in reversed(range(len(self.layers))):
-            W, a, p = self.layers[l], acts[l], f"model.layers.{l}"
+            W, a = self.layers[l], acts[l]
             # down_proj
             d_inter = ops.linear(dx, W["downT"])
             self._lora_bwd([dx], a["inter"], d_inter, l, "mlp_out", row_adapter, saved, Mp)
