@@ -32,17 +32,30 @@ struct AttnParams {
 
 #define NEG_BIG (-1.0e30f)
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
+// One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KiB at the wave-uniform LDS address).  Issued from inline asm on purpose: hipcc
+// otherwise orders every later ds_read behind it with s_waitcnt vmcnt(0) (it cannot prove the read does not alias the DMA
+// destination), which serialises the prefetch of the next K/V tile with the MFMAs of the current one.  The kernel waits for these
+// transfers itself (s_waitcnt vmcnt(0) + s_barrier before the first read of a buffer).
+__device__ __forceinline__ void dma16(const void* gptr, const void* lds_dst) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(m0v) : "memory");
+}
+
+// REL: gated relative-position bias of BEATs compiled in (a separate instantiation keeps its per-score loads and branches out of the
+// common kernel)
+template <int D, bool REL>
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
     constexpr int ROWB = D * 2;              // bytes per K/V row
     constexpr int CH = ROWB / 16;            // 16-byte chunks per row
     constexpr int KS = D / 32;               // MFMA k-steps over the head dim
     constexpr int DB = D / 16;               // 16-wide d blocks of the output
-    __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB];
-    char* kl = lds;
-    char* vl = lds + 64 * ROWB;
+    constexpr int TILE = 64 * ROWB;          // bytes of one staged K (or V) tile
+    constexpr int RPI = 1024 / ROWB;         // rows written by one 1-KiB LDS-DMA wave instruction
+    constexpr int NDMA = 16 / RPI;           // DMA instructions per wave per operand per tile (each wave stages 16 rows)
+    extern __shared__ __attribute__((aligned(16))) char lds[];               // 2 * 2 * 64 * ROWB bytes: [buffer][K | V]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
     const int hk = h / (p.H / p.Hkv);
@@ -56,11 +69,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         const bf16_t* qp = p.q + b * p.q_sb + t * p.q_st + h * p.q_sh + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
+        // retire the Q loads here: left to the compiler, their s_waitcnt vmcnt lands on the first MFMA INSIDE the tile loop and
+        // drains the K/V prefetch DMA on every iteration
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
     }
     const int q_abs = q0 + c + p.q_offset;   // absolute position of this lane's query
     const float* relrow = nullptr;
     float gate = 0.f;
-    if (p.rel_table) {
+    if (REL && p.rel_table) {
         const int tq_ = min(q0 + c, p.Lq - 1);
         relrow = p.rel_table + (int64_t)h * p.rel_stride + (p.rel_off - tq_);
         gate = (p.q_gate ? p.q_gate[((int64_t)b * p.H + h) * p.Lq + tq_] : 1.0f) * 1.4426950408889634f;
@@ -79,22 +96,31 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     const bf16_t* kbase = p.k + b * p.k_sb + hk * p.k_sh;
     const bf16_t* vbase = p.v + b * p.v_sb + hk * p.v_sh;
 
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();     // previous tile fully consumed
-        // ---- stage K (swizzled) and V (linear): 64 rows x CH chunks each
+    // K/V tiles arrive by LDS-DMA into a double buffer: the DMA of tile kt+1 is in flight while tile kt is consumed.
+    // The LDS image is lane-linear per wave instruction (RPI rows x ROWB bytes); the XOR swizzle of K and V is applied to the SOURCE chunk.
+    const int srow = lane / CH, sch = lane % CH;         // row inside the instruction's row group, 16-byte chunk
+    auto stage = [&](int kt, int buf) {
+        char* kb_ = lds + buf * (2 * TILE);
+        char* vb_ = kb_ + TILE;
 #pragma unroll
-        for (int it = 0; it < (64 * CH) / 256; ++it) {
-            const int idx = it * 256 + tid;
-            const int row = idx / CH, ch = idx % CH;
+        for (int i = 0; i < NDMA; ++i) {
+            const int row = wave * 16 + i * RPI + srow;
             const int key = min(kt * 64 + row, p.S - 1);
-            const u32x4 kv4 = *(const u32x4*)(kbase + key * p.k_st + ch * 8);
-            const u32x4 vv4 = *(const u32x4*)(vbase + key * p.v_st + ch * 8);
             int sw;
-            if (CH == 16) sw = ch ^ (row & 15); else sw = ch ^ ((row >> 1) & 7);
-            *(u32x4*)(kl + row * ROWB + sw * 16) = kv4;
-            *(u32x4*)(vl + row * ROWB + ch * 16) = vv4;
+            if (CH == 16) sw = sch ^ (row & 15); else sw = sch ^ ((row >> 1) & 7);
+            dma16(kbase + (int64_t)key * p.k_st + sw * 8, kb_ + (wave * 16 + i * RPI) * ROWB);
+            dma16(vbase + (int64_t)key * p.v_st + sw * 8, vb_ + (wave * 16 + i * RPI) * ROWB);      // V swizzled like K
         }
-        __syncthreads();
+    };
+    if (ntiles > 0) stage(0, 0);
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        const char* kl = lds + buf * (2 * TILE);
+        const char* vl = kl + TILE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
+        __builtin_amdgcn_s_barrier();                          // ... and everyone's; all reads of the other buffer (tile kt-1) are done
+        if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1);
 
         // ---- S^T[key][query] = K · Q^T
         f32x4 s[4];
@@ -111,37 +137,63 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                 s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
             }
         }
-        // ---- mask, online softmax (lane owns query column c; keys 16kb + 4g + r)
+        // ---- mask, online softmax (lane owns query column c; keys 16kb + 4g + r).  Only the diagonal tile (causal) and a partial last
+        // tile need the per-score index tests; every other tile takes the mask-free path (wave-uniform branch).
+        const bool need_mask = (kt * 64 + 63 >= kvlen) || (p.causal && kt * 64 + 63 > q0 + p.q_offset);
         float tmax = NEG_BIG;
-        bool valid[4][4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 64 + kb * 16 + g * 4 + r;
-                const bool ok = key < kvlen && (!p.causal || key <= q_abs);
-                valid[kb][r] = ok;
-                float sv = s[kb][r] * p.scale_log2e;
-                if (relrow && ok) sv += gate * relrow[key];
-                s[kb][r] = sv;
-                tmax = ok ? fmaxf(tmax, sv) : tmax;
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
         float lsum = 0.f;
         bf16x8 pf[2];
+        float alpha;
+        if (need_mask || REL) {
+            bool valid[4][4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = valid[kb][r] ? exp2f(s[kb][r] - m_new) : 0.f;
-                const bf16_t pb = (bf16_t)pv;
-                lsum += (float)pb;           // normalise with the rounded probabilities actually multiplied
-                pf[kb >> 1][(kb & 1) * 4 + r] = pb;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 64 + kb * 16 + g * 4 + r;
+                    const bool ok = key < kvlen && (!p.causal || key <= q_abs);
+                    valid[kb][r] = ok;
+                    float sv = s[kb][r] * p.scale_log2e;
+                    if (REL && relrow && ok) sv += gate * relrow[key];
+                    s[kb][r] = sv;
+                    tmax = ok ? fmaxf(tmax, sv) : tmax;
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            alpha = exp2f(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = valid[kb][r] ? exp2f(s[kb][r] - m_new) : 0.f;
+                    const bf16_t pb = (bf16_t)pv;
+                    lsum += (float)pb;           // normalise with the rounded probabilities actually multiplied
+                    pf[kb >> 1][(kb & 1) * 4 + r] = pb;
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kb][r] *= p.scale_log2e;
+                    tmax = fmaxf(tmax, s[kb][r]);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            alpha = exp2f(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bf16_t pb = (bf16_t)exp2f(s[kb][r] - m_new);
+                    lsum += (float)pb;
+                    pf[kb >> 1][(kb & 1) * 4 + r] = pb;
+                }
+        }
         l_run = l_run * alpha + lsum;
 #pragma unroll
         for (int i = 0; i < DB; ++i) oacc[i] *= alpha;
@@ -154,10 +206,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
             const int key_hi = (2 * pr + 1) * 16 + g * 4 + tq;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
+                // 8 bytes at logical column (db*16 + tp*4) of row key: 16-byte chunk db*2 + (tp>>1), XOR-swizzled per row (without it the
+                // 16 rows of one instruction sit on the same banks: 256-byte rows = one full bank line each)
+                const int chv = db * 2 + (tp >> 1);
+                const int sw_lo = (CH == 16) ? (chv ^ (key_lo & 15)) : (chv ^ ((key_lo >> 1) & 7));
+                const int sw_hi = (CH == 16) ? (chv ^ (key_hi & 15)) : (chv ^ ((key_hi >> 1) & 7));
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(vl + key_lo * ROWB + (db * 16 + tp * 4) * 2));
+                    (__attribute__((address_space(3))) bf16x4*)(char*)(vl + key_lo * ROWB + sw_lo * 16 + (tp & 1) * 8));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(vl + key_hi * ROWB + (db * 16 + tp * 4) * 2));
+                    (__attribute__((address_space(3))) bf16x4*)(char*)(vl + key_hi * ROWB + sw_hi * 16 + (tp & 1) * 8));
                 bf16x8 vf;
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                 vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
@@ -373,8 +430,14 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
                  (bf16_t*)o, o_row_stride, out_map, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
                  scale * 1.4426950408889634f, rel_table, q_gate, rel_stride, rel_off, lse};
     dim3 grid((Lq + 63) / 64, H, B);
-    if (D == 128) attn_prefill_kernel<128><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else attn_prefill_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    hipStream_t s = (hipStream_t)stream;
+    if (rel_table) {
+        if (D == 128) attn_prefill_kernel<128, true><<<grid, 256, 4 * 64 * 256, s>>>(p);
+        else attn_prefill_kernel<64, true><<<grid, 256, 4 * 64 * 128, s>>>(p);
+    } else {
+        if (D == 128) attn_prefill_kernel<128, false><<<grid, 256, 4 * 64 * 256, s>>>(p);
+        else attn_prefill_kernel<64, false><<<grid, 256, 4 * 64 * 128, s>>>(p);
+    }
     MC_CHECK_LAUNCH();
     return 0;
 }

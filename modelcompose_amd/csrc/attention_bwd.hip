@@ -73,7 +73,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* src, int64_t row_stride
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     constexpr int ROWB = D * 2, KS = D / 32, DB = D / 16;
     __shared__ __attribute__((aligned(16))) char lds[3 * 64 * ROWB];
     char* k_sw = lds;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     constexpr int ROWB = D * 2, KS = D / 32, DB = D / 16;
     __shared__ __attribute__((aligned(16))) char lds[4 * 64 * ROWB + 2 * 64 * 4];
     char* q_sw = lds;
