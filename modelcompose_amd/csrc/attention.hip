@@ -32,6 +32,10 @@ struct AttnParams {
 
 #define NEG_BIG (-1.0e30f)
 
+// v_exp_f32 directly: the arguments are (score - running max) <= 0 or (old max - new max) <= 0, so the range fix-up that exp2f()
+// expands to (compare, scale, ldexp: ~4 extra VALU instructions per call, 17 calls per K/V tile) is dead weight
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KiB at the wave-uniform LDS address).  Issued from inline asm on purpose: hipcc
 // otherwise orders every later ds_read behind it with s_waitcnt vmcnt(0) (it cannot prove the read does not alias the DMA
 // destination), which serialises the prefetch of the next K/V tile with the MFMAs of the current one.  The kernel waits for these
@@ -161,13 +165,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax);
-            alpha = exp2f(m_run - m_new);
+            alpha = fast_exp2(m_run - m_new);
             m_run = m_new;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = valid[kb][r] ? exp2f(s[kb][r] - m_new) : 0.f;
+                    const float pv = valid[kb][r] ? fast_exp2(s[kb][r] - m_new) : 0.f;
                     const bf16_t pb = (bf16_t)pv;
                     lsum += (float)pb;           // normalise with the rounded probabilities actually multiplied
                     pf[kb >> 1][(kb & 1) * 4 + r] = pb;
@@ -183,13 +187,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax);
-            alpha = exp2f(m_run - m_new);
+            alpha = fast_exp2(m_run - m_new);
             m_run = m_new;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bf16_t pb = (bf16_t)exp2f(s[kb][r] - m_new);
+                    const bf16_t pb = (bf16_t)fast_exp2(s[kb][r] - m_new);
                     lsum += (float)pb;
                     pf[kb >> 1][(kb & 1) * 4 + r] = pb;
                 }
@@ -350,8 +354,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
             for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
             const bool ok = key[u] < j1;
             const float mn = ok ? fmaxf(m, sdot) : m;
-            const float a = exp2f(m - mn);
-            const float pv = ok ? exp2f(sdot - mn) : 0.f;
+            const float a = fast_exp2(m - mn);
+            const float pv = ok ? fast_exp2(sdot - mn) : 0.f;
             m = mn;
             l = l * a + pv;
 #pragma unroll
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
     for (int o = LPK; o < 64; o <<= 1) {
         const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
         const float mn = fmaxf(m, m2);
-        const float a1 = exp2f(m - mn), a2 = exp2f(m2 - mn);
+        const float a1 = fast_exp2(m - mn), a2 = fast_exp2(m2 - mn);
         l = l * a1 + l2 * a2;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
         float ll = 0.f, aa = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float a = exp2f(red[w][D] - mm);
+            const float a = fast_exp2(red[w][D] - mm);
             ll += red[w][D + 1] * a;
             aa += red[w][tid] * a;
         }
@@ -407,7 +411,7 @@ __global__ void attn_decode_combine_kernel(DecodeParams p) {
     for (int s = 0; s < p.nsplit; ++s) mm = fmaxf(mm, w[s * (D + 2) + D]);
     float ll = 0.f, aa = 0.f;
     for (int s = 0; s < p.nsplit; ++s) {
-        const float a = exp2f(w[s * (D + 2) + D] - mm);
+        const float a = fast_exp2(w[s * (D + 2) + D] - mm);
         ll += w[s * (D + 2) + D + 1] * a;
         aa += w[s * (D + 2) + d] * a;
     }

@@ -18,6 +18,10 @@
 
 #define NEG_BIG (-1.0e30f)
 
+// v_exp_f32 directly: the arguments are (score - running max) <= 0 or (old max - new max) <= 0, so the range fix-up that exp2f()
+// expands to (compare, scale, ldexp: ~4 extra VALU instructions per call, 17 calls per K/V tile) is dead weight
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 struct AttnBwdParams {
     const bf16_t* q; int64_t q_sb, q_st, q_sh;      // [B, Lq, H, D]-like strides (elements)
     const bf16_t* k; int64_t k_sb, k_st, k_sh;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 64 + kb * 16 + g * 4 + r;
                 const bool ok = key < kvlen && (!p.causal || key <= q_abs);
-                const float pv = ok ? exp2f(s[kb][r] * p.scale_log2e - lse) : 0.f;
+                const float pv = ok ? fast_exp2(s[kb][r] * p.scale_log2e - lse) : 0.f;
                 dsf[kb >> 1][(kb & 1) * 4 + r] = (bf16_t)(pv * (dp[kb][r] - delta));
             }
         // dQ^T[d][query] += K^T · dS^T   (K^T through the transposing LDS read of the linear tile)
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
                 const int ql = qb * 16 + g * 4 + r;
                 const int tq_ = qt * 64 + ql;
                 const bool ok = tq_ < p.Lq && key < kvlen && (!p.causal || key <= tq_ + p.q_offset);
-                const float pv = ok ? exp2f(s[qb][r] * p.scale_log2e - lse_t[ql]) : 0.f;
+                const float pv = ok ? fast_exp2(s[qb][r] * p.scale_log2e - lse_t[ql]) : 0.f;
                 pf[qb >> 1][(qb & 1) * 4 + r] = (bf16_t)pv;
                 dsf[qb >> 1][(qb & 1) * 4 + r] = (bf16_t)(pv * (dp[qb][r] - del_t[ql]));
             }
