@@ -87,6 +87,13 @@ int mc_ties_hist(const void* x, int dtype, int64_t ld, int64_t d, int n, int shi
 int mc_ties_merge(const void* x, int dtype, int64_t ld, int64_t d, int n, const float* thr, int8_t* sign, long long* sign_sum, int func,
                   void* out, void* stream);
 
+/* ---- parameter-interference metrics (scripts/model_composition/calculate_metrics.py:26-37, :58-67) ----------------------------
+ * One pass over the n >= 2 task vectors x [n, d]; every workgroup writes 8 double partial sums to partial [mc_merge_metrics_blocks()][8]:
+ * sum (x0-x1)^2, sum x0 x1, sum x0^2, sum x1^2 (L2 / cosine of rows 0, 1), then sum_j |sum_i x_ij| / sum_i |x_ij| and the count of
+ * columns with a non-zero magnitude sum (SSD), and the same pair with each row trimmed to |x| >= thr[i] (TSSD; thr may be NULL).  */
+int mc_merge_metrics(const void* x, int dtype, int64_t ld, int64_t d, int n, const float* thr, double* partial, void* stream);
+int mc_merge_metrics_blocks(void);
+
 /* ---- linear: out[M,N] = act(alpha * x[M,K] W^T + bias) + beta * residual ----------------------------
  * Replaces F.linear at multimodal_llama.py:122 (LocalLoRA base GEMM), :720 (lm_head), the CLIP / projector
  * linears.  K must be a multiple of 64 (zero padded), x rows 16-byte aligned.  out_f32 != 0 -> fp32 out.  */

@@ -78,6 +78,8 @@ _SIGS.update({
     "mc_video_preprocess_u8": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_f), C.POINTER(c_f), c_p, c_p, c_p],
     "mc_ties_hist": [c_p, c_i, c_l, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
     "mc_ties_merge": [c_p, c_i, c_l, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
+    "mc_merge_metrics": [c_p, c_i, c_l, c_l, c_i, c_p, c_p, c_p],
+    "mc_merge_metrics_blocks": [],
     "mc_gemm_grouped_bf16": [C.POINTER(GemmArgsC), c_i, C.POINTER(C.c_int32), C.POINTER(c_p), c_p],
     "mc_attn_bwd_bf16": [C.POINTER(AttnBwdArgsC), c_p],
     "mc_attn_decode_rope_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,

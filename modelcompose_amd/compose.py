@@ -80,25 +80,14 @@ def _elementwise(per_ckpt: Sequence[Dict[str, torch.Tensor]], mean: bool) -> Dic
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
 
-def ties_merge_vectors(flat: torch.Tensor, K, merge_func: str) -> torch.Tensor:
-    """flat [n, d] device tensor (fp32 / bf16 / fp16) -> merged [d] in the same dtype (ties_merging.py:160-179).
-    The k-th smallest magnitude of every row is found exactly by a 3-pass radix select over the float bits of |x| (11 + 11 + 10
-    bits; the 2048-bin histograms come back to the host between passes), then mc_ties_merge elects signs and aggregates."""
+def _kth_magnitude(flat: torch.Tensor, k: int) -> torch.Tensor:
+    """Per row of flat [n, d] (device), the k-th smallest |x| (1-indexed, torch.kthvalue's convention) as an fp32 device tensor [n]:
+    exact 3-pass radix select over the float bits of |x| (11 + 11 + 10 bits; the 2048-bin histograms come back to the host between
+    passes)."""
     import ctypes as C
+    import numpy as np
     from . import _lib
-    if not flat.is_cuda:
-        raise ValueError("ties_merge_vectors needs device (HIP) tensors; this path has no CPU fallback")
-    if flat.dtype not in _DTYPE_CODE:
-        raise ValueError(f"unsupported checkpoint dtype {flat.dtype}")
-    if merge_func not in ("mean", "sum", "max"):
-        raise ValueError(f"Merge method {merge_func} is not defined.")                     # ties_merging.py:155
-    if K >= 1:
-        K = K / 100                                                                         # :89-90
-    flat = flat.contiguous()
     n, d = flat.shape
-    k = d - int(d * K)                                                                      # :97-98: k-th smallest, 1-indexed
-    if not 1 <= k <= d:
-        raise RuntimeError(f"kthvalue(): selected number k out of range for dimension {d}")
     L = _lib.lib()
     code = _DTYPE_CODE[flat.dtype]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -122,8 +111,34 @@ def ties_merge_vectors(flat: torch.Tensor, K, merge_func: str) -> torch.Tensor:
             else:
                 raise RuntimeError("radix select ran past the histogram (NaN in the checkpoint?)")
         prefix = torch.tensor([p - (1 << 32) if p >= (1 << 31) else p for p in pre_host], dtype=torch.int32, device=dev)
-    import numpy as np
     thr = torch.from_numpy(np.array(pre_host, dtype=np.uint32).view(np.float32).copy()).to(dev)     # k-th smallest |x| per row
+    return thr
+
+
+def ties_merge_vectors(flat: torch.Tensor, K, merge_func: str) -> torch.Tensor:
+    """flat [n, d] device tensor (fp32 / bf16 / fp16) -> merged [d] in the same dtype (ties_merging.py:160-179).
+    The k-th smallest magnitude of every row is found exactly by a 3-pass radix select over the float bits of |x| (11 + 11 + 10
+    bits; the 2048-bin histograms come back to the host between passes), then mc_ties_merge elects signs and aggregates."""
+    import ctypes as C
+    from . import _lib
+    if not flat.is_cuda:
+        raise ValueError("ties_merge_vectors needs device (HIP) tensors; this path has no CPU fallback")
+    if flat.dtype not in _DTYPE_CODE:
+        raise ValueError(f"unsupported checkpoint dtype {flat.dtype}")
+    if merge_func not in ("mean", "sum", "max"):
+        raise ValueError(f"Merge method {merge_func} is not defined.")                     # ties_merging.py:155
+    if K >= 1:
+        K = K / 100                                                                         # :89-90
+    flat = flat.contiguous()
+    n, d = flat.shape
+    k = d - int(d * K)                                                                      # :97-98: k-th smallest, 1-indexed
+    if not 1 <= k <= d:
+        raise RuntimeError(f"kthvalue(): selected number k out of range for dimension {d}")
+    thr = _kth_magnitude(flat, k)
+    L = _lib.lib()
+    code = _DTYPE_CODE[flat.dtype]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = flat.device
     sign = torch.empty(d, dtype=torch.int8, device=dev)
     sign_sum = torch.zeros(1, dtype=torch.int64, device=dev)
     out = torch.empty(d, dtype=flat.dtype, device=dev)
@@ -171,6 +186,102 @@ def _ties(per_ckpt: Sequence[Dict[str, torch.Tensor]], func: str, K) -> Dict[str
             out[name] = ts[0]
     out.update(ties_merge_state_dicts(shared, K, func))
     return out
+
+
+def interference_metrics(flat: torch.Tensor, reset_thresh=50) -> Dict[str, float]:
+    """Parameter-interference metrics of n >= 2 task vectors flat [n, d] on the device (calculate_metrics.py:26-37, :58-67):
+    L2 = ||x0 - x1||, Cosine = 1 - cos(x0, x1), SSD = 1 - mean_j |sum_i x_ij| / sum_i |x_ij| over columns with a non-zero magnitude
+    sum, TSSD = SSD of the rows trimmed to their top `reset_thresh` % magnitudes (topk_values_mask, ties_merging.py:88-109).
+    One HBM pass (mc_merge_metrics); the per-workgroup double partial sums are added on the host in block order."""
+    import ctypes as C
+    from . import _lib
+    if not flat.is_cuda:
+        raise ValueError("interference_metrics needs device (HIP) tensors; this path has no CPU fallback")
+    if flat.dtype not in _DTYPE_CODE:
+        raise ValueError(f"unsupported checkpoint dtype {flat.dtype}")
+    if flat.dim() != 2 or flat.shape[0] < 2:
+        raise ValueError("interference_metrics needs at least two task vectors [n, d]")
+    K = reset_thresh / 100 if reset_thresh >= 1 else reset_thresh                           # ties_merging.py:89-90
+    flat = flat.contiguous()
+    n, d = flat.shape
+    k = d - int(d * K)
+    if not 1 <= k <= d:
+        raise RuntimeError(f"kthvalue(): selected number k out of range for dimension {d}")
+    thr = _kth_magnitude(flat, k)
+    L = _lib.lib()
+    partial = torch.empty(L.mc_merge_metrics_blocks(), 8, dtype=torch.float64, device=flat.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.mc_merge_metrics(flat.data_ptr(), _DTYPE_CODE[flat.dtype], flat.stride(0), d, n, thr.data_ptr(), partial.data_ptr(), st),
+               "mc_merge_metrics")
+    a = partial.cpu().sum(dim=0).tolist()
+    cos = a[1] / max((a[2] ** 0.5) * (a[3] ** 0.5), 1e-8)                                   # torch.cosine_similarity's eps clamp
+    return {"L2": a[0] ** 0.5, "Cosine": 1 - cos, "SSD": 1 - a[4] / a[5] if a[5] else float("nan"),
+            "TSSD": 1 - a[6] / a[7] if a[7] else float("nan")}
+
+
+def parse_merge_info(file: str):
+    """calculate_metrics.py:14-24: (input paths, strategy, output path) out of merge_info.txt, or (None, None, None)."""
+    import re
+    m = re.search(r"Inputs:\n(.*?)\n\nOutput\((.*?)\):(.*?)$", open(file).read().strip(), re.DOTALL)
+    if not m:
+        return None, None, None
+    return m.group(1).split("\n"), m.group(2), m.group(3)
+
+
+def calculate_metrics(merged_ckpt: str, reset_thresh=50, device="cuda") -> Dict[str, float]:
+    """calculate_metrics.py:41-76: reload the inputs named by <merged_ckpt>/merge_info.txt, flatten the tensors every input shares
+    (fp32, sorted key order), compute the four metrics on the GPU, write <merged_ckpt>/merge_metrics.txt in the reference's format."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("calculate_metrics runs on the HIP device; no CPU fallback")
+    filepaths, _, _ = parse_merge_info(os.path.join(merged_ckpt, "merge_info.txt"))
+    per_ckpt = [{k: v.float() for k, v in _read_checkpoint(fp)[0].items()} for fp in filepaths]
+    groups: Dict[str, List[torch.Tensor]] = {}
+    for tensors in per_ckpt:
+        for name, t in tensors.items():
+            groups.setdefault(name, []).append(t)
+    n = max(len(v) for v in groups.values())
+    keys = sorted(name for name, ts in groups.items() if len(ts) == n)                      # convert_delta_to_ft keeps the shared ones
+    for name, ts in groups.items():
+        assert len(ts) in (1, n), f"tensor '{name}' appears in {len(ts)} of {n} checkpoints"
+    flat = torch.stack([torch.cat([groups[k][i].reshape(-1) for k in keys]).to(device) for i in range(n)])
+    m = interference_metrics(flat, reset_thresh)
+    with open(os.path.join(merged_ckpt, "merge_metrics.txt"), "w") as f:
+        for name in ("L2", "Cosine", "SSD", "TSSD"):
+            f.write(f"{name}: {m[name]}\n")
+    return m
+
+
+def llava_key_to_multimodal_key(key: str):
+    """scripts/convert_llava_to_multimodal/convert_checkpoint.py:47-56: LLaVA-format tensor name -> multimodal-format name (the
+    'default' LoRA pair becomes the 'vision' adapter, mm_projector / prefix / suffix tokens get the '.vision' slot); None = dropped."""
+    if "lora_A.default" in key or "lora_B.default" in key:
+        return key.replace("default", "vision")
+    for old, new in (("mm_projector", "modal_projectors.vision"), ("prefix_tokens", "prefix_tokens.vision"), ("suffix_tokens", "suffix_tokens.vision")):
+        if old in key:
+            return key.replace(old, new)
+    return None
+
+
+def convert_llava_checkpoint(llava_checkpoint: str, output_path: str) -> None:
+    """convert_checkpoint.py:68-88: read the two-shard LLaVA checkpoint, keep the renamed LoRA tensors in adapter_model.bin and the
+    other renamed tensors in non_lora_trainables.bin, copy the tokenizer / config files.  Shards are memory-mapped (no 13 GB
+    unpickle into anonymous memory); tensors are written byte-exact."""
+    import shutil
+    weights = {}
+    for shard in ("pytorch_model-00001-of-00002.bin", "pytorch_model-00002-of-00002.bin"):
+        weights.update(torch.load(os.path.join(llava_checkpoint, shard), map_location="cpu", mmap=True, weights_only=True))
+    adapter, other = {}, {}
+    for k, v in weights.items():
+        nk = llava_key_to_multimodal_key(k)
+        if not nk:
+            continue
+        (adapter if "lora" in nk else other)[nk] = v
+    os.makedirs(output_path, exist_ok=True)
+    torch.save(adapter, os.path.join(output_path, "adapter_model.bin"))
+    torch.save(other, os.path.join(output_path, "non_lora_trainables.bin"))
+    for f in os.listdir(llava_checkpoint):
+        if f in ("special_tokens_map.json", "tokenizer.model", "tokenizer_config.json", "config.json"):
+            shutil.copy(os.path.join(llava_checkpoint, f), os.path.join(output_path, f))
 
 
 def merge_checkpoints(filepaths: Sequence[str], output_path: str, strategy: str = "sum", K: int = 20):

@@ -134,3 +134,59 @@ extern "C" int mc_ties_merge(const void* x, int dtype, int64_t ld, int64_t d, in
     MC_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- parameter-interference metrics of a merged checkpoint (scripts/model_composition/calculate_metrics.py:26-37, :62-67) ----
+// One pass over the n task vectors accumulates, per workgroup and in double precision,
+//   [0] sum (x0-x1)^2   [1] sum x0*x1   [2] sum x0^2   [3] sum x1^2          (L2 :26-27 and cosine :29-30 use rows 0 and 1 only)
+//   [4] sum_j |sum_i x_ij| / sum_i |x_ij|  over columns with sum_i |x_ij| != 0,  [5] the number of such columns   (SSD :32-37)
+//   [6], [7] the same two with every row trimmed to |x| >= thr[i] (TSSD = SSD of topk_values_mask(K=50), :61-64)
+// partial [gridDim.x][8] is summed on the host in block order, so the result does not depend on scheduling.
+#define METRIC_BLOCKS 1024
+template <typename T>
+__global__ __launch_bounds__(256) void merge_metrics_kernel(const T* __restrict__ x, int64_t ld, int64_t d, int n, const float* __restrict__ thr,
+                                                            double* __restrict__ partial) {
+    __shared__ double red[8][4];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t j = blockIdx.x * 256LL + threadIdx.x; j < d; j += (int64_t)gridDim.x * 256) {
+        float s = 0.f, a = 0.f, st = 0.f, at = 0.f, x0 = 0.f, x1 = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float v = ld_f<T>(x + (int64_t)i * ld, j);
+            if (i == 0) x0 = v;
+            if (i == 1) x1 = v;
+            s += v;
+            a += fabsf(v);
+            const float t = (thr && fabsf(v) >= thr[i]) ? v : 0.f;
+            st += t;
+            at += fabsf(t);
+        }
+        const float df = x0 - x1;
+        acc[0] += (double)(df * df);
+        acc[1] += (double)(x0 * x1);
+        acc[2] += (double)(x0 * x0);
+        acc[3] += (double)(x1 * x1);
+        if (a != 0.f) { acc[4] += (double)fabsf(s / a); acc[5] += 1.0; }
+        if (at != 0.f) { acc[6] += (double)fabsf(st / at); acc[7] += 1.0; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) partial[(int64_t)blockIdx.x * 8 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// x [n][d] (n >= 2) task vectors; thr [n] fp32 trim thresholds or NULL (then [6],[7] are zero); partial: METRIC_BLOCKS*8 doubles.
+extern "C" int mc_merge_metrics(const void* x, int dtype, int64_t ld, int64_t d, int n, const float* thr, double* partial, void* stream) {
+    MC_CHECK_ARG(x && partial && d > 0 && n >= 2, "mc_merge_metrics: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MC_DTYPE_F32) merge_metrics_kernel<float><<<METRIC_BLOCKS, 256, 0, s>>>((const float*)x, ld, d, n, thr, partial);
+    else if (dtype == MC_DTYPE_BF16) merge_metrics_kernel<bf16_t><<<METRIC_BLOCKS, 256, 0, s>>>((const bf16_t*)x, ld, d, n, thr, partial);
+    else if (dtype == MC_DTYPE_F16) merge_metrics_kernel<__half><<<METRIC_BLOCKS, 256, 0, s>>>((const __half*)x, ld, d, n, thr, partial);
+    else { mc_set_error("mc_merge_metrics: unsupported dtype code %d", dtype); return 1; }
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mc_merge_metrics_blocks(void) { return METRIC_BLOCKS; }

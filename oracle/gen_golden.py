@@ -19,6 +19,8 @@ Groups:
   g8  tiny 4-modality composed model end to end (all encoders + projectors + routed LLM + greedy ids)
   g9  stage-2 finetune step: loss + gradients of the trainable set
   g10 TIES merging (ties-mean / sum / max) tensor- and file-level
+  g11 interference metrics (L2 / cosine / SSD / TSSD) tensor- and file-level
+  g12 host callers: length-grouped samplers, LLaVA -> multimodal checkpoint conversion
 """
 from __future__ import annotations
 
@@ -844,8 +846,117 @@ def g10():
     _save("g10_ties", meta=np.array(json.dumps(meta)), **arrays)
 
 
+def g11():
+    """Interference metrics (scripts/model_composition/calculate_metrics.py:26-37, :41-76): the reference's own L2 / cos_sim /
+    soft_sign_dissimilarity / topk_values_mask on stacked task vectors (2 and 3 rows, with exact zeros, all-zero columns and
+    cancelling columns), and one file-level calculate_metrics run on a ties-merged checkpoint directory."""
+    refshim.install()
+    import importlib, io, contextlib
+    mm = importlib.import_module("merge_unimodal_modelcompose")
+    tm = importlib.import_module("ties_merging")
+    cm = importlib.import_module("calculate_metrics")
+    g = torch.Generator().manual_seed(111)
+    arrays, meta = {}, {"cases": []}
+    for n, d in ((2, 4099), (3, 10000)):
+        flat = torch.randn(n, d, generator=g) * 0.02
+        flat[:, 5:40] = 0                                    # all-zero columns (excluded from the SSD mean)
+        flat[0, 100:120] = 0                                 # single zeros
+        flat[1, 200:210] = -flat[0, 200:210]                 # cancelling pairs
+        if n == 3:
+            flat[2, 200:210] = 0
+        trunc, *_ = tm.topk_values_mask(flat.clone(), K=50, return_mask=False)
+        exp = {"L2": float(cm.L2(flat)), "Cosine": float(cm.cos_sim(flat)), "SSD": float(cm.soft_sign_dissimilarity(flat)),
+               "TSSD": float(cm.soft_sign_dissimilarity(trunc))}
+        arrays[f"flat::{n}"] = flat
+        meta["cases"].append({"n": n, "d": d, "expected": exp})
+    with tempfile.TemporaryDirectory() as tmp:
+        shapes = {"model.layers.0.self_attn.q_proj.lora_A.default.weight": (4, 24), "model.layers.0.self_attn.q_proj.lora_B.default.weight": (24, 4),
+                  "model.layers.1.mlp.down_proj.lora_A.default.weight": (4, 40)}
+        paths, in_cfg = [], {}
+        for i, (modal, enc_key) in enumerate((("vision", "mm_vision_encoder"), ("audio", "mm_audio_encoder"))):
+            dd = os.path.join(tmp, f"ckpt-{modal}")
+            os.makedirs(dd)
+            w = {k: torch.randn(shp, generator=g) for k, shp in shapes.items()}
+            w[f"model.modal_projectors.{modal}.0.weight"] = torch.randn(8, 6, generator=g)
+            torch.save(w, os.path.join(dd, "adapter_model.bin"))
+            c = {"model_type": "multimodal", enc_key: f"/ckpts/{modal}", "lora_r": 4, "lora_alpha": 8, "lora_strategy": "modal+language"}
+            json.dump(c, open(os.path.join(dd, "config.json"), "w"))
+            paths.append(dd)
+            in_cfg[modal] = c
+            for k, v in w.items():
+                arrays[f"fin::{modal}::{k}"] = v
+        outp = os.path.join(tmp, "merged")
+        with contextlib.redirect_stdout(io.StringIO()):
+            mm.merge_checkpoints(paths, outp, "ties-mean", K=20)
+            cm.calculate_metrics(outp)
+        meta["order"] = ["vision", "audio"]
+        meta["in_configs"] = in_cfg
+        meta["merge_metrics"] = open(os.path.join(outp, "merge_metrics.txt")).read()
+    _save("g11_metrics", meta=np.array(json.dumps(meta)), **arrays)
+
+
+def g12():
+    """Host-side callers of the path, run from the reference's own code: the length-grouped samplers of the stage-2 trainer
+    (modelcompose/train/llava_trainer.py:38-97) for several sizes / seeds, and the LLaVA -> multimodal checkpoint key mapping
+    (scripts/convert_llava_to_multimodal/convert_checkpoint.py:47-88) on a tiny two-shard checkpoint."""
+    refshim.install()
+    import importlib
+    sys.modules["peft"].PeftMixedModel = refshim._StubObj("peft.PeftMixedModel")
+    import transformers.trainer as tt
+    for nm in ("is_sagemaker_mp_enabled", "get_parameter_names", "has_length", "ALL_LAYERNORM_LAYERS", "ShardedDDPOption", "logger"):
+        if not hasattr(tt, nm):
+            setattr(tt, nm, refshim._StubObj(nm))
+    lt = importlib.import_module("modelcompose.train.llava_trainer")
+    rng = np.random.default_rng(12)
+    meta = {"plain": [], "modality": [], "chunks": []}
+    for (n, bs, ws, seed) in ((37, 4, 2, 1), (64, 4, 4, 2), (7, 2, 2, 3), (256, 16, 8, 4), (100, 3, 5, 5)):
+        lengths = [int(x) for x in rng.integers(1, 700, n)]
+        g = torch.Generator().manual_seed(seed)
+        meta["plain"].append({"lengths": lengths, "batch_size": bs, "world_size": ws, "seed": seed,
+                              "indices": lt.get_length_grouped_indices(lengths, bs, ws, generator=g)})
+    for (n, bs, ws, seed) in ((50, 4, 2, 6), (129, 4, 4, 7), (40, 16, 2, 8)):
+        lengths = [int(x) * (1 if rng.random() < 0.6 else -1) for x in rng.integers(1, 700, n)]
+        torch.manual_seed(1000 + seed)                      # the per-family shuffles draw from the global RNG (generator=None)
+        g = torch.Generator().manual_seed(seed)
+        meta["modality"].append({"lengths": lengths, "batch_size": bs, "world_size": ws, "seed": seed, "global_seed": 1000 + seed,
+                                 "indices": lt.get_modality_length_grouped_indices(lengths, bs, ws, generator=g)})
+    for (n, k) in ((12, 4), (13, 4), (8, 8), (6, 1)):
+        lengths = [int(x) for x in rng.integers(1, 50, 40)]
+        idx = [int(x) for x in rng.permutation(40)[:n]]
+        meta["chunks"].append({"indices": idx, "lengths": lengths, "num_chunks": k, "chunks": lt.split_to_even_chunks(idx, lengths, k)})
+    # checkpoint conversion
+    sys.path.insert(0, refshim.REF_ROOT + "/scripts/convert_llava_to_multimodal")
+    cc = importlib.import_module("convert_checkpoint")
+    arrays = {}
+    g = torch.Generator().manual_seed(12)
+    names1 = ["model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.q_proj.lora_A.default.weight",
+              "model.layers.0.self_attn.q_proj.lora_B.default.weight", "model.prefix_tokens", "model.mm_projector.0.weight"]
+    names2 = ["model.layers.1.mlp.down_proj.lora_A.default.weight", "model.layers.1.mlp.down_proj.lora_B.default.weight", "model.suffix_tokens",
+              "model.mm_projector.0.bias", "model.mm_projector.2.weight", "lm_head.weight", "model.vision_tower.vision_tower.embeddings.cls"]
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "llava")
+        os.makedirs(src)
+        for fn, names in (("pytorch_model-00001-of-00002.bin", names1), ("pytorch_model-00002-of-00002.bin", names2)):
+            w = {k: torch.randn(3, 5, generator=g).to(torch.float16) for k in names}
+            torch.save(w, os.path.join(src, fn))
+            for k, v in w.items():
+                arrays[f"in::{fn}::{k}"] = v.float()
+        json.dump({"model_type": "llava", "hidden_size": 8}, open(os.path.join(src, "config.json"), "w"))
+        open(os.path.join(src, "tokenizer_config.json"), "w").write("{}")
+        open(os.path.join(src, "unrelated.txt"), "w").write("x")
+        out = os.path.join(tmp, "out")
+        import argparse
+        cc.main(argparse.Namespace(llava_checkpoint=src, output_path=out))
+        for fn in ("adapter_model.bin", "non_lora_trainables.bin"):
+            for k, v in torch.load(os.path.join(out, fn)).items():
+                assert v.dtype == torch.float16
+                arrays[f"out::{fn}::{k}"] = v.float()
+        meta["convert_files"] = sorted(os.listdir(out))
+    _save("g12_host", meta=np.array(json.dumps(meta)), **arrays)
+
+
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
-          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
+          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12}
 
 
 def main(argv):

@@ -49,6 +49,22 @@ def ties_merge_vectors(flat: torch.Tensor, K, merge_func: str) -> torch.Tensor:
     raise ValueError(f"Merge method {merge_func} is not defined.")
 
 
+def interference_metrics(flat: torch.Tensor, reset_thresh=50):
+    """scripts/model_composition/calculate_metrics.py:26-37 on the stacked fp32 task vectors (:58-67): L2 and cosine distance of rows
+    0 and 1, soft sign dissimilarity of all rows, and of the rows trimmed by topk_values_mask(K=reset_thresh) (ties_merging.py:88-109)."""
+    def ssd(xy):
+        a, s = xy.abs().sum(dim=0), xy.sum(dim=0)
+        nz = a != 0
+        return float(1 - (s[nz] / a[nz]).abs().mean())
+    K = reset_thresh / 100 if reset_thresh >= 1 else reset_thresh
+    n, d = flat.shape
+    kth = flat.abs().kthvalue(d - int(d * K), dim=1, keepdim=True).values
+    trimmed = flat * (flat.abs() >= kth)
+    return {"L2": float(torch.sqrt(((flat[0] - flat[1]) ** 2).sum())),
+            "Cosine": 1 - torch.cosine_similarity(flat[0].unsqueeze(0), flat[1].unsqueeze(0)).item(),
+            "SSD": ssd(flat), "TSSD": ssd(trimmed)}
+
+
 def ties_merge_state_dicts(checks, K=20, merge_func="mean"):
     """do_merging :182-221: flatten in sorted key order (state_dict_to_vector :22-31), merge, un-flatten."""
     keys = sorted(checks[0])

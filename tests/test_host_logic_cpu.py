@@ -117,3 +117,50 @@ def test_merge_cli_matches_reference_golden(tmp_path):
     if not torch.cuda.is_available():             # TIES runs on the HIP device and fails loudly without one (no CPU fallback)
         with pytest.raises(RuntimeError):
             compose.merge_checkpoints(paths, str(out), "ties-sum")
+
+
+def test_length_grouped_samplers_match_reference():
+    """Index-exact against the reference's llava_trainer samplers (tests/golden/g12_host.npz) for the same generator seeds."""
+    from conftest import load_golden
+    from modelcompose_amd.train import sampler
+    _, meta, _ = load_golden("g12_host")
+    for c in meta["chunks"]:
+        assert sampler.split_to_even_chunks(c["indices"], c["lengths"], c["num_chunks"]) == c["chunks"]
+    for c in meta["plain"]:
+        g = torch.Generator().manual_seed(c["seed"])
+        got = sampler.get_length_grouped_indices(c["lengths"], c["batch_size"], c["world_size"], generator=g)
+        assert got == c["indices"] and sorted(got) == list(range(len(c["lengths"])))
+    for c in meta["modality"]:
+        torch.manual_seed(c["global_seed"])
+        g = torch.Generator().manual_seed(c["seed"])
+        s = sampler.LengthGroupedSampler(c["batch_size"], c["world_size"], lengths=c["lengths"], generator=g, group_by_modality=True)
+        assert list(s) == c["indices"] and len(s) == len(c["lengths"])
+    with pytest.raises(ValueError):
+        sampler.LengthGroupedSampler(2, 2)
+    with pytest.raises(AssertionError):
+        sampler.get_modality_length_grouped_indices([3, 0, -2], 1, 1)
+
+
+def test_convert_llava_checkpoint_matches_reference(tmp_path):
+    """Key mapping and file split of convert_checkpoint.py, byte-exact tensors, only the whitelisted side files copied."""
+    import json
+    from conftest import load_golden
+    from modelcompose_amd import compose
+    a, meta, _ = load_golden("g12_host")
+    src = tmp_path / "llava"
+    src.mkdir()
+    for fn in ("pytorch_model-00001-of-00002.bin", "pytorch_model-00002-of-00002.bin"):
+        torch.save({k.split("::", 2)[2]: v.to(torch.float16) for k, v in a.items() if k.startswith(f"in::{fn}::")}, src / fn)
+    json.dump({"model_type": "llava", "hidden_size": 8}, open(src / "config.json", "w"))
+    (src / "tokenizer_config.json").write_text("{}")
+    (src / "unrelated.txt").write_text("x")
+    out = tmp_path / "out"
+    compose.convert_llava_checkpoint(str(src), str(out))
+    assert sorted(p.name for p in out.iterdir()) == meta["convert_files"]
+    for fn in ("adapter_model.bin", "non_lora_trainables.bin"):
+        got = torch.load(out / fn)
+        exp = {k.split("::", 2)[2]: v for k, v in a.items() if k.startswith(f"out::{fn}::")}
+        assert sorted(got) == sorted(exp)
+        for k in exp:
+            assert got[k].dtype == torch.float16 and torch.equal(got[k].float(), exp[k]), k
+    assert compose.llava_key_to_multimodal_key("model.layers.0.self_attn.q_proj.weight") is None

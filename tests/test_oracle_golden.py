@@ -290,6 +290,16 @@ def test_g10_ties_merging_tensor_and_file_level(tmp_path):
     assert open(out / "merge_info.txt").read().replace(str(tmp_path), "<TMP>") == meta["merge_info"]
 
 
+def test_g11_interference_metrics():
+    """L2 / cosine / SSD / TSSD against the reference's calculate_metrics functions (fp32 reductions: 1e-5 relative)."""
+    from oracle import merge as omerge
+    a, meta, _ = load_golden("g11_metrics")
+    for case in meta["cases"]:
+        got = omerge.interference_metrics(a[f"flat::{case['n']}"], 50)
+        for k, v in case["expected"].items():
+            assert abs(got[k] - v) <= 1e-5 * max(1.0, abs(v)), (case["n"], k, got[k], v)
+
+
 def test_fbank_oracle_against_independent_kaldi_implementation():
     """torchaudio (the reference's fbank) is absent: the oracle's restatement of kaldi.fbank is cross-checked against the
     independent numpy implementation in transformers.audio_utils configured for Kaldi compatibility."""
