@@ -124,6 +124,9 @@ int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgro
 int mc_gemm_profile_enable(int on);
 int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches);
 int mc_gemm_profile_read_bytes(double* total_bytes);   /* algorithmic HBM bytes (operands read once, output written once) of the same launches */
+/* diagnostic: shader clock (GHz) held across the 256x256 kernel's main loop, median over the first n_wg workgroups of the last launch made
+ * with mc_gemm_debug(40) (correct results, stamped build) */
+int mc_gemm_clock_read(int n_wg, double* ghz);
 
 /* ---- norms: LlamaRMSNorm (multimodal_llama.py:405-406, :482) / nn.LayerNorm (CLIP blocks) -------------- */
 int mc_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* out, int64_t ldo, int M, int D, float eps, void* stream);

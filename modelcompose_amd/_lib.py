@@ -30,6 +30,7 @@ _SIGS = {
     "mc_gemm_profile_enable": [c_i],
     "mc_gemm_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)],
     "mc_gemm_profile_read_bytes": [C.POINTER(C.c_double)],
+    "mc_gemm_clock_read": [c_i, C.POINTER(C.c_double)],
     "mc_rmsnorm_bf16": [c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_layernorm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_rope_kv_bf16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

@@ -386,6 +386,9 @@ struct G2Groups {
     const bf16_t* wp[8];
 };
 
+// in-kernel clock diagnostic (ABL bit 3): shader-clock and 100 MHz real-time ticks across one workgroup's main loop
+__device__ unsigned long long g2_stamps[2 * 4096];
+
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx, G2Groups grp, int N, int K,
                                                               Epilogue ep, int tiles_m, int tiles_n) {
@@ -473,9 +476,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
     bf16x8 wf[4][2], xf[2][2][2];
     if (wave_n == 1) __builtin_amdgcn_s_barrier();      // second group runs one barrier behind
     int t = 0;
+    unsigned long long st0 = 0, sr0 = 0;
+    if (ABL & 8) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
     for (; t < nt - 2; ++t) g2_tile<0, ABL>(smem, t, wave, woff, xoff, src, acc, wf, xf);
     g2_tile<1, ABL>(smem, t, wave, woff, xoff, src, acc, wf, xf);
     g2_tile<2, ABL>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf);
+    if (ABL & 8) {
+        const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.x < 4096) { g2_stamps[2 * blockIdx.x] = st1 - st0; g2_stamps[2 * blockIdx.x + 1] = sr1 - sr0; }
+    }
     if (wave_n == 0) __builtin_amdgcn_s_barrier();
 
 #pragma unroll
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
+#include <algorithm>
 #include <vector>
 // Optional live timing of the dominant kernel (gemm_tile256_kernel): HIP events recorded on the launch stream around every launch while
 // enabled (bench.py's roofline object).  Not graph-capturable; leave disabled in normal operation.
@@ -672,6 +682,22 @@ extern "C" int mc_gemm_profile_read(double* total_ms, double* total_flops, int64
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
     if (launches) *launches = (int64_t)g_prof.size();
+    return 0;
+}
+
+// Diagnostic (debug word 40 must have been set for the launches): median over the first n_wg workgroups of the last 256x256 launch of
+// the shader clock held across the main loop, in GHz (delta s_memtime / delta s_memrealtime x 100 MHz).
+extern "C" int mc_gemm_clock_read(int n_wg, double* ghz) {
+    MC_CHECK_ARG(ghz && n_wg > 0 && n_wg <= 4096, "mc_gemm_clock_read: bad arguments");
+    std::vector<unsigned long long> h(2 * (size_t)n_wg);
+    hipError_t e = hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g2_stamps), h.size() * sizeof(unsigned long long));
+    if (e != hipSuccess) { mc_set_error("mc_gemm_clock_read: %s", hipGetErrorString(e)); return 2; }
+    std::vector<double> r;
+    for (int i = 0; i < n_wg; ++i)
+        if (h[2 * i + 1]) r.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1);
+    if (r.empty()) { mc_set_error("mc_gemm_clock_read: no stamps recorded"); return 2; }
+    std::sort(r.begin(), r.end());
+    *ghz = r[r.size() / 2];
     return 0;
 }
 
@@ -761,6 +787,7 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr256_set = true;
     }
     ProfRec rec{};
@@ -774,12 +801,14 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         (void)hipEventRecord(rec.a, s);
     }
 #define G2_LAUNCH(A) gemm_tile256_kernel<A><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n)
-    // debug word bits 3-5: timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1
+    // debug word bits 3-5: timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1;
+    // 40 = correct results + clock stamps around the main loop (mc_gemm_clock_read)
     switch ((g_gemm_dbg >> 3) & 7) {
         case 1: G2_LAUNCH(1); break;
         case 2: G2_LAUNCH(2); break;
         case 3: G2_LAUNCH(3); break;
         case 4: G2_LAUNCH(4); break;
+        case 5: G2_LAUNCH(8); break;
         default: G2_LAUNCH(0); break;
     }
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }

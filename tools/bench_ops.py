@@ -116,6 +116,29 @@ def main():
                 gemm_case(8192, 8192, 8192, rot=1)
                 gemm_case(10928, 4096, 4096, rot=1)
         L.mc_gemm_debug(0)
+    if "clock" in which:
+        # shader clock the chip holds inside the 256x256 kernel's main loop after >= 2 s of back-to-back launches on random data
+        import ctypes as C
+        from modelcompose_amd import _lib, ops
+        L = _lib.lib()
+        for (M, N, K) in ((10928, 4096, 4096), (10928, 22016, 4096), (8192, 8192, 8192)):
+            x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+            w = ops.pack_weight(torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.02)
+            L.mc_gemm_debug(4 + 40)
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < 2.5:
+                for _ in range(20):
+                    ops.linear(x, w)
+                torch.cuda.synchronize()
+                n += 20
+            dt = (time.perf_counter() - t0) / n
+            ghz = C.c_double()
+            _lib.check(L.mc_gemm_clock_read(min(4096, ((M + 255) // 256) * ((N + 255) // 256)), C.byref(ghz)), "mc_gemm_clock_read")
+            L.mc_gemm_debug(0)
+            tf = 2.0 * M * N * K / dt / 1e12
+            print(f"clock M={M} N={N} K={K}: {ghz.value:.3f} GHz in the main loop; {tf:.0f} TFLOP/s (host-timed incl. launch); "
+                  f"MFMA peak at that clock {2.5e3 * ghz.value / 2.4:.0f} TFLOP/s -> {tf / (2.5e3 * ghz.value / 2.4):.2f} of it")
     if "ties" in which:
         from modelcompose_amd import compose
         n, d = 3, 327_155_712                  # the rank-128 default adapter of Vicuna-7B: 0.33 G elements per checkpoint
