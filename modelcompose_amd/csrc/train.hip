@@ -181,12 +181,13 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     __shared__ float red[16];
     const int row = blockIdx.x;
     const float* lr = logits + (int64_t)row * ld;
-    bf16_t* dr = dlogits + (int64_t)row * ldd;
+    bf16_t* dr = dlogits ? dlogits + (int64_t)row * ldd : nullptr;         // dlogits == NULL: loss only (forward(labels=...))
     const int64_t lab = labels[row];
     const int nv = V >> 2;
     if (lab < 0) {
         loss_rows[row] = 0.f;
-        for (int i = threadIdx.x; i < nv; i += 256) *(bf16x4*)(dr + i * 4) = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        if (dr)
+            for (int i = threadIdx.x; i < nv; i += 256) *(bf16x4*)(dr + i * 4) = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
         return;
     }
     float mx = -3.0e38f;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     se = block_sum(se, red);
     const float inv = 1.0f / se;
     if (threadIdx.x == 0) loss_rows[row] = logf(se) + mx - lr[lab];
+    if (!dr) return;
     for (int i = threadIdx.x; i < nv; i += 256) {
         const f32x4 v = *(const f32x4*)(lr + i * 4);
         bf16x4 o;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
 
 extern "C" int mc_ce_loss_f32(const float* logits, int64_t ld, const int64_t* labels, float* loss_rows, void* dlogits_bf16, int64_t ldd, int M,
                               int V, float inv_n, void* stream) {
-    MC_CHECK_ARG(logits && labels && loss_rows && dlogits_bf16 && M > 0 && V > 0 && V % 4 == 0 && ld % 4 == 0 && ldd % 4 == 0, "mc_ce_loss_f32: bad arguments");
+    MC_CHECK_ARG(logits && labels && loss_rows && M > 0 && V > 0 && V % 4 == 0 && ld % 4 == 0 && (!dlogits_bf16 || ldd % 4 == 0), "mc_ce_loss_f32: bad arguments");
     ce_loss_kernel<<<M, 256, 0, (hipStream_t)stream>>>(logits, ld, labels, loss_rows, (bf16_t*)dlogits_bf16, ldd, V, inv_n);
     MC_CHECK_LAUNCH();
     return 0;

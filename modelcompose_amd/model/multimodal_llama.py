@@ -417,9 +417,12 @@ class MultimodalLlamaForCausalLM:
         logits[valid] = lg_r[st["out_map"][valid].long()]
         logits = logits.view(B, Lmax, V)
         loss = None
-        if labels is not None:                                                                # :722-733 (torch CE on device logits)
+        if labels is not None:                                                                # :722-733: shifted CE, mean over kept targets
             lab = torch.from_numpy(plan.labels).to(self.device)
-            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, V), lab[:, 1:].reshape(-1), ignore_index=IGNORE_INDEX)
+            tgt = torch.full((B, Lmax), IGNORE_INDEX, dtype=torch.int64, device=self.device)
+            tgt[:, :-1] = lab[:, 1:]
+            rows, _ = ops.ce_loss(logits.view(B * Lmax, V), tgt.view(-1), 1.0, want_grad=False)
+            loss = rows.sum() / (tgt != IGNORE_INDEX).sum()                                   # nan when every target is ignored, as torch's CE
         return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None)
 
     __call__ = forward

@@ -380,13 +380,14 @@ def act(pre, kind, dy=None):
     return out
 
 
-def ce_loss(logits_f32, labels, inv_n):
-    """labels int64 [M] (already shifted, < 0 ignored) -> (loss_rows fp32 [M], dlogits bf16 [M, V] = (softmax - onehot) * inv_n)."""
+def ce_loss(logits_f32, labels, inv_n, want_grad=True):
+    """labels int64 [M] (already shifted, < 0 ignored) -> (loss_rows fp32 [M], dlogits bf16 [M, V] = (softmax - onehot) * inv_n);
+    want_grad=False skips the gradient (dlogits is None)."""
     M, V = logits_f32.shape
     loss_rows = torch.empty(M, dtype=torch.float32, device=logits_f32.device)
-    dl = torch.empty(M, V, dtype=BF16, device=logits_f32.device)
-    _lib.check(_lib.lib().mc_ce_loss_f32(_p(logits_f32), logits_f32.stride(0), _p(labels), _p(loss_rows), _p(dl), dl.stride(0), M, V, inv_n,
-                                         _stream()), "mc_ce_loss_f32")
+    dl = torch.empty(M, V, dtype=BF16, device=logits_f32.device) if want_grad else None
+    _lib.check(_lib.lib().mc_ce_loss_f32(_p(logits_f32), logits_f32.stride(0), _p(labels), _p(loss_rows), _p(dl), dl.stride(0) if want_grad else 0,
+                                         M, V, inv_n, _stream()), "mc_ce_loss_f32")
     return loss_rows, dl
 
 

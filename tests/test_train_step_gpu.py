@@ -55,3 +55,18 @@ def test_optimizer_step_reduces_the_loss_and_is_deterministic(stepper):
         st.step(*args)
     l1 = st.forward_backward(*args).item()
     assert l1 < l0 - 0.05, (l0, l1)
+
+
+def test_forward_with_labels_returns_the_reference_loss():
+    """MultimodalLlamaForCausalLM.forward(labels=...) (multimodal_llama.py:722-733): shifted CE on the HIP kernel, mean over the
+    kept targets; checked against the reference's loss on the same batch (bf16 forward vs fp32 reference: 2 %)."""
+    from modelcompose_amd.model.builder import build_from_state_dict
+    a, meta, sd = load_golden("g9_train_step")
+    model = build_from_state_dict(dict(meta, lora_dropout=0.0), sd)
+    out = model.forward(a["input_ids"].cuda(), labels=a["labels"].cuda(), modal_inputs={"vision": a["pixels"].cuda()})
+    assert abs(out.loss.item() - a["loss"].item()) < 2e-2 * abs(a["loss"].item())
+    assert out.logits.shape[0] == a["input_ids"].shape[0] and out.logits.dtype == torch.float32
+    # all targets ignored -> nan, like torch's cross_entropy with ignore_index
+    lab = torch.full_like(a["labels"], -100)
+    out = model.forward(a["input_ids"].cuda(), labels=lab.cuda(), modal_inputs={"vision": a["pixels"].cuda()})
+    assert torch.isnan(out.loss)
