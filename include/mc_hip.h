@@ -230,6 +230,15 @@ int mc_decode_state_init(int32_t* state, const int32_t* prompt_lens, int B, int 
 int mc_decode_state_advance(int32_t* state, int B, void* stream);
 int mc_argmax_step_f32(const void* x, int64_t ld, int64_t* next_ids, int64_t* out_ids, int64_t ld_out, const int32_t* step_ptr,
                        int M, int N, void* stream);
+/* Sampled step (generate(do_sample=True, temperature, top_p[, top_k]): eval/model_multimodal_qa_loader.py:94-102, serve/model_worker.py:160-185;
+ * warper semantics of transformers 4.31 generation/logits_process.py): scores = logits / temperature; keep scores >= the top_k-th largest
+ * (top_k = 0: off); drop the ascending prefix whose cumulative softmax mass <= 1 - top_p (top_p = 1: off; the largest always stays);
+ * draw from the renormalised rest by inverse CDF with one Philox4x32-10 uniform per (seed, row, step).  step / seed come from device memory
+ * (step_ptr, seed_ptr[2]) when given, else from step_const / seed_const.  uniform_in [M] (optional) replaces the RNG; probs_out [M][N]
+ * (optional, row stride ldp) receives the final probabilities.  next_ids[m] = token; out_ids[m*ld_out + step] = token when out_ids != NULL. */
+int mc_sample_step_f32(const float* logits, int64_t ld, int64_t* next_ids, int64_t* out_ids, int64_t ld_out, const int32_t* step_ptr,
+                       int step_const, const uint32_t* seed_ptr, unsigned long long seed_const, int M, int N, float temperature, int top_k,
+                       float top_p, const float* uniform_in, float* probs_out, int64_t ldp, void* stream);
 
 /* ---- composed Vicuna backbone runtime (csrc/llm_runtime.cpp) -------------------------------------------
  * Replaces MultimodalLlamaModel.forward + lm_head (model/language_model/multimodal_llama.py:488-619, :720) and the
@@ -250,6 +259,9 @@ int mc_llm_destroy(void* handle);
 int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* final_norm, const void* lm_head_packed,
                        const void* embed_table, const float* cos_table, const float* sin_table);
 int mc_llm_set_option(void* handle, const char* name, int value);        /* "use_graph" */
+/* next-token rule of mc_llm_decode: do_sample = 0 greedy arg-max (default), 1 = mc_sample_step_f32 with these parameters and the seed the
+ * caller stored at state[4B+1], state[4B+2] */
+int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_k, float top_p);
 int mc_llm_workspace_bytes(void* handle, int M, int B, int Lq, int64_t* bytes);
 /* Prefill over M rows in routed order.  group_start / group_adapter are HOST arrays (n_groups+1 / n_groups); the other
  * int32 arrays are device arrays: row_b/row_pos/row_t [M], out_map [B*Lq] (sequence slot -> routed row, -1 = padding),

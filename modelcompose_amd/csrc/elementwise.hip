@@ -442,29 +442,33 @@ __global__ void decode_state_advance_kernel(int32_t* state, int B) {
 }
 
 // argmax + append: next_ids[b] = argmax(logits[b]); out_ids[b*ld + step] = next_ids[b]
-__global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restrict__ x, int64_t ld, int64_t* __restrict__ next_ids,
-                                                          int64_t* __restrict__ out_ids, int64_t ld_out, const int32_t* __restrict__ step_ptr,
-                                                          int N) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
+__global__ __launch_bounds__(1024) void argmax_step_kernel(const float* __restrict__ x, int64_t ld, int64_t* __restrict__ next_ids,
+                                                           int64_t* __restrict__ out_ids, int64_t ld_out, const int32_t* __restrict__ step_ptr,
+                                                           int N) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
     const float* r = x + (int64_t)blockIdx.x * ld;
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const float v = r[i];
-        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    auto take = [&](float v, int i) { if (v > best || (v == best && i < idx)) { best = v; idx = i; } };
+    if ((N & 3) == 0 && (ld & 3) == 0) {            // 16-byte loads: one row of 32000 logits is 8 loads per thread
+        for (int i = threadIdx.x * 4; i < N; i += 4096) {
+            const f32x4 v = *(const f32x4*)(r + i);
+            take(v[0], i); take(v[1], i + 1); take(v[2], i + 2); take(v[3], i + 3);
+        }
+    } else {
+        for (int i = threadIdx.x; i < N; i += 1024) take(r[i], i);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float v2 = __shfl_xor(best, o, 64);
         const int i2 = __shfl_xor(idx, o, 64);
-        if (v2 > best || (v2 == best && i2 < idx)) { best = v2; idx = i2; }
+        take(v2, i2);
     }
     if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        for (int w = 1; w < 16; ++w) take(bv[w], bi[w]);
         next_ids[blockIdx.x] = idx;
         if (out_ids) out_ids[blockIdx.x * ld_out + (step_ptr ? *step_ptr : 0)] = idx;
     }
@@ -486,7 +490,7 @@ extern "C" int mc_decode_state_advance(int32_t* state, int B, void* stream) {
 extern "C" int mc_argmax_step_f32(const void* x, int64_t ld, int64_t* next_ids, int64_t* out_ids, int64_t ld_out,
                                   const int32_t* step_ptr, int M, int N, void* stream) {
     MC_CHECK_ARG(x && next_ids && M > 0 && N > 0, "mc_argmax_step_f32: bad arguments");
-    argmax_step_kernel<<<M, 256, 0, (hipStream_t)stream>>>((const float*)x, ld, next_ids, out_ids, ld_out, step_ptr, N);
+    argmax_step_kernel<<<M, 1024, 0, (hipStream_t)stream>>>((const float*)x, ld, next_ids, out_ids, ld_out, step_ptr, N);
     MC_CHECK_LAUNCH();
     return 0;
 }

@@ -36,8 +36,12 @@ struct Llm {
     bool weights_set = false;
     // decode graph cache
     hipGraphExec_t graph_exec = nullptr;
-    struct Key { int B, Smax; const void *kc, *vc, *ws, *state, *next_ids, *out_ids, *logits; int64_t ld_out; } gkey{};
+    struct Key { int B, Smax; const void *kc, *vc, *ws, *state, *next_ids, *out_ids, *logits; int64_t ld_out; int sample, top_k; float temp, top_p; } gkey{};
     bool use_graph = true;
+    // next-token rule: greedy arg-max, or temperature / top-k / top-p sampling (seed: 2 x u32 at state[4B+1] on the device)
+    bool do_sample = false;
+    float temperature = 1.0f, top_p = 1.0f;
+    int top_k = 0;
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -220,6 +224,17 @@ extern "C" int mc_llm_set_option(void* handle, const char* name, int value) {
     return 1;
 }
 
+extern "C" int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_k, float top_p) {
+    Llm* m = (Llm*)handle;
+    if (!m) { mc_set_error("mc_llm_set_sampling: null handle"); return 1; }
+    if (do_sample && (!(temperature > 0.f) || top_k < 0 || !(top_p >= 0.f && top_p <= 1.f))) {
+        mc_set_error("mc_llm_set_sampling: bad parameters (temperature=%g top_k=%d top_p=%g)", (double)temperature, top_k, (double)top_p);
+        return 1;
+    }
+    m->do_sample = do_sample != 0; m->temperature = temperature; m->top_k = top_k; m->top_p = top_p;
+    return 0;
+}
+
 extern "C" int mc_llm_workspace_bytes(void* handle, int M, int B, int Lq, int64_t* bytes) {
     Llm* m = (Llm*)handle;
     if (!m || !bytes || M <= 0 || B <= 0 || Lq <= 0) { mc_set_error("mc_llm_workspace_bytes: bad arguments"); return 1; }
@@ -283,7 +298,11 @@ static int decode_one_step(Llm* m, int B, int64_t* next_ids, int64_t* out_ids, i
                           nsplit, attn_ws, stream));
     float* lg = logits_step ? logits_step : (float*)w.logits;
     RUN(head_forward(m, w.xl, B, w, lg, stream));
-    RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, out_ids, ld_out, step, B, c.vocab, stream));
+    if (m->do_sample)
+        RUN(mc_sample_step_f32(lg, c.vocab, next_ids, out_ids, ld_out, step, 0, (const uint32_t*)(state + 4 * B + 1), 0ull, B, c.vocab,
+                               m->temperature, m->top_k, m->top_p, nullptr, nullptr, 0, stream));
+    else
+        RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, out_ids, ld_out, step, B, c.vocab, stream));
     RUN(mc_decode_state_advance(state, B, stream));
     return 0;
 }
@@ -305,7 +324,11 @@ extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids
     const int nsplit = decode_nsplit(c, B);
     hipStream_t s = (hipStream_t)stream;
     if (m->use_graph && !logits_out && n_steps > 1) {
-        Llm::Key key{B, Smax, k_cache, v_cache, workspace, state, next_ids, out_ids, nullptr, ld_out};
+        Llm::Key key{};               // zero-initialised incl. padding: compared with memcmp
+        key.B = B; key.Smax = Smax; key.kc = k_cache; key.vc = v_cache; key.ws = workspace; key.state = state; key.next_ids = next_ids;
+        key.out_ids = out_ids; key.logits = nullptr; key.ld_out = ld_out;
+        key.sample = m->do_sample; key.top_k = m->do_sample ? m->top_k : 0;
+        key.temp = m->do_sample ? m->temperature : 0.f; key.top_p = m->do_sample ? m->top_p : 0.f;
         if (!m->graph_exec || memcmp(&key, &m->gkey, sizeof(key)) != 0) {
             if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
             hipGraph_t graph = nullptr;

@@ -389,6 +389,12 @@ class MultimodalLlamaForCausalLM:
             self._cache[("state", B)] = state
         L = _lib.lib()
         _lib.check(L.mc_decode_state_init(_ptr(state), _ptr(st["kv_lens"]), B, step0, _stream()), "mc_decode_state_init")
+        smp = st.get("sampling")
+        if smp is not None:                                       # seed: 2 x u32 behind the step counter of the device state
+            lo, hi = smp[3] & 0xFFFFFFFF, (smp[3] >> 32) & 0xFFFFFFFF
+            state[4 * B + 1:4 * B + 3] = torch.tensor([lo - (1 << 32) if lo >= 1 << 31 else lo, hi - (1 << 32) if hi >= 1 << 31 else hi],
+                                                      dtype=torch.int32)
+        _lib.check(L.mc_llm_set_sampling(self._handle, int(smp is not None), *(smp[:3] if smp else (1.0, 0, 1.0))), "mc_llm_set_sampling")
         logits = torch.empty(n_steps, B, self.config.vocab_size, dtype=torch.float32, device=dev) if want_logits else None
         # the workspace of the prefill is at least as large as the decode one (M >= B)
         _lib.check(L.mc_llm_decode(self._handle, B, n_steps, _ptr(st["next_ids"]), _ptr(out_ids), out_ids.stride(0), _ptr(state),
@@ -430,18 +436,40 @@ class MultimodalLlamaForCausalLM:
     @torch.no_grad()
     def generate(self, input_ids=None, modal_inputs=None, do_sample=False, temperature=None, top_p=None, num_beams=1,
                  max_new_tokens=128, use_cache=True, attention_mask=None, ignore_eos=False, return_step_logits=False, **kw):
-        """Greedy generation (model_multimodal_qa_loader.py:94-102).  Returns LongTensor (B, L_text + n_new): the text-length
-        prompt followed by the new ids, rows that hit EOS are padded with pad_token_id (transformers greedy_search)."""
-        if do_sample or (temperature not in (None, 0, 0.0) and do_sample) or (num_beams not in (None, 1)):
-            raise NotImplementedError("only greedy decoding (do_sample=False, num_beams=1) is implemented on the HIP path")
+        """Greedy or sampled generation (model_multimodal_qa_loader.py:94-102).  Returns LongTensor (B, L_text + n_new): the text-length
+        prompt followed by the new ids, rows that hit EOS are padded with pad_token_id (transformers greedy_search / sample).
+        do_sample=True applies transformers 4.31's warpers in their order (temperature, top_k - GenerationConfig default 50, pass
+        top_k=0 to disable - then top_p) and draws with a Philox stream keyed by `seed` (kwarg; default: drawn from torch's global
+        generator, so torch.manual_seed makes runs repeatable).  Beam search is not implemented."""
+        if num_beams not in (None, 1):
+            raise NotImplementedError("beam search (num_beams > 1) is not implemented on the HIP path")
+        sampling = None
+        if do_sample:
+            T = 1.0 if temperature is None else float(temperature)
+            P = 1.0 if top_p is None else float(top_p)
+            Kk = kw.pop("top_k", 50)
+            Kk = 0 if Kk is None else int(Kk)
+            if not T > 0:                                                                     # logits_process.py TemperatureLogitsWarper
+                raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float, otherwise your next token scores will be invalid.")
+            if P < 0 or P > 1.0:
+                raise ValueError(f"`top_p` has to be a float > 0 and < 1, but is {top_p}")
+            if Kk < 0:
+                raise ValueError(f"`top_k` has to be a strictly positive integer, but is {Kk}")
+            seed = kw.pop("seed", None)
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            sampling = (T, Kk, P, int(seed))
         if input_ids is None:
             raise ValueError("generate() needs input_ids")
         modal_inputs = modal_inputs or {}
         feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
         plan = self._plan(input_ids, attention_mask, None, modal_inputs, feats)
-        st = self._prefill(plan, feats, max_new_tokens, want_logits=return_step_logits)
+        st = self._prefill(plan, feats, max_new_tokens, want_logits=return_step_logits or sampling is not None)
         B = plan.B
         out = torch.zeros(B, max_new_tokens, dtype=torch.int64, device=self.device)
+        if sampling is not None:                                  # first token: same rule, RNG counter -1 (decode steps count from 0)
+            st["next_ids"].copy_(ops.sample_step(st["logits"], sampling[0], sampling[1], sampling[2], seed=sampling[3], step=-1))
+            st["sampling"] = sampling
         out[:, 0] = st["next_ids"]
         step_logits = [st["logits"][None]] if return_step_logits else None
         eos, pad = self.config.eos_token_id, self.config.pad_token_id

@@ -252,6 +252,18 @@ def argmax(logits_f32, out=None):
     return out
 
 
+def sample_step(logits_f32, temperature=1.0, top_k=0, top_p=1.0, seed=0, step=0, uniform=None, want_probs=False):
+    """One sampled token per row of logits [M, V] fp32 (HF warper order: temperature, top-k, top-p, multinomial).  Returns ids int64 [M]
+    (and the final probabilities [M, V] when want_probs)."""
+    M, V = logits_f32.shape
+    ids = torch.empty(M, dtype=torch.int64, device=logits_f32.device)
+    probs = torch.empty(M, V, dtype=torch.float32, device=logits_f32.device) if want_probs else None
+    _lib.check(_lib.lib().mc_sample_step_f32(_p(logits_f32), logits_f32.stride(0), _p(ids), None, 0, None, int(step), None, int(seed) & (2 ** 64 - 1),
+                                             M, V, float(temperature), int(top_k), float(top_p), _p(uniform), _p(probs), V, _stream()),
+               "mc_sample_step_f32")
+    return (ids, probs) if want_probs else ids
+
+
 def im2col(x, kh, kw, sh, sw, Kp=None):
     _req(x, BF16, "x")
     x = x.contiguous()

@@ -88,7 +88,10 @@ def test_generate_eos_padding_and_reference_shape(g4_model):
                          num_beams=1, use_cache=True)
     assert res.dtype == torch.int64 and res.shape[0] == ids.shape[0] and res.shape[1] <= ids.shape[1] + 6
     with pytest.raises(NotImplementedError):
-        model.generate(ids, modal_inputs={"vision": a["pixels"].cuda()}, do_sample=True, temperature=0.2)
+        model.generate(ids, modal_inputs={"vision": a["pixels"].cuda()}, num_beams=2)
+    # the loader's default (--temperature 0.2 -> do_sample=True, model_multimodal_qa_loader.py:96-99) runs on the sampled path
+    res = model.generate(ids, modal_inputs={"vision": a["pixels"].cuda()}, max_new_tokens=6, do_sample=True, temperature=0.2, top_p=None)
+    assert res.dtype == torch.int64 and res.shape[0] == ids.shape[0] and res.shape[1] <= ids.shape[1] + 6
 
 
 def test_splice_api_matches_golden_g3():

@@ -341,3 +341,28 @@ def test_image_preprocess_oracle_against_pil_and_clip_image_processor():
             pil = Image.fromarray(oi.expand2square(img, tuple(int(x * 255) for x in proc.image_mean)) if pad else img)
             ref = proc.preprocess(pil, return_tensors="pt")["pixel_values"][0].numpy()
             assert np.array_equal(oi.clip_preprocess(img, 336, pad), ref), (h, w, pad)
+
+
+def test_sampling_oracle_against_installed_transformers_warpers():
+    """transformers 4.31 is absent; the oracle's restatement of its temperature / top-k / top-p warpers is pinned against the classes of
+    the transformers installed here (their definitions did not change), incl. ties at the top-k boundary and top_p extremes."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from oracle import sampling
+    g = torch.Generator().manual_seed(31)
+    logits = torch.randn(6, 1000, generator=g) * 3
+    logits[0, 10:14] = logits[0].topk(5)[0][-1]              # ties at the 5th largest value
+    for (T, k, p) in ((0.2, 50, 1.0), (1.0, 5, 0.9), (0.7, 0, 0.5), (1.3, 50, 0.01), (1.0, 0, 1.0), (0.5, 1, 0.3)):
+        ref = logits.clone()
+        if T != 1.0:
+            ref = TemperatureLogitsWarper(T)(None, ref)
+        if k:
+            ref = TopKLogitsWarper(k)(None, ref)
+        if p < 1.0:
+            ref = TopPLogitsWarper(p)(None, ref)
+        got = sampling.warp(logits.clone(), T, k, p)
+        assert torch.equal(got, ref), (T, k, p)
+    pr = sampling.probabilities(logits, 0.7, 50, 0.9)
+    u = torch.tensor([0.0, 0.1, 0.5, 0.9, 0.999999, 0.3])
+    ids = sampling.pick(pr, u)
+    assert (pr[torch.arange(6), ids] > 0).all()
+    assert ids[0] == (pr[0] > 0).float().argmax()            # u = 0 -> first kept token in index order
