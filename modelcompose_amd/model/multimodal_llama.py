@@ -459,6 +459,8 @@ class MultimodalLlamaForCausalLM:
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             sampling = (T, Kk, P, int(seed))
+        streamer = kw.pop("streamer", None)
+        criteria = kw.pop("stopping_criteria", None)
         if input_ids is None:
             raise ValueError("generate() needs input_ids")
         modal_inputs = modal_inputs or {}
@@ -475,21 +477,47 @@ class MultimodalLlamaForCausalLM:
         eos, pad = self.config.eos_token_id, self.config.pad_token_id
         pad = eos if pad is None else pad
         done_at = max_new_tokens
-        if max_new_tokens > 1:
-            if ignore_eos:
+        # transformers' per-token hooks (serve/model_worker.py:160-185, eval/model_vqa*.py): streamer.put(prompt) then put(new ids) per
+        # step and end(); stopping_criteria(ids so far, scores) -> True stops every row.  Either one switches to one launch per token.
+        ids_dev = input_ids.to(self.device)
+        stopped_at = None
+
+        def hooks(n_done):                                       # n_done new tokens are in out[:, :n_done]
+            nonlocal stopped_at
+            if streamer is not None:
+                streamer.put(out[:, n_done - 1].cpu())
+            if criteria and stopped_at is None:
+                seq = torch.cat([ids_dev, out[:, :n_done]], dim=1)
+                if any(bool(c(seq, None)) for c in criteria):
+                    stopped_at = n_done
+            return stopped_at is not None
+
+        per_token = streamer is not None or bool(criteria)
+        if streamer is not None:
+            streamer.put(input_ids.cpu())
+        halted = hooks(1) if per_token else False
+        if max_new_tokens > 1 and not halted:
+            if ignore_eos and not per_token:
                 lg = self._decode(st, max_new_tokens - 1, out[:, 1:], 0, want_logits=return_step_logits)
                 if return_step_logits:
                     step_logits.append(lg)
             else:
-                chunk, s = 16, 0
+                chunk, s = (1 if per_token else 16), 0
                 while s < max_new_tokens - 1:
                     n = min(chunk, max_new_tokens - 1 - s)
                     lg = self._decode(st, n, out[:, 1:], s, want_logits=return_step_logits)
                     if return_step_logits:
                         step_logits.append(lg)
                     s += n
-                    if bool(((out[:, :1 + s] == eos).any(dim=1)).all()):            # host sync once per chunk
+                    if per_token and hooks(1 + s):
                         break
+                    if not ignore_eos and bool(((out[:, :1 + s] == eos).any(dim=1)).all()):   # host sync once per chunk
+                        break
+        if streamer is not None:
+            streamer.end()
+        if stopped_at is not None:
+            out = out[:, :stopped_at]
+            done_at = stopped_at
         new = out
         if not ignore_eos:
             is_eos = new == eos

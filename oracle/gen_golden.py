@@ -21,6 +21,7 @@ Groups:
   g10 TIES merging (ties-mean / sum / max) tensor- and file-level
   g11 interference metrics (L2 / cosine / SSD / TSSD) tensor- and file-level
   g12 host callers: length-grouped samplers, LLaVA -> multimodal checkpoint conversion
+  g13 prompt helpers of mm_utils.py: placeholder tokenisation, stopping criteria, expand2square
 """
 from __future__ import annotations
 
@@ -955,8 +956,51 @@ def g12():
     _save("g12_host", meta=np.array(json.dumps(meta)), **arrays)
 
 
+def g13():
+    """Prompt-side helpers of the path, run from the reference's own modelcompose/mm_utils.py (importable untouched): placeholder ->
+    sentinel tokenisation (:43-101), split_string_by_list (:64-79), KeywordsStoppingCriteria (:114-144), expand2square (:14-25),
+    get_model_name_from_path (:103-109), with oracle/toy_tokenizer.py standing in for the LLaMA tokenizer."""
+    refshim.install()
+    import importlib
+    from PIL import Image
+    from .toy_tokenizer import ToyTokenizer
+    mu = importlib.import_module("modelcompose.mm_utils")
+    prompts = ["A chat. USER: <image>\nWhat is shown? ASSISTANT:", "<image><audio> both first", "no placeholders at all",
+               "USER: <video>\n<point>\n<audio>\n<image>\nDescribe. ASSISTANT:", "ends with <image>", "<image>", "",
+               "text <relrep> then <text> then <image> <image>"]
+    meta = {"prompts": prompts, "image_token": [], "modal_token": [], "split": [], "stop": [], "names": []}
+    for add_bos in (True, False):
+        for pr in prompts:
+            tok = ToyTokenizer(add_bos)
+            meta["image_token"].append({"add_bos": add_bos, "prompt": pr, "ids": mu.tokenizer_image_token(pr, tok)})
+            tok = ToyTokenizer(add_bos)
+            meta["modal_token"].append({"add_bos": add_bos, "prompt": pr, "ids": mu.tokenizer_modal_token(pr, tok)})
+    for pr in prompts:
+        meta["split"].append({"prompt": pr, "out": [list(t) for t in mu.split_string_by_list(pr, list(mu.MODAL_TOKEN_MAPPING.keys()))]})
+    tok = ToyTokenizer(True)
+    prompt_ids = torch.tensor([tok("USER: hello there ASSISTANT:").input_ids])
+    for keywords, text in ((["</s>"], "fine thanks </s>"), (["###"], "answer ### more"), (["stop now"], "please stop now ok"), (["never"], "a b c d e")):
+        crit = mu.KeywordsStoppingCriteria(keywords, tok, prompt_ids)
+        new = tok(text).input_ids[1:]
+        verdicts = []
+        for n in range(1, len(new) + 1):
+            seq = torch.cat([prompt_ids, torch.tensor([new[:n]])], dim=1)
+            verdicts.append(bool(crit(seq, None)))
+        meta["stop"].append({"keywords": keywords, "text": text, "verdicts": verdicts})
+    for pth in ("/ckpts/multimodal-vicuna-7b/", "/a/b/checkpoint-200", "model", "x/y/multimodal-lora/checkpoint-5/"):
+        meta["names"].append({"path": pth, "name": mu.get_model_name_from_path(pth)})
+    arrays = {}
+    rng = np.random.default_rng(13)
+    for name, (w, h) in (("wide", (9, 4)), ("tall", (3, 8)), ("square", (5, 5))):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out = mu.expand2square(Image.fromarray(img), (12, 200, 77))
+        arrays[f"img::{name}"] = torch.from_numpy(img.astype(np.int32))
+        arrays[f"sq::{name}"] = torch.from_numpy(np.asarray(out).astype(np.int32))
+    _save("g13_prompt", meta=np.array(json.dumps(meta)), **arrays)
+
+
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
-          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12}
+          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}
 
 
 def main(argv):

@@ -164,3 +164,36 @@ def test_convert_llava_checkpoint_matches_reference(tmp_path):
         for k in exp:
             assert got[k].dtype == torch.float16 and torch.equal(got[k].float(), exp[k]), k
     assert compose.llava_key_to_multimodal_key("model.layers.0.self_attn.q_proj.weight") is None
+
+
+def test_prompt_helpers_match_reference_mm_utils():
+    """tokenizer_image_token / tokenizer_modal_token / split_string_by_list / KeywordsStoppingCriteria / expand2square /
+    get_model_name_from_path against the outputs of the reference's own mm_utils.py (tests/golden/g13_prompt.npz)."""
+    from PIL import Image
+    from conftest import load_golden
+    from modelcompose_amd import mm_utils
+    from modelcompose_amd.constants import MODAL_TOKEN_MAPPING
+    from oracle.toy_tokenizer import ToyTokenizer
+    a, meta, _ = load_golden("g13_prompt")
+    for c in meta["image_token"]:
+        assert mm_utils.tokenizer_image_token(c["prompt"], ToyTokenizer(c["add_bos"])) == c["ids"], c
+    for c in meta["modal_token"]:
+        assert mm_utils.tokenizer_modal_token(c["prompt"], ToyTokenizer(c["add_bos"])) == c["ids"], c
+    t = mm_utils.tokenizer_modal_token(meta["prompts"][3], ToyTokenizer(True), return_tensors="pt")
+    assert t.dtype == torch.int64 and sorted(int(x) for x in t[t < 0]) == [-205, -204, -203, -200]
+    with pytest.raises(ValueError):
+        mm_utils.tokenizer_modal_token("x", ToyTokenizer(True), return_tensors="np")
+    for c in meta["split"]:
+        assert [list(x) for x in mm_utils.split_string_by_list(c["prompt"], list(MODAL_TOKEN_MAPPING.keys()))] == c["out"]
+    tok = ToyTokenizer(True)
+    prompt_ids = torch.tensor([tok("USER: hello there ASSISTANT:").input_ids])
+    for c in meta["stop"]:
+        crit = mm_utils.KeywordsStoppingCriteria(c["keywords"], tok, prompt_ids)
+        new = tok(c["text"]).input_ids[1:]
+        got = [bool(crit(torch.cat([prompt_ids, torch.tensor([new[:n]])], dim=1), None)) for n in range(1, len(new) + 1)]
+        assert got == c["verdicts"], c
+    for c in meta["names"]:
+        assert mm_utils.get_model_name_from_path(c["path"]) == c["name"]
+    for name in ("wide", "tall", "square"):
+        out = mm_utils.expand2square(Image.fromarray(a[f"img::{name}"].numpy().astype(np.uint8)), (12, 200, 77))
+        assert np.array_equal(np.asarray(out).astype(np.int32), a[f"sq::{name}"].numpy())

@@ -109,3 +109,38 @@ def test_generate_with_sampling_end_to_end():
         model.generate(ids, modal_inputs={"vision": px}, do_sample=True, temperature=0.0, max_new_tokens=2)
     with pytest.raises(NotImplementedError):
         model.generate(ids, modal_inputs={"vision": px}, num_beams=3, max_new_tokens=2)
+
+
+def test_generate_streamer_and_stopping_criteria_hooks():
+    """transformers' per-token hooks (serve/model_worker.py:160-185): the streamer sees the prompt, then every new token, then end();
+    a stopping criterion that fires after n tokens truncates the output there; neither changes the tokens."""
+    from modelcompose_amd.model.builder import build_from_state_dict
+    a, meta, sd = load_golden("g4_e2e_vision")
+    model = build_from_state_dict(meta, sd)
+    ids, px = a["input_ids"][:1].cuda(), a["pixels"][:1].cuda()
+    plain = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=7, ignore_eos=True)
+
+    class Streamer:
+        def __init__(self):
+            self.items, self.ended = [], False
+
+        def put(self, v):
+            assert not v.is_cuda
+            self.items.append(v.clone())
+
+        def end(self):
+            self.ended = True
+
+    st = Streamer()
+    res = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=7, ignore_eos=True, streamer=st)
+    assert torch.equal(res, plain) and st.ended
+    assert torch.equal(st.items[0], ids.cpu()) and len(st.items) == 1 + 7
+    assert torch.equal(torch.stack([v.view(-1) for v in st.items[1:]], dim=1), plain[:, ids.shape[1]:].cpu())
+    calls = []
+
+    def after_three(output_ids, scores, **kw):
+        calls.append(output_ids.shape[1])
+        return output_ids.shape[1] >= ids.shape[1] + 3
+
+    res = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=7, ignore_eos=True, stopping_criteria=[after_three])
+    assert torch.equal(res, plain[:, :ids.shape[1] + 3]) and calls == [ids.shape[1] + 1, ids.shape[1] + 2, ids.shape[1] + 3]
