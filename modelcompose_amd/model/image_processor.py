@@ -90,7 +90,7 @@ class HipCLIPImageProcessor:
         if not torch.cuda.is_available():
             raise RuntimeError("HipCLIPImageProcessor runs on the HIP device; no CPU fallback")
         if hasattr(image, "convert"):
-            image = np.asarray(image.convert("RGB"))
+            image = np.array(image.convert("RGB"))                 # a writable copy (np.asarray of a PIL image is read-only)
         img = torch.as_tensor(image)
         if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
             raise ValueError("image must be uint8 [H, W, 3]")
