@@ -36,6 +36,8 @@ int mc_device_info(int* cu_count, int64_t* hbm_bytes, char* arch, int arch_len);
  * Packed layout (see csrc/gemm.hip): [ceil16(N)/16][ceil64(K)/32][64 lanes][8] bf16, zero padded.        */
 int mc_packed_weight_elems(int N, int K, int64_t* out_elems);
 int mc_pack_weight_bf16(const void* w_rowmajor, int64_t ldw, void* packed, int N, int K, void* stream);
+/* same, reading w[n * stride_n + k * stride_k] (stride_n = 1, stride_k = ld packs the transpose of a row-major [K, N] matrix) */
+int mc_pack_weight_strided_bf16(const void* w, int64_t stride_n, int64_t stride_k, void* packed, int N, int K, void* stream);
 int mc_unpack_weight_bf16(const void* packed, void* w_rowmajor, int N, int K, void* stream);
 
 /* W' = W + sum_i scale[i] * B_i * A_i  -> packed (and optionally row-major).  Replaces the per-forward
@@ -149,6 +151,13 @@ int mc_rope_kv_bf16(const void* qkv, int64_t ld, const int32_t* row_b, const int
  * (multimodal_llama.py:408-468), the shifted CrossEntropyLoss (:722-733) and torch.optim.AdamW ---------------------------- */
 int mc_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int Rp, void* stream);   /* out[c][r], cols R..Rp-1 zero */
 int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_adapter, int M, int r, int n_adapters, int n_cols, void* stream);
+/* Weight-gradient GEMM, "TN" form: out[p][q] = alpha * sum_m a[m][p] * b[m][q] (fp32), a [M, P] / b [M, Q] row-major bf16 with row strides
+ * lda / ldb (multiples of 8, 16-byte aligned bases).  The autograd products dW = dy^T x of the trainable LoRA / projector linears
+ * (train_multimodal.py's backward) without transposing activations in HBM.  n_problems (1..3) same-shape products per launch; workspace =
+ * mc_gemm_tn_workspace_floats() floats (0 = not needed).  Deterministic (fixed-order slab reduction, no atomics). */
+int mc_gemm_tn_workspace_floats(int M, int P, int Q, int n_problems, int64_t* floats);
+int mc_gemm_tn_bf16(const void* const* a, int64_t lda, const void* const* b, int64_t ldb, float* const* out, int64_t ldo, int n_problems,
+                    int M, int P, int Q, float alpha, float* workspace, void* stream);
 int mc_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* g, const void* dy, int64_t ldy, const void* dres, int64_t ldr,
                         void* dx, int64_t ldd, int M, int D, float eps, void* stream);
 int mc_swiglu_bwd_bf16(const void* gate_up, int64_t ld, const void* dinter, int64_t ldi, void* dgate_up, int64_t ldg, int M, int I,

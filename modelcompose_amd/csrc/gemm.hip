@@ -21,7 +21,7 @@
 // weight packing
 // ------------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int N, int K, int Np,
-                                   int Kp, int64_t ldw) {
+                                   int Kp, int64_t ldw, int64_t sk = 1) {
     // one thread per 16-byte fragment piece
     const int64_t nfrag = (int64_t)(Np / 16) * (Kp / 32) * 64;
     for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < nfrag; f += (int64_t)gridDim.x * blockDim.x) {
@@ -33,7 +33,7 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restr
         const int k = kb * 32 + (lane >> 4) * 8;
         bf16x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (n < N && k + j < K) ? w[(int64_t)n * ldw + k + j] : (bf16_t)0.0f;
+        for (int j = 0; j < 8; ++j) v[j] = (n < N && k + j < K) ? w[(int64_t)n * ldw + (k + j) * sk] : (bf16_t)0.0f;
         *(bf16x8*)(out + f * 8) = v;
     }
 }
@@ -720,6 +720,16 @@ extern "C" int mc_pack_weight_bf16(const void* w, int64_t ldw, void* packed, int
     const int64_t nfrag = (int64_t)(Np / 16) * (Kp / 32) * 64;
     const int grid = (int)min((int64_t)4096, (nfrag + 255) / 256);
     pack_weight_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)w, (bf16_t*)packed, N, K, Np, Kp, ldw);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mc_pack_weight_strided_bf16(const void* w, int64_t stride_n, int64_t stride_k, void* packed, int N, int K, void* stream) {
+    MC_CHECK_ARG(w && packed && N > 0 && K > 0, "mc_pack_weight_strided_bf16: bad arguments N=%d K=%d", N, K);
+    const int Np = (N + 15) / 16 * 16, Kp = (K + 63) / 64 * 64;
+    const int64_t nfrag = (int64_t)(Np / 16) * (Kp / 32) * 64;
+    const int grid = (int)min((int64_t)4096, (nfrag + 255) / 256);
+    pack_weight_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)w, (bf16_t*)packed, N, K, Np, Kp, stride_n, stride_k);
     MC_CHECK_LAUNCH();
     return 0;
 }

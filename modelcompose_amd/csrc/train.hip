@@ -327,3 +327,147 @@ extern "C" int mc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream
     MC_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Weight-gradient GEMM in "TN" form:  out[p][q] = alpha * sum_m a[m][p] * b[m][q]   (fp32 out; a [M, P], b [M, Q] row-major bf16).
+// The LoRA gradients of the finetune step are of this shape (dB = dy^T T, dA = mask(dT)^T x: train/step.py): the reduction runs over the
+// token rows, the slow dimension of both operands.  Instead of transposing the activations in HBM (two full passes) the 64-row chunks are
+// staged row-major in LDS and both MFMA operands are fetched with the transposing LDS read (ds_read_b64_tr_b16), which hands lane i of a
+// 16-lane group column i of a 4-row block.  Rows are padded to 160 B so that the 8 rows one read touches start on distinct 8-bank windows.
+// The work is HBM / L2-bound (2*M*P*Q flops on M*(P+Q)*2 bytes with Q or P = n_adapters*r = 256): 64x64 output tiles, one per workgroup;
+// when that gives fewer than ~2 workgroups per CU the token range is split in `splits` slabs reduced in fixed order by a second kernel.
+// Up to 3 problems of the same shape share a launch (the q / k / v projections).
+#define TN_ROWB 160
+struct TnParams {
+    const bf16_t* a[3]; const bf16_t* b[3]; float* out[3];
+    int64_t lda, ldb, ldo;
+    int M, P, Q, splits;
+    float alpha;
+    float* slabs;          // [problem][split][P][Q] when splits > 1
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
+    __shared__ __attribute__((aligned(16))) char la[64 * TN_ROWB];
+    __shared__ __attribute__((aligned(16))) char lb[64 * TN_ROWB];
+    const int prob = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+    const bf16_t* A = p.a[prob];
+    const bf16_t* B = p.b[prob];
+    const int p0 = blockIdx.y * 64, q0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int g = lane >> 4, c16 = lane & 15, tq = c16 >> 2, tp = c16 & 3;
+    // rows of this split, in 64-row chunks
+    const int rows_per = ((p.M + p.splits - 1) / p.splits + 63) / 64 * 64;
+    const int m_begin = split * rows_per, m_end = min(p.M, m_begin + rows_per);
+    // staging: thread t loads 16 B at (row t>>3 [+32], col chunk t&7) of each operand
+    const int srow = tid >> 3, sch = tid & 7;
+    u32x4 ra[2], rb[2];
+    auto load = [&](int mb) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = mb + srow + 32 * h;
+            const bool ok = m < m_end;
+            const int pc = p0 + sch * 8, qc = q0 + sch * 8;
+            ra[h] = (ok && pc < p.P) ? *(const u32x4*)(A + (int64_t)m * p.lda + pc) : (u32x4){0u, 0u, 0u, 0u};
+            rb[h] = (ok && qc < p.Q) ? *(const u32x4*)(B + (int64_t)m * p.ldb + qc) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (m_begin < m_end) load(m_begin);
+    for (int mb = m_begin; mb < m_end; mb += 64) {
+        __syncthreads();                                   // previous chunk's fragment reads are done
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *(u32x4*)(la + (srow + 32 * h) * TN_ROWB + sch * 16) = ra[h];
+            *(u32x4*)(lb + (srow + 32 * h) * TN_ROWB + sch * 16) = rb[h];
+        }
+        __syncthreads();
+        if (mb + 64 < m_end) load(mb + 64);                // next chunk's global loads fly under this chunk's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r_lo = ks * 32 + g * 4 + tq, r_hi = r_lo + 16;
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int colb = (wp * 32 + i * 16 + tp * 4) * 2;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(la + r_lo * TN_ROWB + colb));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(la + r_hi * TN_ROWB + colb));
+                fa[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const int colq = (wq * 32 + i * 16 + tp * 4) * 2;
+                const bf16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lb + r_lo * TN_ROWB + colq));
+                const bf16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lb + r_hi * TN_ROWB + colq));
+                fb[i] = (bf16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[row = 4g + r][col = c16] of the (i, j) block: out[p0 + wp*32 + i*16 + 4g + r][q0 + wq*32 + j*16 + c16]
+    float* dst = p.splits > 1 ? p.slabs + ((int64_t)(prob * p.splits + split) * p.P) * p.Q : p.out[prob];
+    const int64_t ldd = p.splits > 1 ? p.Q : p.ldo;
+    const float sc = p.splits > 1 ? 1.0f : p.alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pr = p0 + wp * 32 + i * 16 + g * 4 + r, qc = q0 + wq * 32 + j * 16 + c16;
+                if (pr < p.P && qc < p.Q) dst[(int64_t)pr * ldd + qc] = acc[i][j][r] * sc;
+            }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(TnParams p) {
+    const int prob = blockIdx.y;
+    const int64_t n = (int64_t)p.P * p.Q;
+    const float* s = p.slabs + (int64_t)prob * p.splits * n;
+    float* out = p.out[prob];
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = s[i];
+        for (int k = 1; k < p.splits; ++k) v += s[k * n + i];
+        out[(i / p.Q) * p.ldo + (i % p.Q)] = v * p.alpha;
+    }
+}
+
+// n_problems (1..3) products of the same shape in one launch.  workspace: n_problems * splits * P * Q floats when the kernel decides to
+// split (query the size with mc_gemm_tn_workspace_floats); may be NULL when that returns 0.
+static int tn_splits(int M, int P, int Q, int n_problems) {
+    const int64_t tiles = (int64_t)((P + 63) / 64) * ((Q + 63) / 64) * n_problems;
+    int s = 1;
+    while (tiles * s < 512 && s < 8 && M / (s * 2) >= 256) s *= 2;
+    return s;
+}
+extern "C" int mc_gemm_tn_workspace_floats(int M, int P, int Q, int n_problems, int64_t* floats) {
+    MC_CHECK_ARG(floats && M > 0 && P > 0 && Q > 0 && n_problems >= 1 && n_problems <= 3, "mc_gemm_tn_workspace_floats: bad arguments");
+    const int s = tn_splits(M, P, Q, n_problems);
+    *floats = s > 1 ? (int64_t)n_problems * s * P * Q : 0;
+    return 0;
+}
+extern "C" int mc_gemm_tn_bf16(const void* const* a, int64_t lda, const void* const* b, int64_t ldb, float* const* out, int64_t ldo, int n_problems,
+                               int M, int P, int Q, float alpha, float* workspace, void* stream) {
+    MC_CHECK_ARG(a && b && out && n_problems >= 1 && n_problems <= 3 && M > 0 && P > 0 && Q > 0, "mc_gemm_tn_bf16: bad arguments");
+    MC_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && P % 8 == 0 && Q % 8 == 0, "mc_gemm_tn_bf16: P, Q and the row strides must be multiples of 8");
+    TnParams p{};
+    for (int i = 0; i < n_problems; ++i) {
+        MC_CHECK_ARG(a[i] && b[i] && out[i] && ((uintptr_t)a[i] % 16) == 0 && ((uintptr_t)b[i] % 16) == 0, "mc_gemm_tn_bf16: null / unaligned operand %d", i);
+        p.a[i] = (const bf16_t*)a[i]; p.b[i] = (const bf16_t*)b[i]; p.out[i] = out[i];
+    }
+    p.lda = lda; p.ldb = ldb; p.ldo = ldo; p.M = M; p.P = P; p.Q = Q; p.alpha = alpha;
+    p.splits = tn_splits(M, P, Q, n_problems);
+    p.slabs = workspace;
+    MC_CHECK_ARG(p.splits == 1 || workspace, "mc_gemm_tn_bf16: workspace missing (%d splits)", p.splits);
+    hipStream_t s = (hipStream_t)stream;
+    gemm_tn_kernel<<<dim3((Q + 63) / 64, (P + 63) / 64, n_problems * p.splits), 256, 0, s>>>(p);
+    if (p.splits > 1) {
+        const int64_t n = (int64_t)P * Q;
+        gemm_tn_reduce_kernel<<<dim3((int)min((int64_t)2048, (n + 255) / 256), n_problems), 256, 0, s>>>(p);
+    }
+    MC_CHECK_LAUNCH();
+    return 0;
+}

@@ -362,6 +362,49 @@ def transpose(x, Rp=None, out=None):
     return out
 
 
+_tn_ws = {}
+
+
+def gemm_tn(a_list, b_list, out_list, alpha=1.0):
+    """out_i[P, Q] (fp32) = alpha * a_i^T b_i for up to 3 same-shape problems; a_i [M, P], b_i [M, Q] bf16 with contiguous rows."""
+    a0, b0 = a_list[0], b_list[0]
+    M, P = a0.shape
+    Q = b0.shape[1]
+    n = len(a_list)
+    L = _lib.lib()
+    need = C.c_int64(0)
+    _lib.check(L.mc_gemm_tn_workspace_floats(M, P, Q, n, C.byref(need)), "mc_gemm_tn_workspace_floats")
+    ws = None
+    if need.value:
+        ws = _tn_ws.get(a0.device)
+        if ws is None or ws.numel() < need.value:
+            ws = torch.empty(need.value, dtype=torch.float32, device=a0.device)
+            _tn_ws[a0.device] = ws
+    for t in list(a_list) + list(b_list):
+        if t.stride(1) != 1 or t.dtype != BF16:
+            raise ValueError("gemm_tn operands must be bf16 with contiguous rows")
+    if any(t.stride(0) != a0.stride(0) for t in a_list) or any(t.stride(0) != b0.stride(0) for t in b_list) or \
+            any(o.stride(0) != out_list[0].stride(0) or o.dtype != torch.float32 for o in out_list):
+        raise ValueError("gemm_tn: the problems of one launch must share strides; outputs are fp32")
+    pa = (C.c_void_p * n)(*[t.data_ptr() for t in a_list])
+    pb = (C.c_void_p * n)(*[t.data_ptr() for t in b_list])
+    po = (C.c_void_p * n)(*[t.data_ptr() for t in out_list])
+    _lib.check(L.mc_gemm_tn_bf16(pa, a0.stride(0), pb, b0.stride(0), po, out_list[0].stride(0), n, M, P, Q, float(alpha), _p(ws), _stream()),
+               "mc_gemm_tn_bf16")
+    return out_list
+
+
+def pack_weight_t(w_t: torch.Tensor, out: Optional[torch.Tensor] = None) -> PackedWeight:
+    """Packed form of W = w_t^T for a row-major w_t [K, N] (no transposed copy in HBM)."""
+    _req(w_t, BF16, "w_t")
+    K, N = w_t.shape
+    if w_t.stride(1) != 1:
+        raise ValueError("w_t must have contiguous rows")
+    data = torch.empty(packed_elems(N, K), dtype=BF16, device=w_t.device) if out is None else out
+    _lib.check(_lib.lib().mc_pack_weight_strided_bf16(_p(w_t), 1, w_t.stride(0), _p(data), N, K, _stream()), "mc_pack_weight_strided_bf16")
+    return PackedWeight(data, N, K)
+
+
 def lora_mask_rows(t, row_adapter, r, n_adapters):
     """t [M, n_linears * n_adapters * r]: zero every r-wide block that does not belong to the row's adapter."""
     _lib.check(_lib.lib().mc_lora_mask_rows_bf16(_p(t), t.stride(0), _p(row_adapter), t.shape[0], r, n_adapters, t.shape[1], _stream()),

@@ -157,6 +157,19 @@ class MultimodalTrainStep:
         self.G = torch.zeros(off, dtype=F32, device=dev)
         self.m1, self.m2 = torch.zeros_like(self.G), torch.zeros_like(self.G)
         self.P16 = ops.cast_bf16(self.P)
+        self._packed: Dict[str, ops.PackedWeight] = {}
+        self._repack()
+
+    def _repack(self):
+        """MFMA-fragment forms of the LoRA matrices, refreshed once per optimizer step: A_in and B_cat as they multiply in the forward,
+        and their transposes (packed straight from the row-major masters, no transposed copy) for the input-gradient GEMMs."""
+        for name, p in self.params.items():
+            if not (name.endswith(".A_in") or name.endswith(".B_cat")):
+                continue
+            w = self.view(self.P16, name)
+            old, oldT = self._packed.get(name), self._packed.get(name + ".T")
+            self._packed[name] = ops.pack_weight(w, out=None if old is None else old.data)
+            self._packed[name + ".T"] = ops.pack_weight_t(w, out=None if oldT is None else oldT.data)
 
     def view(self, buf, name):
         p = self.params[name]
@@ -187,33 +200,29 @@ class MultimodalTrainStep:
         """For the linears of a group (same input x): y_j += s * mask(x A_j^T) B_j^T, in place on the views ys[j] ([M, N_j]).
         One GEMM projects x onto all stacked A matrices; the routing mask zeroes, per row, the rank blocks of the other adapters."""
         lins = dict(GROUPS)[gname]
-        A16 = self.view(self.P16, f"model.layers.{layer}.{gname}.A_in")
-        T = ops.linear(x, ops.pack_weight(A16))                                      # [M, n_linears * R]
+        T = ops.linear(x, self._packed[f"model.layers.{layer}.{gname}.A_in"])         # [M, n_linears * R]
         ops.lora_mask_rows(T, row_adapter, self.r, self.nA)
         for j, (blk, lin) in enumerate(lins):
-            B16 = self.view(self.P16, f"model.layers.{layer}.{blk}.{lin}.B_cat")
-            ops.linear(T[:, j * self.R:(j + 1) * self.R], ops.pack_weight(B16), residual=ys[j], out=ys[j], alpha=self.scale)
+            ops.linear(T[:, j * self.R:(j + 1) * self.R], self._packed[f"model.layers.{layer}.{blk}.{lin}.B_cat"], residual=ys[j], out=ys[j],
+                       alpha=self.scale)
         saved[f"{layer}.{gname}.T"] = T
 
     def _lora_bwd(self, dys, x, dx, layer, gname, row_adapter, saved, Mp):
-        """dx += s * mask(dT) A_in with dT_j = dy_j B_j;  dB_j = s dy_j^T T_j;  dA_in = s mask(dT)^T x."""
+        """dx += s * mask(dT) A_in with dT_j = dy_j B_j;  dB_j = s dy_j^T T_j;  dA_in = s mask(dT)^T x.  The two weight gradients reduce
+        over the token rows: TN GEMMs straight from the row-major activations (one launch for the same-shape linears of the group)."""
         lins = dict(GROUPS)[gname]
         aname = f"model.layers.{layer}.{gname}.A_in"
-        A16 = self.view(self.P16, aname)
         T = saved[f"{layer}.{gname}.T"]
         M = T.shape[0]
         dT = torch.empty(M, len(lins) * self.R, dtype=BF16, device=self.dev)
-        for j, (blk, lin) in enumerate(lins):
-            B16 = self.view(self.P16, f"model.layers.{layer}.{blk}.{lin}.B_cat")
-            ops.linear(dys[j], ops.pack_weight(ops.transpose(B16)), out=dT[:, j * self.R:(j + 1) * self.R])   # dy_j . B_j
+        bnames = [f"model.layers.{layer}.{blk}.{lin}.B_cat" for blk, lin in lins]
+        for j, bn in enumerate(bnames):
+            ops.linear(dys[j], self._packed[bn + ".T"], out=dT[:, j * self.R:(j + 1) * self.R])              # dy_j . B_j
         ops.lora_mask_rows(dT, row_adapter, self.r, self.nA)
-        ops.linear(dT, ops.pack_weight(ops.transpose(A16)), residual=dx, out=dx, alpha=self.scale)
-        for j, (blk, lin) in enumerate(lins):
-            Tj = T[:, j * self.R:(j + 1) * self.R]
-            ops.linear(ops.transpose(dys[j], Rp=Mp), ops.pack_weight(ops.transpose(Tj, Rp=Mp)),
-                       out=self.view(self.G, f"model.layers.{layer}.{blk}.{lin}.B_cat"), out_f32=True, alpha=self.scale)
-        ops.linear(ops.transpose(dT, Rp=Mp), ops.pack_weight(ops.transpose(x, Rp=Mp)), out=self.view(self.G, aname), out_f32=True,
-                   alpha=self.scale)
+        ops.linear(dT, self._packed[aname + ".T"], residual=dx, out=dx, alpha=self.scale)
+        ops.gemm_tn(list(dys), [T[:, j * self.R:(j + 1) * self.R] for j in range(len(lins))], [self.view(self.G, bn) for bn in bnames],
+                    alpha=self.scale)
+        ops.gemm_tn([dT], [x], [self.view(self.G, aname)], alpha=self.scale)
 
     # ------------------------------------------------------------------ one step
     def forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
@@ -391,11 +400,11 @@ class MultimodalTrainStep:
                 wname = f"model.modal_projectors.{modal}.{k}"
                 hin = saved[f"proj.{modal}.h{k_i}"] if k_i > 0 else saved[f"proj.{modal}.in"]
                 # dW[o][i] = sum_m d[m][o] hin[m][i];  db = colsum(d)
-                ops.linear(ops.transpose(d, Rp=Mfp), ops.pack_weight(ops.transpose(hin, Rp=Mfp)), out=self.view(self.G, wname), out_f32=True)
+                ops.gemm_tn([d], [hin], [self.view(self.G, wname)])
                 ops.colsum(d, out=self.view(self.G, wname.replace("weight", "bias")))
                 if k_i > 0:
                     w16 = self.view(self.P16, wname)
-                    dh = ops.linear(d, ops.pack_weight(ops.transpose(w16)))
+                    dh = ops.linear(d, ops.pack_weight_t(w16))
                     d = ops.act(saved[f"proj.{modal}.pre{k_i}"], "gelu", dy=dh)
 
     # ------------------------------------------------------------------ exchange + update
@@ -408,6 +417,7 @@ class MultimodalTrainStep:
         self.step_count += 1
         ops.adamw(self.P, self.G, self.m1, self.m2, self.P16, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
                   grad_scale=1.0 / self.world)
+        self._repack()
 
     def step(self, input_ids, labels, modal_inputs) -> torch.Tensor:
         loss = self.forward_backward(input_ids, labels, modal_inputs)

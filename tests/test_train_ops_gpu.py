@@ -130,3 +130,32 @@ def test_transpose_mask_colsum_rope_adamw(ops):
         ops.adamw(p, g * 4.0, m, vv, p16, 1e-2, 0.9, 0.95, 1e-8, 0.1, step, grad_scale=0.25)
     assert torch.allclose(p, p_ref.detach(), rtol=1e-5, atol=1e-6)
     assert torch.equal(p16, p.to(BF))
+
+
+@pytest.mark.parametrize("M,P,Q,n", [(2728, 4096, 256, 1), (2728, 512, 4096, 1), (300, 72, 136, 1), (1000, 128, 256, 3), (64, 64, 64, 2), (2728, 256, 4096, 1)])
+def test_gemm_tn_weight_gradient_form(M, P, Q, n):
+    """out = alpha * a^T b from row-major activations (transposing LDS reads): against fp32 torch on the same bf16 inputs; batched
+    problems are strided views of one buffer (the q / k / v slices of dqkv); split launches reduce in fixed order (bitwise repeatable)."""
+    from modelcompose_amd import ops
+    g = torch.Generator().manual_seed(M + P + Q)
+    abuf = (torch.randn(M, n * P, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    bbuf = (torch.randn(M, n * Q, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    a_list = [abuf[:, i * P:(i + 1) * P] for i in range(n)]
+    b_list = [bbuf[:, i * Q:(i + 1) * Q] for i in range(n)]
+    outs = [torch.full((P, Q), float("nan"), device="cuda") for _ in range(n)]
+    ops.gemm_tn(a_list, b_list, outs, alpha=0.5)
+    for a, b, o in zip(a_list, b_list, outs):
+        ref = 0.5 * (a.float().t() @ b.float())
+        assert (o - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6      # fp32 accumulation in a different order
+    again = [torch.empty(P, Q, device="cuda") for _ in range(n)]
+    ops.gemm_tn(a_list, b_list, again, alpha=0.5)
+    assert all(torch.equal(x, y) for x, y in zip(outs, again))
+
+
+def test_pack_weight_from_transposed_source():
+    from modelcompose_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for (K, N) in ((256, 4096), (100, 72), (4096, 256)):
+        w_t = torch.randn(K, N, generator=g).to(torch.bfloat16).cuda()
+        assert torch.equal(ops.unpack_weight(ops.pack_weight_t(w_t)), w_t.t().contiguous())
+        assert torch.equal(ops.pack_weight_t(w_t).data, ops.pack_weight(w_t.t().contiguous()).data)
