@@ -107,7 +107,9 @@ int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* b
  * swiglu: the packed weight interleaves gate_proj / up_proj per 16-row block (block 2j = gate rows 16j.., block 2j+1 = up rows
  * 16j..); out is [M, N/2] bf16 = silu(gate) * up (LocalLoraMLP.forward, multimodal_llama.py:381-388).
  * split_k > 1 (M <= 64 only): K is split over workgroups; slice s stores its fp32 partial sums (x row_scale x alpha) in slab s
- * of out = fp32 [split_k][M][ldo]; mc_residual_rms_bf16 adds the slabs in order into the hidden state (no atomics).      */
+ * of out = fp32 [split_k][M][ldo]; mc_residual_rms_bf16 adds the slabs in order into the hidden state (no atomics).
+ * split_k < 0 (M > 64): "auto" - launches that would leave most CUs idle (few output tiles, long K: the LoRA rank projections of the
+ * finetune step) are split along K into library-owned fp32 slabs, summed in fixed order, then given the normal epilogue.          */
 typedef struct mc_gemm_args {
     const void* x; int64_t ldx; const void* w_packed; const void* bias; const void* residual; int64_t ldr;
     void* out; int64_t ldo; int M, N, K; int act; int out_f32; float alpha, beta;

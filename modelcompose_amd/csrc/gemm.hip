@@ -144,7 +144,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const bf16_t* __restr
 
     const int kblocks = K >> 5;           // 32-wide k blocks in the packed weight
     const int nblocks = (N + 15) >> 4;
-    const int nt = K / TK;
+    // split-K (gridDim.y > 1): this workgroup reduces K-tiles [t_begin, t_end) and stores raw fp32 partial sums into slab blockIdx.y
+    const int nt_all = K / TK;
+    const int per_split = (nt_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_begin = (int)blockIdx.y * per_split, t_end = min(nt_all, t_begin + per_split);
+    if (gridDim.y > 1) ep.out = (float*)ep.out + (int64_t)blockIdx.y * M * ep.ldo;
 
     // per-lane global sources -------------------------------------------------
     // W: wave w stages fragment blocks c = 4w..4w+3 of the 16 (8 nb x 2 kb) in a stage
@@ -196,12 +200,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const bf16_t* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) xrow[j] = wave_m * 64 + j * 16 + c16;
 
-    stage(0, 0);
+    if (t_begin < t_end) stage(t_begin, 0);
     int buf = 0;
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < nt) stage(t + 1, buf ^ 1);
+        if (t + 1 < t_end) stage(t + 1, buf ^ 1);
         const char* wb = smem + buf * (2 * TILE_BYTES);
         const char* xb = wb + TILE_BYTES;
         // all 16 fragments of the K-tile are requested up front (one exposed LDS latency per tile instead of
@@ -633,6 +637,18 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
     }
 }
 
+// Split-K second stage for the 128x128 kernel: sums the fp32 slabs [S][M][N] in fixed order and applies the real epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, int M, int N, Epilogue ep) {
+    const int nq = N >> 2;
+    const int64_t total = (int64_t)M * nq;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / nq), n = (int)(i % nq) * 4;
+        f32x4 v = *(const f32x4*)(slabs + (int64_t)m * N + n);
+        for (int k = 1; k < S; ++k) v += *(const f32x4*)(slabs + ((int64_t)k * M + m) * N + n);
+        epilogue_store4(ep, m, n, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
@@ -648,6 +664,21 @@ std::vector<ProfRec> g_prof;
 }  // namespace
 
 extern "C" int mc_gemm_debug(int v) { g_gemm_dbg = v; return 0; }
+
+// library-owned scratch for the automatic split-K of under-filled 128x128 launches (one process drives one GPU and one compute stream; the
+// buffer only grows, and growing synchronises the device first so no launch in flight still reads the old one)
+static float* splitk_workspace(size_t floats) {
+    static float* buf = nullptr;
+    static size_t cap = 0;
+    if (floats > cap) {
+        (void)hipDeviceSynchronize();
+        if (buf) (void)hipFree(buf);
+        buf = nullptr; cap = 0;
+        if (hipMalloc((void**)&buf, floats * sizeof(float)) != hipSuccess) { buf = nullptr; return nullptr; }
+        cap = floats;
+    }
+    return buf;
+}
 
 // 256x256 tiles need enough tiles to fill most of the 256 CUs; bit 1 of the debug word forces the 128x128 kernel, bit 2 the 256x256 one
 static bool use_tile256(int M, int N, int K) {
@@ -868,8 +899,26 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
             (void)hipFuncSetAttribute((const void*)gemm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_set = true;
         }
-        gemm_tile_kernel<<<tiles_m * tiles_n, 256, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep,
-                                                             tiles_m, tiles_n, g_gemm_dbg);
+        // split_k < 0 = "auto": under-filled grids with a long reduction (the rank projections x A^T and dy B of the LoRA branches in the
+        // finetune step: N = n_adapters * r columns, K = 4096 ... 11008) are split along K so that ~2 workgroups per CU are resident; slabs
+        // are summed in fixed order (deterministic).  Opt-in because the split depends on M: inference keeps batch-invariant rounding.
+        const int tiles = tiles_m * tiles_n, nt = K / TK;
+        int S = 1;
+        if (a->split_k < 0 && !a->swiglu && !(g_gemm_dbg & (2 | 512)) && tiles < 192 && nt >= 16) {
+            S = min(min(8, 512 / tiles), nt / 8);
+            if (S < 2) S = 1;
+        }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (S > 1 && (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) S = 1;     // no allocation while capturing
+        float* slabs = S > 1 ? splitk_workspace((size_t)S * M * N) : nullptr;
+        if (S > 1 && slabs) {
+            Epilogue raw{nullptr, nullptr, 0, slabs, N, MC_ACT_NONE, 1, 1.0f, 0.0f, nullptr, 0};
+            gemm_tile_kernel<<<dim3(tiles, S), 256, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, raw, tiles_m, tiles_n, g_gemm_dbg);
+            const int64_t total = (int64_t)M * (N >> 2);
+            splitk_reduce_kernel<<<(int)min((int64_t)2048, (total + 255) / 256), 256, 0, s>>>(slabs, S, M, N, ep);
+        } else {
+            gemm_tile_kernel<<<tiles, 256, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep, tiles_m, tiles_n, g_gemm_dbg);
+        }
     }
     MC_CHECK_LAUNCH();
     return 0;

@@ -106,8 +106,10 @@ def compose_weight(w: Optional[torch.Tensor], terms: Sequence, N: int, K: int, r
 
 
 def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           out_f32: bool = False, alpha: float = 1.0, bias: bool = True, beta: float = 1.0) -> torch.Tensor:
-    """out[M,N] = act(alpha * x W^T + b) + beta * residual.  x: [M, Kp] bf16 (Kp = K padded to 64, pad columns zero)."""
+           out_f32: bool = False, alpha: float = 1.0, bias: bool = True, beta: float = 1.0, auto_split: bool = False) -> torch.Tensor:
+    """out[M,N] = act(alpha * x W^T + b) + beta * residual.  x: [M, Kp] bf16 (Kp = K padded to 64, pad columns zero).
+    auto_split: let the library split K when the launch would under-fill the GPU (training-time rank projections; the choice depends
+    on M, so inference leaves it off to stay batch-invariant)."""
     _req(x, BF16, "x")
     if x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("x must be 2-D with contiguous rows")
@@ -117,6 +119,12 @@ def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.
     if out is None:
         out = torch.empty(M, w.N, dtype=torch.float32 if out_f32 else BF16, device=x.device)
     b = w.bias if bias else None
+    if auto_split:
+        a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), w.data.data_ptr(), 0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
+                           0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, w.N, w.Kp, ACT[act],
+                           1 if out_f32 else 0, alpha, beta, 0, 0, -1)
+        _lib.check(_lib.lib().mc_gemm_ex_bf16(C.byref(a), _stream()), "mc_gemm_ex_bf16")
+        return out
     _lib.check(_lib.lib().mc_gemm_bf16(_p(x), x.stride(0), _p(w.data), _p(b), _p(residual),
                                        0 if residual is None else residual.stride(0), _p(out), out.stride(0), M, w.N, w.Kp,
                                        ACT[act], 1 if out_f32 else 0, alpha, beta, _stream()), "mc_gemm_bf16")

@@ -200,7 +200,7 @@ class MultimodalTrainStep:
         """For the linears of a group (same input x): y_j += s * mask(x A_j^T) B_j^T, in place on the views ys[j] ([M, N_j]).
         One GEMM projects x onto all stacked A matrices; the routing mask zeroes, per row, the rank blocks of the other adapters."""
         lins = dict(GROUPS)[gname]
-        T = ops.linear(x, self._packed[f"model.layers.{layer}.{gname}.A_in"])         # [M, n_linears * R]
+        T = ops.linear(x, self._packed[f"model.layers.{layer}.{gname}.A_in"], auto_split=True)         # [M, n_linears * R]
         ops.lora_mask_rows(T, row_adapter, self.r, self.nA)
         for j, (blk, lin) in enumerate(lins):
             ops.linear(T[:, j * self.R:(j + 1) * self.R], self._packed[f"model.layers.{layer}.{blk}.{lin}.B_cat"], residual=ys[j], out=ys[j],
@@ -217,7 +217,7 @@ class MultimodalTrainStep:
         dT = torch.empty(M, len(lins) * self.R, dtype=BF16, device=self.dev)
         bnames = [f"model.layers.{layer}.{blk}.{lin}.B_cat" for blk, lin in lins]
         for j, bn in enumerate(bnames):
-            ops.linear(dys[j], self._packed[bn + ".T"], out=dT[:, j * self.R:(j + 1) * self.R])              # dy_j . B_j
+            ops.linear(dys[j], self._packed[bn + ".T"], out=dT[:, j * self.R:(j + 1) * self.R], auto_split=True)      # dy_j . B_j
         ops.lora_mask_rows(dT, row_adapter, self.r, self.nA)
         ops.linear(dT, self._packed[aname + ".T"], residual=dx, out=dx, alpha=self.scale)
         ops.gemm_tn(list(dys), [T[:, j * self.R:(j + 1) * self.R] for j in range(len(lins))], [self.view(self.G, bn) for bn in bnames],

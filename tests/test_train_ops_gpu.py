@@ -159,3 +159,22 @@ def test_pack_weight_from_transposed_source():
         w_t = torch.randn(K, N, generator=g).to(torch.bfloat16).cuda()
         assert torch.equal(ops.unpack_weight(ops.pack_weight_t(w_t)), w_t.t().contiguous())
         assert torch.equal(ops.pack_weight_t(w_t).data, ops.pack_weight(w_t.t().contiguous()).data)
+
+
+def test_linear_auto_split_k_matches_unsplit_and_is_deterministic():
+    """The opt-in split-K of under-filled launches (LoRA rank projections: few output tiles, long K): same result as the unsplit kernel
+    up to fp32 summation order, bitwise repeatable, all epilogue features intact; the default path is untouched."""
+    from modelcompose_amd import ops
+    g = torch.Generator().manual_seed(17)
+    for (M, N, K) in ((2728, 256, 11008), (2728, 768, 4096), (300, 128, 2048)):
+        x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+        res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+        pw = ops.pack_weight(w)
+        base = ops.linear(x, pw, residual=res, alpha=0.5)
+        a = ops.linear(x, pw, residual=res, alpha=0.5, auto_split=True)
+        b = ops.linear(x, pw, residual=res, alpha=0.5, auto_split=True)
+        assert torch.equal(a, b)
+        assert (a.float() - base.float()).abs().max().item() <= 2 ** -7 * base.float().abs().max().item()       # one bf16 ulp of the output scale
+        ref = 0.5 * (x.float() @ w.float().t()) + res.float()
+        assert (a.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
