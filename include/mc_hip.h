@@ -38,6 +38,9 @@ int mc_packed_weight_elems(int N, int K, int64_t* out_elems);
 int mc_pack_weight_bf16(const void* w_rowmajor, int64_t ldw, void* packed, int N, int K, void* stream);
 /* same, reading w[n * stride_n + k * stride_k] (stride_n = 1, stride_k = ld packs the transpose of a row-major [K, N] matrix) */
 int mc_pack_weight_strided_bf16(const void* w, int64_t stride_n, int64_t stride_k, void* packed, int N, int K, void* stream);
+/* n packs in one launch; descs_dev: DEVICE array of { const void* src; void* dst; int64_t stride_n, stride_k; int32_t N, K; } (32 bytes each);
+ * every descriptor is processed by blocks_per_desc workgroups (the finetune step refreshes all LoRA fragment images this way) */
+int mc_pack_weight_batch_bf16(const void* descs_dev, int n, int blocks_per_desc, void* stream);
 int mc_unpack_weight_bf16(const void* packed, void* w_rowmajor, int N, int K, void* stream);
 
 /* W' = W + sum_i scale[i] * B_i * A_i  -> packed (and optionally row-major).  Replaces the per-forward

@@ -34,6 +34,7 @@ _SIGS = {
     "mc_gemm_tn_workspace_floats": [c_i, c_i, c_i, c_i, C.POINTER(C.c_int64)],
     "mc_gemm_tn_bf16": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p],
     "mc_pack_weight_strided_bf16": [c_p, c_l, c_l, c_p, c_i, c_i, c_p],
+    "mc_pack_weight_batch_bf16": [c_p, c_i, c_i, c_p],
     "mc_rmsnorm_bf16": [c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_layernorm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_rope_kv_bf16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

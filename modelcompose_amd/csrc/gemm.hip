@@ -38,6 +38,41 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restr
     }
 }
 
+// Many packs in one launch (the finetune step refreshes ~1400 LoRA fragment images after every optimizer step): blockIdx.y = descriptor.
+struct PackDesc { const bf16_t* src; bf16_t* dst; int64_t sn, sk; int N, K; };
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackDesc* __restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    const int Np = (d.N + 15) / 16 * 16, Kp = (d.K + 63) / 64 * 64;
+    const int kbn = Kp / 32;
+    const int64_t nfrag = (int64_t)(Np / 16) * kbn * 64;
+    for (int64_t f = blockIdx.x * 256LL + threadIdx.x; f < nfrag; f += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(f & 63);
+        const int64_t blk = f >> 6;
+        const int kb = (int)(blk % kbn), nb = (int)(blk / kbn);
+        const int n = nb * 16 + (lane & 15);
+        const int k = kb * 32 + (lane >> 4) * 8;
+        bf16x8 v;
+        if (d.sk == 1 && n < d.N && k + 8 <= d.K && ((d.sn & 7) == 0)) {
+            v = *(const bf16x8*)(d.src + (int64_t)n * d.sn + k);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (n < d.N && k + j < d.K) ? d.src[(int64_t)n * d.sn + (k + j) * d.sk] : (bf16_t)0.0f;
+        }
+        *(bf16x8*)(d.dst + f * 8) = v;
+    }
+}
+
+// descs: n descriptors in DEVICE memory {src, dst, stride_n, stride_k, N, K} (layout of struct PackDesc: 2 pointers, 2 int64, 2 int32)
+extern "C" int mc_pack_weight_batch_bf16(const void* descs_dev, int n, int blocks_per_desc, void* stream) {
+    MC_CHECK_ARG(descs_dev && n > 0 && blocks_per_desc > 0, "mc_pack_weight_batch_bf16: bad arguments");
+    for (int i = 0; i < n; i += 65535) {
+        const int cnt = min(65535, n - i);
+        pack_weight_batch_kernel<<<dim3(blocks_per_desc, cnt), 256, 0, (hipStream_t)stream>>>((const PackDesc*)descs_dev + i);
+    }
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
 __global__ void unpack_weight_kernel(const bf16_t* __restrict__ p, bf16_t* __restrict__ w, int N, int K, int Kp) {
     const int64_t total = (int64_t)N * K;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {

@@ -161,15 +161,28 @@ class MultimodalTrainStep:
         self._repack()
 
     def _repack(self):
-        """MFMA-fragment forms of the LoRA matrices, refreshed once per optimizer step: A_in and B_cat as they multiply in the forward,
-        and their transposes (packed straight from the row-major masters, no transposed copy) for the input-gradient GEMMs."""
-        for name, p in self.params.items():
-            if not (name.endswith(".A_in") or name.endswith(".B_cat")):
-                continue
-            w = self.view(self.P16, name)
-            old, oldT = self._packed.get(name), self._packed.get(name + ".T")
-            self._packed[name] = ops.pack_weight(w, out=None if old is None else old.data)
-            self._packed[name + ".T"] = ops.pack_weight_t(w, out=None if oldT is None else oldT.data)
+        """MFMA-fragment forms of the LoRA matrices, refreshed once per optimizer step in ONE launch: A_in and B_cat as they multiply in
+        the forward, and their transposes (packed straight from the row-major bf16 masters, no transposed copy) for the input-gradient
+        GEMMs.  The descriptor table (source / destination addresses never change) is built on first use."""
+        if not self._packed:
+            descs = []
+            for name, p in self.params.items():
+                if not (name.endswith(".A_in") or name.endswith(".B_cat")):
+                    continue
+                w = self.view(self.P16, name)
+                N, K = w.shape
+                fw = ops.PackedWeight(torch.empty(ops.packed_elems(N, K), dtype=BF16, device=self.dev), N, K)
+                tr = ops.PackedWeight(torch.empty(ops.packed_elems(K, N), dtype=BF16, device=self.dev), K, N)
+                self._packed[name], self._packed[name + ".T"] = fw, tr
+                descs.append((w.data_ptr(), fw.data.data_ptr(), w.stride(0), 1, N, K))
+                descs.append((w.data_ptr(), tr.data.data_ptr(), 1, w.stride(0), K, N))          # W' = w^T: W'[n][k] = w[k][n]
+            rec = np.zeros(len(descs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("sn", "<i8"), ("sk", "<i8"), ("N", "<i4"), ("K", "<i4")]))
+            for i, dsc in enumerate(descs):
+                rec[i] = dsc
+            self._pack_descs = torch.from_numpy(rec.view(np.uint8).copy()).to(self.dev)
+            self._n_pack = len(descs)
+        from .. import _lib
+        _lib.check(_lib.lib().mc_pack_weight_batch_bf16(self._pack_descs.data_ptr(), self._n_pack, 16, ops._stream()), "mc_pack_weight_batch_bf16")
 
     def view(self, buf, name):
         p = self.params[name]
