@@ -375,8 +375,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
     __shared__ __attribute__((aligned(16))) char la[64 * TN_ROWB];
     __shared__ __attribute__((aligned(16))) char lb[64 * TN_ROWB];
     const int prob = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
-    const bf16_t* A = p.a[prob];
-    const bf16_t* B = p.b[prob];
+    // (selects, not a dynamically indexed kernel-argument array: that would be re-fetched from memory inside the loop)
+    const bf16_t* A = prob == 0 ? p.a[0] : prob == 1 ? p.a[1] : p.a[2];
+    const bf16_t* B = prob == 0 ? p.b[0] : prob == 1 ? p.b[1] : p.b[2];
     const int p0 = blockIdx.y * 64, q0 = blockIdx.x * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave >> 1, wq = wave & 1;
@@ -390,11 +391,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
     auto load = [&](int mb) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            // unconditional loads from clamped (always valid) addresses, zeroed afterwards: no divergent branch around a load
             const int m = mb + srow + 32 * h;
             const bool ok = m < m_end;
+            const int mc = min(m, p.M - 1);
             const int pc = p0 + sch * 8, qc = q0 + sch * 8;
-            ra[h] = (ok && pc < p.P) ? *(const u32x4*)(A + (int64_t)m * p.lda + pc) : (u32x4){0u, 0u, 0u, 0u};
-            rb[h] = (ok && qc < p.Q) ? *(const u32x4*)(B + (int64_t)m * p.ldb + qc) : (u32x4){0u, 0u, 0u, 0u};
+            const u32x4 va = *(const u32x4*)(A + (int64_t)mc * p.lda + (pc < p.P ? pc : 0));
+            const u32x4 vb = *(const u32x4*)(B + (int64_t)mc * p.ldb + (qc < p.Q ? qc : 0));
+            ra[h] = (ok && pc < p.P) ? va : (u32x4){0u, 0u, 0u, 0u};
+            rb[h] = (ok && qc < p.Q) ? vb : (u32x4){0u, 0u, 0u, 0u};
         }
     };
     f32x4 acc[2][2];
@@ -448,6 +453,101 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
             }
 }
 
+// Wide variant: the workgroup tile spans 256 columns of one operand and 64 of the other (TPB x TQB 64-column blocks = 1x4 or 4x1), so when
+// P or Q is the rank dimension (n_adapters * r = 256 per linear) the large activation is streamed exactly once.  Each wave owns a 64x64
+// output block (4x4 MFMA tiles: 16 MFMAs per 16 transposing reads per 32-row k-step); the next 64-row chunk (40 KiB) is prefetched into
+// registers under the MFMAs of the current one.
+template <int TPB, int TQB>
+__global__ __launch_bounds__(256) void gemm_tn_wide_kernel(TnParams p) {
+    constexpr int TP = TPB * 64, TQ = TQB * 64;
+    constexpr int SA = TP * 2 + 32, SB = TQ * 2 + 32;          // padded row strides (bytes): 8 consecutive rows start on distinct 8-bank windows
+    constexpr int CPR = (TP + TQ) / 8;                          // 16-byte chunks per staged row (A part then B part)
+    constexpr int NLD = 64 * CPR / 256;                         // chunks per thread per 64-row step
+    __shared__ __attribute__((aligned(16))) char lds[64 * SA + 64 * SB];
+    char* const la = lds;
+    char* const lb = lds + 64 * SA;
+    const int prob = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+    const bf16_t* A = prob == 0 ? p.a[0] : prob == 1 ? p.a[1] : p.a[2];
+    const bf16_t* B = prob == 0 ? p.b[0] : prob == 1 ? p.b[1] : p.b[2];
+    const int p0 = blockIdx.y * TP, q0 = blockIdx.x * TQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pa0 = TPB == 1 ? 0 : wave * 64, qb0 = TPB == 1 ? wave * 64 : 0;
+    const int g = lane >> 4, c16 = lane & 15, tq = c16 >> 2, tp = c16 & 3;
+    const int rows_per = ((p.M + p.splits - 1) / p.splits + 63) / 64 * 64;
+    const int m_begin = split * rows_per, m_end = min(p.M, m_begin + rows_per);
+    // staging plan (loop invariant): chunk idx = tid + 256 i  ->  row idx / CPR, column chunk idx % CPR.  The A / B choice is folded into
+    // one base pointer + row stride per chunk; loads are unconditional from clamped addresses and zeroed afterwards.
+    int srow[NLD], lds_off[NLD];
+    const bf16_t* gsrc[NLD];
+    int64_t gld[NLD];
+    bool inb[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / CPR, c = idx - r * CPR;
+        const bool isA = c < TP / 8;
+        srow[i] = r;
+        const int col = isA ? p0 + c * 8 : q0 + (c - TP / 8) * 8;
+        inb[i] = isA ? col < p.P : col < p.Q;
+        gld[i] = isA ? p.lda : p.ldb;
+        gsrc[i] = (isA ? A : B) + (inb[i] ? col : 0);
+        lds_off[i] = isA ? r * SA + c * 16 : 64 * SA + r * SB + (c - TP / 8) * 16;
+    }
+    u32x4 reg[NLD];
+    auto load = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int m = mb + srow[i];
+            const u32x4 v = *(const u32x4*)(gsrc[i] + (int64_t)min(m, p.M - 1) * gld[i]);
+            reg[i] = (inb[i] && m < m_end) ? v : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (m_begin < m_end) load(m_begin);
+    for (int mb = m_begin; mb < m_end; mb += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *(u32x4*)(lds + lds_off[i]) = reg[i];
+        __syncthreads();
+        if (mb + 64 < m_end) load(mb + 64);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r_lo = ks * 32 + g * 4 + tq, r_hi = r_lo + 16;
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ca = (pa0 + i * 16 + tp * 4) * 2, cb = (qb0 + i * 16 + tp * 4) * 2;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(la + r_lo * SA + ca));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(la + r_hi * SA + ca));
+                fa[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const bf16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lb + r_lo * SB + cb));
+                const bf16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lb + r_hi * SB + cb));
+                fb[i] = (bf16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* dst = p.splits > 1 ? p.slabs + ((int64_t)(prob * p.splits + split) * p.P) * p.Q : p.out[prob];
+    const int64_t ldd = p.splits > 1 ? p.Q : p.ldo;
+    const float sc = p.splits > 1 ? 1.0f : p.alpha;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pr = p0 + pa0 + i * 16 + g * 4 + r, qc = q0 + qb0 + j * 16 + c16;
+                if (pr < p.P && qc < p.Q) dst[(int64_t)pr * ldd + qc] = acc[i][j][r] * sc;
+            }
+}
+
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(TnParams p) {
     const int prob = blockIdx.y;
     const int64_t n = (int64_t)p.P * p.Q;
@@ -462,10 +562,19 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(TnParams p) {
 
 // n_problems (1..3) products of the same shape in one launch.  workspace: n_problems * splits * P * Q floats when the kernel decides to
 // split (query the size with mc_gemm_tn_workspace_floats); may be NULL when that returns 0.
+// variant: 1 = 64x256 tile (Q spans the rank), 2 = 256x64 (P spans the rank), 0 = 64x64
+static int tn_variant(int P, int Q) {
+    if (Q % 256 == 0 && Q <= 512 && P >= Q) return 1;
+    if (P % 256 == 0 && P <= 1024 && Q >= P) return 2;
+    return 0;
+}
 static int tn_splits(int M, int P, int Q, int n_problems) {
-    const int64_t tiles = (int64_t)((P + 63) / 64) * ((Q + 63) / 64) * n_problems;
+    const int v = tn_variant(P, Q);
+    const int tp = v == 2 ? 256 : 64, tq = v == 1 ? 256 : 64;
+    const int64_t tiles = (int64_t)((P + tp - 1) / tp) * ((Q + tq - 1) / tq) * n_problems;
+    const int64_t want = v ? 256 : 512;
     int s = 1;
-    while (tiles * s < 512 && s < 8 && M / (s * 2) >= 256) s *= 2;
+    while (tiles * s < want && s < 8 && M / (s * 2) >= 256) s *= 2;
     return s;
 }
 extern "C" int mc_gemm_tn_workspace_floats(int M, int P, int Q, int n_problems, int64_t* floats) {
@@ -488,7 +597,10 @@ extern "C" int mc_gemm_tn_bf16(const void* const* a, int64_t lda, const void* co
     p.slabs = workspace;
     MC_CHECK_ARG(p.splits == 1 || workspace, "mc_gemm_tn_bf16: workspace missing (%d splits)", p.splits);
     hipStream_t s = (hipStream_t)stream;
-    gemm_tn_kernel<<<dim3((Q + 63) / 64, (P + 63) / 64, n_problems * p.splits), 256, 0, s>>>(p);
+    const int variant = tn_variant(P, Q);
+    if (variant == 1) gemm_tn_wide_kernel<1, 4><<<dim3((Q + 255) / 256, (P + 63) / 64, n_problems * p.splits), 256, 0, s>>>(p);
+    else if (variant == 2) gemm_tn_wide_kernel<4, 1><<<dim3((Q + 63) / 64, (P + 255) / 256, n_problems * p.splits), 256, 0, s>>>(p);
+    else gemm_tn_kernel<<<dim3((Q + 63) / 64, (P + 63) / 64, n_problems * p.splits), 256, 0, s>>>(p);
     if (p.splits > 1) {
         const int64_t n = (int64_t)P * Q;
         gemm_tn_reduce_kernel<<<dim3((int)min((int64_t)2048, (n + 255) / 256), n_problems), 256, 0, s>>>(p);

@@ -51,7 +51,7 @@ class _Param:
 
 class MultimodalTrainStep:
     def __init__(self, model: MultimodalLlamaForCausalLM, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 bucket_layers: int = 4, process_group=None):
+                 bucket_layers: int = 4, process_group=None, overlap_wgrad: bool = True):
         cfg = model.config
         if float(getattr(cfg, "lora_dropout", 0.0) or 0.0) != 0.0:
             raise NotImplementedError("lora_dropout > 0 (nn.Dropout on the LoRA input, multimodal_llama.py:133) is not implemented; set it to 0")
@@ -78,6 +78,9 @@ class MultimodalTrainStep:
         except Exception:
             self.world = 1
         self.step_count = 0
+        # weight-gradient (TN) GEMMs run on a second HIP stream: they only feed the gradient buffer, so they overlap the main stream's
+        # input-gradient GEMMs, which at B*L = 2728 rows fill only 176 of the 256 CUs
+        self._wstream = torch.cuda.Stream(device=self.dev) if overlap_wgrad else None
         self._build_frozen()
         self._build_trainable()
         self._buckets = bucket_ranges(self.layer_end, cfg.num_hidden_layers, bucket_layers, self.n_params)
@@ -220,6 +223,22 @@ class MultimodalTrainStep:
                        alpha=self.scale)
         saved[f"{layer}.{gname}.T"] = T
 
+    def _wgrad(self, a_list, b_list, out_list, alpha=1.0):
+        """out_i = alpha * a_i^T b_i into the gradient buffer, on the side stream once the operands are complete on the main stream."""
+        if self._wstream is None:
+            return ops.gemm_tn(a_list, b_list, out_list, alpha=alpha)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._wstream):
+            self._wstream.wait_event(ready)
+            ops.gemm_tn(a_list, b_list, out_list, alpha=alpha)
+        for t in list(a_list) + list(b_list):
+            t.record_stream(self._wstream)                          # the allocator must not recycle them under the side stream
+
+    def _join_wgrad(self):
+        if self._wstream is not None:
+            torch.cuda.current_stream().wait_stream(self._wstream)
+
     def _lora_bwd(self, dys, x, dx, layer, gname, row_adapter, saved, Mp):
         """dx += s * mask(dT) A_in with dT_j = dy_j B_j;  dB_j = s dy_j^T T_j;  dA_in = s mask(dT)^T x.  The two weight gradients reduce
         over the token rows: TN GEMMs straight from the row-major activations (one launch for the same-shape linears of the group)."""
@@ -233,9 +252,9 @@ class MultimodalTrainStep:
             ops.linear(dys[j], self._packed[bn + ".T"], out=dT[:, j * self.R:(j + 1) * self.R], auto_split=True)      # dy_j . B_j
         ops.lora_mask_rows(dT, row_adapter, self.r, self.nA)
         ops.linear(dT, self._packed[aname + ".T"], residual=dx, out=dx, alpha=self.scale)
-        ops.gemm_tn(list(dys), [T[:, j * self.R:(j + 1) * self.R] for j in range(len(lins))], [self.view(self.G, bn) for bn in bnames],
+        self._wgrad(list(dys), [T[:, j * self.R:(j + 1) * self.R] for j in range(len(lins))], [self.view(self.G, bn) for bn in bnames],
                     alpha=self.scale)
-        ops.gemm_tn([dT], [x], [self.view(self.G, aname)], alpha=self.scale)
+        self._wgrad([dT], [x], [self.view(self.G, aname)], alpha=self.scale)
 
     # ------------------------------------------------------------------ one step
     def forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
@@ -330,9 +349,11 @@ class MultimodalTrainStep:
             if self.world > 1:
                 for (ready, lo, hi) in self._buckets:
                     if ready == l:
+                        self._join_wgrad()
                         handles.append(self._allreduce_async(lo, hi))
         # ---- spliced feature blocks -> prefix / suffix tokens and the projectors
         self._backward_features(dx, plan, feats, saved)
+        self._join_wgrad()
         if self.world > 1:
             for (ready, lo, hi) in self._buckets:
                 if ready == -1:
@@ -413,7 +434,7 @@ class MultimodalTrainStep:
                 wname = f"model.modal_projectors.{modal}.{k}"
                 hin = saved[f"proj.{modal}.h{k_i}"] if k_i > 0 else saved[f"proj.{modal}.in"]
                 # dW[o][i] = sum_m d[m][o] hin[m][i];  db = colsum(d)
-                ops.gemm_tn([d], [hin], [self.view(self.G, wname)])
+                self._wgrad([d], [hin], [self.view(self.G, wname)])
                 ops.colsum(d, out=self.view(self.G, wname.replace("weight", "bias")))
                 if k_i > 0:
                     w16 = self.view(self.P16, wname)
