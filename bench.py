@@ -41,10 +41,12 @@ def parse():
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--workload", default="generate", choices=["generate", "train", "mcub4"],
+    ap.add_argument("--workload", default="generate", choices=["generate", "train", "mcub4", "iav"],
                     help="generate = BASELINE configs[1] (the headline metric); train = configs[4], the stage-2 finetune step "
                          "(forward + backward + gradient all-reduce + AdamW), per-GPU batch 4; mcub4 = configs[3], the 4-modality "
-                         "composed model on MCUB-4-shaped inputs (image + 10 s audio + 8-frame video + 8192-point cloud), per-GPU batch 2")
+                         "composed model on MCUB-4-shaped inputs (image + 10 s audio + 8-frame video + 8192-point cloud), per-GPU batch 2; "
+                         "iav = the metric string's literal inputs (336 px image + 10 s audio + 8-frame video) on configs[2]'s 3-way composed "
+                         "model (online-merge-reset 3 x 0.333), per-GPU batch 4")
     return ap.parse_args()
 
 
@@ -138,21 +140,23 @@ def train_main(args, world, rank, local):
 
 def mcub4_main(args, world, rank, local):
     """BASELINE configs[3]: vision + audio + video + point composed Vicuna-7B (online-merge-reset, 4 x 0.25), MCUB-4-shaped synthetic
-    inputs: 336 px image, 1024x128 fbank (10 s), 8 x 224 px frames, 8192 x 6 point cloud; spliced length 3337; greedy decode."""
+    inputs: 336 px image, 1024x128 fbank (10 s), 8 x 224 px frames, 8192 x 6 point cloud; spliced length 3337; greedy decode.
+    --workload iav: the same loop without the point modality on the 3-way composed model of configs[2] (3 x 0.333; spliced length 2790)."""
     from modelcompose_amd import synthetic
     from modelcompose_amd.dist import gather_ids
     from modelcompose_amd.model.builder import build_from_state_dict
     dev = torch.device("cuda", local)
-    modals = ("vision", "audio", "video", "point")
-    reset = ",".join(f"default-{m}=0.25" for m in modals)
+    iav = args.workload == "iav"
+    modals = ("vision", "audio", "video") if iav else ("vision", "audio", "video", "point")
+    reset = ",".join(f"default-{m}={0.333 if iav else 0.25}" for m in modals)
     meta = synthetic.vicuna7b_meta(modals, reset, layers=args.layers)
     sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
     model = build_from_state_dict(meta, sd, device=dev)
     del sd
     model._raw = {}
     torch.cuda.empty_cache()
-    B = 2 if args.batch == 16 else args.batch
-    ids = synthetic.synthetic_prompt(B, [-200, -203, -204, -205], seed=rank).to(dev)
+    B = (4 if iav else 2) if args.batch == 16 else args.batch
+    ids = synthetic.synthetic_prompt(B, [-200, -203, -204] + ([] if iav else [-205]), seed=rank).to(dev)
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     rnd = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
     fbank = rnd(B, 1024, 128) * 0.5
@@ -163,7 +167,10 @@ def mcub4_main(args, world, rank, local):
           "audio": {"audio_inputs": fbank.to(torch.bfloat16), "audio_padding_mask": torch.zeros(B, 1024, dtype=torch.bool, device=dev)},
           "video": rnd(B, 3, 8, 224, 224).to(torch.bfloat16),
           "point": torch.cat([xyz, torch.rand(B, 8192, 3, generator=g, device=dev)], -1).to(torch.bfloat16)}
-    model.model.modal_encoders["point"].fps_start = torch.zeros(B, dtype=torch.long)
+    if iav:
+        del mi["point"]
+    else:
+        model.model.modal_encoders["point"].fps_start = torch.zeros(B, dtype=torch.long)
 
     def step():
         out = model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True)
@@ -189,10 +196,13 @@ def mcub4_main(args, world, rank, local):
     if rank == 0:
         feats, _ = model.encode_modal_inputs(mi, model.prefix_tokens, model.suffix_tokens)
         print(json.dumps({
-            "metric": "samples/sec (whole node) composed-Vicuna-7B greedy gen, img+audio+video+point", "value": round(world * B * args.steps / dt, 4),
+            "metric": "samples/sec (whole node) composed-Vicuna-7B greedy gen, " + ("img+audio+video" if iav else "img+audio+video+point"),
+            "value": round(world * B * args.steps / dt, 4),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[3]: 4-modality composed Vicuna-7B (online-merge-reset 4 x 0.25; 9 adapters), MCUB-4-shaped inputs, "
+            "config": {"workload": ("configs[2] model with the metric's inputs: 3-way composed Vicuna-7B (online-merge-reset 3 x 0.333; 7 adapters), "
+                                    "336 px image + 10 s audio + 8-frame video, " if iav else
+                                    "configs[3]: 4-modality composed Vicuna-7B (online-merge-reset 4 x 0.25; 9 adapters), MCUB-4-shaped inputs, ") +
                                    f"batch {B} per GPU, {args.new_tokens} greedy tokens", "per_gpu_batch": B, "new_tokens": args.new_tokens,
                        "layers": args.layers, "parallelism": f"dp{world}",
                        "spliced_length": int(ids.shape[1] - 4 + sum(f.shape[1] for f in feats.values())),
@@ -214,7 +224,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if args.workload == "train":
         return train_main(args, world, rank, local)
-    if args.workload == "mcub4":
+    if args.workload in ("mcub4", "iav"):
         return mcub4_main(args, world, rank, local)
     from modelcompose_amd import _lib, synthetic
     from modelcompose_amd.dist import gather_ids
