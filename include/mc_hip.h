@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 3
+#define MC_ABI_VERSION 4
 
 /* activation codes for mc_gemm_bf16 */
 #define MC_ACT_NONE 0
@@ -111,12 +111,14 @@ int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* b
  * 16j..); out is [M, N/2] bf16 = silu(gate) * up (LocalLoraMLP.forward, multimodal_llama.py:381-388).
  * split_k > 1 (M <= 64 only): K is split over workgroups; slice s stores its fp32 partial sums (x row_scale x alpha) in slab s
  * of out = fp32 [split_k][M][ldo]; mc_residual_rms_bf16 adds the slabs in order into the hidden state (no atomics).
+ * rms_eps > 0 (M <= 64, no row_scale): the kernel computes the RMSNorm factor rsqrt(mean_k x[m][k]^2 + rms_eps) of every row from the x
+ * fragments it streams anyway and uses it as row_scale - the decode path needs no separate normalisation pass.
  * split_k < 0 (M > 64): "auto" - launches that would leave most CUs idle (few output tiles, long K: the LoRA rank projections of the
  * finetune step) are split along K into library-owned fp32 slabs, summed in fixed order, then given the normal epilogue.          */
 typedef struct mc_gemm_args {
     const void* x; int64_t ldx; const void* w_packed; const void* bias; const void* residual; int64_t ldr;
     void* out; int64_t ldo; int M, N, K; int act; int out_f32; float alpha, beta;
-    const float* row_scale; int swiglu; int split_k;
+    const float* row_scale; int swiglu; int split_k; float rms_eps;
 } mc_gemm_args;
 int mc_gemm_ex_bf16(const mc_gemm_args* args, void* stream);
 

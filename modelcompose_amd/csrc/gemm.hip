@@ -99,6 +99,8 @@ struct Epilogue {
     const float* row_scale;  // [M] fp32 or null: accumulator row m is multiplied by row_scale[m] (RMSNorm 1/rms with the
                              // norm weight folded into W at compose time: LlamaRMSNorm, multimodal_llama.py:405-406)
     int swiglu;              // 16-row weight blocks alternate gate/up: out[m][16*(nb/2) + c] = silu(gate) * up (LocalLoraMLP :381-388)
+    float rms_eps;           // > 0 (skinny kernel only): row m is scaled by rsqrt(mean_k x[m][k]^2 + rms_eps), computed from the x fragments the
+                             // kernel streams anyway (LlamaRMSNorm factor without a separate pass; replaces row_scale)
 };
 
 __device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n, f32x4 v) {
@@ -589,6 +591,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int b = 0; b < MB; ++b) acc[r][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float ss[MB];                                  // this lane's share of sum_k x[m][k]^2 (row m = 16 b + c16, its 8-element k pieces)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) ss[b] = 0.f;
+    auto sumsq = [&](const bf16x8& v, float& a) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; a = fmaf(f, f, a); }
+    };
 
     int kb = kb0;
     for (; kb + U <= kb1; kb += U) {
@@ -607,6 +616,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int b = 0; b < MB; ++b) acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][r], xf[u][b], acc[r][b], 0, 0, 0);
+        if (ep.rms_eps > 0.f) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int b = 0; b < MB; ++b) sumsq(xf[u][b], ss[b]);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) wptr[r] += U * 512;
 #pragma unroll
@@ -616,6 +631,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
         bf16x8 xf[MB];
 #pragma unroll
         for (int b = 0; b < MB; ++b) { xf[b] = *(const bf16x8*)(xptr[b]); xptr[b] += 32; }
+        if (ep.rms_eps > 0.f) {
+#pragma unroll
+            for (int b = 0; b < MB; ++b) sumsq(xf[b], ss[b]);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             bf16x8 wf = __builtin_nontemporal_load((const bf16x8*)wptr[r]);
@@ -628,7 +647,25 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave][r][b][lane][0] = acc[r][b];
+    __shared__ float redss[SK_WAVES][MB][16];
+    if (ep.rms_eps > 0.f) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            float v = ss[b];
+            v += __shfl_xor(v, 16, 64);                       // the four k pieces (q4) of the row
+            v += __shfl_xor(v, 32, 64);
+            if (q4 == 0) redss[wave][b][c16] = v;
+        }
+    }
     __syncthreads();
+    // row factor of row m = 16 b + c16 (the row every epilogue below gives this lane): waves summed in fixed order
+    auto row_factor = [&](int b) -> float {
+        if (!(ep.rms_eps > 0.f)) return 1.0f;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) t += redss[w][b][c16];
+        return rsqrtf(t / (float)K + ep.rms_eps);
+    };
     if (partial) {
         // element (m, nl) of the [16*MB, 16*R] tile lives at red[w][nl>>4][m>>4][lane = (c>>2)<<4 | (m&15)][c&3], c = nl & 15;
         // consecutive threads take consecutive columns of one row: contiguous 256-byte segments
@@ -657,7 +694,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
             }
             const int m = b * 16 + c16;
             const int nb = nb0 + 2 * rp;
-            if (m < M && (nb + 1) * 16 < N) epilogue_store4_swiglu(ep, m, (nb >> 1) * 16 + q4 * 4, g, u);
+            Epilogue e2 = ep;
+            e2.alpha = ep.alpha * row_factor(b);
+            if (m < M && (nb + 1) * 16 < N) epilogue_store4_swiglu(e2, m, (nb >> 1) * 16 + q4 * 4, g, u);
         }
         return;
     }
@@ -668,7 +707,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
         for (int w = 1; w < SK_WAVES; ++w) s += *(f32x4*)&red[w][r][b][lane][0];
         const int m = b * 16 + c16;
         const int n = (nb0 + r) * 16 + q4 * 4;
-        if (m < M && n < N) epilogue_store4(ep, m, n, s);
+        Epilogue e2 = ep;
+        e2.alpha = ep.alpha * row_factor(b);
+        if (m < M && n < N) epilogue_store4(e2, m, n, s);
     }
 }
 
@@ -906,8 +947,10 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
     const int split_k = a->split_k > 1 ? a->split_k : 1;
     MC_CHECK_ARG(split_k == 1 || (M <= 64 && a->out_f32 && !a->bias && !a->residual && !a->swiglu && a->act == MC_ACT_NONE),
                  "mc_gemm_ex_bf16: split_k accumulates raw fp32 partial sums (M <= 64, out_f32, no bias/act/residual)");
+    MC_CHECK_ARG(!(a->rms_eps > 0.f) || (M <= 64 && !a->row_scale && split_k == 1),
+                 "mc_gemm_ex_bf16: rms_eps (in-kernel RMS factor) needs M <= 64, no row_scale and no split_k");
     Epilogue ep{(const bf16_t*)a->bias, (const bf16_t*)a->residual, a->ldr, a->out, a->ldo, a->act, a->out_f32, a->alpha, a->beta,
-                a->row_scale, a->swiglu};
+                a->row_scale, a->swiglu, a->rms_eps > 0.f ? a->rms_eps : 0.f};
     hipStream_t s = (hipStream_t)stream;
     if (M <= 64) {
         const int mb = (M + 15) / 16;
@@ -947,7 +990,7 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
         if (S > 1 && (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) S = 1;     // no allocation while capturing
         float* slabs = S > 1 ? splitk_workspace((size_t)S * M * N) : nullptr;
         if (S > 1 && slabs) {
-            Epilogue raw{nullptr, nullptr, 0, slabs, N, MC_ACT_NONE, 1, 1.0f, 0.0f, nullptr, 0};
+            Epilogue raw{nullptr, nullptr, 0, slabs, N, MC_ACT_NONE, 1, 1.0f, 0.0f, nullptr, 0, 0.f};
             gemm_tile_kernel<<<dim3(tiles, S), 256, lds, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, raw, tiles_m, tiles_n, g_gemm_dbg);
             const int64_t total = (int64_t)M * (N >> 2);
             splitk_reduce_kernel<<<(int)min((int64_t)2048, (total + 255) / 256), 256, 0, s>>>(slabs, S, M, N, ep);
@@ -965,7 +1008,7 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = w_packed; a.bias = bias; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = act; a.out_f32 = out_f32; a.alpha = alpha; a.beta = beta;
-    a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1;
+    a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1; a.rms_eps = 0.f;
     return mc_gemm_ex_bf16(&a, stream);
 }
 
@@ -1015,7 +1058,7 @@ extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, cons
     a.out = (char*)args->out + (int64_t)base * args->ldo * (args->out_f32 ? 4 : 2);
     if (args->residual) a.residual = (const char*)args->residual + (int64_t)base * args->ldr * 2;
     if (args->row_scale) a.row_scale = args->row_scale + base;
-    Epilogue ep{(const bf16_t*)a.bias, (const bf16_t*)a.residual, a.ldr, a.out, a.ldo, a.act, a.out_f32, a.alpha, a.beta, a.row_scale, a.swiglu};
+    Epilogue ep{(const bf16_t*)a.bias, (const bf16_t*)a.residual, a.ldr, a.out, a.ldo, a.act, a.out_f32, a.alpha, a.beta, a.row_scale, a.swiglu, 0.f};
     G2Groups grp{};
     int t = 0, k = 0;
     for (int g = 0; g < n_groups; ++g) {

@@ -89,16 +89,16 @@ int gemm_ex(const void* x, int64_t ldx, const void* w, const void* residual, int
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = w; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = out_f32; a.alpha = 1.0f; a.beta = 1.0f;
-    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = split_k;
+    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = split_k; a.rms_eps = 0.f;
     return mc_gemm_ex_bf16(&a, stream);
 }
 
 int gemm_grouped(const void* x, int64_t ldx, const void* residual, int64_t ldr, void* out, int64_t ldo, int N, int K, const float* row_scale,
-                 int swiglu, int n_groups, const int32_t* gstart, const void* const* weights, void* stream) {
+                 int swiglu, int n_groups, const int32_t* gstart, const void* const* weights, void* stream, float rms_eps = 0.f) {
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = nullptr; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = 0; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = 0; a.alpha = 1.0f; a.beta = 1.0f;
-    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = 1;
+    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = 1; a.rms_eps = rms_eps;
     return mc_gemm_grouped_bf16(&a, n_groups, gstart, weights, stream);
 }
 
@@ -115,7 +115,11 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     char* kcl = kc + (size_t)layer * kv_layer;
     char* vcl = vc + (size_t)layer * kv_layer;
     const float scale = 1.0f / sqrtf((float)D);
-    const bool split = decode && M <= 64;   // skinny decode shapes: split-K slabs + residual_rms instead of an in-epilogue residual
+    // skinny decode shapes (M <= 64): no normalisation pass at all - the GEMMs that read the hidden state compute its 1/rms from the x
+    // fragments they stream (rms_eps), o_proj / down_proj add the residual in their epilogue: 5 launches per layer
+    const bool skinny = decode && M <= 64;
+    const float* rs_in = skinny ? nullptr : w.rs;
+    const float eps_in = skinny ? c.rms_eps : 0.f;
     auto W = [&](int adapter, int which) { return m->layer_w[((size_t)layer * c.n_adapters + adapter) * 4 + which]; };
 
     // weights of every group for linear `which`
@@ -125,7 +129,7 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
         return (const void* const*)wg;
     };
     // q|k|v = (x / rms) . (W_qkv diag(g_in))^T                                                  (:440-443, :262-268)
-    RUN(gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, w.rs, 0, n_groups, gstart, W_all(0), stream));
+    RUN(gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in));
     if (decode) {
         // one token per sequence (row b = sequence b): RoPE, the cache append and the attention are one launch (:281-312)
         RUN(mc_attn_decode_rope_bf16(w.qkv, qkvd, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl, Hkv * Smax * D, D,
@@ -139,23 +143,13 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
                                  (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, stream));
     }
     // x += o_proj(attn)  (:447);  then 1/rms of the new x for post_attention_layernorm (:462)
-    if (split) {
-        RUN(gemm_ex(w.attn, hd, W(gadapter[0], 1), nullptr, 0, w.part, hd, M, (int)hd, (int)hd, 1, nullptr, 0, kDecodeSplitK, stream));
-        RUN(mc_residual_rms_bf16(x, hd, w.part, hd, kDecodeSplitK, w.rs, M, (int)hd, c.rms_eps, stream));
-    } else {
-        RUN(gemm_grouped(w.attn, hd, x, hd, x, hd, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream));
-        RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
-    }
+    RUN(gemm_grouped(w.attn, hd, x, hd, x, hd, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream));
+    if (!skinny) RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
     // inter = silu(gate) * up with gate|up = (x / rms) . (W_gu diag(g_post))^T                 (:380-390)
-    RUN(gemm_grouped(x, hd, nullptr, 0, w.inter, I, (int)(2 * I), (int)hd, w.rs, 1, n_groups, gstart, W_all(2), stream));
+    RUN(gemm_grouped(x, hd, nullptr, 0, w.inter, I, (int)(2 * I), (int)hd, rs_in, 1, n_groups, gstart, W_all(2), stream, eps_in));
     // x += down_proj(inter)  (:466);  then 1/rms for the next layer's input_layernorm / the final norm
-    if (split) {
-        RUN(gemm_ex(w.inter, I, W(gadapter[0], 3), nullptr, 0, w.part, hd, M, (int)hd, (int)I, 1, nullptr, 0, kDecodeSplitK, stream));
-        RUN(mc_residual_rms_bf16(x, hd, w.part, hd, kDecodeSplitK, w.rs, M, (int)hd, c.rms_eps, stream));
-    } else {
-        RUN(gemm_grouped(w.inter, I, x, hd, x, hd, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream));
-        RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
-    }
+    RUN(gemm_grouped(w.inter, I, x, hd, x, hd, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream));
+    if (!skinny) RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
     return 0;
 }
 
@@ -292,7 +286,7 @@ static int decode_one_step(Llm* m, int B, int64_t* next_ids, int64_t* out_ids, i
     const int32_t* zeros = state + 3 * B;
     const int32_t* step = state + 4 * B;
     RUN(mc_embed_rows_bf16(m->embed, c.hidden, next_ids, w.xl, c.hidden, nullptr, B, c.hidden, stream));
-    RUN(mc_rms_scale_bf16(w.xl, c.hidden, w.rs, B, c.hidden, c.rms_eps, stream));
+    if (B > 64) RUN(mc_rms_scale_bf16(w.xl, c.hidden, w.rs, B, c.hidden, c.rms_eps, stream));        // M <= 64: computed inside the GEMMs
     for (int l = 0; l < c.n_layers; ++l)
         RUN(layer_forward(m, l, w.xl, B, 1, gs, gad, w, iota, pos, zeros, nullptr, kvlen, B, 1, (char*)k_cache, (char*)v_cache, Smax, true,
                           nsplit, attn_ws, stream));

@@ -122,7 +122,7 @@ def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.
     if auto_split:
         a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), w.data.data_ptr(), 0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
                            0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, w.N, w.Kp, ACT[act],
-                           1 if out_f32 else 0, alpha, beta, 0, 0, -1)
+                           1 if out_f32 else 0, alpha, beta, 0, 0, -1, 0.0)
         _lib.check(_lib.lib().mc_gemm_ex_bf16(C.byref(a), _stream()), "mc_gemm_ex_bf16")
         return out
     _lib.check(_lib.lib().mc_gemm_bf16(_p(x), x.stride(0), _p(w.data), _p(b), _p(residual),
@@ -132,7 +132,7 @@ def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.
 
 
 def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor] = None, swiglu: bool = False, split_k: int = 1,
-              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False, rms_eps: float = 0.0) -> torch.Tensor:
     """mc_gemm_ex_bf16: row_scale fp32 [M] (1/rms of a folded RMSNorm), swiglu (gate/up interleaved per 16 rows -> [M, N/2]),
     split_k > 1 (M <= 64): fp32 partial slabs [split_k, M, N]."""
     _req(x, BF16, "x")
@@ -148,7 +148,7 @@ def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor
     a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), w.data.data_ptr(), 0, 0 if residual is None else residual.data_ptr(),
                        0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(-2), M, w.N, w.Kp, 0,
                        1 if (out_f32 or split_k > 1) else 0, 1.0, 1.0, 0 if row_scale is None else row_scale.data_ptr(),
-                       1 if swiglu else 0, split_k)
+                       1 if swiglu else 0, split_k, float(rms_eps))
     _lib.check(_lib.lib().mc_gemm_ex_bf16(C.byref(a), _stream()), "mc_gemm_ex_bf16")
     return out
 

@@ -441,3 +441,29 @@ def test_attn_decode_with_fused_rope_and_kv_append(ops, D, H, nsplit):
     ops.attn_decode_rope(qkv, cos, sin, kc2, vc2, o2, lens_d, B, H, H, Smax, D, nsplit=nsplit, workspace=ws)
     assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
     close_bf16(o2, o1.float(), rel=2 ** -7)
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 64])
+def test_skinny_gemm_in_kernel_rms_factor(M):
+    """rms_eps > 0: the decode GEMMs compute rsqrt(mean x^2 + eps) per row from the fragments they stream; same result as the
+    separate rms_scale pass + row_scale epilogue (fp32 sums in a different order: one bf16 ulp of the output scale), with and
+    without the fused SwiGLU epilogue."""
+    from modelcompose_amd import ops
+    g = torch.Generator().manual_seed(M)
+    K, N = 4096, 1024
+    x = (torch.randn(M, K, generator=g) * 1.7).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    pw = ops.pack_weight(w)
+    rs = ops.rms_scale(x, 1e-5)
+    for swiglu in (False, True):
+        ref = ops.linear_ex(x, pw, row_scale=rs, swiglu=swiglu)
+        got = ops.linear_ex(x, pw, swiglu=swiglu, rms_eps=1e-5)
+        assert (got.float() - ref.float()).abs().max().item() <= 2 ** -7 * ref.float().abs().max().item()
+        again = ops.linear_ex(x, pw, swiglu=swiglu, rms_eps=1e-5)
+        assert torch.equal(got, again)
+    xf = x.float()
+    exact = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)) @ w.float().t()
+    got = ops.linear_ex(x, pw, rms_eps=1e-5)
+    assert (got.float() - exact).abs().max().item() <= 2 ** -7 * exact.abs().max().item()
+    with pytest.raises(Exception):
+        ops.linear_ex(torch.zeros(100, K, dtype=torch.bfloat16, device="cuda"), pw, rms_eps=1e-5)      # M > 64

@@ -116,6 +116,31 @@ def main():
                 gemm_case(8192, 8192, 8192, rot=1)
                 gemm_case(10928, 4096, 4096, rot=1)
         L.mc_gemm_debug(0)
+    if "blas" in which:
+        # context only (not on the product path): the vendor library GEMM torch.matmul dispatches to (hipBLASLt / rocBLAS) on the same
+        # shapes and random data, next to the hand-written 256x256 kernel
+        from modelcompose_amd import ops
+        for (M, N, K) in ((10928, 12288, 4096), (10928, 4096, 4096), (10928, 22016, 4096), (10928, 4096, 11008), (8192, 8192, 8192), (2728, 4096, 4096)):
+            x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+            w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.02
+            pw = ops.pack_weight(w)
+            res = {}
+            for name, fn in (("vendor (torch.matmul)", lambda: torch.matmul(x, w.t())), ("libmc_hip", lambda: ops.linear(x, pw))):
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                best = 1e9
+                for rep in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    best = min(best, e0.elapsed_time(e1) / 20)
+                res[name] = best
+            fl = 2.0 * M * N * K
+            print(f"gemm M={M} N={N} K={K}: " + "   ".join(f"{k} {v*1e3:7.1f} us {fl/v/1e9:7.0f} TFLOP/s" for k, v in res.items()))
     if "clock" in which:
         # shader clock the chip holds inside the 256x256 kernel's main loop after >= 2 s of back-to-back launches on random data
         import ctypes as C
