@@ -142,6 +142,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise MCError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       f"(or `make -C modelcompose_amd/csrc`). There is no CPU fallback.")
+    # torch first: its wheel carries its own libamdhip64; if libmc_hip.so were loaded before it, the system HIP runtime would be bound
+    # to our kernels and torch's copy to the tensors - two runtimes in one process, and our launches see "no ROCm-capable device"
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.mc_last_error.restype = C.c_char_p
     L.mc_last_error.argtypes = []
