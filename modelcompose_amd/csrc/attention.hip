@@ -45,6 +45,13 @@ __device__ __forceinline__ void dma16(const void* gptr, const void* lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(m0v) : "memory");
 }
 
+// Same, scalar-base form: address = wave-uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset.  The offsets of a K/V tile are the
+// same for every tile (row-in-tile * stride + swizzled chunk), so the loop needs no vector address arithmetic at all: only the base moves.
+__device__ __forceinline__ void dma16s(const void* base_uniform, uint32_t off, const void* lds_dst) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base_uniform), "s"(m0v) : "memory");
+}
+
 // REL: gated relative-position bias of BEATs compiled in (a separate instantiation keeps its per-score loads and branches out of the
 // common kernel)
 template <int D, bool REL>
@@ -61,9 +68,23 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
+    // XCD-aware block order.  Workgroups are dealt to the 8 XCDs round-robin by linear id, so the query blocks of one (batch, head) - which
+    // all stream the same K/V - would land on 8 different L2s and each would fetch that K/V from the fabric again.  Give every XCD a
+    // contiguous range of the logical order instead (query block fastest): one (batch, head) stays on one XCD and its K/V tiles are L2
+    // hits after the first reader.  Within a (batch, head) the causal query blocks run longest-first.
+    int qblk, h, b;
+    {
+        const int nx = gridDim.x, ny = gridDim.y;
+        const int total = nx * ny * (int)gridDim.z;
+        const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, idx = lin >> 3;
+        const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        qblk = nx - 1 - v % nx;
+        h = (v / nx) % ny;
+        b = v / (nx * ny);
+    }
     const int hk = h / (p.H / p.Hkv);
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = qblk * 64 + wave * 16;
     const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
 
     // Q fragments (B operand: col = query c, k = d)
@@ -94,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
 
     // number of key tiles this workgroup needs
     int last_key = kvlen;                    // exclusive
-    if (p.causal) last_key = min(last_key, blockIdx.x * 64 + 63 + p.q_offset + 1);
+    if (p.causal) last_key = min(last_key, qblk * 64 + 63 + p.q_offset + 1);
     const int ntiles = (last_key + 63) / 64;
 
     const bf16_t* kbase = p.k + b * p.k_sb + hk * p.k_sh;
@@ -103,9 +124,31 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
     // K/V tiles arrive by LDS-DMA into a double buffer: the DMA of tile kt+1 is in flight while tile kt is consumed.
     // The LDS image is lane-linear per wave instruction (RPI rows x ROWB bytes); the XOR swizzle of K and V is applied to the SOURCE chunk.
     const int srow = lane / CH, sch = lane % CH;         // row inside the instruction's row group, 16-byte chunk
+    // per-lane byte offsets inside a tile (loop invariant); tiles that reach past the last allocated row S-1 (only the final tile of a
+    // buffer whose row count is not a multiple of 64, e.g. CLIP's 577 tokens) take the clamped 64-bit-address path instead
+    uint32_t koff[NDMA], voff[NDMA];
+    const bool off32_ok = 64LL * p.k_st * 2 + ROWB < (1LL << 31) && 64LL * p.v_st * 2 + ROWB < (1LL << 31);
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int row = wave * 16 + i * RPI + srow;
+        int sw;
+        if (CH == 16) sw = sch ^ (row & 15); else sw = sch ^ ((row >> 1) & 7);
+        koff[i] = (uint32_t)(((int64_t)row * p.k_st + sw * 8) * 2);
+        voff[i] = (uint32_t)(((int64_t)row * p.v_st + sw * 8) * 2);
+    }
     auto stage = [&](int kt, int buf) {
         char* kb_ = lds + buf * (2 * TILE);
         char* vb_ = kb_ + TILE;
+        if (off32_ok && kt * 64 + 63 < p.S) {
+            const bf16_t* kt_k = kbase + (int64_t)kt * 64 * p.k_st;
+            const bf16_t* kt_v = vbase + (int64_t)kt * 64 * p.v_st;
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                dma16s(kt_k, koff[i], kb_ + (wave * 16 + i * RPI) * ROWB);
+                dma16s(kt_v, voff[i], vb_ + (wave * 16 + i * RPI) * ROWB);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
             const int row = wave * 16 + i * RPI + srow;
