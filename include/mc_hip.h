@@ -197,6 +197,7 @@ int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh
                          int S, int D, int causal, int q_offset, float scale, const float* rel_table, int rel_stride, int rel_off,
                          const float* q_gate, void* stream);   /* rel_table/q_gate: gated relative-position bias of BEATs, may be null */
 /* as mc_attn_prefill_bf16, plus lse [B, H, Lq] fp32 = log2-sum-exp of the scaled scores (input of mc_attn_bwd_bf16) */
+int mc_attn_debug(int v);      /* diagnostics: bit 0 forces the 64-query prefill kernel, bit 1 allows the 128-query one at any length */
 int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
                              int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
                              int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B, int H, int Hkv, int Lq,

@@ -54,15 +54,19 @@ __device__ __forceinline__ void dma16s(const void* base_uniform, uint32_t off, c
 
 // REL: gated relative-position bias of BEATs compiled in (a separate instantiation keeps its per-score loads and branches out of the
 // common kernel)
-template <int D, bool REL>
-__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
+// QW: waves per workgroup (4 or 8).  Every wave owns 16 query rows whatever QW is (same registers); 8 waves share each staged K/V tile
+// between 128 queries, which halves the LDS fills, DMA issues and barriers per query and puts 4 waves on every SIMD at two workgroups per CU.
+template <int D, bool REL, int QW>
+__global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) {
     constexpr int ROWB = D * 2;              // bytes per K/V row
     constexpr int CH = ROWB / 16;            // 16-byte chunks per row
     constexpr int KS = D / 32;               // MFMA k-steps over the head dim
     constexpr int DB = D / 16;               // 16-wide d blocks of the output
     constexpr int TILE = 64 * ROWB;          // bytes of one staged K (or V) tile
     constexpr int RPI = 1024 / ROWB;         // rows written by one 1-KiB LDS-DMA wave instruction
-    constexpr int NDMA = 16 / RPI;           // DMA instructions per wave per operand per tile (each wave stages 16 rows)
+    constexpr int WROWS = 64 / QW;           // rows of a K/V tile staged by one wave
+    constexpr int NDMA = WROWS / RPI;        // DMA instructions per wave per operand per tile
+    constexpr int QB = 16 * QW;              // query rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char lds[];               // 2 * 2 * 64 * ROWB bytes: [buffer][K | V]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
         b = v / (nx * ny);
     }
     const int hk = h / (p.H / p.Hkv);
-    const int q0 = qblk * 64 + wave * 16;
+    const int q0 = qblk * QB + wave * 16;
     const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
 
     // Q fragments (B operand: col = query c, k = d)
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
 
     // number of key tiles this workgroup needs
     int last_key = kvlen;                    // exclusive
-    if (p.causal) last_key = min(last_key, qblk * 64 + 63 + p.q_offset + 1);
+    if (p.causal) last_key = min(last_key, qblk * QB + QB - 1 + p.q_offset + 1);
     const int ntiles = (last_key + 63) / 64;
 
     const bf16_t* kbase = p.k + b * p.k_sb + hk * p.k_sh;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
     const bool off32_ok = 64LL * p.k_st * 2 + ROWB < (1LL << 31) && 64LL * p.v_st * 2 + ROWB < (1LL << 31);
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-        const int row = wave * 16 + i * RPI + srow;
+        const int row = wave * WROWS + i * RPI + srow;
         int sw;
         if (CH == 16) sw = sch ^ (row & 15); else sw = sch ^ ((row >> 1) & 7);
         koff[i] = (uint32_t)(((int64_t)row * p.k_st + sw * 8) * 2);
@@ -144,19 +148,19 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
             const bf16_t* kt_v = vbase + (int64_t)kt * 64 * p.v_st;
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) {
-                dma16s(kt_k, koff[i], kb_ + (wave * 16 + i * RPI) * ROWB);
-                dma16s(kt_v, voff[i], vb_ + (wave * 16 + i * RPI) * ROWB);
+                dma16s(kt_k, koff[i], kb_ + (wave * WROWS + i * RPI) * ROWB);
+                dma16s(kt_v, voff[i], vb_ + (wave * WROWS + i * RPI) * ROWB);
             }
             return;
         }
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const int row = wave * 16 + i * RPI + srow;
+            const int row = wave * WROWS + i * RPI + srow;
             const int key = min(kt * 64 + row, p.S - 1);
             int sw;
             if (CH == 16) sw = sch ^ (row & 15); else sw = sch ^ ((row >> 1) & 7);
-            dma16(kbase + (int64_t)key * p.k_st + sw * 8, kb_ + (wave * 16 + i * RPI) * ROWB);
-            dma16(vbase + (int64_t)key * p.v_st + sw * 8, vb_ + (wave * 16 + i * RPI) * ROWB);      // V swizzled like K
+            dma16(kbase + (int64_t)key * p.k_st + sw * 8, kb_ + (wave * WROWS + i * RPI) * ROWB);
+            dma16(vbase + (int64_t)key * p.v_st + sw * 8, vb_ + (wave * WROWS + i * RPI) * ROWB);      // V swizzled like K
         }
     };
     if (ntiles > 0) stage(0, 0);
@@ -168,6 +172,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
         __builtin_amdgcn_s_barrier();                          // ... and everyone's; all reads of the other buffer (tile kt-1) are done
         if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1);
+        // causal: a tile that starts after this wave's last query contributes nothing (only the upper waves of a 128-query block reach
+        // the block's last key tile); the wave still took part in the staging and the barrier above
+        if (p.causal && kt * 64 > q0 + 15 + p.q_offset) continue;
 
         // ---- S^T[key][query] = K · Q^T
         f32x4 s[4];
@@ -462,6 +469,9 @@ __global__ void attn_decode_combine_kernel(DecodeParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+static int g_attn_dbg = 0;
+extern "C" int mc_attn_debug(int v) { g_attn_dbg = v; return 0; }      // bit 0: force the 64-query kernel, bit 1: allow the 128-query one at any length (A/B timing)
+
 extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb,
                                         int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
                                         void* o, int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B,
@@ -476,14 +486,28 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
     AttnParams p{(const bf16_t*)q, q_sb, q_st, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
                  (bf16_t*)o, o_row_stride, out_map, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
                  scale * 1.4426950408889634f, rel_table, q_gate, rel_stride, rel_off, lse};
-    dim3 grid((Lq + 63) / 64, H, B);
     hipStream_t s = (hipStream_t)stream;
-    if (rel_table) {
-        if (D == 128) attn_prefill_kernel<128, true><<<grid, 256, 4 * 64 * 256, s>>>(p);
-        else attn_prefill_kernel<64, true><<<grid, 256, 4 * 64 * 128, s>>>(p);
+    // 128-query workgroups (8 waves) for long sequences (measured on MI355X, causal, D = 128: L = 2792 426 vs 475 us, 599 TFLOP/s; at
+    // L = 682 the coarser causal diagonal costs more than the sharing saves, 204 vs 190 us), 64-query ones otherwise
+    const bool wide = ((g_attn_dbg & 2) || Lq >= 1024) && (int64_t)((Lq + 127) / 128) * H * B >= 512 && !(g_attn_dbg & 1);
+    if (wide) {
+        dim3 grid((Lq + 127) / 128, H, B);
+        if (rel_table) {
+            if (D == 128) attn_prefill_kernel<128, true, 8><<<grid, 512, 4 * 64 * 256, s>>>(p);
+            else attn_prefill_kernel<64, true, 8><<<grid, 512, 4 * 64 * 128, s>>>(p);
+        } else {
+            if (D == 128) attn_prefill_kernel<128, false, 8><<<grid, 512, 4 * 64 * 256, s>>>(p);
+            else attn_prefill_kernel<64, false, 8><<<grid, 512, 4 * 64 * 128, s>>>(p);
+        }
     } else {
-        if (D == 128) attn_prefill_kernel<128, false><<<grid, 256, 4 * 64 * 256, s>>>(p);
-        else attn_prefill_kernel<64, false><<<grid, 256, 4 * 64 * 128, s>>>(p);
+        dim3 grid((Lq + 63) / 64, H, B);
+        if (rel_table) {
+            if (D == 128) attn_prefill_kernel<128, true, 4><<<grid, 256, 4 * 64 * 256, s>>>(p);
+            else attn_prefill_kernel<64, true, 4><<<grid, 256, 4 * 64 * 128, s>>>(p);
+        } else {
+            if (D == 128) attn_prefill_kernel<128, false, 4><<<grid, 256, 4 * 64 * 256, s>>>(p);
+            else attn_prefill_kernel<64, false, 4><<<grid, 256, 4 * 64 * 128, s>>>(p);
+        }
     }
     MC_CHECK_LAUNCH();
     return 0;

@@ -467,3 +467,25 @@ def test_skinny_gemm_in_kernel_rms_factor(M):
     assert (got.float() - exact).abs().max().item() <= 2 ** -7 * exact.abs().max().item()
     with pytest.raises(Exception):
         ops.linear_ex(torch.zeros(100, K, dtype=torch.bfloat16, device="cuda"), pw, rms_eps=1e-5)      # M > 64
+
+
+@pytest.mark.parametrize("causal", [True, False])
+def test_prefill_attention_128_query_workgroups_match_64_query_ones(causal):
+    """The 8-wave (128-query) instantiation used for long sequences computes exactly what the 4-wave one does (same per-wave arithmetic,
+    other tile ownership): bitwise equal outputs, incl. ragged kv_lens and a query count that is not a multiple of 128."""
+    from modelcompose_amd import _lib, ops
+    B, H, D, L, S = 2, 32, 128, 1100, 1152
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, L, H, D, generator=g).to(torch.bfloat16).cuda()
+    k = torch.randn(B, H, S, D, generator=g).to(torch.bfloat16).cuda()
+    v = torch.randn(B, H, S, D, generator=g).to(torch.bfloat16).cuda()
+    lens = torch.tensor([L, 900], dtype=torch.int32, device="cuda")
+    outs = []
+    for dbg in (1, 0):
+        _lib.lib().mc_attn_debug(dbg)
+        out = torch.zeros(B * L, H * D, dtype=torch.bfloat16, device="cuda")
+        ops.attn_prefill(q, k, v, out, B, H, H, L, S, D, (L * H * D, H * D, D), (H * S * D, D, S * D), (H * S * D, D, S * D), H * D, causal, kv_lens=lens)
+        outs.append(out)
+    _lib.lib().mc_attn_debug(0)
+    assert torch.equal(outs[0], outs[1])
+    assert outs[0].float().abs().sum().item() > 0

@@ -195,9 +195,24 @@ def main():
         k = torch.randn(B, H, 1024, D, device="cuda").to(BF)
         v = torch.randn(B, H, 1024, D, device="cuda").to(BF)
         out = torch.empty(B * L, H * D, dtype=BF, device="cuda")
-        t = timeit(lambda: ops.attn_prefill(q, k, v, out, B, H, H, L, L, D, (L*H*D, H*D, D), (H*1024*D, D, 1024*D), (H*1024*D, D, 1024*D), H*D, True))
-        fl = 4.0 * L * L * D * H * B / 2
-        print(f"attn prefill B={B} L={L}: {t*1e6:9.1f} us {fl/t/1e12:7.1f} TFLOP/s (causal-counted)")
+        from modelcompose_amd import _lib
+        for dbg, nm in ((1, "64-query workgroups"), (2, "128-query workgroups")):
+            _lib.lib().mc_attn_debug(dbg)
+            t = timeit(lambda: ops.attn_prefill(q, k, v, out, B, H, H, L, L, D, (L*H*D, H*D, D), (H*1024*D, D, 1024*D), (H*1024*D, D, 1024*D), H*D, True))
+            fl = 4.0 * L * L * D * H * B / 2
+            print(f"attn prefill B={B} L={L} {nm}: {t*1e6:9.1f} us {fl/t/1e12:7.1f} TFLOP/s (causal-counted)")
+        _lib.lib().mc_attn_debug(0)
+        Ll = 2792
+        ql = torch.randn(4, Ll, H, D, device="cuda").to(BF)
+        kl = torch.randn(4, H, 2816, D, device="cuda").to(BF)
+        vl = torch.randn(4, H, 2816, D, device="cuda").to(BF)
+        ol = torch.empty(4 * Ll, H * D, dtype=BF, device="cuda")
+        for dbg, nm in ((1, "64-query workgroups"), (2, "128-query workgroups")):
+            _lib.lib().mc_attn_debug(dbg)
+            t = timeit(lambda: ops.attn_prefill(ql, kl, vl, ol, 4, H, H, Ll, Ll, D, (Ll*H*D, H*D, D), (H*2816*D, D, 2816*D), (H*2816*D, D, 2816*D), H*D, True))
+            fl = 4.0 * Ll * Ll * D * H * 4 / 2
+            print(f"attn prefill B=4 L={Ll} {nm}: {t*1e6:9.1f} us {fl/t/1e12:7.1f} TFLOP/s (causal-counted)")
+        _lib.lib().mc_attn_debug(0)
         for S in (700, 3400):
             Smax = S + 128
             kc = torch.randn(B, H, Smax, D, device="cuda").to(BF)
