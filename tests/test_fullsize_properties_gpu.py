@@ -72,3 +72,36 @@ def test_zero_coefficients_compose_to_the_base_weights():
     p1 = ops.unpack_weight(ops.compose_weight(w, [(a, b, 0.75)], N, K))
     p2 = ops.unpack_weight(ops.compose_weight(w, [(a, b, 0.5), (a, b, 0.25)], N, K))
     assert (p1.float() - p2.float()).abs().max().item() <= 2 ** -7 * w.float().abs().max().item()
+
+
+def test_merge_kernels_at_full_adapter_size():
+    """TIES merging and the interference metrics on task vectors of the real rank-128 default-adapter size (327 M elements, no oracle
+    run affordable): identities that hold for any size.
+      * two identical checkpoints merge to themselves (mean / max) or to twice themselves (sum) on the entries K keeps - bit-exact
+        (a power-of-two count: torch's bf16 sum-then-divide is exact only then);
+      * K = 100 % with one sign-agreeing pair is the plain mean;
+      * metrics: d(x, x) = 0 for L2 / cosine / SSD; L2 scales linearly, cosine and SSD are scale-invariant; SSD(x, -x) = 1."""
+    from modelcompose_amd import compose
+    d = 327_155_712
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = (torch.randn(d, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    flat = torch.stack([x, x])
+    m = compose.ties_merge_vectors(flat, 20, "mean")
+    kept = m != 0
+    assert torch.equal(m[kept], x[kept]) and 0.19 < kept.float().mean().item() < 0.21           # top 20 % survive, untouched
+    assert torch.equal(compose.ties_merge_vectors(flat, 20, "max")[kept], x[kept])
+    s = compose.ties_merge_vectors(flat, 20, "sum")
+    assert torch.equal(s[kept], (x[kept].float() * 2).to(torch.bfloat16))
+    del flat, m, s
+    xf = x.float()
+    y = (torch.randn(d, generator=g, device="cuda") * 0.02)
+    same = compose.interference_metrics(torch.stack([xf, xf]), 50)
+    assert same["L2"] == 0.0 and abs(same["Cosine"]) < 1e-6 and abs(same["SSD"]) < 1e-9 and abs(same["TSSD"]) < 1e-9
+    a = compose.interference_metrics(torch.stack([xf, y]), 50)
+    b = compose.interference_metrics(torch.stack([xf * 4, y * 4]), 50)
+    assert abs(b["L2"] - 4 * a["L2"]) <= 1e-6 * b["L2"]
+    for k in ("Cosine", "SSD", "TSSD"):
+        assert abs(a[k] - b[k]) <= 1e-9, k                                                       # powers of two: exact scale invariance
+    assert abs(a["Cosine"] - 1.0) < 1e-3 and 0.26 < a["SSD"] < 0.30          # independent Gaussians: E|x+y|/(|x|+|y|) = 0.72
+    opp = compose.interference_metrics(torch.stack([xf, -xf]), 50)
+    assert abs(opp["SSD"] - 1.0) < 1e-12 and abs(opp["Cosine"] - 2.0) < 1e-6
