@@ -48,11 +48,9 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Ws {          // carve-up of the caller-provided workspace
     char *qkv, *qseq, *attn, *inter, *xl, *nl, *logits;
-    float *rs, *part;
+    float* rs;
     size_t total;
 };
-
-constexpr int kDecodeSplitK = 4;
 
 Ws carve(const mc_llm_config& c, int M, int B, int Lq, char* base) {
     const size_t hd = c.hidden, qkvd = (size_t)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
@@ -64,7 +62,6 @@ Ws carve(const mc_llm_config& c, int M, int B, int Lq, char* base) {
     w.attn = take((size_t)M * hd * 2);
     w.inter = take((size_t)M * c.inter * 2);
     w.rs = (float*)take((size_t)M * 4);
-    w.part = (float*)take(M <= 64 ? (size_t)kDecodeSplitK * M * hd * 4 : 0);
     w.xl = take((size_t)B * hd * 2);
     w.nl = take((size_t)B * hd * 2);
     w.logits = take((size_t)B * c.vocab * 4);
