@@ -28,6 +28,8 @@ from typing import Dict, List, Sequence, Tuple
 
 import torch
 
+from .checkpoint_io import load_tensors
+
 # config key -> modality, in the reference's lookup order (:15-21)
 _MODAL_OF_KEY: Tuple[Tuple[str, str], ...] = (
     ("mm_vision_encoder", "vision"), ("mm_vision_tower", "vision"), ("mm_vision2_encoder", "vision2"),
@@ -49,7 +51,7 @@ def _read_checkpoint(path: str) -> Tuple[Dict[str, torch.Tensor], dict]:
         tensors_file = os.path.join(path, "mm_projector.bin")
     with open(os.path.join(path, "config.json")) as f:
         cfg = json.load(f)
-    return torch.load(tensors_file, map_location="cpu"), cfg
+    return load_tensors(tensors_file), cfg
 
 
 def _online_merge(per_ckpt: Sequence[Dict[str, torch.Tensor]], modals: Sequence[str]) -> Dict[str, torch.Tensor]:
@@ -269,7 +271,7 @@ def convert_llava_checkpoint(llava_checkpoint: str, output_path: str) -> None:
     import shutil
     weights = {}
     for shard in ("pytorch_model-00001-of-00002.bin", "pytorch_model-00002-of-00002.bin"):
-        weights.update(torch.load(os.path.join(llava_checkpoint, shard), map_location="cpu", mmap=True, weights_only=True))
+        weights.update(load_tensors(os.path.join(llava_checkpoint, shard)))
     adapter, other = {}, {}
     for k, v in weights.items():
         nk = llava_key_to_multimodal_key(k)

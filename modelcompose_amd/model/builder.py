@@ -11,6 +11,8 @@ from typing import Dict, Optional
 
 import torch
 
+from ..checkpoint_io import load_tensors
+
 from .clip import ClipVisionConfig, HipClipVisionTower
 from .config import MultimodalConfig, infer_modals
 from .multimodal_llama import MultimodalLlamaForCausalLM
@@ -21,7 +23,7 @@ def _load_file(path: str) -> Dict[str, torch.Tensor]:
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
-    return torch.load(path, map_location="cpu")
+    return load_tensors(path)
 
 
 def load_base_state_dict(path: str) -> Dict[str, torch.Tensor]:
@@ -106,10 +108,10 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         adapter_path = os.path.join(model_path, "adapter_model.bin")                     # :157-162
         if not os.path.exists(adapter_path):
             adapter_path = os.path.join(model_path, "mm_projector.bin")
-        model.load_state_dict(torch.load(adapter_path, map_location="cpu"))
+        model.load_state_dict(load_tensors(adapter_path))
         nl = os.path.join(model_path, "non_lora_trainables.bin")                         # :164-168
         if os.path.exists(nl):
-            model.load_state_dict(torch.load(nl, map_location="cpu"))
+            model.load_state_dict(load_tensors(nl))
     for modal, enc in model.model.modal_encoders.items():                                # :180-183
         enc.load_model()
     model.finalize()

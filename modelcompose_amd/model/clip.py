@@ -15,6 +15,8 @@ from typing import Dict, Optional
 
 import torch
 
+from ..checkpoint_io import load_tensors
+
 from .. import ops
 
 BF16 = torch.bfloat16
@@ -91,7 +93,7 @@ class HipClipVisionTower:
                     from safetensors.torch import load_file
                     sd = load_file(p)
                 else:
-                    sd = torch.load(p, map_location="cpu")
+                    sd = load_tensors(p)
                 break
         if sd is None:
             raise FileNotFoundError(f"no CLIP weights (model.safetensors / pytorch_model.bin) under {path}")

@@ -16,6 +16,8 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+from ..checkpoint_io import load_tensors
+
 from .. import ops
 from .clip import _strip
 
@@ -69,7 +71,7 @@ class HipBeatsAudioEncoder:
         except Exception:
             self.audio_processor = None
         if audio_encoder is not None and os.path.isfile(str(audio_encoder)):
-            ck = torch.load(audio_encoder, map_location="cpu")
+            ck = load_tensors(audio_encoder)
             self.cfg = BeatsConfig(ck["cfg"])
             if not delay_load:
                 self.load_state_dict(ck["model"])
@@ -85,7 +87,7 @@ class HipBeatsAudioEncoder:
 
     def load_model(self):
         if not self.is_loaded:
-            ck = torch.load(self.audio_encoder_name, map_location="cpu")
+            ck = load_tensors(self.audio_encoder_name)
             self.cfg = BeatsConfig(ck["cfg"])
             self.load_state_dict(ck["model"])
 
@@ -454,7 +456,7 @@ class HipPointEncoder:
 
     def load_model(self):
         if not self.is_loaded:
-            self.load_state_dict(torch.load(self.point_encoder_name, map_location="cpu"))
+            self.load_state_dict(load_tensors(self.point_encoder_name))
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         if any(k.startswith("point_encoder.") for k in sd):

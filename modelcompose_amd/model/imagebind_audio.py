@@ -13,6 +13,8 @@ from typing import Dict, Optional
 
 import torch
 
+from ..checkpoint_io import load_tensors
+
 from .. import ops
 
 BF16 = torch.bfloat16
@@ -51,7 +53,7 @@ class HipImageBindAudioEncoder:
         if not self.is_loaded:
             if not self.ckpt_path:
                 raise FileNotFoundError("Can't load ImageBindModel, since ckpt_path is invalid.")      # imagebind_model.py:545
-            self.load_state_dict(torch.load(self.ckpt_path, map_location="cpu"))
+            self.load_state_dict(load_tensors(self.ckpt_path))
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         c, dev = self.cfg, self.device
