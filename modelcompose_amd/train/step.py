@@ -212,46 +212,79 @@ class MultimodalTrainStep:
         return out
 
     # ------------------------------------------------------------------ helpers
-    def _lora_fwd(self, x, ys, layer, gname, row_adapter, saved):
-        """For the linears of a group (same input x): y_j += s * mask(x A_j^T) B_j^T, in place on the views ys[j] ([M, N_j]).
-        One GEMM projects x onto all stacked A matrices; the routing mask zeroes, per row, the rank blocks of the other adapters."""
-        lins = dict(GROUPS)[gname]
-        T = ops.linear(x, self._packed[f"model.layers.{layer}.{gname}.A_in"], auto_split=True)         # [M, n_linears * R]
-        ops.lora_mask_rows(T, row_adapter, self.r, self.nA)
-        for j, (blk, lin) in enumerate(lins):
+    def _on_side(self, fn, *used):
+        """Run fn() on the side stream once everything enqueued so far on the main stream is complete; returns an event that marks its
+        completion (None without a side stream: fn ran inline).  `used`: main-stream tensors fn reads."""
+        if self._wstream is None:
+            fn()
+            return None
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._wstream):
+            self._wstream.wait_event(ready)
+            fn()
+            done = torch.cuda.Event()
+            done.record()
+        for t in used:
+            t.record_stream(self._wstream)                          # the allocator must not recycle them under the side stream
+        return done
+
+    def _lora_fwd_begin(self, x, layer, gname, row_adapter):
+        """Rank projection of a group, T = mask(x [A_0; A_1; ..]^T) ([M, n_linears * R]; the routing mask zeroes, per row, the rank blocks
+        of the other adapters).  It only depends on x, so it runs on the side stream next to the base GEMM of the same input."""
+        box = {}
+
+        def run():
+            T = ops.linear(x, self._packed[f"model.layers.{layer}.{gname}.A_in"], auto_split=True)
+            ops.lora_mask_rows(T, row_adapter, self.r, self.nA)
+            box["T"] = T
+        done = self._on_side(run, x)
+        return box["T"], done
+
+    def _lora_fwd_end(self, T, done, ys, layer, gname, saved):
+        """y_j += s * T_j B_j^T in place on the views ys[j] ([M, N_j]) of the base GEMM's output."""
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+            T.record_stream(torch.cuda.current_stream())
+        for j, (blk, lin) in enumerate(dict(GROUPS)[gname]):
             ops.linear(T[:, j * self.R:(j + 1) * self.R], self._packed[f"model.layers.{layer}.{blk}.{lin}.B_cat"], residual=ys[j], out=ys[j],
                        alpha=self.scale)
         saved[f"{layer}.{gname}.T"] = T
 
     def _wgrad(self, a_list, b_list, out_list, alpha=1.0):
         """out_i = alpha * a_i^T b_i into the gradient buffer, on the side stream once the operands are complete on the main stream."""
-        if self._wstream is None:
-            return ops.gemm_tn(a_list, b_list, out_list, alpha=alpha)
-        ready = torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(self._wstream):
-            self._wstream.wait_event(ready)
-            ops.gemm_tn(a_list, b_list, out_list, alpha=alpha)
-        for t in list(a_list) + list(b_list):
-            t.record_stream(self._wstream)                          # the allocator must not recycle them under the side stream
+        self._on_side(lambda: ops.gemm_tn(a_list, b_list, out_list, alpha=alpha), *a_list, *b_list)
 
     def _join_wgrad(self):
         if self._wstream is not None:
             torch.cuda.current_stream().wait_stream(self._wstream)
 
-    def _lora_bwd(self, dys, x, dx, layer, gname, row_adapter, saved, Mp):
-        """dx += s * mask(dT) A_in with dT_j = dy_j B_j;  dB_j = s dy_j^T T_j;  dA_in = s mask(dT)^T x.  The two weight gradients reduce
-        over the token rows: TN GEMMs straight from the row-major activations (one launch for the same-shape linears of the group)."""
+    def _lora_bwd_begin(self, dys, layer, gname, row_adapter):
+        """dT = mask([dy_j B_j]_j) on the side stream, next to the base input-gradient GEMM that reads the same dy."""
+        lins = dict(GROUPS)[gname]
+        M = dys[0].shape[0]
+        box = {}
+
+        def run():
+            dT = torch.empty(M, len(lins) * self.R, dtype=BF16, device=self.dev)
+            for j, (blk, lin) in enumerate(lins):
+                ops.linear(dys[j], self._packed[f"model.layers.{layer}.{blk}.{lin}.B_cat.T"], out=dT[:, j * self.R:(j + 1) * self.R], auto_split=True)
+            ops.lora_mask_rows(dT, row_adapter, self.r, self.nA)
+            box["dT"] = dT
+        done = self._on_side(run, *dys)
+        return box["dT"], done
+
+    def _lora_bwd_end(self, dT, done, dys, x, dx, layer, gname, saved):
+        """dx += s * dT A_in;  dB_j = s dy_j^T T_j;  dA_in = s dT^T x.  The two weight gradients reduce over the token rows: TN GEMMs
+        straight from the row-major activations (one launch for the same-shape linears of the group), on the side stream."""
         lins = dict(GROUPS)[gname]
         aname = f"model.layers.{layer}.{gname}.A_in"
         T = saved[f"{layer}.{gname}.T"]
-        M = T.shape[0]
-        dT = torch.empty(M, len(lins) * self.R, dtype=BF16, device=self.dev)
-        bnames = [f"model.layers.{layer}.{blk}.{lin}.B_cat" for blk, lin in lins]
-        for j, bn in enumerate(bnames):
-            ops.linear(dys[j], self._packed[bn + ".T"], out=dT[:, j * self.R:(j + 1) * self.R], auto_split=True)      # dy_j . B_j
-        ops.lora_mask_rows(dT, row_adapter, self.r, self.nA)
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+            dT.record_stream(torch.cuda.current_stream())
         ops.linear(dT, self._packed[aname + ".T"], residual=dx, out=dx, alpha=self.scale)
+        bnames = [f"model.layers.{layer}.{blk}.{lin}.B_cat" for blk, lin in lins]
         self._wgrad(list(dys), [T[:, j * self.R:(j + 1) * self.R] for j in range(len(lins))], [self.view(self.G, bn) for bn in bnames],
                     alpha=self.scale)
         self._wgrad([dT], [x], [self.view(self.G, aname)], alpha=self.scale)
@@ -291,22 +324,26 @@ class MultimodalTrainStep:
         for l, W in enumerate(self.layers):
             a = {"x": x}
             n1 = ops.rmsnorm(x, W["g_in"], eps)
+            T, ev = self._lora_fwd_begin(n1, l, "attn_in", row_adapter)
             qkv = ops.linear(n1, W["qkv"])
-            self._lora_fwd(n1, [qkv[:, j * HD:(j + 1) * HD] for j in range(3)], l, "attn_in", row_adapter, saved)
+            self._lora_fwd_end(T, ev, [qkv[:, j * HD:(j + 1) * HD] for j in range(3)], l, "attn_in", saved)
             q_seq = torch.empty(M, HD, dtype=BF16, device=dev)
             kc, vc = (torch.empty(B, Hh, L, D, dtype=BF16, device=dev) for _ in range(2))
             ops.rope_kv(qkv, row_b, row_t, row_t, self.cos, self.sin, q_seq, kc, vc, Hh, Hh, D, L, L)
             attn = torch.empty(M, HD, dtype=BF16, device=dev)
             lse = torch.empty(B * Hh * L, dtype=F32, device=dev)
             ops.attn_prefill_lse(q_seq, kc, vc, attn, lse, B, Hh, L, L, D, st_q, st_kv, st_kv, HD, True)
+            T, ev = self._lora_fwd_begin(attn, l, "attn_out", row_adapter)
             x1 = ops.linear(attn, W["o"], residual=x)
-            self._lora_fwd(attn, [x1], l, "attn_out", row_adapter, saved)
+            self._lora_fwd_end(T, ev, [x1], l, "attn_out", saved)
             n2 = ops.rmsnorm(x1, W["g_post"], eps)
+            T, ev = self._lora_fwd_begin(n2, l, "mlp_in", row_adapter)
             gu = ops.linear(n2, W["gu"])
-            self._lora_fwd(n2, [gu[:, :I], gu[:, I:]], l, "mlp_in", row_adapter, saved)
+            self._lora_fwd_end(T, ev, [gu[:, :I], gu[:, I:]], l, "mlp_in", saved)
             inter = ops.silu_mul(gu, I)
+            T, ev = self._lora_fwd_begin(inter, l, "mlp_out", row_adapter)
             x2 = ops.linear(inter, W["down"], residual=x1)
-            self._lora_fwd(inter, [x2], l, "mlp_out", row_adapter, saved)
+            self._lora_fwd_end(T, ev, [x2], l, "mlp_out", saved)
             a.update(n1=n1, q=q_seq, kc=kc, vc=vc, attn=attn, lse=lse, x1=x1, n2=n2, gu=gu, inter=inter)
             acts.append(a)
             x = x2
@@ -327,23 +364,28 @@ class MultimodalTrainStep:
         for l in reversed(range(len(self.layers))):
             W, a = self.layers[l], acts[l]
             # down_proj
+            dT, ev = self._lora_bwd_begin([dx], l, "mlp_out", row_adapter)
             d_inter = ops.linear(dx, W["downT"])
-            self._lora_bwd([dx], a["inter"], d_inter, l, "mlp_out", row_adapter, saved, Mp)
+            self._lora_bwd_end(dT, ev, [dx], a["inter"], d_inter, l, "mlp_out", saved)
             dgu = ops.swiglu_bwd(a["gu"], d_inter)
+            dT, ev = self._lora_bwd_begin([dgu[:, :I], dgu[:, I:]], l, "mlp_in", row_adapter)
             dn2 = ops.linear(dgu, W["guT"])
-            self._lora_bwd([dgu[:, :I], dgu[:, I:]], a["n2"], dn2, l, "mlp_in", row_adapter, saved, Mp)
+            self._lora_bwd_end(dT, ev, [dgu[:, :I], dgu[:, I:]], a["n2"], dn2, l, "mlp_in", saved)
             dx1 = ops.rmsnorm_bwd(a["x1"], W["g_post"], dn2, eps, dres=dx)
             # o_proj
+            dT, ev = self._lora_bwd_begin([dx1], l, "attn_out", row_adapter)
             d_attn = ops.linear(dx1, W["oT"])
-            self._lora_bwd([dx1], a["attn"], d_attn, l, "attn_out", row_adapter, saved, Mp)
+            self._lora_bwd_end(dT, ev, [dx1], a["attn"], d_attn, l, "attn_out", saved)
             # attention + RoPE
             dqkv = torch.empty(M, 3 * HD, dtype=BF16, device=dev)
             st3 = (L * 3 * HD, 3 * HD, D)
             ops.attn_bwd(a["q"], a["kc"], a["vc"], a["attn"], d_attn, a["lse"], dqkv, dqkv[:, HD:], dqkv[:, 2 * HD:], B, Hh, L, L, D,
                          st_q, st_kv, st_kv, st_q, st3, st3, st3, True)
             ops.rope_inplace(dqkv, row_t, self.cos, self.sin, 2 * Hh, D, -1.0)
+            dqs = [dqkv[:, j * HD:(j + 1) * HD] for j in range(3)]
+            dT, ev = self._lora_bwd_begin(dqs, l, "attn_in", row_adapter)
             dn1 = ops.linear(dqkv, W["qkvT"])
-            self._lora_bwd([dqkv[:, j * HD:(j + 1) * HD] for j in range(3)], a["n1"], dn1, l, "attn_in", row_adapter, saved, Mp)
+            self._lora_bwd_end(dT, ev, dqs, a["n1"], dn1, l, "attn_in", saved)
             dx = ops.rmsnorm_bwd(a["x"], W["g_in"], dn1, eps, dres=dx1)
             acts[l] = None
             if self.world > 1:
