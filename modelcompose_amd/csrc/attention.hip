@@ -332,9 +332,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
     float qv[8];
     float knew[8], vnew[8];
     const bool fused = p.qkv != nullptr;
-    int cache_len = kvlen;                    // keys read from the cache
+    const int cache_len = fused ? kvlen - 1 : kvlen;          // keys read from the cache (fused: the new token's key comes from registers)
+    const int per = (cache_len + p.nsplit - 1) / p.nsplit;
+    const int j0 = split * per, j1 = min(j0 + per, cache_len);
+    const bf16_t* kb = p.k + b * p.k_sb + hk * p.k_sh + dl;
+    const bf16_t* vb = p.v + b * p.v_sb + hk * p.v_sh + dl;
+    constexpr int UN = 4;
+    // The first batch of cached K/V rows is requested before anything else: the q/k rotation and the cache append below (a dependent
+    // chain of small loads, and a store the compiler will not move loads across) then run under its HBM latency instead of ahead of it.
+    bf16x8 k8[UN], v8[UN];
+    auto request = [&](int j) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kc = min(j + u * 4 * KPW + slot, p.S - 1);
+            k8[u] = __builtin_nontemporal_load((const bf16x8*)(kb + (int64_t)kc * p.k_st));
+            v8[u] = __builtin_nontemporal_load((const bf16x8*)(vb + (int64_t)kc * p.v_st));
+        }
+    };
+    int j = j0 + wave * KPW;
+    if (j < j1) request(j);
     if (fused) {
-        cache_len = kvlen - 1;
         const int pos = kvlen - 1;
         const bf16_t* row = p.qkv + (int64_t)b * p.qkv_ld;
         const bf16x8 q8 = *(const bf16x8*)(row + h * D + dl);
@@ -365,10 +382,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) qv[i] = (float)q8[i] * p.scale_log2e;
     }
-    const int per = (cache_len + p.nsplit - 1) / p.nsplit;
-    const int j0 = split * per, j1 = min(j0 + per, cache_len);
-    const bf16_t* kb = p.k + b * p.k_sb + hk * p.k_sh + dl;
-    const bf16_t* vb = p.v + b * p.v_sb + hk * p.v_sh + dl;
     float m = NEG_BIG, l = 0.f, acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -384,33 +397,31 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
         for (int i = 0; i < 8; ++i) acc[i] = vnew[i];
     }
 
-    constexpr int UN = 4;
-    for (int j = j0 + wave * KPW; j < j1; j += 4 * KPW * UN) {
-        bf16x8 k8[UN], v8[UN];
-        int key[UN];
+    // register double buffer: the next batch is requested before the current one is consumed
+    while (j < j1) {
+        bf16x8 kc8[UN], vc8[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { kc8[u] = k8[u]; vc8[u] = v8[u]; }
+        const int jn = j + 4 * KPW * UN;
+        if (jn < j1) request(jn);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            key[u] = j + u * 4 * KPW + slot;
-            const int kc = min(key[u], p.S - 1);
-            k8[u] = __builtin_nontemporal_load((const bf16x8*)(kb + (int64_t)kc * p.k_st));
-            v8[u] = __builtin_nontemporal_load((const bf16x8*)(vb + (int64_t)kc * p.v_st));
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
+            const int key = j + u * 4 * KPW + slot;
             float sdot = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) sdot += qv[i] * (float)k8[u][i];
+            for (int i = 0; i < 8; ++i) sdot += qv[i] * (float)kc8[u][i];
 #pragma unroll
             for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
-            const bool ok = key[u] < j1;
+            const bool ok = key < j1;
             const float mn = ok ? fmaxf(m, sdot) : m;
             const float a = fast_exp2(m - mn);
             const float pv = ok ? fast_exp2(sdot - mn) : 0.f;
             m = mn;
             l = l * a + pv;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pv * (float)v8[u][i];
+            for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pv * (float)vc8[u][i];
         }
+        j = jn;
     }
     // merge the KPW key slots of the wave (lanes with equal dl)
 #pragma unroll

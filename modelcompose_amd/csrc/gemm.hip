@@ -616,12 +616,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int b = 0; b < MB; ++b) acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][r], xf[u][b], acc[r][b], 0, 0, 0);
-        if (ep.rms_eps > 0.f) {
+        // (unconditional: a branch in the streaming loop costs the load pipelining far more than these 8 FMAs per fragment)
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int b = 0; b < MB; ++b) sumsq(xf[u][b], ss[b]);
-        }
+            for (int b = 0; b < MB; ++b) sumsq(xf[u][b], ss[b]);
 #pragma unroll
         for (int r = 0; r < R; ++r) wptr[r] += U * 512;
 #pragma unroll
@@ -631,10 +630,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
         bf16x8 xf[MB];
 #pragma unroll
         for (int b = 0; b < MB; ++b) { xf[b] = *(const bf16x8*)(xptr[b]); xptr[b] += 32; }
-        if (ep.rms_eps > 0.f) {
 #pragma unroll
-            for (int b = 0; b < MB; ++b) sumsq(xf[b], ss[b]);
-        }
+        for (int b = 0; b < MB; ++b) sumsq(xf[b], ss[b]);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             bf16x8 wf = __builtin_nontemporal_load((const bf16x8*)wptr[r]);

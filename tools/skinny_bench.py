@@ -35,3 +35,16 @@ for (N, K, name) in ((4096, 4096, "o_proj"), (4096, 11008, "down_proj"), (12288,
     for nm, fn in (("no split, residual epilogue", nosplit), ("split-4 + residual_rms", split)):
         t = timeit(fn)
         print(f"{name:10s} N={N} K={K} {nm:30s}: {t*1e6:7.2f} us  {by/t/1e12:5.2f} TB/s")
+
+# lm_head and gate|up shapes through the default path (R chosen by the library)
+for (N, K, name, sw) in ((32000, 4096, "lm_head", False), (22016, 4096, "gate|up swiglu", True)):
+    ws = [ops.pack_weight(torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.02) for _ in range(4)]
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+    i = [0]
+    for eps in (0.0, 1e-5):
+        out = torch.empty(M, N // 2 if sw else N, device="cuda", dtype=torch.float32 if not sw else torch.bfloat16)
+        def f():
+            i[0] = (i[0] + 1) % 4
+            ops.linear_ex(x, ws[i[0]], swiglu=sw, out=out, out_f32=not sw, rms_eps=eps)
+        t = timeit(f)
+        print(f"{name:14s} N={N} K={K} rms_eps={eps}: {t*1e6:7.2f} us  {N*K*2/t/1e12:5.2f} TB/s")
