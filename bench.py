@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="debug only (train): weight-gradient / rank-projection GEMMs on the main stream")
+    ap.add_argument("--gemm-debug", type=int, default=0, help="debug only: mc_gemm_debug word (A/B of kernel variants; e.g. 2048 = no 192-column tiles)")
     ap.add_argument("--workload", default="generate", choices=["generate", "train", "mcub4", "iav"],
                     help="generate = BASELINE configs[1] (the headline metric); train = configs[4], the stage-2 finetune step "
                          "(forward + backward + gradient all-reduce + AdamW), per-GPU batch 4; mcub4 = configs[3], the 4-modality "
@@ -96,7 +98,7 @@ def train_main(args, world, rank, local):
     meta["lora_dropout"] = 0.0
     sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
     model = build_from_state_dict(meta, sd, device=dev)
-    st = MultimodalTrainStep(model, lr=2e-4)
+    st = MultimodalTrainStep(model, lr=2e-4, overlap_wgrad=not args.no_overlap)
     del sd
     model._raw = {}
     torch.cuda.empty_cache()
@@ -222,6 +224,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if args.gemm_debug:
+        from modelcompose_amd import _lib as _l
+        _l.lib().mc_gemm_debug(args.gemm_debug)
     if args.workload == "train":
         return train_main(args, world, rank, local)
     if args.workload in ("mcub4", "iav"):

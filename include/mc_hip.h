@@ -130,6 +130,9 @@ int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, const int32_t* 
 
 /* live HIP-event timing of the large-M GEMM kernel on its launch stream (bench.py roofline) */
 int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgroup computes tile (0,0)) */
+/* library-wide GEMM policy: "tile192" (default 1) lets the large-M kernel use 192-column tiles when they fill the 256 CUs better than
+ * 256-column ones (under-filled launches); 0 = callers that run other work beside such launches keep the wider tile */
+int mc_gemm_set_option(const char* name, int value);
 int mc_gemm_profile_enable(int on);
 int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches);
 int mc_gemm_profile_read_bytes(double* total_bytes);   /* algorithmic HBM bytes (operands read once, output written once) of the same launches */

@@ -331,7 +331,9 @@ struct G2Src {
 // ABL: timing-only ablations (bit 0 no LDS-DMA, bit 1 no fragment reads, bit 2 DMA always from K-tiles 0/1)
 // Rejected placements of the two DMA instructions of a phase (measured): inside the MFMA half (-5 %), one in each
 // half (-5 %); reading X0 of the next K-tile during P4 to balance the fragment reads 8/4/8/4 (+-0).
-template <int MODE, int ABL>
+// NI: 16-column weight blocks per (wave_n, nh) quadrant: 4 = 256-column tiles, 3 = 192-column tiles (the fourth block slot of every LDS
+// piece is then staged with a duplicate and never read, which keeps the DMA count per wave - and so the counted waits - unchanged)
+template <int MODE, int ABL, int NI>
 __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, int xoff, const G2Src& src,
                                         f32x4 (&acc)[2][4][2][2], bf16x8 (&wf)[4][2], bf16x8 (&xf)[2][2][2]) {
     char* cur = smem + (t & 1) * G2_STAGE;
@@ -356,7 +358,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
     auto read_w = [&](int nh) {
         if ((ABL & 2) && t > 0) return;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) wf[i][kk] = *(const bf16x8*)(cur + nh * 16384 + woff + i * 2048 + kk * 1024);
     };
@@ -390,7 +392,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
                     acc[nh][i][mh][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][kk], xf[mh][jj][kk], acc[nh][i][mh][jj], 0, 0, 0);
@@ -430,7 +432,7 @@ struct G2Groups {
 // in-kernel clock diagnostic (ABL bit 3): shader-clock and 100 MHz real-time ticks across one workgroup's main loop
 __device__ unsigned long long g2_stamps[2 * 4096];
 
-template <int ABL>
+template <int ABL, int NI = 4>
 __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx, G2Groups grp, int N, int K,
                                                               Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -457,7 +459,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
 #pragma unroll
     for (int i = 1; i < 8; ++i)
         if (i < grp.n && tm >= grp.tile_start[i]) gi = i;
-    const int m0 = grp.row_start[gi] + (tm - grp.tile_start[gi]) * 256, n0 = tn * 256;
+    constexpr int NT = NI * 64;                   // tile width in weight rows: 2 wave_n x 2 nh x NI blocks of 16
+    const int m0 = grp.row_start[gi] + (tm - grp.tile_start[gi]) * 256, n0 = tn * NT;
     const int M = grp.row_start[gi + 1];          // rows of this tile beyond the group's end are clamped on load and not stored
     const bf16_t* wp = grp.wp[gi];
 
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
             const int c = wave * 2 + e;
             // W: block c of piece h  ->  (wn, i, kk)
             const int wn = c >> 3, i = (c >> 1) & 3, kk = c & 1;
-            const int nb = min((n0 >> 4) + wn * 8 + h * 4 + i, nblocks - 1);
+            const int nb = min((n0 >> 4) + wn * (2 * NI) + h * NI + min(i, NI - 1), nblocks - 1);
             src.w[h][e] = (uint32_t)((((int64_t)nb * kblocks + kk) * 512 + lane * 8) * 2);
             // X: block c of piece h  ->  8 rows of wave_m group wm
             const int wm = c >> 2, r8 = c & 3;
@@ -519,9 +522,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
     int t = 0;
     unsigned long long st0 = 0, sr0 = 0;
     if (ABL & 8) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
-    for (; t < nt - 2; ++t) g2_tile<0, ABL>(smem, t, wave, woff, xoff, src, acc, wf, xf);
-    g2_tile<1, ABL>(smem, t, wave, woff, xoff, src, acc, wf, xf);
-    g2_tile<2, ABL>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf);
+    for (; t < nt - 2; ++t) g2_tile<0, ABL, NI>(smem, t, wave, woff, xoff, src, acc, wf, xf);
+    g2_tile<1, ABL, NI>(smem, t, wave, woff, xoff, src, acc, wf, xf);
+    g2_tile<2, ABL, NI>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf);
     if (ABL & 8) {
         const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0 && blockIdx.x < 4096) { g2_stamps[2 * blockIdx.x] = st1 - st0; g2_stamps[2 * blockIdx.x + 1] = sr1 - sr0; }
@@ -535,20 +538,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tile256_kernel(const bf16_t* __re
             const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
             if (m >= M) continue;
             if (ep.swiglu) {
+                // gate / up blocks alternate along N: consecutive block pairs of this wave's 2*NI blocks (a pair may straddle the nh halves
+                // when NI is odd; both halves are this lane's registers)
 #pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                    for (int i = 0; i < 4; i += 2) {
-                        const int n = n0 + wave_n * 128 + nh * 64 + i * 16;
-                        if (n + 16 < N) epilogue_store4_swiglu(ep, m, (n >> 1) + q4 * 4, acc[nh][i][mh][jj], acc[nh][i + 1][mh][jj]);
-                    }
+                for (int f = 0; f < 2 * NI; f += 2) {
+                    const int n = n0 + wave_n * (2 * NI * 16) + f * 16;
+                    if (n + 16 < N) epilogue_store4_swiglu(ep, m, (n >> 1) + q4 * 4, acc[f / NI][f % NI][mh][jj], acc[(f + 1) / NI][(f + 1) % NI][mh][jj]);
+                }
                 continue;
             }
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = n0 + wave_n * 128 + nh * 64 + i * 16 + q4 * 4;
+                for (int i = 0; i < NI; ++i) {
+                    const int n = n0 + wave_n * (2 * NI * 16) + nh * (NI * 16) + i * 16 + q4 * 4;
                     if (n < N) epilogue_store4(ep, m, n, acc[nh][i][mh][jj]);
                 }
         }
@@ -726,6 +729,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // host launchers
 // ------------------------------------------------------------------------------------------
 #include <algorithm>
+#include <cstring>
 #include <vector>
 // Optional live timing of the dominant kernel (gemm_tile256_kernel): HIP events recorded on the launch stream around every launch while
 // enabled (bench.py's roofline object).  Not graph-capturable; leave disabled in normal operation.
@@ -754,13 +758,40 @@ static float* splitk_workspace(size_t floats) {
 }
 
 // 256x256 tiles need enough tiles to fill most of the 256 CUs; bit 1 of the debug word forces the 128x128 kernel, bit 2 the 256x256 one
+// Tile width of the large-M kernel for m_tiles row tiles: 256 columns, or 192 when that fills the 256 CUs better.  One workgroup per CU,
+// so a launch takes ceil(tiles / 256) rounds; a 192-column tile does 3/4 of the work of a 256-column one at ~0.92 of its MFMA efficiency
+// (12 instead of 16 MFMAs per phase behind the same X reads and DMA issues).  M = 2728 (the finetune step), N = 4096: 176 tiles of 256
+// fill 69 % of the CUs, 242 tiles of 192 fill 95 %.  debug word bit 10 forces 192, bit 11 forces 256.
+static bool g_tile192 = true;
+// "tile192" = 0 keeps the large-M kernel on 256-column tiles: for callers that fill the idle CUs of an under-filled launch themselves
+// (the finetune step runs its rank-projection and weight-gradient GEMMs on a second stream next to the base GEMMs: measured on one
+// device, samples/s  overlap + 256: 33.4, overlap + 192: 31.8, no overlap + 192: 32.8, no overlap + 256: 31.1)
+extern "C" int mc_gemm_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "tile192")) { g_tile192 = value != 0; return 0; }
+    mc_set_error("mc_gemm_set_option: unknown option '%s'", name ? name : "(null)");
+    return 1;
+}
+
+static int tile_ni(int64_t m_tiles, int N, bool swiglu) {
+    if (g_gemm_dbg & 2048) return 4;
+    if (!g_tile192 && !(g_gemm_dbg & 1024)) return 4;
+    if (swiglu) return 4;
+    if (g_gemm_dbg & 1024) return 3;
+    const int64_t t256 = m_tiles * ((N + 255) / 256), t192 = m_tiles * ((N + 191) / 192);
+    const double e256 = (double)t256 / (256.0 * ((t256 + 255) / 256));
+    const double e192 = 0.92 * (double)t192 / (256.0 * ((t192 + 255) / 256));
+    return e192 > e256 * 1.05 ? 3 : 4;
+}
+
+// 256-row tiles need enough tiles to fill most of the 256 CUs; bit 1 of the debug word forces the 128x128 kernel, bit 2 the 256-row one
 static bool use_tile256(int M, int N, int K) {
     if (K < 128) return false;
     if (g_gemm_dbg & 2) return false;
     if (g_gemm_dbg & 4) return true;
     // measured crossover on MI355X (tools/bench_ops.py mid): 176 tiles (M=2732, N=4096) 1.15-1.4x faster than the 128x128 kernel,
     // 112 tiles (M=1552) 1.3-1.4x slower
-    const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    const int64_t mt = (M + 255) / 256;
+    const int64_t tiles = mt * ((N + (tile_ni(mt, N, false) == 3 ? 191 : 255)) / (tile_ni(mt, N, false) == 3 ? 192 : 256));
     return tiles >= 144;
 }
 
@@ -892,7 +923,8 @@ static int skinny_rows(int nblocks, int mb, int split_k, bool swiglu) {
 // one launch of the 256x256 kernel over the m-tiles of all groups (M_total = rows over all groups, for the live profile)
 static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_total, const Epilogue& ep, hipStream_t s) {
     const int N = a->N, K = a->K;
-    const int tiles_m = grp.tile_start[grp.n], tiles_n = (N + 255) / 256;
+    const int ni = tile_ni(grp.tile_start[grp.n], N, a->swiglu != 0);
+    const int tiles_m = grp.tile_start[grp.n], tiles_n = ni == 3 ? (N + 191) / 192 : (N + 255) / 256;
     static bool attr256_set = false;
     const int lds = 2 * G2_STAGE;
     if (!attr256_set) {
@@ -902,6 +934,7 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr256_set = true;
     }
     ProfRec rec{};
@@ -917,7 +950,9 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
 #define G2_LAUNCH(A) gemm_tile256_kernel<A><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n)
     // debug word bits 3-5: timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1;
     // 40 = correct results + clock stamps around the main loop (mc_gemm_clock_read)
-    switch ((g_gemm_dbg >> 3) & 7) {
+    if (ni == 3) {
+        gemm_tile256_kernel<0, 3><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n);
+    } else switch ((g_gemm_dbg >> 3) & 7) {
         case 1: G2_LAUNCH(1); break;
         case 2: G2_LAUNCH(2); break;
         case 3: G2_LAUNCH(3); break;

@@ -292,6 +292,17 @@ class MultimodalTrainStep:
     # ------------------------------------------------------------------ one step
     def forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
         """Returns the loss (fp32 scalar tensor); gradients of this rank's batch are left in self.G."""
+        from .. import _lib
+        if self._wstream is None:
+            return self._forward_backward(input_ids, labels, modal_inputs, attention_mask)
+        # the side stream fills the CUs an under-filled base GEMM leaves idle; narrower tiles would compete with it for them
+        _lib.check(_lib.lib().mc_gemm_set_option(b"tile192", 0), "mc_gemm_set_option")
+        try:
+            return self._forward_backward(input_ids, labels, modal_inputs, attention_mask)
+        finally:
+            _lib.lib().mc_gemm_set_option(b"tile192", 1)
+
+    def _forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
         model, cfg, dev = self.model, self.cfg, self.dev
         Hd, I, Hh, D, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
         HD = Hh * D

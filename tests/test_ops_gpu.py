@@ -60,7 +60,7 @@ def test_gemm_matches_fp32_matmul(ops, M, N, K):
     close_bf16(got, ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 192), (257, 4096, 1024), (2000, 1028, 4096), (3000, 4096, 11008)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 192), (257, 4096, 1024), (2000, 1028, 4096), (3000, 4096, 11008), (2728, 4096, 4096)])
 def test_gemm_tile256_kernel_bit_identical_to_tile128(ops, M, N, K):
     """The 256x256 ping-pong kernel (forced through the debug word) accumulates every output in the same k order as the 128x128
     kernel: outputs must be bit-identical, and both within bf16 rounding of the fp32 matmul (edge tiles in M and N, K tails)."""
@@ -74,12 +74,15 @@ def test_gemm_tile256_kernel_bit_identical_to_tile128(ops, M, N, K):
     try:
         L.mc_gemm_debug(2)
         small = ops.linear(x, pw, act="gelu", residual=r)
-        L.mc_gemm_debug(4)
+        L.mc_gemm_debug(4 + 2048)                           # 256-row kernel, 256-column tiles
         big = ops.linear(x, pw, act="gelu", residual=r)
         big32 = ops.linear(x, pw, out_f32=True)
+        L.mc_gemm_debug(4 + 1024)                           # 256-row kernel, 192-column tiles
+        wide192 = ops.linear(x, pw, act="gelu", residual=r)
     finally:
         L.mc_gemm_debug(0)
     assert torch.equal(small, big)
+    assert torch.equal(small, wide192)
     close_bf16(big, F.gelu(x.float() @ w.float().t() + b.float()) + r.float())
     ref = x.float() @ w.float().t() + b.float()
     assert (big32.cpu() - ref.cpu()).abs().max().item() <= 1e-3 * ref.abs().max().item()

@@ -141,6 +141,17 @@ def main():
                 res[name] = best
             fl = 2.0 * M * N * K
             print(f"gemm M={M} N={N} K={K}: " + "   ".join(f"{k} {v*1e3:7.1f} us {fl/v/1e9:7.0f} TFLOP/s" for k, v in res.items()))
+    if "t192" in which:
+        # 256-column vs 192-column tiles of the large-M kernel on the under-filled shapes of the finetune step / small-batch prefill
+        from modelcompose_amd import _lib
+        L = _lib.lib()
+        for rep in range(2):
+            for d, nm in ((4 + 2048, "256-column tiles"), (4 + 1024, "192-column tiles"), (0, "library choice")):
+                L.mc_gemm_debug(d)
+                print(nm)
+                for (M, N, K) in ((2728, 4096, 4096), (2728, 4096, 11008), (2728, 4096, 22016), (2728, 4096, 12288), (2728, 11008, 4096), (9232, 1024, 4096), (2792, 4096, 4096)):
+                    gemm_case(M, N, K, rot=1)
+        L.mc_gemm_debug(0)
     if "clock" in which:
         # shader clock the chip holds inside the 256x256 kernel's main loop after >= 2 s of back-to-back launches on random data
         import ctypes as C
