@@ -141,6 +141,16 @@ def main():
                 res[name] = best
             fl = 2.0 * M * N * K
             print(f"gemm M={M} N={N} K={K}: " + "   ".join(f"{k} {v*1e3:7.1f} us {fl/v/1e9:7.0f} TFLOP/s" for k, v in res.items()))
+    if "lb" in which:
+        from modelcompose_amd import _lib
+        L = _lib.lib()
+        for rep in range(3):
+            for d, nm in ((4 + 2048, "launch_bounds(512,2): 128 VGPRs + AGPRs"), (4 + 2048 + 48, "launch_bounds(512,1): 224 VGPRs")):
+                L.mc_gemm_debug(d)
+                print(nm)
+                for (M, N, K) in ((10928, 12288, 4096), (10928, 4096, 4096), (10928, 22016, 4096), (10928, 4096, 11008), (8192, 8192, 8192)):
+                    gemm_case(M, N, K, rot=1)
+        L.mc_gemm_debug(0)
     if "t192" in which:
         # 256-column vs 192-column tiles of the large-M kernel on the under-filled shapes of the finetune step / small-batch prefill
         from modelcompose_amd import _lib
