@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+# MC_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL init, barriers, gathers, the MAX all-reduce of the timing) in a world of one
+# process: the only way to exercise it on a single-GPU box
+DIST = os.environ.get("MC_BENCH_FORCE_DIST", "") == "1"
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0                      # spec HBM3E peak
 
@@ -98,7 +101,7 @@ def train_main(args, world, rank, local):
     meta["lora_dropout"] = 0.0
     sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
     model = build_from_state_dict(meta, sd, device=dev)
-    st = MultimodalTrainStep(model, lr=2e-4, overlap_wgrad=not args.no_overlap)
+    st = MultimodalTrainStep(model, lr=2e-4, overlap_wgrad=not args.no_overlap, force_exchange=DIST)
     del sd
     model._raw = {}
     torch.cuda.empty_cache()
@@ -110,7 +113,7 @@ def train_main(args, world, rank, local):
     pixels = torch.randn(B, 3, 336, 336, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
 
     def barrier():
-        if world > 1:
+        if DIST or world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -123,7 +126,7 @@ def train_main(args, world, rank, local):
         loss = st.step(ids, labels, {"vision": pixels})
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if DIST or world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -136,7 +139,7 @@ def train_main(args, world, rank, local):
                                    f"batch {B} per GPU, 683-token sequences, fwd+bwd+all-reduce+AdamW", "per_gpu_batch": B,
                        "layers": args.layers, "parallelism": f"ddp{world}", "trainable_params": int(st.n_params),
                        "final_loss": float(loss.item())}}), flush=True)
-    if world > 1:
+    if DIST or world > 1:
         torch.distributed.destroy_process_group()
 
 
@@ -176,10 +179,10 @@ def mcub4_main(args, world, rank, local):
 
     def step():
         out = model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True)
-        return gather_ids(out[:, ids.shape[1]:], world)
+        return gather_ids(out[:, ids.shape[1]:], world, force=DIST)
 
     def barrier():
-        if world > 1:
+        if DIST or world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -191,7 +194,7 @@ def mcub4_main(args, world, rank, local):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if DIST or world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -209,7 +212,7 @@ def mcub4_main(args, world, rank, local):
                        "layers": args.layers, "parallelism": f"dp{world}",
                        "spliced_length": int(ids.shape[1] - 4 + sum(f.shape[1] for f in feats.values())),
                        "block_tokens": {m: int(f.shape[1]) for m, f in feats.items()}, "ids_shape": list(out.shape)}}), flush=True)
-    if world > 1:
+    if DIST or world > 1:
         torch.distributed.destroy_process_group()
 
 
@@ -220,7 +223,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
-    if world > 1:
+    if DIST or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -254,10 +257,10 @@ def main():
 
     def step():
         out = model.generate(ids, modal_inputs=modal_inputs, max_new_tokens=args.new_tokens, ignore_eos=True)
-        return gather_ids(out[:, ids.shape[1]:], world)
+        return gather_ids(out[:, ids.shape[1]:], world, force=DIST)
 
     def barrier():
-        if world > 1:
+        if DIST or world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -276,12 +279,12 @@ def main():
     L.mc_gemm_profile_read(C.byref(ms), C.byref(fl), C.byref(n))
     alg_bytes = C.c_double(0)
     L.mc_gemm_profile_read_bytes(C.byref(alg_bytes))
-    if world > 1:
+    if DIST or world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
-        if world > 1:
+        if DIST or world > 1:
             torch.distributed.destroy_process_group()
         return
     value = world * B * args.steps / dt
@@ -312,7 +315,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.new_tokens)
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if DIST or world > 1:
         torch.distributed.destroy_process_group()
 
 

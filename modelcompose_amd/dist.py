@@ -20,9 +20,10 @@ def get_chunk(lst: Sequence, n: int, k: int):
     return split_list(lst, n)[k]
 
 
-def gather_ids(ids: torch.Tensor, world_size: int) -> torch.Tensor:
-    """All ranks' generated ids [B, T] -> [world*B, T], rank-major = the order of the reference's `cat` of chunk files."""
-    if world_size == 1:
+def gather_ids(ids: torch.Tensor, world_size: int, force: bool = False) -> torch.Tensor:
+    """All ranks' generated ids [B, T] -> [world*B, T], rank-major = the order of the reference's `cat` of chunk files.
+    force: run the collective even in a world of one (exercises the RCCL path on a single GPU)."""
+    if world_size == 1 and not force:
         return ids
     import torch.distributed as dist
     out = torch.empty((world_size * ids.shape[0],) + tuple(ids.shape[1:]), dtype=ids.dtype, device=ids.device)

@@ -51,7 +51,7 @@ class _Param:
 
 class MultimodalTrainStep:
     def __init__(self, model: MultimodalLlamaForCausalLM, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 bucket_layers: int = 4, process_group=None, overlap_wgrad: bool = True):
+                 bucket_layers: int = 4, process_group=None, overlap_wgrad: bool = True, force_exchange: bool = False):
         cfg = model.config
         if float(getattr(cfg, "lora_dropout", 0.0) or 0.0) != 0.0:
             raise NotImplementedError("lora_dropout > 0 (nn.Dropout on the LoRA input, multimodal_llama.py:133) is not implemented; set it to 0")
@@ -77,6 +77,8 @@ class MultimodalTrainStep:
                 self.world = dist.get_world_size(process_group)
         except Exception:
             self.world = 1
+        # force_exchange: run the bucketed all-reduce even in a world of one process (exercises the RCCL path on a single GPU)
+        self._exchange = self.world > 1 or (force_exchange and torch.distributed.is_available() and torch.distributed.is_initialized())
         self.step_count = 0
         # weight-gradient (TN) GEMMs run on a second HIP stream: they only feed the gradient buffer, so they overlap the main stream's
         # input-gradient GEMMs, which at B*L = 2728 rows fill only 176 of the 256 CUs
@@ -399,7 +401,7 @@ class MultimodalTrainStep:
             self._lora_bwd_end(dT, ev, dqs, a["n1"], dn1, l, "attn_in", saved)
             dx = ops.rmsnorm_bwd(a["x"], W["g_in"], dn1, eps, dres=dx1)
             acts[l] = None
-            if self.world > 1:
+            if self._exchange:
                 for (ready, lo, hi) in self._buckets:
                     if ready == l:
                         self._join_wgrad()
@@ -407,7 +409,7 @@ class MultimodalTrainStep:
         # ---- spliced feature blocks -> prefix / suffix tokens and the projectors
         self._backward_features(dx, plan, feats, saved)
         self._join_wgrad()
-        if self.world > 1:
+        if self._exchange:
             for (ready, lo, hi) in self._buckets:
                 if ready == -1:
                     handles.append(self._allreduce_async(lo, hi))
