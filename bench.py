@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pipeline", action="store_true", help="generate workload: two generation pipelines on two HIP streams (decode of batch i "
+                    "beside the prefill of batch i+1, MultimodalLlamaForCausalLM.generate_pipelined); every step still is one full batch")
     ap.add_argument("--no-overlap", action="store_true", help="debug only (train): weight-gradient / rank-projection GEMMs on the main stream")
     ap.add_argument("--gemm-debug", type=int, default=0, help="debug only: mc_gemm_debug word (A/B of kernel variants; e.g. 2048 = no 192-column tiles)")
     ap.add_argument("--workload", default="generate", choices=["generate", "train", "mcub4", "iav"],
@@ -264,14 +266,20 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n):
+        if not args.pipeline:
+            for _ in range(n):
+                step()
+            return
+        for out in model.generate_pipelined(((ids, modal_inputs) for _ in range(n)), max_new_tokens=args.new_tokens, ignore_eos=True):
+            gather_ids(out[:, ids.shape[1]:], world, force=DIST)
+
+    run_steps(args.warmup)
     L = _lib.lib()
     barrier()
     L.mc_gemm_profile_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     L.mc_gemm_profile_enable(0)
@@ -304,7 +312,7 @@ def main():
         "config": {"workload": "configs[1]: vision-only composed Vicuna-7B (LocalLoRA r128: default+vision adapters), "
                                f"batch {B} synthetic 336px images per GPU, 683-token spliced prompt, {args.new_tokens} greedy tokens",
                    "per_gpu_batch": B, "new_tokens": args.new_tokens, "layers": args.layers, "parallelism": f"dp{world}",
-                   "decode_graph": not args.no_graph},
+                   "decode_graph": not args.no_graph, "pipelined": bool(args.pipeline)},
         "roofline": {"bound": "mfma", "kernel": "gemm_tile256_kernel", "achieved": round(achieved, 2),
                      "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                      "traffic": traffic, "launches": int(n.value),

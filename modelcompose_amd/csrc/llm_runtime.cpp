@@ -35,8 +35,13 @@ struct Llm {
     const float* sin_t = nullptr;
     bool weights_set = false;
     // decode graph cache
-    hipGraphExec_t graph_exec = nullptr;
-    struct Key { int B, Smax; const void *kc, *vc, *ws, *state, *next_ids, *out_ids, *logits; int64_t ld_out; int sample, top_k; float temp, top_p; } gkey{};
+    // decode-step graphs, keyed by every pointer / parameter baked into the captured launches; a few entries so that two generation
+    // pipelines (their own KV cache, workspace and state each) can alternate without re-capturing
+    struct Key { int B, Smax; const void *kc, *vc, *ws, *state, *next_ids, *out_ids, *logits; int64_t ld_out; int sample, top_k; float temp, top_p; };
+    static constexpr int kGraphs = 4;
+    hipGraphExec_t graph_exec[kGraphs] = {nullptr, nullptr, nullptr, nullptr};
+    Key gkey[kGraphs] = {};
+    int graph_next = 0;                      // round-robin victim
     bool use_graph = true;
     // next-token rule: greedy arg-max, or temperature / top-k / top-p sampling (seed: 2 x u32 at state[4B+1] on the device)
     bool do_sample = false;
@@ -184,7 +189,8 @@ extern "C" int mc_llm_create(const mc_llm_config* cfg, void** handle) {
 extern "C" int mc_llm_destroy(void* handle) {
     Llm* m = (Llm*)handle;
     if (!m) return 0;
-    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    for (int i = 0; i < Llm::kGraphs; ++i)
+        if (m->graph_exec[i]) (void)hipGraphExecDestroy(m->graph_exec[i]);
     delete m;
     return 0;
 }
@@ -203,7 +209,8 @@ extern "C" int mc_llm_set_weights(void* handle, const void* const* layer_w, cons
     m->final_norm = final_norm; m->lm_head = lm_head_packed; m->embed = embed_table;
     m->cos_t = cos_table; m->sin_t = sin_table;
     m->weights_set = true;
-    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    for (int i = 0; i < Llm::kGraphs; ++i)
+        if (m->graph_exec[i]) { (void)hipGraphExecDestroy(m->graph_exec[i]); m->graph_exec[i] = nullptr; }
     return 0;
 }
 
@@ -320,25 +327,30 @@ extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids
         key.out_ids = out_ids; key.logits = nullptr; key.ld_out = ld_out;
         key.sample = m->do_sample; key.top_k = m->do_sample ? m->top_k : 0;
         key.temp = m->do_sample ? m->temperature : 0.f; key.top_p = m->do_sample ? m->top_p : 0.f;
-        if (!m->graph_exec || memcmp(&key, &m->gkey, sizeof(key)) != 0) {
-            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+        int slot = -1;
+        for (int i = 0; i < Llm::kGraphs; ++i)
+            if (m->graph_exec[i] && memcmp(&key, &m->gkey[i], sizeof(key)) == 0) { slot = i; break; }
+        if (slot < 0) {
+            slot = m->graph_next;
+            m->graph_next = (m->graph_next + 1) % Llm::kGraphs;
+            if (m->graph_exec[slot]) { (void)hipGraphExecDestroy(m->graph_exec[slot]); m->graph_exec[slot] = nullptr; }
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 int rc = decode_one_step(m, B, next_ids, out_ids, ld_out, state, k_cache, v_cache, Smax, w, attn_ws, nsplit, nullptr, stream);
                 e = hipStreamEndCapture(s, &graph);
                 if (rc == 0 && e == hipSuccess && graph) {
-                    e = hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0);
-                    if (e != hipSuccess) m->graph_exec = nullptr;
+                    e = hipGraphInstantiate(&m->graph_exec[slot], graph, nullptr, nullptr, 0);
+                    if (e != hipSuccess) m->graph_exec[slot] = nullptr;
                 }
                 if (graph) (void)hipGraphDestroy(graph);
             }
             (void)hipGetLastError();
-            if (m->graph_exec) m->gkey = key;
+            if (m->graph_exec[slot]) m->gkey[slot] = key;
         }
-        if (m->graph_exec) {
+        if (m->graph_exec[slot]) {
             for (int i = 0; i < n_steps; ++i) {
-                hipError_t e = hipGraphLaunch(m->graph_exec, s);
+                hipError_t e = hipGraphLaunch(m->graph_exec[slot], s);
                 if (e != hipSuccess) { mc_set_error("mc_llm_decode: hipGraphLaunch: %s", hipGetErrorString(e)); return 2; }
             }
             return 0;

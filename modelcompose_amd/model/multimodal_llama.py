@@ -336,23 +336,25 @@ class MultimodalLlamaForCausalLM:
         return None, am, past_key_values, emb.view(B, Lmax, -1), lab, mam
 
     # ------------------------------------------------------------------ device forward
-    def _buffers(self, B, Smax, M, Lq):
+    def _buffers(self, B, Smax, M, Lq, slot=0):
+        """KV cache + workspace of generation pipeline `slot` (generate_pipelined alternates two slots; everything a captured decode
+        graph points at lives here, so every slot keeps replaying its own graph)."""
         cfg, dev = self.config, self.device
-        key = ("kv", B, Smax)
+        key = ("kv", slot, B, Smax)
         if key not in self._cache:
-            for k in [k for k in self._cache if k[0] == "kv"]:
+            for k in [k for k in self._cache if k[0] == "kv" and k[1] == slot]:
                 del self._cache[k]
             shape = (cfg.num_hidden_layers, B, cfg.num_key_value_heads, Smax, cfg.head_dim)
             self._cache[key] = (torch.zeros(shape, dtype=BF16, device=dev), torch.zeros(shape, dtype=BF16, device=dev))
         nbytes = C.c_int64(0)
         _lib.check(_lib.lib().mc_llm_workspace_bytes(self._handle, M, B, Lq, C.byref(nbytes)), "mc_llm_workspace_bytes")
-        ws = self._cache.get(("ws",))
+        ws = self._cache.get(("ws", slot))
         if ws is None or ws.numel() < nbytes.value:
             ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-            self._cache[("ws",)] = ws
+            self._cache[("ws", slot)] = ws
         return self._cache[key], ws
 
-    def _prefill(self, plan: SplicePlan, feats, max_new_tokens: int, want_hidden=False, want_logits=True):
+    def _prefill(self, plan: SplicePlan, feats, max_new_tokens: int, want_hidden=False, want_logits=True, slot=0):
         if getattr(self, "_dirty", True):
             self.finalize()
         cfg, dev = self.config, self.device
@@ -362,7 +364,7 @@ class MultimodalLlamaForCausalLM:
         if Lmax + max_new_tokens > cfg.max_position_embeddings:
             raise ValueError(f"sequence length {Lmax}+{max_new_tokens} exceeds max_position_embeddings {cfg.max_position_embeddings}")
         Smax = ops.ceil_to(Lmax + max_new_tokens, 64)
-        (kc, vc), ws = self._buffers(B, Smax, M, Lmax)
+        (kc, vc), ws = self._buffers(B, Smax, M, Lmax, slot)
         x = torch.empty(M, cfg.hidden_size, dtype=BF16, device=dev)
         self._gather_rows(plan, feats, lay.order_b, lay.order_t, x)
         i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
@@ -370,7 +372,10 @@ class MultimodalLlamaForCausalLM:
         out_map, kv_lens, last_rows = i32(lay.out_map), i32(plan.lens), i32(lay.last_rows)
         hidden = torch.empty(M, cfg.hidden_size, dtype=BF16, device=dev) if want_hidden else None
         logits = torch.empty(B, cfg.vocab_size, dtype=torch.float32, device=dev) if want_logits else None
-        next_ids = torch.empty(B, dtype=torch.int64, device=dev)
+        next_ids = self._cache.get(("next_ids", slot, B))          # persistent: the decode graph of this slot points at it
+        if next_ids is None:
+            next_ids = torch.empty(B, dtype=torch.int64, device=dev)
+            self._cache[("next_ids", slot, B)] = next_ids
         gs = np.ascontiguousarray(lay.group_start, dtype=np.int32)
         ga = np.ascontiguousarray(lay.group_adapter, dtype=np.int32)
         _lib.check(_lib.lib().mc_llm_prefill(self._handle, _ptr(x), M, len(ga), gs.ctypes.data_as(C.c_void_p), ga.ctypes.data_as(C.c_void_p),
@@ -378,15 +383,16 @@ class MultimodalLlamaForCausalLM:
                                              _ptr(kc), _ptr(vc), Smax, _ptr(ws), _ptr(hidden), _ptr(logits), _ptr(next_ids), _stream()),
                    "mc_llm_prefill")
         return dict(plan=plan, layout=lay, kc=kc, vc=vc, ws=ws, Smax=Smax, logits=logits, next_ids=next_ids, hidden=hidden,
-                    kv_lens=kv_lens, out_map=out_map)
+                    kv_lens=kv_lens, out_map=out_map, slot=slot)
 
     def _decode(self, st, n_steps: int, out_ids: torch.Tensor, step0: int, want_logits=False):
         B = st["plan"].B
         dev = self.device
-        state = self._cache.get(("state", B))
+        slot = st.get("slot", 0)
+        state = self._cache.get(("state", slot, B))
         if state is None:
             state = torch.zeros(4 * B + 4, dtype=torch.int32, device=dev)
-            self._cache[("state", B)] = state
+            self._cache[("state", slot, B)] = state
         L = _lib.lib()
         _lib.check(L.mc_decode_state_init(_ptr(state), _ptr(st["kv_lens"]), B, step0, _stream()), "mc_decode_state_init")
         smp = st.get("sampling")
@@ -435,7 +441,8 @@ class MultimodalLlamaForCausalLM:
 
     @torch.no_grad()
     def generate(self, input_ids=None, modal_inputs=None, do_sample=False, temperature=None, top_p=None, num_beams=1,
-                 max_new_tokens=128, use_cache=True, attention_mask=None, ignore_eos=False, return_step_logits=False, **kw):
+                 max_new_tokens=128, use_cache=True, attention_mask=None, ignore_eos=False, return_step_logits=False, slot=0,
+                 prefill_done=None, **kw):
         """Greedy or sampled generation (model_multimodal_qa_loader.py:94-102).  Returns LongTensor (B, L_text + n_new): the text-length
         prompt followed by the new ids, rows that hit EOS are padded with pad_token_id (transformers greedy_search / sample).
         do_sample=True applies transformers 4.31's warpers in their order (temperature, top_k - GenerationConfig default 50, pass
@@ -466,9 +473,16 @@ class MultimodalLlamaForCausalLM:
         modal_inputs = modal_inputs or {}
         feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
         plan = self._plan(input_ids, attention_mask, None, modal_inputs, feats)
-        st = self._prefill(plan, feats, max_new_tokens, want_logits=return_step_logits or sampling is not None)
+        st = self._prefill(plan, feats, max_new_tokens, want_logits=return_step_logits or sampling is not None, slot=slot)
+        if prefill_done is not None:
+            prefill_done.record()                                  # generate_pipelined: the other pipeline's prefill may start now
         B = plan.B
-        out = torch.zeros(B, max_new_tokens, dtype=torch.int64, device=self.device)
+        out = self._cache.get(("out_ids", slot, B, max_new_tokens))   # persistent for the same reason as next_ids (the result is a copy)
+        if out is None:
+            out = torch.zeros(B, max_new_tokens, dtype=torch.int64, device=self.device)
+            self._cache[("out_ids", slot, B, max_new_tokens)] = out
+        else:
+            out.zero_()
         if sampling is not None:                                  # first token: same rule, RNG counter -1 (decode steps count from 0)
             st["next_ids"].copy_(ops.sample_step(st["logits"], sampling[0], sampling[1], sampling[2], seed=sampling[3], step=-1))
             st["sampling"] = sampling
@@ -531,6 +545,39 @@ class MultimodalLlamaForCausalLM:
         if return_step_logits:
             return res, torch.cat(step_logits, 0).transpose(0, 1)[:, :new.shape[1]]
         return res
+
+    @torch.no_grad()
+    def generate_pipelined(self, batches, **kw):
+        """Throughput mode for a stream of batches (the eval loop): yields generate()'s result for every (input_ids, modal_inputs) pair of
+        `batches`, in order.  Two generation pipelines (own KV cache, workspace, decode state and graph each) alternate on two HIP
+        streams: the decode of batch i - HBM-bound, the MFMA pipes idle - runs beside the encoders + prefill of batch i+1 - MFMA-bound,
+        HBM idle.  The prefill of batch i+1 is ordered after the prefill of batch i (event), so the two never compete for the matrix
+        units.  Same tokens as sequential generate() calls; host syncs inside generate() (EOS checks without ignore_eos) shorten the
+        overlap but do not break it."""
+        cur = torch.cuda.current_stream()
+        streams = self._cache.get(("pipe_streams",))
+        if streams is None:
+            streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+            self._cache[("pipe_streams",)] = streams
+        pending = None
+        last_prefill = None
+        for i, (input_ids, modal_inputs) in enumerate(batches):
+            slot = i & 1
+            s = streams[slot]
+            s.wait_stream(cur)                                     # inputs produced on the caller's stream
+            if last_prefill is not None:
+                s.wait_event(last_prefill)
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(s):
+                out = self.generate(input_ids, modal_inputs=modal_inputs, slot=slot, prefill_done=ev, **kw)
+            last_prefill = ev
+            if pending is not None:
+                pending[1].synchronize()
+                yield pending[0]
+            pending = (out, s)
+        if pending is not None:
+            pending[1].synchronize()
+            yield pending[0]
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):
         """multimodal_llama.py:747-767 (kept for API parity; generate() does not call it)."""

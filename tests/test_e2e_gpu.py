@@ -294,3 +294,25 @@ def test_eval_model_driver_writes_the_answers_file_and_shards_by_chunk(tmp_path,
     # and chunk 1 structurally
     assert [r["text"] for r in part0] == [r["text"] for r in full[:2]]
     assert [r["question_id"] for r in part0 + part1] == [r["question_id"] for r in full]
+
+
+def test_generate_pipelined_equals_sequential_generate(g4_model):
+    """Two alternating generation pipelines on two streams produce exactly the tokens of sequential generate() calls, batch after
+    batch (different prompts / images per batch, greedy and sampled, with and without EOS handling)."""
+    model, a, meta, sd = g4_model
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for i in range(5):
+        ids = a["input_ids"].clone()
+        ids[:, 1:4] = torch.randint(3, 100, (ids.shape[0], 3), generator=g)
+        px = (a["pixels"] + 0.1 * i).cuda()
+        batches.append((ids.cuda(), {"vision": px}))
+    for kw in (dict(max_new_tokens=6, ignore_eos=True), dict(max_new_tokens=6), dict(max_new_tokens=5, ignore_eos=True, do_sample=True, temperature=1.3, seed=7)):
+        seq = [model.generate(ids, modal_inputs=mi, **kw) for ids, mi in batches]
+        pip = list(model.generate_pipelined(iter(batches), **kw))
+        assert len(pip) == len(seq)
+        for x, y in zip(seq, pip):
+            assert torch.equal(x, y)
+    # and the plain path still works afterwards (slot 0 buffers reused)
+    again = model.generate(batches[0][0], modal_inputs=batches[0][1], max_new_tokens=5, ignore_eos=True, do_sample=True, temperature=1.3, seed=7)
+    assert torch.equal(again, seq[0])
