@@ -4,7 +4,8 @@ Mirror of modelcompose/eval/model_multimodal_qa_loader.py:24-154 with the same C
 unchanged: one process per GPU, rank k evaluating chunk k (the reference shards by process and concatenates the answer files).
 
 Differences, all opt-in: `--batch-size B` runs B questions per generate() call (the reference is fixed at 1; prompts in a batch are
-right-padded by the collator and spliced per row); `--max-new-tokens` (reference: constant 128); answer ids come from a counter-free
+right-padded by the collator and spliced per row); `--pipeline` overlaps the decode of one batch with the prefill of the next;
+`--max-new-tokens` (reference: constant 128); answer ids come from a counter-free
 uuid4 hex prefix instead of shortuuid (absent from this image)."""
 from __future__ import annotations
 
@@ -58,15 +59,28 @@ def eval_model(args, loaded=None):
     conv = conv_templates[args.conv_mode]
     stop_str = conv.sep if conv.sep_style != SeparatorStyle.TWO else conv.sep2
     n_done = 0
-    with open(answers_file, "w") as ans_file:
+    gen_kw = dict(do_sample=args.temperature > 0, temperature=args.temperature, top_p=args.top_p, num_beams=args.num_beams,
+                  max_new_tokens=getattr(args, "max_new_tokens", 128), use_cache=True)
+    meta = []                                                       # prompt length of every batch handed to the model, in order
+
+    def batches():
         for batch in loader:
             input_ids = batch["input_ids"].to(model.device)
             modal_inputs = _to_device(batch["modal_inputs"], model.device, torch.bfloat16) if "modal_inputs" in batch else {}
-            kw = {"attention_mask": batch["attention_mask"].to(model.device)} if input_ids.shape[0] > 1 else {}
-            with torch.inference_mode():
-                output_ids = model.generate(input_ids, modal_inputs=modal_inputs, do_sample=args.temperature > 0, temperature=args.temperature,
-                                            top_p=args.top_p, num_beams=args.num_beams, max_new_tokens=getattr(args, "max_new_tokens", 128),
-                                            use_cache=True, **kw)
+            meta.append(input_ids)
+            yield input_ids, modal_inputs
+
+    def results():
+        if getattr(args, "pipeline", False):                        # decode of batch i beside the prefill of batch i+1
+            yield from model.generate_pipelined(batches(), **gen_kw)
+        else:
+            for input_ids, modal_inputs in batches():
+                with torch.inference_mode():
+                    yield model.generate(input_ids, modal_inputs=modal_inputs, **gen_kw)
+
+    with open(answers_file, "w") as ans_file:
+        for k, output_ids in enumerate(results()):
+            input_ids = meta[k]
             n_in = input_ids.shape[1]
             if int((input_ids != output_ids[:, :n_in]).sum().item()) > 0:
                 print("[Warning] output_ids are not the same as the input_ids")
@@ -99,6 +113,7 @@ def parse_args(argv=None):
     p.add_argument("--no_add_image_token", action="store_true")
     p.add_argument("--batch-size", type=int, default=1)
     p.add_argument("--max-new-tokens", type=int, default=128)
+    p.add_argument("--pipeline", action="store_true", help="overlap the decode of one batch with the prefill of the next (generate_pipelined)")
     args = p.parse_args(argv)
     if args.model_base == "" or args.model_base == "None":                                  # :141-142
         args.model_base = None

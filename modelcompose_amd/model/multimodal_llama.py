@@ -345,12 +345,14 @@ class MultimodalLlamaForCausalLM:
             for k in [k for k in self._cache if k[0] == "kv" and k[1] == slot]:
                 del self._cache[k]
             shape = (cfg.num_hidden_layers, B, cfg.num_key_value_heads, Smax, cfg.head_dim)
-            self._cache[key] = (torch.zeros(shape, dtype=BF16, device=dev), torch.zeros(shape, dtype=BF16, device=dev))
+            with torch.inference_mode(False):                      # cached buffers outlive the call: never inference tensors
+                self._cache[key] = (torch.zeros(shape, dtype=BF16, device=dev), torch.zeros(shape, dtype=BF16, device=dev))
         nbytes = C.c_int64(0)
         _lib.check(_lib.lib().mc_llm_workspace_bytes(self._handle, M, B, Lq, C.byref(nbytes)), "mc_llm_workspace_bytes")
         ws = self._cache.get(("ws", slot))
         if ws is None or ws.numel() < nbytes.value:
-            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            with torch.inference_mode(False):
+                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
             self._cache[("ws", slot)] = ws
         return self._cache[key], ws
 
@@ -374,7 +376,8 @@ class MultimodalLlamaForCausalLM:
         logits = torch.empty(B, cfg.vocab_size, dtype=torch.float32, device=dev) if want_logits else None
         next_ids = self._cache.get(("next_ids", slot, B))          # persistent: the decode graph of this slot points at it
         if next_ids is None:
-            next_ids = torch.empty(B, dtype=torch.int64, device=dev)
+            with torch.inference_mode(False):
+                next_ids = torch.empty(B, dtype=torch.int64, device=dev)
             self._cache[("next_ids", slot, B)] = next_ids
         gs = np.ascontiguousarray(lay.group_start, dtype=np.int32)
         ga = np.ascontiguousarray(lay.group_adapter, dtype=np.int32)
@@ -391,7 +394,8 @@ class MultimodalLlamaForCausalLM:
         slot = st.get("slot", 0)
         state = self._cache.get(("state", slot, B))
         if state is None:
-            state = torch.zeros(4 * B + 4, dtype=torch.int32, device=dev)
+            with torch.inference_mode(False):
+                state = torch.zeros(4 * B + 4, dtype=torch.int32, device=dev)
             self._cache[("state", slot, B)] = state
         L = _lib.lib()
         _lib.check(L.mc_decode_state_init(_ptr(state), _ptr(st["kv_lens"]), B, step0, _stream()), "mc_decode_state_init")
@@ -479,7 +483,8 @@ class MultimodalLlamaForCausalLM:
         B = plan.B
         out = self._cache.get(("out_ids", slot, B, max_new_tokens))   # persistent for the same reason as next_ids (the result is a copy)
         if out is None:
-            out = torch.zeros(B, max_new_tokens, dtype=torch.int64, device=self.device)
+            with torch.inference_mode(False):
+                out = torch.zeros(B, max_new_tokens, dtype=torch.int64, device=self.device)
             self._cache[("out_ids", slot, B, max_new_tokens)] = out
         else:
             out.zero_()

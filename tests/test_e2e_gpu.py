@@ -277,16 +277,19 @@ def test_eval_model_driver_writes_the_answers_file_and_shards_by_chunk(tmp_path,
     json.dump(qs, open(qfile, "w"))
     procs = {"vision": HipCLIPImageProcessor(size=28, crop_size=28)}
 
-    def run(num_chunks, chunk_idx, out):
+    def run(num_chunks, chunk_idx, out, pipeline=False):
         tok = ToyTokenizer(True, model_max_length=256)
         args = SimpleNamespace(model_path="/ckpts/multimodal-tiny", model_base=None, question_file=str(qfile), answers_file=str(out), conv_mode="v1",
-                               num_chunks=num_chunks, chunk_idx=chunk_idx, temperature=0.0, top_p=None, num_beams=1, batch_size=1, max_new_tokens=5)
+                               num_chunks=num_chunks, chunk_idx=chunk_idx, temperature=0.0, top_p=None, num_beams=1, batch_size=1, max_new_tokens=5,
+                               pipeline=pipeline)
         n = eval_model(args, loaded=(tok, model, procs, 2048))
         return n, [json.loads(l) for l in open(out)]
 
     n, full = run(1, 0, tmp_path / "all.jsonl")
     assert n == 4 and [r["question_id"] for r in full] == ["q0", "q1", "q2", "q3"]
     assert all(r["model_id"] == "multimodal-tiny" and r["prompt"] == q["conversations"][0]["value"] for r, q in zip(full, qs))
+    np_, piped = run(1, 0, tmp_path / "piped.jsonl", pipeline=True)
+    assert np_ == 4 and [(r["question_id"], r["text"]) for r in piped] == [(r["question_id"], r["text"]) for r in full]
     n0, part0 = run(2, 0, tmp_path / "c0.jsonl")
     n1, part1 = run(2, 1, tmp_path / "c1.jsonl")
     assert n0 == 2 and n1 == 2
