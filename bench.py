@@ -320,6 +320,20 @@ def main():
                      "avg_flops_per_launch": fl.value / max(n.value, 1),
                      "avg_algorithmic_bytes_per_launch": alg_bytes.value / max(n.value, 1)},
     }
+    if world == 1 and not args.pipeline:
+        # informational, outside the timed region and outside the contract's fields: the same K batches through generate_pipelined (two
+        # generation pipelines on two HIP streams).  Kept out of `value` because concurrent launches stretch the per-launch durations the
+        # roofline object is computed from.
+        args.pipeline = True
+        run_steps(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - t0
+        args.pipeline = False
+        line["pipelined"] = {"value": round(B * args.steps / dtp, 4), "unit": "samples/s", "ms_per_step": round(dtp / args.steps * 1e3, 3),
+                             "note": "bench.py --pipeline: decode of batch i overlapped with encoders + prefill of batch i+1; same tokens"}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.new_tokens)
     print(json.dumps(line), flush=True)
