@@ -12,8 +12,7 @@
 //       lse / delta are lane scalars and dS^T feeds  dQ^T += K^T·dS^T  straight from registers.
 //   attn_bwd_dkv_kernel : one workgroup = 4 waves x 16 keys, loops over query tiles.  S = Q·K^T and dP = dO·V^T put one
 //       key on a lane; P and dS feed  dV^T += dO^T·P  and  dK^T += Q^T·dS  from registers.
-// Tiles are staged twice in LDS where both a row read (XOR-swizzled, ds_read_b128) and a transposed read
-// (linear, ds_read_b64_tr_b16) are needed.
+// One XOR-swizzled LDS copy per tile serves both the row reads (ds_read_b128) and the transposed reads (ds_read_b64_tr_b16, tr_off).
 #include "common.h"
 
 #define NEG_BIG (-1.0e30f)
@@ -60,6 +59,14 @@ __device__ __forceinline__ int swz(int ch, int row) {
     return (D == 128) ? (ch ^ (row & 15)) : (ch ^ ((row >> 1) & 7));
 }
 
+// byte offset, inside a swizzled tile, of the 8 bytes a transposing read (ds_read_b64_tr_b16) needs for logical column block `db`
+// (16 columns) / quarter `tp` (4 columns) of `row`: the 16-byte chunk is XOR-swizzled exactly as the row reads expect, so one LDS copy
+// of a tile serves both access patterns (and the 8 rows of one read group land on distinct banks, as in the forward kernel's V reads)
+template <int D>
+__device__ __forceinline__ int tr_off(int row, int db, int tp) {
+    return row * (D * 2) + swz<D>(db * 2 + (tp >> 1), row) * 16 + (tp & 1) * 8;
+}
+
 // stage 64 rows x D of src (row stride in elements) into a swizzled and/or linear LDS tile; rows >= n_valid are clamped
 template <int D, bool SW, bool LIN>
 __device__ __forceinline__ void stage_tile(const bf16_t* src, int64_t row_stride, int row0, int n_rows_total, char* sw_tile, char* lin_tile,
@@ -79,10 +86,9 @@ __device__ __forceinline__ void stage_tile(const bf16_t* src, int64_t row_stride
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     constexpr int ROWB = D * 2, KS = D / 32, DB = D / 16;
-    __shared__ __attribute__((aligned(16))) char lds[3 * 64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB];
     char* k_sw = lds;
-    char* k_lin = lds + 64 * ROWB;
-    char* v_sw = lds + 2 * 64 * ROWB;
+    char* v_sw = lds + 64 * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        stage_tile<D, true, true>(kbase, p.k_st, kt * 64, p.S, k_sw, k_lin, tid);
+        stage_tile<D, true, false>(kbase, p.k_st, kt * 64, p.S, k_sw, nullptr, tid);
         stage_tile<D, true, false>(vbase, p.v_st, kt * 64, p.S, v_sw, nullptr, tid);
         __syncthreads();
         f32x4 s[4], dp[4];
@@ -149,9 +155,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(k_lin + key_lo * ROWB + (db * 16 + tp * 4) * 2));
+                    (__attribute__((address_space(3))) bf16x4*)(k_sw + tr_off<D>(key_lo, db, tp)));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(k_lin + key_hi * ROWB + (db * 16 + tp * 4) * 2));
+                    (__attribute__((address_space(3))) bf16x4*)(k_sw + tr_off<D>(key_hi, db, tp)));
                 bf16x8 kf;
                 kf[0] = lo[0]; kf[1] = lo[1]; kf[2] = lo[2]; kf[3] = lo[3];
                 kf[4] = hi[0]; kf[5] = hi[1]; kf[6] = hi[2]; kf[7] = hi[3];
@@ -173,12 +179,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     constexpr int ROWB = D * 2, KS = D / 32, DB = D / 16;
-    __shared__ __attribute__((aligned(16))) char lds[4 * 64 * ROWB + 2 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB + 2 * 64 * 4];
     char* q_sw = lds;
-    char* q_lin = lds + 64 * ROWB;
-    char* o_sw = lds + 2 * 64 * ROWB;
-    char* o_lin = lds + 3 * 64 * ROWB;
-    float* lse_t = (float*)(lds + 4 * 64 * ROWB);
+    char* o_sw = lds + 64 * ROWB;
+    float* lse_t = (float*)(lds + 2 * 64 * ROWB);
     float* del_t = lse_t + 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -209,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 
     for (int qt = first_q; qt < nq; ++qt) {
         __syncthreads();
-        stage_tile<D, true, true>(qbase, p.q_st, qt * 64, p.Lq, q_sw, q_lin, tid);
-        stage_tile<D, true, true>(dobase, p.o_st, qt * 64, p.Lq, o_sw, o_lin, tid);
+        stage_tile<D, true, false>(qbase, p.q_st, qt * 64, p.Lq, q_sw, nullptr, tid);
+        stage_tile<D, true, false>(dobase, p.o_st, qt * 64, p.Lq, o_sw, nullptr, tid);
         if (tid < 64) {
             const int tt = min(qt * 64 + tid, p.Lq - 1);
             lse_t[tid] = p.lse[stat0 + tt];
@@ -252,11 +256,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
             const int r_hi = (2 * pr + 1) * 16 + g * 4 + tq;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const int coff = (db * 16 + tp * 4) * 2;
-                const bf16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(o_lin + r_lo * ROWB + coff));
-                const bf16x4 ohi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(o_lin + r_hi * ROWB + coff));
-                const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(q_lin + r_lo * ROWB + coff));
-                const bf16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(q_lin + r_hi * ROWB + coff));
+                const int off_lo = tr_off<D>(r_lo, db, tp), off_hi = tr_off<D>(r_hi, db, tp);
+                const bf16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(o_sw + off_lo));
+                const bf16x4 ohi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(o_sw + off_hi));
+                const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(q_sw + off_lo));
+                const bf16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(q_sw + off_hi));
                 bf16x8 of, qf;
                 of[0] = olo[0]; of[1] = olo[1]; of[2] = olo[2]; of[3] = olo[3]; of[4] = ohi[0]; of[5] = ohi[1]; of[6] = ohi[2]; of[7] = ohi[3];
                 qf[0] = qlo[0]; qf[1] = qlo[1]; qf[2] = qlo[2]; qf[3] = qlo[3]; qf[4] = qhi[0]; qf[5] = qhi[1]; qf[6] = qhi[2]; qf[7] = qhi[3];
