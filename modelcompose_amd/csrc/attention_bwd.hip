@@ -38,20 +38,22 @@ struct AttnBwdParams {
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnBwdParams p) {
-    // one wave per (b, h, t) row; D/8 lanes active
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // D/8 lanes per (b, h, t) row, 64 / (D/8) rows per wave: every lane loads 16 bytes of O and of dO
+    constexpr int LPR = D / 8, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
     const int total = p.B * p.H * p.Lq;
-    if (row >= total) return;
-    const int t = row % p.Lq, h = (row / p.Lq) % p.H, b = row / (p.Lq * p.H);
+    const bool ok = row < total;
+    const int rr = ok ? row : 0;
+    const int t = rr % p.Lq, h = (rr / p.Lq) % p.H, b = rr / (p.Lq * p.H);
+    const int64_t off = b * p.o_sb + t * p.o_st + h * p.o_sh + (lane % LPR) * 8;
+    const bf16x8 a = *(const bf16x8*)(p.o + off), d = *(const bf16x8*)(p.d_o + off);
     float s = 0.f;
-    if (lane < D / 8) {
-        const int64_t off = b * p.o_sb + t * p.o_st + h * p.o_sh + lane * 8;
-        const bf16x8 a = *(const bf16x8*)(p.o + off), d = *(const bf16x8*)(p.d_o + off);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)d[j];
-    }
-    s = wave_sum(s);
-    if (lane == 0) p.delta[row] = s;
+    for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)d[j];
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (ok && lane % LPR == 0) p.delta[row] = s;
 }
 
 template <int D>
@@ -116,11 +118,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     const bf16_t* kbase = p.k + b * p.k_sb + h * p.k_sh;
     const bf16_t* vbase = p.v + b * p.v_sb + h * p.v_sh;
 
+    // the next key tile (K, V) travels from global memory into registers under the MFMAs of the current one
+    constexpr int CHB = ROWB / 16, NLD = (64 * CHB) / 256;
+    u32x4 pk[NLD], pv[NLD];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx / CHB, ch = idx % CHB;
+            const int r = min(kt * 64 + row, p.S - 1);
+            pk[it] = *(const u32x4*)(kbase + (int64_t)r * p.k_st + ch * 8);
+            pv[it] = *(const u32x4*)(vbase + (int64_t)r * p.v_st + ch * 8);
+        }
+    };
+    if (ntiles > 0) gload(0);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        stage_tile<D, true, false>(kbase, p.k_st, kt * 64, p.S, k_sw, nullptr, tid);
-        stage_tile<D, true, false>(vbase, p.v_st, kt * 64, p.S, v_sw, nullptr, tid);
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx / CHB, ch = idx % CHB;
+            *(u32x4*)(k_sw + row * ROWB + swz<D>(ch, row) * 16) = pk[it];
+            *(u32x4*)(v_sw + row * ROWB + swz<D>(ch, row) * 16) = pv[it];
+        }
         __syncthreads();
+        if (kt + 1 < ntiles) gload(kt + 1);
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -211,16 +233,38 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     const bf16_t* dobase = p.d_o + b * p.o_sb + h * p.o_sh;
     const int64_t stat0 = ((int64_t)b * p.H + h) * p.Lq;
 
-    for (int qt = first_q; qt < nq; ++qt) {
-        __syncthreads();
-        stage_tile<D, true, false>(qbase, p.q_st, qt * 64, p.Lq, q_sw, nullptr, tid);
-        stage_tile<D, true, false>(dobase, p.o_st, qt * 64, p.Lq, o_sw, nullptr, tid);
+    // the next query tile (Q, dO, lse, delta) travels from global memory into registers under the MFMAs of the current one
+    constexpr int CHB = ROWB / 16, NLD = (64 * CHB) / 256;
+    u32x4 pq[NLD], po[NLD];
+    float plse = 0.f, pdel = 0.f;
+    auto gload = [&](int qt) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx / CHB, ch = idx % CHB;
+            const int r = min(qt * 64 + row, p.Lq - 1);
+            pq[it] = *(const u32x4*)(qbase + (int64_t)r * p.q_st + ch * 8);
+            po[it] = *(const u32x4*)(dobase + (int64_t)r * p.o_st + ch * 8);
+        }
         if (tid < 64) {
             const int tt = min(qt * 64 + tid, p.Lq - 1);
-            lse_t[tid] = p.lse[stat0 + tt];
-            del_t[tid] = p.delta[stat0 + tt];
+            plse = p.lse[stat0 + tt];
+            pdel = p.delta[stat0 + tt];
         }
+    };
+    if (first_q < nq) gload(first_q);
+    for (int qt = first_q; qt < nq; ++qt) {
         __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx / CHB, ch = idx % CHB;
+            *(u32x4*)(q_sw + row * ROWB + swz<D>(ch, row) * 16) = pq[it];
+            *(u32x4*)(o_sw + row * ROWB + swz<D>(ch, row) * 16) = po[it];
+        }
+        if (tid < 64) { lse_t[tid] = plse; del_t[tid] = pdel; }
+        __syncthreads();
+        if (qt + 1 < nq) gload(qt + 1);
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
@@ -296,11 +340,11 @@ extern "C" int mc_attn_bwd_bf16(const mc_attn_bwd_args* a, void* stream) {
     const int rows = a->B * a->H * a->Lq;
     dim3 gq((a->Lq + 63) / 64, a->H, a->B), gk((a->S + 63) / 64, a->H, a->B);
     if (a->D == 128) {
-        attn_delta_kernel<128><<<(rows + 3) / 4, 256, 0, s>>>(p);
+        attn_delta_kernel<128><<<(rows + 15) / 16, 256, 0, s>>>(p);                 // 4 waves x 4 rows
         attn_bwd_dq_kernel<128><<<gq, 256, 0, s>>>(p);
         attn_bwd_dkv_kernel<128><<<gk, 256, 0, s>>>(p);
     } else {
-        attn_delta_kernel<64><<<(rows + 3) / 4, 256, 0, s>>>(p);
+        attn_delta_kernel<64><<<(rows + 31) / 32, 256, 0, s>>>(p);                  // 4 waves x 8 rows
         attn_bwd_dq_kernel<64><<<gq, 256, 0, s>>>(p);
         attn_bwd_dkv_kernel<64><<<gk, 256, 0, s>>>(p);
     }
