@@ -144,3 +144,20 @@ def test_generate_streamer_and_stopping_criteria_hooks():
 
     res = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=7, ignore_eos=True, stopping_criteria=[after_three])
     assert torch.equal(res, plain[:, :ids.shape[1] + 3]) and calls == [ids.shape[1] + 1, ids.shape[1] + 2, ids.shape[1] + 3]
+
+
+def test_sampling_edge_cases():
+    """top_k >= vocab disables the filter; a tiny temperature collapses the distribution onto the arg-max; top_p = 1 keeps everything;
+    invalid parameters raise like the transformers warpers (ValueError through the C ABI's status 1)."""
+    from modelcompose_amd import ops
+    from oracle import sampling
+    x = _logits(4, 1000, 21)
+    _, pr = ops.sample_step(x.cuda(), 1.0, 5000, 1.0, want_probs=True)
+    assert (pr.cpu() - torch.softmax(x, -1)).abs().max().item() < 2e-6 and (pr > 0).all()
+    ids = ops.sample_step(x.cuda(), 1e-4, 0, 1.0, seed=3)
+    assert torch.equal(ids.cpu(), x.argmax(-1))
+    _, pr = ops.sample_step(x.cuda(), 0.9, 0, 1.0, want_probs=True)
+    assert (pr.cpu() - sampling.probabilities(x, 0.9, 0, 1.0)).abs().max().item() < 2e-6
+    for bad in (dict(temperature=0.0), dict(temperature=-1.0), dict(top_p=1.5), dict(top_k=-2)):
+        with pytest.raises(ValueError):
+            ops.sample_step(x.cuda(), **{**dict(temperature=1.0, top_k=0, top_p=1.0), **bad})
