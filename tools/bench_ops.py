@@ -141,6 +141,17 @@ def main():
                 res[name] = best
             fl = 2.0 * M * N * K
             print(f"gemm M={M} N={N} K={K}: " + "   ".join(f"{k} {v*1e3:7.1f} us {fl/v/1e9:7.0f} TFLOP/s" for k, v in res.items()))
+    if "clip" in which:
+        # encoder-tower shapes (CLIP-L/336: 16 x 577 rows; LanguageBind video: 32 frames x 257 rows), kernel variants on one device
+        from modelcompose_amd import _lib
+        L = _lib.lib()
+        for rep in range(2):
+            for d, nm in ((2, "128x128 kernel"), (4 + 2048, "256-row kernel, 256-column tiles"), (4 + 1024, "256-row kernel, 192-column tiles"), (0, "library choice")):
+                L.mc_gemm_debug(d)
+                print(nm)
+                for (M, N, K) in ((9232, 3072, 1024), (9232, 1024, 1024), (9232, 4096, 1024), (9232, 1024, 4096), (8224, 3072, 1024), (8224, 1024, 1024), (8224, 4096, 1024), (8224, 1024, 4096)):
+                    gemm_case(M, N, K, rot=1)
+        L.mc_gemm_debug(0)
     if "lb" in which:
         from modelcompose_amd import _lib
         L = _lib.lib()
