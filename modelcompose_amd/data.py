@@ -289,3 +289,10 @@ class DataCollatorForSupervisedDataset:
             elif key == "point":
                 out[key] = proc(items)
         return out
+
+
+def make_multimodal_data_module(tokenizer, data_args, modal_data_configs) -> Dict:
+    """data/__init__.py:5-17: dataset + collator for supervised finetuning (train_multimodal.py:484-486)."""
+    train_dataset = MultimodalDataset(data_path=data_args.data_path, tokenizer=tokenizer, data_args=data_args)
+    collator = DataCollatorForSupervisedDataset(tokenizer=tokenizer, modal_processors=data_args.modal_processors, modal_configs=modal_data_configs)
+    return dict(train_dataset=train_dataset, eval_dataset=None, data_collator=collator)

@@ -19,7 +19,7 @@ import torch
 from .. import conversation as conversation_lib
 from ..conversation import SeparatorStyle, conv_templates
 from ..data import ChunkedMultimodalDataset, DataCollatorForSupervisedDataset
-from ..dist import get_chunk
+from ..dist import get_chunk, split_list  # noqa: F401
 from ..mm_utils import get_model_name_from_path
 from ..model.builder import load_pretrained_model
 
