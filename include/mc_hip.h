@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 4
+#define MC_ABI_VERSION 5
 
 /* activation codes for mc_gemm_bf16 */
 #define MC_ACT_NONE 0
@@ -279,6 +279,9 @@ int mc_llm_destroy(void* handle);
 int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* final_norm, const void* lm_head_packed,
                        const void* embed_table, const float* cos_table, const float* sin_table);
 int mc_llm_set_option(void* handle, const char* name, int value);        /* "use_graph" */
+/* read back: "use_graph"; "graph_active" = 1 when the last mc_llm_decode replayed a hipGraph (0: one launch per kernel); "graph_captures" /
+ * "graph_failures" = decode-step graphs captured / capture attempts that failed since mc_llm_create */
+int mc_llm_get_option(void* handle, const char* name, int* value);
 /* next-token rule of mc_llm_decode: do_sample = 0 greedy arg-max (default), 1 = mc_sample_step_f32 with these parameters and the seed the
  * caller stored at state[4B+1], state[4B+2] */
 int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_k, float top_p);
@@ -290,8 +293,12 @@ int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups, const int3
                    const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t, const int32_t* out_map,
                    const int32_t* kv_lens, const int32_t* last_rows, int B, int Lq, void* k_cache, void* v_cache, int Smax,
                    void* workspace, void* hidden_out, float* logits_out, int64_t* next_ids, void* stream);
+/* Greedy / sampled decode of n_steps tokens on the device.  kv_len_max (host value) = the largest number of keys any sequence already has in
+ * the cache (prompt length + tokens decoded so far); kv_len_max + n_steps > Smax is refused (error 1).  n_groups of mc_llm_prefill <= 64.
+ * With "use_graph" the step is captured once per buffer set and replayed from a hipGraph; stream 0 (the legacy null stream, on which HIP
+ * refuses capture) is served by a handle-owned stream ordered against stream 0 with events - see mc_llm_get_option("graph_active").       */
 int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids, int64_t* out_ids, int64_t ld_out, int32_t* state,
-                  void* k_cache, void* v_cache, int Smax, void* workspace, float* logits_out, void* stream);
+                  void* k_cache, void* v_cache, int Smax, int kv_len_max, void* workspace, float* logits_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -123,7 +123,8 @@ _SIGS.update({
     "mc_sample_step_f32": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_p, C.c_uint64, c_i, c_i, c_f, c_i, c_f, c_p, c_p, c_l, c_p],
     "mc_llm_workspace_bytes": [c_p, c_i, c_i, c_i, C.POINTER(c_l)],
     "mc_llm_prefill": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
-    "mc_llm_decode": [c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
+    "mc_llm_decode": [c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
+    "mc_llm_get_option": [c_p, C.c_char_p, C.POINTER(c_i)],
 })
 # optional symbols added by later ABI revisions are bound if present
 _OPTIONAL: dict = {}

@@ -43,11 +43,20 @@ struct Llm {
     Key gkey[kGraphs] = {};
     int graph_next = 0;                      // round-robin victim
     bool use_graph = true;
+    // hipStreamBeginCapture is refused on the legacy null stream (torch's default current stream).  Callers that pass stream 0 have their
+    // decode graphs captured and replayed on this handle-owned non-blocking stream, ordered against stream 0 by the two events.
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // observability (mc_llm_get_option): did the last mc_llm_decode replay a graph; captures made; captures that failed
+    int graph_active = 0, graph_captures = 0, graph_failures = 0;
+    bool capture_warned = false;
     // next-token rule: greedy arg-max, or temperature / top-k / top-p sampling (seed: 2 x u32 at state[4B+1] on the device)
     bool do_sample = false;
     float temperature = 1.0f, top_p = 1.0f;
     int top_k = 0;
 };
+
+constexpr int kMaxGroups = 64;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -124,8 +133,8 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     const float eps_in = skinny ? c.rms_eps : 0.f;
     auto W = [&](int adapter, int which) { return m->layer_w[((size_t)layer * c.n_adapters + adapter) * 4 + which]; };
 
-    // weights of every group for linear `which`
-    const void* wg[64];
+    // weights of every group for linear `which` (n_groups <= kMaxGroups is checked by mc_llm_prefill; decode has one group)
+    const void* wg[kMaxGroups];
     auto W_all = [&](int which) {
         for (int g = 0; g < n_groups; ++g) wg[g] = W(gadapter[g], which);
         return (const void* const*)wg;
@@ -191,6 +200,9 @@ extern "C" int mc_llm_destroy(void* handle) {
     if (!m) return 0;
     for (int i = 0; i < Llm::kGraphs; ++i)
         if (m->graph_exec[i]) (void)hipGraphExecDestroy(m->graph_exec[i]);
+    if (m->own_stream) { (void)hipStreamSynchronize(m->own_stream); (void)hipStreamDestroy(m->own_stream); }
+    if (m->ev_in) (void)hipEventDestroy(m->ev_in);
+    if (m->ev_out) (void)hipEventDestroy(m->ev_out);
     delete m;
     return 0;
 }
@@ -219,6 +231,17 @@ extern "C" int mc_llm_set_option(void* handle, const char* name, int value) {
     if (!m || !name) { mc_set_error("mc_llm_set_option: null argument"); return 1; }
     if (!strcmp(name, "use_graph")) { m->use_graph = value != 0; return 0; }
     mc_set_error("mc_llm_set_option: unknown option '%s'", name);
+    return 1;
+}
+
+extern "C" int mc_llm_get_option(void* handle, const char* name, int* value) {
+    Llm* m = (Llm*)handle;
+    if (!m || !name || !value) { mc_set_error("mc_llm_get_option: null argument"); return 1; }
+    if (!strcmp(name, "use_graph")) { *value = m->use_graph ? 1 : 0; return 0; }
+    if (!strcmp(name, "graph_active")) { *value = m->graph_active; return 0; }
+    if (!strcmp(name, "graph_captures")) { *value = m->graph_captures; return 0; }
+    if (!strcmp(name, "graph_failures")) { *value = m->graph_failures; return 0; }
+    mc_set_error("mc_llm_get_option: unknown option '%s'", name);
     return 1;
 }
 
@@ -251,8 +274,9 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
     Llm* m = (Llm*)handle;
     RUN(check_handle(m, "mc_llm_prefill"));
     if (!x_routed || !group_start || !group_adapter || !row_b || !row_pos || !row_t || !out_map || !k_cache || !v_cache || !workspace ||
-        M <= 0 || B <= 0 || Lq <= 0 || n_groups <= 0 || Smax < Lq) {
-        mc_set_error("mc_llm_prefill: bad arguments (M=%d B=%d Lq=%d Smax=%d groups=%d)", M, B, Lq, Smax, n_groups);
+        M <= 0 || B <= 0 || Lq <= 0 || n_groups <= 0 || n_groups > kMaxGroups || Smax < Lq) {
+        mc_set_error("mc_llm_prefill: bad arguments (M=%d B=%d Lq=%d Smax=%d groups=%d, at most %d groups)", M, B, Lq, Smax, n_groups,
+                     kMaxGroups);
         return 1;
     }
     for (int g = 0; g < n_groups; ++g)
@@ -309,19 +333,52 @@ static int decode_one_step(Llm* m, int B, int64_t* next_ids, int64_t* out_ids, i
 // argmax) and is updated in place; out_ids[b*ld_out + step] receives each new token, step read from the device state.
 // logits_out (optional) [n_steps][B][vocab] fp32 for parity tests (disables graph replay).
 extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids, int64_t* out_ids, int64_t ld_out, int32_t* state,
-                             void* k_cache, void* v_cache, int Smax, void* workspace, float* logits_out, void* stream) {
+                             void* k_cache, void* v_cache, int Smax, int kv_len_max, void* workspace, float* logits_out, void* stream) {
     Llm* m = (Llm*)handle;
     RUN(check_handle(m, "mc_llm_decode"));
     if (!next_ids || !state || !k_cache || !v_cache || !workspace || B <= 0 || n_steps < 0) {
         mc_set_error("mc_llm_decode: bad arguments");
         return 1;
     }
+    // every step appends one key per sequence: the longest sequence must still fit after the last step (attn_decode clamps the
+    // length to Smax, so an overrun would silently overwrite the last cache slot instead of failing)
+    if (kv_len_max < 0 || (int64_t)kv_len_max + n_steps > Smax) {
+        mc_set_error("mc_llm_decode: KV cache overflow: %d cached keys + %d steps > Smax %d", kv_len_max, n_steps, Smax);
+        return 1;
+    }
+    m->graph_active = 0;
     const mc_llm_config& c = m->cfg;
     Ws w = carve(c, B, B, 1, (char*)workspace);
     void* attn_ws = (char*)workspace + w.total;
     const int nsplit = decode_nsplit(c, B);
     hipStream_t s = (hipStream_t)stream;
     if (m->use_graph && !logits_out && n_steps > 1) {
+        // graphs cannot be captured on the legacy null stream: run this call's launches on the handle's own stream, after everything the
+        // caller has queued on stream 0 (ev_in) and before anything it queues afterwards (ev_out)
+        hipStream_t gs = s;
+        if (s == nullptr) {
+            if (!m->own_stream) {
+                if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->ev_out, hipEventDisableTiming) != hipSuccess) {
+                    mc_set_error("mc_llm_decode: cannot create the decode stream: %s", hipGetErrorString(hipGetLastError()));
+                    return 2;
+                }
+            }
+            gs = m->own_stream;
+            if (hipEventRecord(m->ev_in, s) != hipSuccess || hipStreamWaitEvent(gs, m->ev_in, 0) != hipSuccess) {
+                mc_set_error("mc_llm_decode: stream hand-over: %s", hipGetErrorString(hipGetLastError()));
+                return 2;
+            }
+        }
+        auto hand_back = [&]() -> int {
+            if (gs == s) return 0;
+            if (hipEventRecord(m->ev_out, gs) != hipSuccess || hipStreamWaitEvent(s, m->ev_out, 0) != hipSuccess) {
+                mc_set_error("mc_llm_decode: stream hand-back: %s", hipGetErrorString(hipGetLastError()));
+                return 2;
+            }
+            return 0;
+        };
         Llm::Key key{};               // zero-initialised incl. padding: compared with memcmp
         key.B = B; key.Smax = Smax; key.kc = k_cache; key.vc = v_cache; key.ws = workspace; key.state = state; key.next_ids = next_ids;
         key.out_ids = out_ids; key.logits = nullptr; key.ld_out = ld_out;
@@ -335,26 +392,38 @@ extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids
             m->graph_next = (m->graph_next + 1) % Llm::kGraphs;
             if (m->graph_exec[slot]) { (void)hipGraphExecDestroy(m->graph_exec[slot]); m->graph_exec[slot] = nullptr; }
             hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            hipError_t e = hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
-                int rc = decode_one_step(m, B, next_ids, out_ids, ld_out, state, k_cache, v_cache, Smax, w, attn_ws, nsplit, nullptr, stream);
-                e = hipStreamEndCapture(s, &graph);
-                if (rc == 0 && e == hipSuccess && graph) {
+                int rc = decode_one_step(m, B, next_ids, out_ids, ld_out, state, k_cache, v_cache, Smax, w, attn_ws, nsplit, nullptr, gs);
+                hipError_t e2 = hipStreamEndCapture(gs, &graph);
+                if (rc != 0) e = hipErrorUnknown;
+                else if (e2 != hipSuccess || !graph) e = e2 != hipSuccess ? e2 : hipErrorUnknown;
+                else {
                     e = hipGraphInstantiate(&m->graph_exec[slot], graph, nullptr, nullptr, 0);
                     if (e != hipSuccess) m->graph_exec[slot] = nullptr;
                 }
                 if (graph) (void)hipGraphDestroy(graph);
             }
             (void)hipGetLastError();
-            if (m->graph_exec[slot]) m->gkey[slot] = key;
+            if (m->graph_exec[slot]) { m->gkey[slot] = key; ++m->graph_captures; }
+            else {
+                ++m->graph_failures;
+                if (!m->capture_warned) {
+                    fprintf(stderr, "libmc_hip: mc_llm_decode: decode graph capture failed (%s); falling back to one launch per kernel\n",
+                            hipGetErrorString(e));
+                    m->capture_warned = true;
+                }
+            }
         }
         if (m->graph_exec[slot]) {
             for (int i = 0; i < n_steps; ++i) {
-                hipError_t e = hipGraphLaunch(m->graph_exec[slot], s);
+                hipError_t e = hipGraphLaunch(m->graph_exec[slot], gs);
                 if (e != hipSuccess) { mc_set_error("mc_llm_decode: hipGraphLaunch: %s", hipGetErrorString(e)); return 2; }
             }
-            return 0;
+            m->graph_active = 1;
+            return hand_back();
         }
+        RUN(hand_back());             // nothing was queued on the decode stream: the eager path below runs on the caller's stream
     }
     for (int i = 0; i < n_steps; ++i)
         RUN(decode_one_step(m, B, next_ids, out_ids, ld_out, state, k_cache, v_cache, Smax, w, attn_ws, nsplit,

@@ -68,15 +68,18 @@ def eval_model(args, loaded=None):
             input_ids = batch["input_ids"].to(model.device)
             modal_inputs = _to_device(batch["modal_inputs"], model.device, torch.bfloat16) if "modal_inputs" in batch else {}
             meta.append(input_ids)
-            yield input_ids, modal_inputs
+            # batch 1 (the reference): no mask, as the reference's generate() call.  Batched: the collator right-pads the prompts; the mask
+            # gives every row its own length, so each row generates exactly what it would alone
+            am = batch["attention_mask"].to(model.device) if input_ids.shape[0] > 1 and "attention_mask" in batch else None
+            yield input_ids, modal_inputs, am
 
     def results():
         if getattr(args, "pipeline", False):                        # decode of batch i beside the prefill of batch i+1
             yield from model.generate_pipelined(batches(), **gen_kw)
         else:
-            for input_ids, modal_inputs in batches():
+            for input_ids, modal_inputs, am in batches():
                 with torch.inference_mode():
-                    yield model.generate(input_ids, modal_inputs=modal_inputs, **gen_kw)
+                    yield model.generate(input_ids, modal_inputs=modal_inputs, attention_mask=am, **gen_kw)
 
     with open(answers_file, "w") as ans_file:
         for k, output_ids in enumerate(results()):

@@ -360,6 +360,11 @@ class MultimodalLlamaForCausalLM:
         if getattr(self, "_dirty", True):
             self.finalize()
         cfg, dev = self.config, self.device
+        if not plan.mask_is_suffix:
+            raise NotImplementedError("attention_mask with zeros before the last attended token (left padding / holes) is not implemented on "
+                                      "the HIP path: sequences are described by one length each; right-pad the batch")
+        if int(plan.valid_lens.min()) < 1:
+            raise ValueError("a sample of the batch has no attended token")
         routed = cfg.lora_strategy in ("modal", "modal+language") and bool(plan.modal_masks)     # :703-704
         lay = routed_layout(plan, {m: self.modal_names.index(m) for m in plan.modal_order}, routed)
         B, Lmax, M = plan.B, plan.Lmax, lay.M
@@ -371,7 +376,7 @@ class MultimodalLlamaForCausalLM:
         self._gather_rows(plan, feats, lay.order_b, lay.order_t, x)
         i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
         row_b, row_t = i32(lay.order_b), i32(lay.order_t)
-        out_map, kv_lens, last_rows = i32(lay.out_map), i32(plan.lens), i32(lay.last_rows)
+        out_map, kv_lens, last_rows = i32(lay.out_map), i32(plan.valid_lens), i32(lay.last_rows)
         hidden = torch.empty(M, cfg.hidden_size, dtype=BF16, device=dev) if want_hidden else None
         logits = torch.empty(B, cfg.vocab_size, dtype=torch.float32, device=dev) if want_logits else None
         next_ids = self._cache.get(("next_ids", slot, B))          # persistent: the decode graph of this slot points at it
@@ -407,9 +412,17 @@ class MultimodalLlamaForCausalLM:
         _lib.check(L.mc_llm_set_sampling(self._handle, int(smp is not None), *(smp[:3] if smp else (1.0, 0, 1.0))), "mc_llm_set_sampling")
         logits = torch.empty(n_steps, B, self.config.vocab_size, dtype=torch.float32, device=dev) if want_logits else None
         # the workspace of the prefill is at least as large as the decode one (M >= B)
+        kv_len_max = int(st["plan"].valid_lens.max()) + step0    # keys already cached by the longest sequence
         _lib.check(L.mc_llm_decode(self._handle, B, n_steps, _ptr(st["next_ids"]), _ptr(out_ids), out_ids.stride(0), _ptr(state),
-                                   _ptr(st["kc"]), _ptr(st["vc"]), st["Smax"], _ptr(st["ws"]), _ptr(logits), _stream()), "mc_llm_decode")
+                                   _ptr(st["kc"]), _ptr(st["vc"]), st["Smax"], kv_len_max, _ptr(st["ws"]), _ptr(logits), _stream()),
+                   "mc_llm_decode")
         return logits
+
+    def runtime_option(self, name: str) -> int:
+        """mc_llm_get_option: 'graph_active' (the last decode call replayed a hipGraph), 'graph_captures', 'graph_failures', 'use_graph'."""
+        v = C.c_int(0)
+        _lib.check(_lib.lib().mc_llm_get_option(self._handle, name.encode(), C.byref(v)), "mc_llm_get_option")
+        return v.value
 
     # ------------------------------------------------------------------ public API
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
@@ -553,8 +566,8 @@ class MultimodalLlamaForCausalLM:
 
     @torch.no_grad()
     def generate_pipelined(self, batches, **kw):
-        """Throughput mode for a stream of batches (the eval loop): yields generate()'s result for every (input_ids, modal_inputs) pair of
-        `batches`, in order.  Two generation pipelines (own KV cache, workspace, decode state and graph each) alternate on two HIP
+        """Throughput mode for a stream of batches (the eval loop): yields generate()'s result for every (input_ids, modal_inputs[,
+        attention_mask]) tuple of `batches`, in order.  Two generation pipelines (own KV cache, workspace, decode state and graph each) alternate on two HIP
         streams: the decode of batch i - HBM-bound, the MFMA pipes idle - runs beside the encoders + prefill of batch i+1 - MFMA-bound,
         HBM idle.  The prefill of batch i+1 is ordered after the prefill of batch i (event), so the two never compete for the matrix
         units.  Same tokens as sequential generate() calls; host syncs inside generate() (EOS checks without ignore_eos) shorten the
@@ -566,7 +579,9 @@ class MultimodalLlamaForCausalLM:
             self._cache[("pipe_streams",)] = streams
         pending = None
         last_prefill = None
-        for i, (input_ids, modal_inputs) in enumerate(batches):
+        for i, item in enumerate(batches):
+            input_ids, modal_inputs = item[0], item[1]
+            am = item[2] if len(item) > 2 else None                # optional right-padding mask of the batch
             slot = i & 1
             s = streams[slot]
             s.wait_stream(cur)                                     # inputs produced on the caller's stream
@@ -574,7 +589,7 @@ class MultimodalLlamaForCausalLM:
                 s.wait_event(last_prefill)
             ev = torch.cuda.Event()
             with torch.cuda.stream(s):
-                out = self.generate(input_ids, modal_inputs=modal_inputs, slot=slot, prefill_done=ev, **kw)
+                out = self.generate(input_ids, modal_inputs=modal_inputs, attention_mask=am, slot=slot, prefill_done=ev, **kw)
             last_prefill = ev
             if pending is not None:
                 pending[1].synchronize()

@@ -22,7 +22,7 @@ _SENT = {v: k for k, v in MODAL_TOKEN_INDEXES.items()}
 class SplicePlan:
     B: int
     L_text: int
-    lens: np.ndarray                 # [B] spliced length per sample
+    lens: np.ndarray                 # [B] spliced length per sample (text pads included, as the reference's embeds)
     Lmax: int
     # per spliced token, sequence order (b-major): -1 padded to Lmax
     tok_id: np.ndarray               # [B, Lmax] int64 text token id or -1
@@ -33,6 +33,10 @@ class SplicePlan:
     modal_masks: Dict[str, np.ndarray]       # incl. 'default'; None-equivalent = {} when no modal blocks exist
     modal_order: List[str] = field(default_factory=list)
     items_used: Dict[str, int] = field(default_factory=dict)
+    # device path: attended length per sample = lens minus the run of masked-out text tokens at the end (right padding).  The kernels
+    # take a length per sequence, so masks with zeros anywhere else (left padding, holes) are flagged and refused there.
+    valid_lens: Optional[np.ndarray] = None
+    mask_is_suffix: bool = True
 
 
 def plan_splice(input_ids: np.ndarray, attention_mask: Optional[np.ndarray], labels: Optional[np.ndarray],
@@ -92,8 +96,11 @@ def plan_splice(input_ids: np.ndarray, attention_mask: Optional[np.ndarray], lab
         for m in masks:
             acc |= masks[m]
         masks["default"] = ~acc
+    n_att = attention_mask.astype(bool).sum(1)
+    suffix_only = bool(all(attention_mask[b, :n_att[b]].all() for b in range(B)))
+    valid_lens = (lens - (L - n_att)).astype(np.int32)
     return SplicePlan(B, L, lens, Lmax, tok_id, src_modal, src_row, out_labels, am, masks, modal_order,
-                      {m: cur[m] for m in modal_order})
+                      {m: cur[m] for m in modal_order}, valid_lens, suffix_only)
 
 
 @dataclass
@@ -110,7 +117,8 @@ class RoutedLayout:
 def routed_layout(plan: SplicePlan, adapter_of_modal: Dict[str, int], routed: bool) -> RoutedLayout:
     """Group valid tokens by adapter (stable in (b, t) order inside a group)."""
     B, Lmax = plan.tok_id.shape
-    valid = np.arange(Lmax)[None, :] < plan.lens[:, None]
+    lens = plan.lens if plan.valid_lens is None else plan.valid_lens
+    valid = np.arange(Lmax)[None, :] < lens[:, None]
     adapter = np.zeros((B, Lmax), dtype=np.int32)
     if routed:
         for i, m in enumerate(plan.modal_order):
@@ -124,6 +132,6 @@ def routed_layout(plan: SplicePlan, adapter_of_modal: Dict[str, int], routed: bo
     starts = [int(np.searchsorted(ad, g, side="left")) for g in groups] + [M]
     out_map = np.full(B * Lmax, -1, dtype=np.int32)
     out_map[bb * Lmax + tt] = np.arange(M, dtype=np.int32)
-    last = out_map[np.arange(B) * Lmax + (plan.lens - 1)]
+    last = out_map[np.arange(B) * Lmax + (lens - 1)]
     return RoutedLayout(M, bb.astype(np.int32), tt.astype(np.int32), np.array(starts, dtype=np.int32),
                         np.array(groups, dtype=np.int32), out_map, last.astype(np.int32))

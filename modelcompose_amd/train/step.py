@@ -123,6 +123,10 @@ class MultimodalTrainStep:
 
         def add(name, tensor):
             nonlocal off
+            if off % 4:                                            # 16-byte aligned slices: AdamW runs per parameter group (see optimizer_step)
+                pad = 4 - off % 4
+                init.append(torch.zeros(pad, dtype=F32, device=self.dev))
+                off += pad
             params.append(_Param(name, off, tensor.shape))
             init.append(tensor.reshape(-1).to(self.dev, F32))
             off += tensor.numel()
@@ -141,6 +145,8 @@ class MultimodalTrainStep:
                 add(f"model.layers.{l}.{gname}.A_in", torch.cat(a_rows, 0))           # [n_linears*nA*r, K], linear-major, adapter, rank
             self.layer_end[l] = off
         self.proj_modals = []
+        self.aux_lo = off                                          # projector / prefix / suffix parameters live in [aux_lo, n_params)
+        n_before = len(params)
         for m, proj in self.model.model.modal_projectors.items():
             if not isinstance(proj, HipMlpProjector):
                 raise NotImplementedError(f"projector of modality '{m}' is not an MLP/linear projector: its backward is not implemented")
@@ -157,6 +163,14 @@ class MultimodalTrainStep:
                 add(f"{which}.{m}", d[m].float())
         self.params = {p.name: p for p in params}
         self.n_params = off
+        # per-modality parameter groups outside the decoder layers.  A modality absent from a batch contributes no gradient: the reference
+        # leaves .grad = None there, so AdamW skips those tensors entirely (no moment decay, no step count) - mirrored in optimizer_step
+        self.aux_params: Dict[str, List[_Param]] = {}
+        for p_ in params[n_before:]:
+            modal = p_.name.split(".")[2] if p_.name.startswith("model.modal_projectors.") else p_.name.split(".", 1)[1]
+            self.aux_params.setdefault(modal, []).append(p_)
+        self._aux_steps = {m: 0 for m in self.aux_params}
+        self._present: List[str] = []
         dev = self.dev
         self.P = torch.cat(init)
         self.G = torch.zeros(off, dtype=F32, device=dev)
@@ -315,6 +329,13 @@ class MultimodalTrainStep:
         saved: Dict[str, torch.Tensor] = {}
         feats = self._encode(modal_inputs, saved)
         plan = model._plan(input_ids, None, labels, modal_inputs, feats)
+        # modalities without a block in this batch get no gradient; their slices of G still hold the previous step's values (every kernel
+        # overwrites, nothing accumulates), so clear them before they can reach the all-reduce
+        self._present = [m for m in plan.modal_order if m in self.aux_params]
+        for m, plist in self.aux_params.items():
+            if m not in self._present:
+                for p_ in plist:
+                    self.G[p_.off:p_.off + p_.n].zero_()
         if not (plan.lens == plan.Lmax).all():
             raise NotImplementedError("ragged spliced lengths are not implemented in the training step")
         B, L = plan.B, plan.Lmax
@@ -504,8 +525,19 @@ class MultimodalTrainStep:
     def optimizer_step(self):
         """AdamW on the mean gradient over ranks (DDP semantics: all-reduce SUM, then 1 / world_size)."""
         self.step_count += 1
-        ops.adamw(self.P, self.G, self.m1, self.m2, self.P16, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
+        b1, b2 = self.betas
+        lo = self.aux_lo
+        ops.adamw(self.P[:lo], self.G[:lo], self.m1[:lo], self.m2[:lo], self.P16[:lo], self.lr, b1, b2, self.eps, self.wd, self.step_count,
                   grad_scale=1.0 / self.world)
+        # projector / prefix / suffix tensors: only those of modalities that were in the batch (torch.optim.AdamW skips grad-None tensors and
+        # keeps a step count per tensor).  Under data parallelism a modality must be present on every rank or on none (as with DDP, where a
+        # parameter unused on one rank is an error without find_unused_parameters).
+        for m in self._present:
+            self._aux_steps[m] += 1
+            for p_ in self.aux_params[m]:
+                sl = slice(p_.off, p_.off + p_.n)
+                ops.adamw(self.P[sl], self.G[sl], self.m1[sl], self.m2[sl], self.P16[sl], self.lr, b1, b2, self.eps, self.wd, self._aux_steps[m],
+                          grad_scale=1.0 / self.world)
         self._repack()
 
     def step(self, input_ids, labels, modal_inputs) -> torch.Tensor:

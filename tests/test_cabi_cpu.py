@@ -53,6 +53,28 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     assert L.mc_llm_prefill(h, None, 1, 1, None, None, None, None, None, None, None, None, 1, 1, None, None, 1, None, None,
                             None, None, None) == 1
     assert b"mc_llm_set_weights has not been called" in L.mc_last_error()
+    v = C.c_int(-1)
+    assert L.mc_llm_get_option(h, b"graph_active", C.byref(v)) == 0 and v.value == 0
+    assert L.mc_llm_get_option(h, b"no_such_option", C.byref(v)) == 1
+    assert L.mc_llm_destroy(h) == 0
+
+
+def test_runtime_bounds_are_enforced_in_the_c_abi(lib):
+    """the group table of mc_llm_prefill is a fixed 64-entry array and mc_llm_decode appends one key per step: both bounds are
+    checked by the library itself (not only by the Python wrapper), before any launch."""
+    L = lib.lib()
+    cfg = lib.LlmConfigC(128, 192, 1, 2, 2, 64, 128, 1, 256, 1e-5)
+    h = C.c_void_p(0)
+    assert L.mc_llm_create(C.byref(cfg), C.byref(h)) == 0
+    one = C.c_void_p(16)                                          # non-null dummy device pointers: validation precedes any dereference
+    ptrs = (C.c_void_p * 4)(16, 16, 16, 16)
+    assert L.mc_llm_set_weights(h, ptrs, one, one, one, one, one) == 0
+    gs = (C.c_int32 * 66)(*range(66))
+    ga = (C.c_int32 * 65)(*([0] * 65))
+    rc = L.mc_llm_prefill(h, one, 65, 65, gs, ga, one, one, one, one, one, one, 1, 65, one, one, 128, one, None, None, one, None)
+    assert rc == 1 and b"at most 64 groups" in L.mc_last_error()
+    rc = L.mc_llm_decode(h, 1, 8, one, one, 8, one, one, one, 64, 60, one, None, None)
+    assert rc == 1 and b"KV cache overflow" in L.mc_last_error()
     assert L.mc_llm_destroy(h) == 0
 
 

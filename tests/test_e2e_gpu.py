@@ -319,3 +319,57 @@ def test_generate_pipelined_equals_sequential_generate(g4_model):
     # and the plain path still works afterwards (slot 0 buffers reused)
     again = model.generate(batches[0][0], modal_inputs=batches[0][1], max_new_tokens=5, ignore_eos=True, do_sample=True, temperature=1.3, seed=7)
     assert torch.equal(again, seq[0])
+
+
+def test_decode_graph_is_really_replayed_on_the_default_stream(g4_model):
+    """hipStreamBeginCapture is refused on the legacy null stream (torch's default current stream).  The runtime captures
+    and replays on its own stream then; the query must say a graph ran, and the tokens must equal the one-launch-per-kernel path's."""
+    from modelcompose_amd import _lib
+    model, a, meta, sd = g4_model
+    ids, px = a["input_ids"].cuda(), a["pixels"].cuda()
+    assert torch.cuda.current_stream().cuda_stream == 0
+    fails0 = model.runtime_option("graph_failures")
+    out_g = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=8, ignore_eos=True)
+    assert model.runtime_option("graph_active") == 1 and model.runtime_option("graph_failures") == fails0
+    # results are visible to work queued on the default stream afterwards without a host sync (event hand-back)
+    first = out_g[:, ids.shape[1]:].clone()
+    _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"use_graph", 0), "set_option")
+    try:
+        out_e = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=8, ignore_eos=True)
+        assert model.runtime_option("graph_active") == 0
+    finally:
+        _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"use_graph", 1), "set_option")
+    assert torch.equal(first, out_e[:, ids.shape[1]:])
+    # a caller-owned stream is captured on directly
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out_s = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=8, ignore_eos=True)
+        assert model.runtime_option("graph_active") == 1
+    s.synchronize()
+    assert torch.equal(out_s, out_g)
+
+
+def test_right_padded_batch_equals_per_sample_and_other_masks_raise(g4_model):
+    """A batch right-padded by the collator with its attention mask: every row generates exactly what it generates alone (the device
+    path takes one length per sequence); masks with zeros elsewhere are refused, not silently attended."""
+    model, a, meta, sd = g4_model
+    V = -200
+    g = torch.Generator().manual_seed(5)
+    r = lambda n: torch.randint(3, 97, (n,), generator=g).tolist()
+    rows = [[1] + r(3) + [V, 13] + r(6), [1] + r(2) + [V, 13] + r(3), [1] + r(7)]
+    L = max(len(x) for x in rows)
+    ids = torch.tensor([x + [0] * (L - len(x)) for x in rows])
+    am = torch.tensor([[1] * len(x) + [0] * (L - len(x)) for x in rows], dtype=torch.bool)
+    px = torch.cat([a["pixels"][:1], a["pixels"][:1] * 0.5])
+    n_new = 5
+    res, lg = model.generate(ids.cuda(), modal_inputs={"vision": px.cuda()}, attention_mask=am.cuda(), max_new_tokens=n_new, ignore_eos=True,
+                             return_step_logits=True)
+    for b, row in enumerate(rows):
+        mi = {"vision": px[b:b + 1].cuda()} if V in row else {}
+        r1, l1 = model.generate(torch.tensor([row]).cuda(), modal_inputs=mi, max_new_tokens=n_new, ignore_eos=True, return_step_logits=True)
+        assert torch.equal(l1[0, 0], lg[b, 0]), b                        # prefill logits: bitwise (batch-invariant kernels)
+        assert torch.equal(r1[0, len(row):], res[b, L:]), b
+    left = am.flip(1)
+    with pytest.raises(NotImplementedError):
+        model.generate(ids.cuda(), modal_inputs={"vision": px.cuda()}, attention_mask=left.cuda(), max_new_tokens=2)
