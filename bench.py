@@ -1,22 +1,31 @@
 #!/usr/bin/env python
-"""Headline benchmark: samples/s of composed-Vicuna-7B greedy generation (BASELINE.json metric).
+"""Headline benchmark: samples/s of composed-Vicuna-7B greedy generation on the metric's inputs (BASELINE.json `metric`:
+"composed-Vicuna-7B greedy gen, img+audio+video").
 
 A "step" = one pass of the hot path over one batch of synthetic input on every rank:
-  CLIP-ViT-L/14-336 encode -> mlp2x_gelu projector -> splice -> LocalLoRA-composed Vicuna-7B prefill ->
-  32 greedy tokens (device-resident loop) -> all-gather of the generated ids (N > 1).
-Workload at every N = BASELINE.json configs[1]: vision-only Vicuna-7B bf16, batch 16 synthetic 336 px images per GPU
-(weak scaling: per-GPU work fixed).  Inputs and weights are resident in HBM before the timed region.
+  CLIP-ViT-L/14-336 + BEATs/Q-Former + LanguageBind-Video encode -> projectors -> splice (2792 tokens per sample) ->
+  LocalLoRA-composed Vicuna-7B prefill (3-way online-merge-reset, routed adapters) -> 32 greedy tokens (device-resident loop,
+  hipGraph) -> all-gather of the generated ids (N > 1).
+Default workload `iav` = the metric's config: BASELINE configs[2]'s model (online-merge-reset vision/audio/video = 0.333) fed
+336 px image + 10 s audio + 8-frame video, batch 16 per GPU (weak scaling: per-GPU work fixed).  Inputs and weights are
+resident in HBM before the timed region.  Other workloads (parity-test configs, not the headline): `vision` = configs[1],
+`mcub4` = configs[3], `train` = configs[4].
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
-  roofline     – the dominant kernel (gemm_tile256_kernel, MFMA-bound): algorithmic FLOPs per launch / average launch
-                 duration measured live with HIP events on the launch stream during the timed steps
-  cpu_baseline – the oracle (CPU port of the reference algorithm, torch fp32, all host cores) on a bounded sample
+Prints ONE JSON line on rank 0 (contract in the task prompt) with these extra objects, all measured OUTSIDE the timed region
+in a separate profiled pass of the same step:
+  roofline        – the dominant kernel (gemm_tile256_kernel, MFMA-bound): algorithmic FLOPs per launch / average launch duration
+                    from HIP events on the launch stream
+  roofline_decode – the decode step (HBM-bound): algorithmic bytes per step (weights once + the KV cache once) / step time of the
+                    graph-replayed loop, plus every decode kernel class's own HBM fraction from event-bracketed launches
+  stages          – encode / prefill / decode milliseconds per step
+  cpu_baseline    – the oracle (CPU port of the reference algorithm, torch fp32, host cores) on a bounded sample of the same workload
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -33,64 +42,116 @@ DIST = os.environ.get("MC_BENCH_FORCE_DIST", "") == "1"
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0                      # spec HBM3E peak
 
+WORKLOADS = {
+    # name: (modalities, sentinels, default per-GPU batch, metric suffix, description)
+    "iav": (("vision", "audio", "video"), [-200, -203, -204], 16, "img+audio+video",
+            "metric config = configs[2]'s model (3-way composed Vicuna-7B, online-merge-reset vision/audio/video = 0.333; routed adapters "
+            "default/audio/vision/video) with the metric's inputs: 336 px image + 10 s audio (1024x128 fbank) + 8-frame 224 px video"),
+    "vision": (("vision",), [-200], 16, "img",
+               "configs[1]: vision-only composed Vicuna-7B (LocalLoRA r128: default+vision adapters), synthetic 336 px images"),
+    "mcub4": (("vision", "audio", "video", "point"), [-200, -203, -204, -205], 4, "img+audio+video+point",
+              "configs[3]: 4-modality composed Vicuna-7B (online-merge-reset 4 x 0.25), MCUB-4-shaped inputs: 336 px image + 10 s audio + "
+              "8-frame video + 8192-point cloud"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the workload's default: 16 for iav / vision, 4 for mcub4 / train)")
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (roofline objects become null)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--pipeline", action="store_true", help="generate workload: two generation pipelines on two HIP streams (decode of batch i "
-                    "beside the prefill of batch i+1, MultimodalLlamaForCausalLM.generate_pipelined); every step still is one full batch")
+    ap.add_argument("--pipeline", action="store_true", help="two generation pipelines on two HIP streams (decode of batch i beside the prefill of "
+                    "batch i+1, MultimodalLlamaForCausalLM.generate_pipelined); every step still is one full batch")
     ap.add_argument("--no-overlap", action="store_true", help="debug only (train): weight-gradient / rank-projection GEMMs on the main stream")
-    ap.add_argument("--gemm-debug", type=int, default=0, help="debug only: mc_gemm_debug word (A/B of kernel variants; e.g. 2048 = no 192-column tiles)")
-    ap.add_argument("--workload", default="generate", choices=["generate", "train", "mcub4", "iav"],
-                    help="generate = BASELINE configs[1] (the headline metric); train = configs[4], the stage-2 finetune step "
-                         "(forward + backward + gradient all-reduce + AdamW), per-GPU batch 4; mcub4 = configs[3], the 4-modality "
-                         "composed model on MCUB-4-shaped inputs (image + 10 s audio + 8-frame video + 8192-point cloud), per-GPU batch 2; "
-                         "iav = the metric string's literal inputs (336 px image + 10 s audio + 8-frame video) on configs[2]'s 3-way composed "
-                         "model (online-merge-reset 3 x 0.333), per-GPU batch 4")
-    return ap.parse_args()
+    ap.add_argument("--gemm-debug", type=int, default=0, help="debug only: mc_gemm_debug word (A/B of kernel variants)")
+    ap.add_argument("--workload", default="iav", choices=["iav", "vision", "generate", "mcub4", "train"],
+                    help="iav (default) = the metric's config; vision (alias generate) = configs[1]; mcub4 = configs[3]; train = configs[4], the "
+                         "stage-2 finetune step (forward + backward + gradient all-reduce + AdamW)")
+    a = ap.parse_args()
+    if a.workload == "generate":
+        a.workload = "vision"
+    return a
 
 
-def cpu_baseline(new_tokens: int):
-    """Oracle = CPU port of the reference algorithm (branch-form LocalLoRA on all tokens, mask-sum routing), torch fp32.
-    Bounded sample: BASELINE config 1 (1 image, ~683-token prompt, `new_tokens` greedy tokens) with 2 and with 4 of the 32
-    decoder layers; the per-layer cost from the difference is scaled to 32 layers, fixed costs (CLIP-L, projector, lm_head,
-    splice) are measured in full."""
+# ------------------------------------------------------------------------------------------------------------------- inputs
+def synthetic_inputs(modals, B, dev, seed):
+    """image N(0,1) (B,3,336,336); BEATs fbank N(0,0.5²) (B,1024,128) with the last 26 frames zero (10 s = 998 frames),
+    padding mask all False; video N(0,1) (B,3,8,224,224); points xyz uniform in the unit ball, rgb U[0,1], (B,8192,6)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
+    mi = {}
+    if "vision" in modals:
+        mi["vision"] = rnd(B, 3, 336, 336).to(torch.bfloat16)
+    if "audio" in modals:
+        fbank = rnd(B, 1024, 128) * 0.5
+        fbank[:, 998:] = 0
+        mi["audio"] = {"audio_inputs": fbank.to(torch.bfloat16), "audio_padding_mask": torch.zeros(B, 1024, dtype=torch.bool, device=dev)}
+    if "video" in modals:
+        mi["video"] = rnd(B, 3, 8, 224, 224).to(torch.bfloat16)
+    if "point" in modals:
+        xyz = rnd(B, 8192, 3)
+        xyz = xyz / xyz.norm(dim=-1, keepdim=True).clamp_min(1e-6) * torch.rand(B, 8192, 1, generator=g, device=dev) ** (1 / 3)
+        mi["point"] = torch.cat([xyz, torch.rand(B, 8192, 3, generator=g, device=dev)], -1).to(torch.bfloat16)
+    return mi
+
+
+def workload_meta(name, layers):
+    from modelcompose_amd import synthetic
+    modals = WORKLOADS[name][0]
+    reset = None if len(modals) == 1 else ",".join(f"default-{m}={round(1.0 / len(modals), 3)}" for m in modals)
+    return synthetic.vicuna7b_meta(modals, reset, layers=layers)
+
+
+# ------------------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(workload: str, new_tokens: int):
+    """Oracle = CPU port of the reference algorithm (branch-form LocalLoRA on all tokens, mask-sum routing, every encoder), torch fp32.
+    Bounded sample of the SAME workload: one sample (batch 1, the reference's eval batch), `new_tokens` greedy tokens, timed with 1 and
+    with 3 of the 32 decoder layers; the per-layer cost from the difference is scaled to 32, the fixed cost (encoders,
+    projectors, splice, lm_head) is measured in full."""
     from modelcompose_amd import synthetic
     from oracle import pipeline
     # torch's intra-op pool degrades badly far beyond ~32 threads on these op sizes (256 threads measured 70x slower)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    modals, sentinels = WORKLOADS[workload][0], WORKLOADS[workload][1]
     times = {}
     gen_dev = "cuda" if torch.cuda.is_available() else "cpu"      # weights are only GENERATED on the GPU, then moved to host fp32
-    for nl in (2, 4):
-        meta = synthetic.vicuna7b_meta(("vision",), None, layers=nl)
+    lo, hi = 1, 3
+    for nl in (lo, hi):
+        meta = workload_meta(workload, nl)
         sd = synthetic.synthetic_state_dict(meta, device=gen_dev, seed=7, dtype=torch.float32)
         sd = {k: v.cpu() for k, v in sd.items()}
         om = pipeline.OracleModel.from_state_dict(sd, meta)
-        ids = synthetic.synthetic_prompt(1, [-200])
-        px = torch.randn(1, 3, 336, 336)
+        ids = synthetic.synthetic_prompt(1, sentinels)
+        mi = synthetic_inputs(modals, 1, gen_dev, 3)
+        mi = {k: ({kk: (vv.float().cpu() if vv.is_floating_point() else vv.cpu()) for kk, vv in v.items()} if isinstance(v, dict) else v.float().cpu())
+              for k, v in mi.items()}
+        if "point" in mi:
+            meta["fps_start"] = [0]
         with torch.no_grad():
-            om.generate(ids, {"vision": px}, max_new_tokens=2, ignore_eos=True)      # untimed warm-up (thread pool, allocator)
+            if nl == lo:
+                om.generate(ids, mi, max_new_tokens=1, ignore_eos=True)               # untimed warm-up (thread pool, allocator)
             t0 = time.perf_counter()
-            om.generate(ids, {"vision": px}, max_new_tokens=new_tokens, ignore_eos=True)
+            om.generate(ids, mi, max_new_tokens=new_tokens, ignore_eos=True)
             times[nl] = time.perf_counter() - t0
         del sd, om
-    per_layer = max((times[4] - times[2]) / 2.0, 1e-9)
-    fixed = max(times[2] - 2 * per_layer, 0.0)
+    per_layer = max((times[hi] - times[lo]) / (hi - lo), 1e-9)
+    fixed = max(times[lo] - lo * per_layer, 0.0)
     full = fixed + 32 * per_layer
     return {"value": 1.0 / full, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch fp32 CPU port of the reference path) on BASELINE config 1: 1x336px image, 683-token prompt, "
-                      f"{new_tokens} greedy tokens; timed with 2 and 4 of 32 decoder layers ({times[2]:.2f}s, {times[4]:.2f}s), "
-                      f"per-layer cost x32 + measured fixed cost (CLIP-L/14-336, projector, lm_head) = {full:.1f}s per sample"}
+            "sample": f"oracle (torch fp32 CPU port of the reference path, batch 1 as the reference's eval loop) on one sample of the same "
+                      f"workload ({WORKLOADS[workload][3]}, {new_tokens} greedy tokens), timed with {lo} and {hi} of 32 decoder layers "
+                      f"({times[lo]:.1f}s, {times[hi]:.1f}s): per-layer cost x32 + measured fixed cost (all encoders, projectors, splice, "
+                      f"lm_head) = {full:.1f}s per sample; a full 32-layer run of this sample in the build container is recorded in DESIGN.md"}
 
 
+# ------------------------------------------------------------------------------------------------------------------- train (configs[4])
 def train_main(args, world, rank, local):
     """BASELINE configs[4]: stage-2 finetune step of the vision LocalLoRA model (adapters default + vision, r=128), per-GPU batch 4
     synthetic image-text pairs (683-token spliced sequence, the last 60 tokens are targets), bf16 compute, fp32 master weights;
@@ -107,7 +168,7 @@ def train_main(args, world, rank, local):
     del sd
     model._raw = {}
     torch.cuda.empty_cache()
-    B = 4 if args.batch == 16 else args.batch
+    B = args.batch or 4
     ids = synthetic.synthetic_prompt(B, [-200], seed=rank).to(dev)
     labels = ids.clone()
     labels[:, :-60] = -100
@@ -145,42 +206,112 @@ def train_main(args, world, rank, local):
         torch.distributed.destroy_process_group()
 
 
-def mcub4_main(args, world, rank, local):
-    """BASELINE configs[3]: vision + audio + video + point composed Vicuna-7B (online-merge-reset, 4 x 0.25), MCUB-4-shaped synthetic
-    inputs: 336 px image, 1024x128 fbank (10 s), 8 x 224 px frames, 8192 x 6 point cloud; spliced length 3337; greedy decode.
-    --workload iav: the same loop without the point modality on the 3-way composed model of configs[2] (3 x 0.333; spliced length 2790)."""
-    from modelcompose_amd import synthetic
+# ------------------------------------------------------------------------------------------------------------------- profiled pass
+PK_NAMES = ["qkv_gemm", "rope_kv", "attention", "o_gemm", "rms", "gate_up_gemm", "down_gemm", "lm_head_gemm", "other"]
+
+
+def profiled_pass(model, step_fn, cfg, B, new_tokens, n_steps):
+    """Roofline evidence, outside the throughput timing.  Pass A (graph decode, as shipped): GEMM events + stage events.  Pass B (one
+    launch per kernel): every decode kernel class bracketed by events."""
+    from modelcompose_amd import _lib
+    L = _lib.lib()
+    # ---- pass A
+    L.mc_gemm_profile_enable(1)
+    stages = {"encode": 0.0, "prefill": 0.0, "decode": 0.0}
+    lens = None
+    evs = []
+    for _ in range(n_steps):
+        ev = {}
+        step_fn(stage_events=ev)
+        evs.append(ev)
+    torch.cuda.synchronize()
+    L.mc_gemm_profile_enable(0)
+    for ev in evs:
+        for k in stages:
+            stages[k] += ev[k][0].elapsed_time(ev[k][1]) / n_steps
+        lens = ev["spliced_lens"]
+    graph_active = model.runtime_option("graph_active")
+    ms, fl, n, by = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_double(0)
+    L.mc_gemm_profile_read(C.byref(ms), C.byref(fl), C.byref(n))
+    L.mc_gemm_profile_read_bytes(C.byref(by))
+    achieved = (fl.value / max(ms.value, 1e-9)) / 1e9          # flops/ms -> TFLOP/s
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")     # HBM bytes per launch from separate rocprofv3 PMC passes (tools/profile_round.sh)
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == cfg["workload_name"] and tj.get("per_gpu_batch") == B:     # only a pass over THIS workload counts
+                traffic = tj.get("gemm_tile256_kernel_bytes_per_launch")
+                traffic_src = f"profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, round {tj.get('round')}, {tj.get('date')})"
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "kernel": "gemm_tile256_kernel", "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "launches": int(n.value), "avg_launch_us": round(ms.value / max(n.value, 1) * 1e3, 2),
+                "avg_flops_per_launch": fl.value / max(n.value, 1), "avg_algorithmic_bytes_per_launch": by.value / max(n.value, 1),
+                "share_of_step": round(ms.value / n_steps / max(sum(stages.values()), 1e-9), 4)}
+    # ---- decode roofline: algorithmic bytes of one step = every decoder weight + lm_head once, K and V of every cached key once
+    Hd, I, V, Ln, H, D = cfg["hidden"], cfg["inter"], cfg["vocab"], cfg["layers"], cfg["heads"], cfg["head_dim"]
+    wbytes = {"qkv_gemm": 2.0 * 3 * Hd * Hd, "o_gemm": 2.0 * Hd * Hd, "gate_up_gemm": 2.0 * 2 * I * Hd, "down_gemm": 2.0 * Hd * I,
+              "lm_head_gemm": 2.0 * V * Hd}
+    n_dec = new_tokens - 1
+    # step i (0-based) attends lens + i + 1 keys per sequence
+    kv_keys = float(sum(int(l) + i + 1 for l in lens for i in range(n_dec))) / max(n_dec, 1)      # summed over the batch, average per step
+    kv_bytes_layer = kv_keys * H * D * 2 * 2.0
+    step_bytes = Ln * (wbytes["qkv_gemm"] + wbytes["o_gemm"] + wbytes["gate_up_gemm"] + wbytes["down_gemm"] + kv_bytes_layer) + wbytes["lm_head_gemm"]
+    step_ms = stages["decode"] / max(n_dec, 1)
+    dec = {"bound": "hbm", "kernel": "decode step (5 launches per layer + lm_head + argmax, hipGraph replay)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+           "achieved": round(step_bytes / max(step_ms, 1e-9) / 1e6, 1), "frac": round(step_bytes / max(step_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+           "bytes_per_step": step_bytes, "ms_per_step": round(step_ms, 4), "graph_active": bool(graph_active),
+           "avg_keys_per_sequence": round(kv_keys / B, 1)}
+    # ---- pass B: per-kernel-class durations of the decode step, one launch per kernel with events around it
+    _lib.check(L.mc_llm_set_option(model._handle, b"profile", 1), "profile")
+    step_fn()
+    torch.cuda.synchronize()
+    _lib.check(L.mc_llm_set_option(model._handle, b"profile", 0), "profile")
+    nk = L.mc_llm_profile_kinds()
+    per = {}
+    for phase, pname in ((0, "prefill"), (1, "decode")):
+        tm, cnt = (C.c_double * nk)(), (C.c_int64 * nk)()
+        _lib.check(L.mc_llm_profile_read(model._handle, phase, tm, cnt), "profile_read")
+        per[pname] = {PK_NAMES[k]: (tm[k], cnt[k]) for k in range(nk) if cnt[k]}
+    kern = {}
+    for name, (tms, cnt) in per["decode"].items():
+        us = tms / cnt * 1e3
+        b = wbytes.get(name, kv_bytes_layer if name == "attention" else None)
+        kern[name] = {"avg_us": round(us, 2), "launches": int(cnt)}
+        if b is not None:
+            kern[name].update(bytes=b, gbs=round(b / us / 1e3, 1), frac=round(b / us / 1e3 / HBM_PEAK_GBS, 4))
+    dec["kernels"] = kern
+    dec["kernels_note"] = "per-class averages from a pass with one launch per kernel, each bracketed by HIP events on the launch stream (the shipped path replays a graph)"
+    pre = {name: {"total_ms": round(tms, 3), "launches": int(cnt)} for name, (tms, cnt) in per["prefill"].items()}
+    return roofline, dec, {k: round(v, 3) for k, v in stages.items()}, pre
+
+
+# ------------------------------------------------------------------------------------------------------------------- generate workloads
+def generate_main(args, world, rank, local):
+    from modelcompose_amd import _lib, synthetic
     from modelcompose_amd.dist import gather_ids
     from modelcompose_amd.model.builder import build_from_state_dict
+    name = args.workload
+    modals, sentinels, defB, msuffix, desc = WORKLOADS[name]
     dev = torch.device("cuda", local)
-    iav = args.workload == "iav"
-    modals = ("vision", "audio", "video") if iav else ("vision", "audio", "video", "point")
-    reset = ",".join(f"default-{m}={0.333 if iav else 0.25}" for m in modals)
-    meta = synthetic.vicuna7b_meta(modals, reset, layers=args.layers)
+    meta = workload_meta(name, args.layers)
     sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
     model = build_from_state_dict(meta, sd, device=dev)
+    model.use_graph = not args.no_graph
+    _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"use_graph", 0 if args.no_graph else 1), "set_option")
     del sd
     model._raw = {}
     torch.cuda.empty_cache()
-    B = (4 if iav else 2) if args.batch == 16 else args.batch
-    ids = synthetic.synthetic_prompt(B, [-200, -203, -204] + ([] if iav else [-205]), seed=rank).to(dev)
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
-    rnd = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
-    fbank = rnd(B, 1024, 128) * 0.5
-    fbank[:, 998:] = 0
-    xyz = rnd(B, 8192, 3)
-    xyz = xyz / xyz.norm(dim=-1, keepdim=True).clamp_min(1e-6) * torch.rand(B, 8192, 1, generator=g, device=dev) ** (1 / 3)
-    mi = {"vision": rnd(B, 3, 336, 336).to(torch.bfloat16),
-          "audio": {"audio_inputs": fbank.to(torch.bfloat16), "audio_padding_mask": torch.zeros(B, 1024, dtype=torch.bool, device=dev)},
-          "video": rnd(B, 3, 8, 224, 224).to(torch.bfloat16),
-          "point": torch.cat([xyz, torch.rand(B, 8192, 3, generator=g, device=dev)], -1).to(torch.bfloat16)}
-    if iav:
-        del mi["point"]
-    else:
+    B = args.batch or defB
+    ids = synthetic.synthetic_prompt(B, sentinels, seed=rank).to(dev)
+    mi = synthetic_inputs(modals, B, dev, 100 + rank)
+    if "point" in modals:
         model.model.modal_encoders["point"].fps_start = torch.zeros(B, dtype=torch.long)
 
-    def step():
-        out = model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True)
+    def step(**kw):
+        out = model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True, **kw)
         return gather_ids(out[:, ids.shape[1]:], world, force=DIST)
 
     def barrier():
@@ -188,32 +319,67 @@ def mcub4_main(args, world, rank, local):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n):
+        if not args.pipeline:
+            for _ in range(n):
+                step()
+            return
+        for out in model.generate_pipelined(((ids, mi) for _ in range(n)), max_new_tokens=args.new_tokens, ignore_eos=True):
+            gather_ids(out[:, ids.shape[1]:], world, force=DIST)
+
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if DIST or world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    if rank == 0:
-        feats, _ = model.encode_modal_inputs(mi, model.prefix_tokens, model.suffix_tokens)
-        print(json.dumps({
-            "metric": "samples/sec (whole node) composed-Vicuna-7B greedy gen, " + ("img+audio+video" if iav else "img+audio+video+point"),
-            "value": round(world * B * args.steps / dt, 4),
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("configs[2] model with the metric's inputs: 3-way composed Vicuna-7B (online-merge-reset 3 x 0.333; 7 adapters), "
-                                    "336 px image + 10 s audio + 8-frame video, " if iav else
-                                    "configs[3]: 4-modality composed Vicuna-7B (online-merge-reset 4 x 0.25; 9 adapters), MCUB-4-shaped inputs, ") +
-                                   f"batch {B} per GPU, {args.new_tokens} greedy tokens", "per_gpu_batch": B, "new_tokens": args.new_tokens,
-                       "layers": args.layers, "parallelism": f"dp{world}",
-                       "spliced_length": int(ids.shape[1] - 4 + sum(f.shape[1] for f in feats.values())),
-                       "block_tokens": {m: int(f.shape[1]) for m, f in feats.items()}, "ids_shape": list(out.shape)}}), flush=True)
+    if rank != 0:
+        if DIST or world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    feats, _ = model.encode_modal_inputs(mi, model.prefix_tokens, model.suffix_tokens)
+    spliced = int(ids.shape[1] - len(sentinels) + sum(f.shape[1] for f in feats.values()))
+    value = world * B * args.steps / dt
+    line = {
+        "metric": f"samples/sec (whole node) composed-Vicuna-7B greedy gen, {msuffix}",
+        "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{desc}; batch {B} per GPU, {spliced}-token spliced prompt, {args.new_tokens} greedy tokens",
+                   "workload_name": name, "per_gpu_batch": B, "new_tokens": args.new_tokens, "layers": args.layers, "spliced_length": spliced,
+                   "block_tokens": {m: int(f.shape[1]) for m, f in feats.items()}, "adapters": list(model.modal_names),
+                   "parallelism": f"dp{world}", "decode_graph_requested": not args.no_graph, "pipelined": bool(args.pipeline)},
+        "roofline": None, "roofline_decode": None,
+    }
+    del feats
+    if not args.no_profile and not args.pipeline:
+        cfgd = dict(hidden=meta["hidden_size"], inter=meta["intermediate_size"], vocab=meta["vocab_size"], layers=args.layers,
+                    heads=meta["num_attention_heads"], head_dim=meta["hidden_size"] // meta["num_attention_heads"], workload_name=name)
+        roofline, dec, stages, pre = profiled_pass(model, step, cfgd, B, args.new_tokens, min(args.steps, 3))
+        line["roofline"], line["roofline_decode"], line["stages_ms"] = roofline, dec, stages
+        line["prefill_kernel_classes_ms"] = pre
+        line["config"]["decode_graph"] = dec["graph_active"]
+    if world == 1 and not args.pipeline and not args.no_profile and name != "mcub4":
+        # informational, outside the timed region and outside the contract's fields: the same K batches through generate_pipelined
+        args.pipeline = True
+        run_steps(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - t0
+        args.pipeline = False
+        line["pipelined"] = {"value": round(B * args.steps / dtp, 4), "unit": "samples/s", "ms_per_step": round(dtp / args.steps * 1e3, 3),
+                             "note": "bench.py --pipeline: decode of batch i overlapped with encoders + prefill of batch i+1; same tokens"}
+    if world == 1 and not args.no_cpu_baseline:
+        del model
+        torch.cuda.empty_cache()
+        line["cpu_baseline"] = cpu_baseline(name, args.new_tokens)
+    print(json.dumps(line), flush=True)
     if DIST or world > 1:
         torch.distributed.destroy_process_group()
 
@@ -234,111 +400,7 @@ def main():
         _l.lib().mc_gemm_debug(args.gemm_debug)
     if args.workload == "train":
         return train_main(args, world, rank, local)
-    if args.workload in ("mcub4", "iav"):
-        return mcub4_main(args, world, rank, local)
-    from modelcompose_amd import _lib, synthetic
-    from modelcompose_amd.dist import gather_ids
-    from modelcompose_amd.model.builder import build_from_state_dict
-    import ctypes as C
-
-    dev = torch.device("cuda", local)
-    meta = synthetic.vicuna7b_meta(("vision",), None, layers=args.layers)
-    sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
-    model = build_from_state_dict(meta, sd, device=dev)
-    model.use_graph = not args.no_graph
-    _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"use_graph", 0 if args.no_graph else 1), "set_option")
-    del sd
-    model._raw = {}
-    torch.cuda.empty_cache()
-
-    B = args.batch
-    ids = synthetic.synthetic_prompt(B, [-200], seed=rank).to(dev)
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
-    pixels = torch.randn(B, 3, 336, 336, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    modal_inputs = {"vision": pixels}
-
-    def step():
-        out = model.generate(ids, modal_inputs=modal_inputs, max_new_tokens=args.new_tokens, ignore_eos=True)
-        return gather_ids(out[:, ids.shape[1]:], world, force=DIST)
-
-    def barrier():
-        if DIST or world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    def run_steps(n):
-        if not args.pipeline:
-            for _ in range(n):
-                step()
-            return
-        for out in model.generate_pipelined(((ids, modal_inputs) for _ in range(n)), max_new_tokens=args.new_tokens, ignore_eos=True):
-            gather_ids(out[:, ids.shape[1]:], world, force=DIST)
-
-    run_steps(args.warmup)
-    L = _lib.lib()
-    barrier()
-    L.mc_gemm_profile_enable(1)
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    L.mc_gemm_profile_enable(0)
-    ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
-    L.mc_gemm_profile_read(C.byref(ms), C.byref(fl), C.byref(n))
-    alg_bytes = C.c_double(0)
-    L.mc_gemm_profile_read_bytes(C.byref(alg_bytes))
-    if DIST or world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank != 0:
-        if DIST or world > 1:
-            torch.distributed.destroy_process_group()
-        return
-    value = world * B * args.steps / dt
-    achieved = (fl.value / max(ms.value, 1e-9)) / 1e9          # flops/ms -> TFLOP/s
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")     # HBM bytes per launch from the rocprofv3 PMC passes (see profiles/)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("gemm_tile256_kernel_bytes_per_launch")
-        except Exception:
-            traffic = None
-    line = {
-        "metric": "samples/sec (whole node) composed-Vicuna-7B greedy gen",
-        "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "configs[1]: vision-only composed Vicuna-7B (LocalLoRA r128: default+vision adapters), "
-                               f"batch {B} synthetic 336px images per GPU, 683-token spliced prompt, {args.new_tokens} greedy tokens",
-                   "per_gpu_batch": B, "new_tokens": args.new_tokens, "layers": args.layers, "parallelism": f"dp{world}",
-                   "decode_graph": not args.no_graph, "pipelined": bool(args.pipeline)},
-        "roofline": {"bound": "mfma", "kernel": "gemm_tile256_kernel", "achieved": round(achieved, 2),
-                     "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
-                     "traffic": traffic, "launches": int(n.value),
-                     "avg_launch_us": round(ms.value / max(n.value, 1) * 1e3, 2),
-                     "avg_flops_per_launch": fl.value / max(n.value, 1),
-                     "avg_algorithmic_bytes_per_launch": alg_bytes.value / max(n.value, 1)},
-    }
-    if world == 1 and not args.pipeline:
-        # informational, outside the timed region and outside the contract's fields: the same K batches through generate_pipelined (two
-        # generation pipelines on two HIP streams).  Kept out of `value` because concurrent launches stretch the per-launch durations the
-        # roofline object is computed from.
-        args.pipeline = True
-        run_steps(2)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        torch.cuda.synchronize()
-        dtp = time.perf_counter() - t0
-        args.pipeline = False
-        line["pipelined"] = {"value": round(B * args.steps / dtp, 4), "unit": "samples/s", "ms_per_step": round(dtp / args.steps * 1e3, 3),
-                             "note": "bench.py --pipeline: decode of batch i overlapped with encoders + prefill of batch i+1; same tokens"}
-    if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.new_tokens)
-    print(json.dumps(line), flush=True)
-    if DIST or world > 1:
-        torch.distributed.destroy_process_group()
+    return generate_main(args, world, rank, local)
 
 
 if __name__ == "__main__":

@@ -168,6 +168,10 @@ int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_adapter, int 
 int mc_gemm_tn_workspace_floats(int M, int P, int Q, int n_problems, int64_t* floats);
 int mc_gemm_tn_bf16(const void* const* a, int64_t lda, const void* const* b, int64_t ldb, float* const* out, int64_t ldo, int n_problems,
                     int M, int P, int Q, float alpha, float* workspace, void* stream);
+/* nn.Dropout(p) on the LoRA input (multimodal_llama.py:133-148) with a counter-based Philox4x32-10 mask keyed by (seed, stream_id, element):
+ * out = (accumulate ? out : 0) + alpha * x * keep / (1 - p).  The same call regenerates the mask in the backward pass.                */
+int mc_dropout_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int K, float p, unsigned long long seed,
+                    unsigned int stream_id, int accumulate, float alpha, void* stream);
 int mc_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* g, const void* dy, int64_t ldy, const void* dres, int64_t ldr,
                         void* dx, int64_t ldd, int M, int D, float eps, void* stream);
 int mc_swiglu_bwd_bf16(const void* gate_up, int64_t ld, const void* dinter, int64_t ldi, void* dgate_up, int64_t ldg, int M, int I,
@@ -282,6 +286,12 @@ int mc_llm_set_option(void* handle, const char* name, int value);        /* "use
 /* read back: "use_graph"; "graph_active" = 1 when the last mc_llm_decode replayed a hipGraph (0: one launch per kernel); "graph_captures" /
  * "graph_failures" = decode-step graphs captured / capture attempts that failed since mc_llm_create */
 int mc_llm_get_option(void* handle, const char* name, int* value);
+/* "profile" option (mc_llm_set_option): while 1, every launch of the layer loop is bracketed by HIP events on its stream (profiled decode
+ * calls run one launch per kernel, no graph).  mc_llm_profile_read sums them per kernel class - index 0 q|k|v GEMM, 1 RoPE + cache append
+ * (prefill), 2 attention, 3 o_proj GEMM, 4 RMS factor (prefill), 5 gate|up GEMM + SwiGLU, 6 down_proj GEMM, 7 lm_head GEMM, 8 other - for
+ * phase 0 (prefill) or 1 (decode); arrays of mc_llm_profile_kinds() entries.  Enabling the option clears the records.                  */
+int mc_llm_profile_kinds(void);
+int mc_llm_profile_read(void* handle, int phase, double* total_ms, int64_t* launches);
 /* next-token rule of mc_llm_decode: do_sample = 0 greedy arg-max (default), 1 = mc_sample_step_f32 with these parameters and the seed the
  * caller stored at state[4B+1], state[4B+2] */
 int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_k, float top_p);

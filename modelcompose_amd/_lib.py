@@ -103,6 +103,7 @@ _SIGS.update({
     "mc_rope_inplace_bf16": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "mc_adamw_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p],
     "mc_cast_f32_bf16": [c_p, c_p, c_l, c_p],
+    "mc_dropout_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_f, C.c_uint64, C.c_uint32, c_i, c_f, c_p],
     "mc_add_rows_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_p],
     "mc_zero_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_im2col_ex_bf16": [c_p, c_l, c_l, c_l, c_l, c_p] + [c_i] * 15 + [c_p],
@@ -125,6 +126,8 @@ _SIGS.update({
     "mc_llm_prefill": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
     "mc_llm_decode": [c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "mc_llm_get_option": [c_p, C.c_char_p, C.POINTER(c_i)],
+    "mc_llm_profile_kinds": [],
+    "mc_llm_profile_read": [c_p, c_i, C.POINTER(C.c_double), C.POINTER(c_l)],
 })
 # optional symbols added by later ABI revisions are bound if present
 _OPTIONAL: dict = {}

@@ -434,17 +434,29 @@ __device__ unsigned long long g2_stamps[2 * 4096];
 
 template <int ABL, int NI = 4>
 __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx, G2Groups grp, int N, int K,
-                                                              Epilogue ep, int tiles_m, int tiles_n) {
+                                                              Epilogue ep, int tiles_m, int tiles_n, int raster) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA destinations stay on the scalar unit
     const int wave_n = wave >> 2, wave_m = wave & 3;
     const int c16 = lane & 15, q4 = lane >> 4;
 
-    // XCD-aware tile order (same scheme as gemm_tile_kernel): contiguous chunk per XCD, 4 m-tiles per n-tile column
+    // XCD-aware tile order.  Logical order: groups of 8 m-tiles, inside a group n-tile columns, m fastest, so that 32 consecutive
+    // tiles are an 8 x 4 block (12 tile-rows of operands for 32 tiles through one XCD's L2).  Blocks b and b+8 of the grid share an XCD
+    // (round-robin dispatch; speed only).  raster 0: every XCD owns a contiguous eighth of the logical order - the XCDs work on
+    // different m-groups, 8 groups' activations (8 x 256 x K each) plus the weight sweep are live in the 256-MiB Infinity Cache.
+    // raster 1 (large M): the 32-tile blocks are dealt round-robin over the XCDs, so all eight work on the SAME m-group at the same
+    // time: its activations are fetched from HBM once and hit the Infinity Cache for the other seven, and the weight matrix, re-swept
+    // once per m-group, stays resident - L2 misses become Infinity-Cache hits instead of HBM round trips.
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
-    {
+    if (raster == 1) {
+        const int full = nwg & ~255;
+        if (bid < full) {
+            const int xcd = bid & 7, idx = bid >> 3;
+            bid = (((idx >> 5) << 3) + xcd) * 32 + (idx & 31);
+        }
+    } else {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
@@ -939,11 +951,15 @@ static float* splitk_workspace(size_t floats) {
 // (12 instead of 16 MFMAs per phase behind the same X reads and DMA issues).  M = 2728 (the finetune step), N = 4096: 176 tiles of 256
 // fill 69 % of the CUs, 242 tiles of 192 fill 95 %.  debug word bit 10 forces 192, bit 11 forces 256.
 static bool g_tile192 = true;
+static bool g_raster_auto = true;          // "raster_shared" option
+static int g_raster_min_tiles = 1024;      // launches with at least this many tiles deal their 32-tile blocks round-robin over the XCDs
 // "tile192" = 0 keeps the large-M kernel on 256-column tiles: for callers that fill the idle CUs of an under-filled launch themselves
 // (the finetune step runs its rank-projection and weight-gradient GEMMs on a second stream next to the base GEMMs: measured on one
 // device, samples/s  overlap + 256: 33.4, overlap + 192: 31.8, no overlap + 192: 32.8, no overlap + 256: 31.1)
 extern "C" int mc_gemm_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tile192")) { g_tile192 = value != 0; return 0; }
+    if (name && !strcmp(name, "raster_shared")) { g_raster_auto = value != 0; return 0; }
+    if (name && !strcmp(name, "raster_min_tiles")) { g_raster_min_tiles = value; return 0; }
     mc_set_error("mc_gemm_set_option: unknown option '%s'", name ? name : "(null)");
     return 1;
 }
@@ -1124,11 +1140,13 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
                            (a->residual ? (double)M_total * N : 0.0));
         (void)hipEventRecord(rec.a, s);
     }
-#define G2_LAUNCH(A) gemm_tile256_kernel<A><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n)
+    // debug word bit 16 forces raster 0, bit 17 forces raster 1
+    const int raster = (g_gemm_dbg & 65536) ? 0 : ((g_gemm_dbg & 131072) ? 1 : (g_raster_auto && tiles_m * tiles_n >= g_raster_min_tiles ? 1 : 0));
+#define G2_LAUNCH(A) gemm_tile256_kernel<A><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster)
     // debug word bits 3-5: timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1;
     // 40 = correct results + clock stamps around the main loop (mc_gemm_clock_read)
     if (ni == 3) {
-        gemm_tile256_kernel<0, 3><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n);
+        gemm_tile256_kernel<0, 3><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);
     } else switch ((g_gemm_dbg >> 3) & 7) {
         case 1: G2_LAUNCH(1); break;
         case 2: G2_LAUNCH(2); break;

@@ -50,6 +50,11 @@ struct Llm {
     // observability (mc_llm_get_option): did the last mc_llm_decode replay a graph; captures made; captures that failed
     int graph_active = 0, graph_captures = 0, graph_failures = 0;
     bool capture_warned = false;
+    // live per-kernel-class timing ("profile" option; bench.py's roofline_decode object): HIP events recorded on the launch stream around
+    // every launch of the layer loop while enabled.  Profiled decode calls run one launch per kernel (events are not captured into graphs).
+    struct PRec { int phase, kind; hipEvent_t a, b; };
+    bool prof_on = false;
+    std::vector<PRec> prof;
     // next-token rule: greedy arg-max, or temperature / top-k / top-p sampling (seed: 2 x u32 at state[4B+1] on the device)
     bool do_sample = false;
     float temperature = 1.0f, top_p = 1.0f;
@@ -87,6 +92,25 @@ Ws carve(const mc_llm_config& c, int M, int B, int Lq, char* base) {
     do {                             \
         int rc__ = (call);           \
         if (rc__ != 0) return rc__;  \
+    } while (0)
+
+// kernel classes of the layer loop (mc_llm_profile_read)
+enum { PK_QKV = 0, PK_ROPE, PK_ATTN, PK_O, PK_RMS, PK_GATE_UP, PK_DOWN, PK_HEAD, PK_OTHER, PK_COUNT };
+
+// RUN with optional event bracketing on the launch stream
+#define RUNP(m_, phase_, kind_, stream_, call)                                         \
+    do {                                                                               \
+        hipEvent_t pa__ = nullptr, pb__ = nullptr;                                     \
+        if ((m_)->prof_on) {                                                           \
+            (void)hipEventCreate(&pa__); (void)hipEventCreate(&pb__);                  \
+            (void)hipEventRecord(pa__, (hipStream_t)(stream_));                        \
+        }                                                                              \
+        int rc__ = (call);                                                             \
+        if ((m_)->prof_on) {                                                           \
+            (void)hipEventRecord(pb__, (hipStream_t)(stream_));                        \
+            (m_)->prof.push_back({(phase_), (kind_), pa__, pb__});                     \
+        }                                                                              \
+        if (rc__ != 0) return rc__;                                                    \
     } while (0)
 
 int check_handle(Llm* m, const char* fn) {
@@ -139,36 +163,37 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
         for (int g = 0; g < n_groups; ++g) wg[g] = W(gadapter[g], which);
         return (const void* const*)wg;
     };
+    const int ph = decode ? 1 : 0;
     // q|k|v = (x / rms) . (W_qkv diag(g_in))^T                                                  (:440-443, :262-268)
-    RUN(gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in));
+    RUNP(m, ph, PK_QKV, stream, gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in));
     if (decode) {
         // one token per sequence (row b = sequence b): RoPE, the cache append and the attention are one launch (:281-312)
-        RUN(mc_attn_decode_rope_bf16(w.qkv, qkvd, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl, Hkv * Smax * D, D,
-                                     (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit, scale,
-                                     stream));
+        RUNP(m, ph, PK_ATTN, stream, mc_attn_decode_rope_bf16(w.qkv, qkvd, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
+                                     Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit,
+                                     scale, stream));
     } else {
-        RUN(mc_rope_kv_bf16(w.qkv, qkvd, row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, M, (int)H, (int)Hkv, (int)D, Lq,
-                            Smax, stream));
-        RUN(mc_attn_prefill_bf16(w.qseq, (int64_t)Lq * H * D, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
-                                 Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, out_map, kv_lens, B, (int)H, (int)Hkv, Lq, Smax,
-                                 (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, stream));
+        RUNP(m, ph, PK_ROPE, stream, mc_rope_kv_bf16(w.qkv, qkvd, row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, M, (int)H, (int)Hkv,
+                                     (int)D, Lq, Smax, stream));
+        RUNP(m, ph, PK_ATTN, stream, mc_attn_prefill_bf16(w.qseq, (int64_t)Lq * H * D, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
+                                     Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, out_map, kv_lens, B, (int)H, (int)Hkv, Lq, Smax,
+                                     (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, stream));
     }
     // x += o_proj(attn)  (:447);  then 1/rms of the new x for post_attention_layernorm (:462)
-    RUN(gemm_grouped(w.attn, hd, x, hd, x, hd, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream));
-    if (!skinny) RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
+    RUNP(m, ph, PK_O, stream, gemm_grouped(w.attn, hd, x, hd, x, hd, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream));
+    if (!skinny) RUNP(m, ph, PK_RMS, stream, mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
     // inter = silu(gate) * up with gate|up = (x / rms) . (W_gu diag(g_post))^T                 (:380-390)
-    RUN(gemm_grouped(x, hd, nullptr, 0, w.inter, I, (int)(2 * I), (int)hd, rs_in, 1, n_groups, gstart, W_all(2), stream, eps_in));
+    RUNP(m, ph, PK_GATE_UP, stream, gemm_grouped(x, hd, nullptr, 0, w.inter, I, (int)(2 * I), (int)hd, rs_in, 1, n_groups, gstart, W_all(2), stream, eps_in));
     // x += down_proj(inter)  (:466);  then 1/rms for the next layer's input_layernorm / the final norm
-    RUN(gemm_grouped(w.inter, I, x, hd, x, hd, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream));
-    if (!skinny) RUN(mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
+    RUNP(m, ph, PK_DOWN, stream, gemm_grouped(w.inter, I, x, hd, x, hd, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream));
+    if (!skinny) RUNP(m, ph, PK_RMS, stream, mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
     return 0;
 }
 
-int head_forward(Llm* m, const char* xl, int B, const Ws& w, float* logits, void* stream) {
+int head_forward(Llm* m, const char* xl, int B, const Ws& w, float* logits, void* stream, int phase) {
     const mc_llm_config& c = m->cfg;
-    RUN(mc_rmsnorm_bf16(xl, c.hidden, m->final_norm, w.nl, c.hidden, B, c.hidden, c.rms_eps, stream));
-    RUN(mc_gemm_bf16(w.nl, c.hidden, m->lm_head, nullptr, nullptr, 0, logits, c.vocab, B, c.vocab, c.hidden, MC_ACT_NONE, 1, 1.0f, 1.0f,
-                     stream));
+    RUNP(m, phase, PK_OTHER, stream, mc_rmsnorm_bf16(xl, c.hidden, m->final_norm, w.nl, c.hidden, B, c.hidden, c.rms_eps, stream));
+    RUNP(m, phase, PK_HEAD, stream, mc_gemm_bf16(w.nl, c.hidden, m->lm_head, nullptr, nullptr, 0, logits, c.vocab, B, c.vocab, c.hidden,
+                                                 MC_ACT_NONE, 1, 1.0f, 1.0f, stream));
     return 0;
 }
 
@@ -203,6 +228,7 @@ extern "C" int mc_llm_destroy(void* handle) {
     if (m->own_stream) { (void)hipStreamSynchronize(m->own_stream); (void)hipStreamDestroy(m->own_stream); }
     if (m->ev_in) (void)hipEventDestroy(m->ev_in);
     if (m->ev_out) (void)hipEventDestroy(m->ev_out);
+    for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     delete m;
     return 0;
 }
@@ -230,6 +256,14 @@ extern "C" int mc_llm_set_option(void* handle, const char* name, int value) {
     Llm* m = (Llm*)handle;
     if (!m || !name) { mc_set_error("mc_llm_set_option: null argument"); return 1; }
     if (!strcmp(name, "use_graph")) { m->use_graph = value != 0; return 0; }
+    if (!strcmp(name, "profile")) {
+        if (value && !m->prof_on) {
+            for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+            m->prof.clear();
+        }
+        m->prof_on = value != 0;
+        return 0;
+    }
     mc_set_error("mc_llm_set_option: unknown option '%s'", name);
     return 1;
 }
@@ -243,6 +277,24 @@ extern "C" int mc_llm_get_option(void* handle, const char* name, int* value) {
     if (!strcmp(name, "graph_failures")) { *value = m->graph_failures; return 0; }
     mc_set_error("mc_llm_get_option: unknown option '%s'", name);
     return 1;
+}
+
+extern "C" int mc_llm_profile_kinds(void) { return PK_COUNT; }
+
+// total_ms / launches: [PK_COUNT] each, for phase 0 (prefill) or 1 (decode), over the launches since the "profile" option was last enabled
+extern "C" int mc_llm_profile_read(void* handle, int phase, double* total_ms, int64_t* launches) {
+    Llm* m = (Llm*)handle;
+    if (!m || !total_ms || !launches || (phase != 0 && phase != 1)) { mc_set_error("mc_llm_profile_read: bad arguments"); return 1; }
+    for (int k = 0; k < PK_COUNT; ++k) { total_ms[k] = 0.0; launches[k] = 0; }
+    for (auto& r : m->prof) {
+        if (r.phase != phase) continue;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) { mc_set_error("mc_llm_profile_read: %s", hipGetErrorString(e)); return 2; }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        total_ms[r.kind] += t; launches[r.kind] += 1;
+    }
+    return 0;
 }
 
 extern "C" int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_k, float top_p) {
@@ -295,7 +347,7 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
     if (last_rows && (logits_out || next_ids)) {
         RUN(mc_copy_rows_bf16(x_routed, c.hidden, last_rows, w.xl, c.hidden, nullptr, B, c.hidden, stream));
         float* lg = logits_out ? logits_out : (float*)w.logits;
-        RUN(head_forward(m, w.xl, B, w, lg, stream));
+        RUN(head_forward(m, w.xl, B, w, lg, stream, 0));
         if (next_ids) RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, nullptr, 0, nullptr, B, c.vocab, stream));
     }
     return 0;
@@ -313,19 +365,19 @@ static int decode_one_step(Llm* m, int B, int64_t* next_ids, int64_t* out_ids, i
     const int32_t* iota = state + 2 * B;
     const int32_t* zeros = state + 3 * B;
     const int32_t* step = state + 4 * B;
-    RUN(mc_embed_rows_bf16(m->embed, c.hidden, next_ids, w.xl, c.hidden, nullptr, B, c.hidden, stream));
+    RUNP(m, 1, PK_OTHER, stream, mc_embed_rows_bf16(m->embed, c.hidden, next_ids, w.xl, c.hidden, nullptr, B, c.hidden, stream));
     if (B > 64) RUN(mc_rms_scale_bf16(w.xl, c.hidden, w.rs, B, c.hidden, c.rms_eps, stream));        // M <= 64: computed inside the GEMMs
     for (int l = 0; l < c.n_layers; ++l)
         RUN(layer_forward(m, l, w.xl, B, 1, gs, gad, w, iota, pos, zeros, nullptr, kvlen, B, 1, (char*)k_cache, (char*)v_cache, Smax, true,
                           nsplit, attn_ws, stream));
     float* lg = logits_step ? logits_step : (float*)w.logits;
-    RUN(head_forward(m, w.xl, B, w, lg, stream));
+    RUN(head_forward(m, w.xl, B, w, lg, stream, 1));
     if (m->do_sample)
         RUN(mc_sample_step_f32(lg, c.vocab, next_ids, out_ids, ld_out, step, 0, (const uint32_t*)(state + 4 * B + 1), 0ull, B, c.vocab,
                                m->temperature, m->top_k, m->top_p, nullptr, nullptr, 0, stream));
     else
-        RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, out_ids, ld_out, step, B, c.vocab, stream));
-    RUN(mc_decode_state_advance(state, B, stream));
+        RUNP(m, 1, PK_OTHER, stream, mc_argmax_step_f32(lg, c.vocab, next_ids, out_ids, ld_out, step, B, c.vocab, stream));
+    RUNP(m, 1, PK_OTHER, stream, mc_decode_state_advance(state, B, stream));
     return 0;
 }
 
@@ -352,7 +404,7 @@ extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids
     void* attn_ws = (char*)workspace + w.total;
     const int nsplit = decode_nsplit(c, B);
     hipStream_t s = (hipStream_t)stream;
-    if (m->use_graph && !logits_out && n_steps > 1) {
+    if (m->use_graph && !logits_out && n_steps > 1 && !m->prof_on) {
         // graphs cannot be captured on the legacy null stream: run this call's launches on the handle's own stream, after everything the
         // caller has queued on stream 0 (ev_in) and before anything it queues afterwards (ev_out)
         hipStream_t gs = s;

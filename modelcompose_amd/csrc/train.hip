@@ -53,6 +53,61 @@ extern "C" int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_ad
 }
 
 // ------------------------------------------------------------------------------------------
+// nn.Dropout on the LoRA input (LocalLoraLinear.forward, multimodal_llama.py:133-148: lora_A(lora_dropout(x)), p = 0.05 in the stage-2
+// scripts).  Counter-based mask: element e = m*K + k of stream `stream_id` is kept iff word (e & 3) of
+// Philox4x32-10(counter = (e >> 2 lo, e >> 2 hi, stream_id, 0), key = (seed_lo, seed_hi)) >= p * 2^32, so the backward pass (and the
+// CPU oracle, oracle/philox.py) regenerates the identical mask from (seed, stream_id) instead of storing it.
+//   out[m][k] = (accumulate ? out[m][k] : 0) + alpha * x[m][k] * keep / (1 - p)
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int M, int K,
+                                                      uint32_t thr, float inv_keep, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
+                                                      int accumulate, float alpha) {
+    const int nv = K >> 3;
+    const int64_t total = (int64_t)M * nv;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / nv), c = (int)(i % nv);
+        const uint64_t e4 = ((uint64_t)m * (uint64_t)K + (uint64_t)c * 8) >> 2;          // K % 8 == 0: a vector never straddles two counters' quads
+        uint32_t r0[4], r1[4];
+        philox4((uint32_t)e4, (uint32_t)(e4 >> 32), stream_id, 0u, seed_lo, seed_hi, r0);
+        philox4((uint32_t)(e4 + 1), (uint32_t)((e4 + 1) >> 32), stream_id, 0u, seed_lo, seed_hi, r1);
+        const bf16x8 xv = *(const bf16x8*)(x + (int64_t)m * ldx + c * 8);
+        bf16x8 o;
+        if (accumulate) o = *(const bf16x8*)(out + (int64_t)m * ldo + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t r = j < 4 ? r0[j] : r1[j - 4];
+            const float v = r >= thr ? alpha * (float)xv[j] * inv_keep : 0.f;
+            o[j] = (bf16_t)(accumulate ? (float)o[j] + v : v);
+        }
+        *(bf16x8*)(out + (int64_t)m * ldo + c * 8) = o;
+    }
+}
+
+extern "C" int mc_dropout_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int K, float p, unsigned long long seed,
+                               unsigned int stream_id, int accumulate, float alpha, void* stream) {
+    MC_CHECK_ARG(x && out && M > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "mc_dropout_bf16: bad arguments");
+    MC_CHECK_ARG(p >= 0.f && p < 1.f, "mc_dropout_bf16: dropout probability has to be between 0 and 1, but got %g", (double)p);
+    const double t = (double)p * 4294967296.0;
+    const uint32_t thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    const int64_t total = (int64_t)M * (K >> 3);
+    dropout_kernel<<<(int)min((int64_t)8192, (total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, K, thr, 1.0f / (1.0f - p), (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, accumulate, alpha);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // RMSNorm backward (LlamaRMSNorm: y = g * x * rs, rs = rsqrt(mean(x^2) + eps)):
 //   dx = rs * (g*dy) - x * rs^3 * mean(x * g*dy)   (+ dres: the residual branch's gradient)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ g,

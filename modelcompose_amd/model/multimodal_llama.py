@@ -299,7 +299,11 @@ class MultimodalLlamaForCausalLM:
         tok = plan.tok_id[order_b, order_t]
         sm = plan.src_modal[order_b, order_t]
         sr = plan.src_row[order_b, order_t]
-        text = np.nonzero(sm < 0)[0]
+        pad = np.nonzero((sm < 0) & (tok < 0))[0]                  # slots behind a sample's spliced length (padded layouts): zero rows
+        if len(pad):
+            ops.copy_rows(out, out, len(pad), torch.full((len(pad),), -1, dtype=torch.int32, device=dev),
+                          torch.from_numpy(pad.astype(np.int32)).to(dev))
+        text = np.nonzero((sm < 0) & (tok >= 0))[0]
         if len(text):
             ids = torch.from_numpy(tok[text]).to(dev)
             ops.embed_rows(self.model.embed_tokens, ids, out, torch.from_numpy(text.astype(np.int32)).to(dev))
@@ -485,12 +489,25 @@ class MultimodalLlamaForCausalLM:
             sampling = (T, Kk, P, int(seed))
         streamer = kw.pop("streamer", None)
         criteria = kw.pop("stopping_criteria", None)
+        # stage_events (dict, optional): receives torch.cuda.Event pairs recorded on the current stream around the three stages, as
+        # {"encode": (e0, e1), "prefill": (e1, e2), "decode": (e2, e3)} (bench.py: stage times and the decode roofline)
+        stage_events = kw.pop("stage_events", None)
+
+        def mark():
+            if stage_events is None:
+                return None
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
         if input_ids is None:
             raise ValueError("generate() needs input_ids")
         modal_inputs = modal_inputs or {}
+        e0 = mark()
         feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
+        e1 = mark()
         plan = self._plan(input_ids, attention_mask, None, modal_inputs, feats)
         st = self._prefill(plan, feats, max_new_tokens, want_logits=return_step_logits or sampling is not None, slot=slot)
+        e2 = mark()
         if prefill_done is not None:
             prefill_done.record()                                  # generate_pipelined: the other pipeline's prefill may start now
         B = plan.B
@@ -547,6 +564,8 @@ class MultimodalLlamaForCausalLM:
                         break
         if streamer is not None:
             streamer.end()
+        if stage_events is not None:
+            stage_events.update(encode=(e0, e1), prefill=(e1, e2), decode=(e2, mark()), spliced_lens=plan.valid_lens.copy())
         if stopped_at is not None:
             out = out[:, :stopped_at]
             done_at = stopped_at

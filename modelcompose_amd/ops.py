@@ -490,6 +490,15 @@ def adamw(p32, g32, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
                "mc_adamw_f32")
 
 
+def dropout(x, p: float, seed: int, stream_id: int, out=None, accumulate: bool = False, alpha: float = 1.0):
+    """out = (accumulate ? out : 0) + alpha * x * keep / (1 - p); keep from Philox4x32-10 keyed by (seed, stream_id, element index)."""
+    M, K = x.shape
+    out = torch.empty(M, K, dtype=BF16, device=x.device) if out is None else out
+    _lib.check(_lib.lib().mc_dropout_bf16(_p(x), x.stride(0), _p(out), out.stride(0), M, K, float(p), int(seed) & (2 ** 64 - 1), int(stream_id),
+                                          int(accumulate), float(alpha), _stream()), "mc_dropout_bf16")
+    return out
+
+
 def cast_bf16(x32, out=None):
     out = torch.empty(x32.shape, dtype=BF16, device=x32.device) if out is None else out
     _lib.check(_lib.lib().mc_cast_f32_bf16(_p(x32), _p(out), x32.numel(), _stream()), "mc_cast_f32_bf16")

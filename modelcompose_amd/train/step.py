@@ -16,8 +16,13 @@ Restructuring that keeps the function:
     One pair of skinny GEMMs serves all adapters, and the same mask routes the gradients.
   * nothing is recomputed: activations of all layers stay resident (≈0.4 GB per layer at B=4, L=682 — the reference checkpoints
     per layer, multimodal_llama.py:567-583, because it targets 80 GB parts).
-Limits of this version (raise, never fall back): equal-length samples without padding, MLP / linear projectors only,
-lora_dropout must be 0 (the reference applies nn.Dropout(0.05) to the LoRA input in training, multimodal_llama.py:133)."""
+  * lora_dropout (nn.Dropout on the LoRA input, multimodal_llama.py:133-148; 0.05 in run_finetune_*_damc.sh): counter-based Philox masks
+    keyed by (seed, step, layer, linear, element) - regenerated in the backward pass instead of stored; one mask per (linear, token): a
+    token only uses its own adapter's branch, so the reference's independent per-adapter masks are the same distribution.
+  * padded / ragged batches (collator: multimodal_dataset.py:148-214; splice padding: multimodal_arch.py:390-430): rows keep the
+    reference's padded [B, Lmax] layout - pad slots are zero embeddings, masked as attention keys by a per-sample length, ignored by
+    the loss (-100) - so they contribute exactly zero to every gradient, as in the reference.
+Limits of this version (raise, never fall back): MLP / linear projectors only (no Q-Former backward), right padding only."""
 from __future__ import annotations
 
 import math
@@ -51,10 +56,12 @@ class _Param:
 
 class MultimodalTrainStep:
     def __init__(self, model: MultimodalLlamaForCausalLM, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 bucket_layers: int = 4, process_group=None, overlap_wgrad: bool = True, force_exchange: bool = False):
+                 bucket_layers: int = 4, process_group=None, overlap_wgrad: bool = True, force_exchange: bool = False, dropout_seed: int = 0):
         cfg = model.config
-        if float(getattr(cfg, "lora_dropout", 0.0) or 0.0) != 0.0:
-            raise NotImplementedError("lora_dropout > 0 (nn.Dropout on the LoRA input, multimodal_llama.py:133) is not implemented; set it to 0")
+        self.p = float(getattr(cfg, "lora_dropout", 0.0) or 0.0)
+        if not 0.0 <= self.p < 1.0:
+            raise ValueError(f"dropout probability has to be between 0 and 1, but got {self.p}")
+        self.dropout_seed = int(dropout_seed)
         if cfg.reset_scaling_weights is not None:
             raise NotImplementedError("training a composed (reset_scaling_weights) checkpoint is not what the reference's stage-2 scripts do")
         if cfg.num_key_value_heads != cfg.num_attention_heads:
@@ -79,6 +86,10 @@ class MultimodalTrainStep:
             self.world = 1
         # force_exchange: run the bucketed all-reduce even in a world of one process (exercises the RCCL path on a single GPU)
         self._exchange = self.world > 1 or (force_exchange and torch.distributed.is_available() and torch.distributed.is_initialized())
+        self.rank = 0
+        if self.world > 1:
+            import torch.distributed as dist
+            self.rank = dist.get_rank(process_group)
         self.step_count = 0
         # weight-gradient (TN) GEMMs run on a second HIP stream: they only feed the gradient buffer, so they overlap the main stream's
         # input-gradient GEMMs, which at B*L = 2728 rows fill only 176 of the 256 CUs
@@ -195,6 +206,15 @@ class MultimodalTrainStep:
                 self._packed[name], self._packed[name + ".T"] = fw, tr
                 descs.append((w.data_ptr(), fw.data.data_ptr(), w.stride(0), 1, N, K))
                 descs.append((w.data_ptr(), tr.data.data_ptr(), 1, w.stride(0), K, N))          # W' = w^T: W'[n][k] = w[k][n]
+                if self.p > 0 and name.endswith(".A_in"):
+                    # with dropout every linear of a group sees its own dropped input: per-linear views of the stacked image (block rows are
+                    # contiguous) for the forward, per-linear transposes for the input gradient
+                    Kp = ops.ceil_to(K, 64)
+                    for j in range(N // self.R):
+                        self._packed[f"{name}.{j}"] = ops.PackedWeight(fw.data[j * self.R * Kp:(j + 1) * self.R * Kp], self.R, K)
+                        trj = ops.PackedWeight(torch.empty(ops.packed_elems(K, self.R), dtype=BF16, device=self.dev), K, self.R)
+                        self._packed[f"{name}.{j}.T"] = trj
+                        descs.append((w.data_ptr() + j * self.R * w.stride(0) * 2, trj.data.data_ptr(), 1, w.stride(0), K, self.R))
             rec = np.zeros(len(descs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("sn", "<i8"), ("sk", "<i8"), ("N", "<i4"), ("K", "<i4")]))
             for i, dsc in enumerate(descs):
                 rec[i] = dsc
@@ -245,16 +265,37 @@ class MultimodalTrainStep:
             t.record_stream(self._wstream)                          # the allocator must not recycle them under the side stream
         return done
 
+    _LIN_ID = {"q_proj": 0, "k_proj": 1, "v_proj": 2, "o_proj": 3, "gate_proj": 4, "up_proj": 5, "down_proj": 6}
+
+    def _stream_id(self, layer, lin):
+        return layer * 8 + self._LIN_ID[lin]
+
+    def dropout_keep_scale(self, layer: int, lin: str, M: int, K: int) -> torch.Tensor:
+        """keep / (1 - p) of the LAST step's mask of one linear, [M, K] (tests: the oracle applies the same masks)."""
+        return ops.dropout(torch.ones(M, K, dtype=BF16, device=self.dev), self.p, self._seed, self._stream_id(layer, lin)).float()
+
     def _lora_fwd_begin(self, x, layer, gname, row_adapter):
         """Rank projection of a group, T = mask(x [A_0; A_1; ..]^T) ([M, n_linears * R]; the routing mask zeroes, per row, the rank blocks
         of the other adapters).  It only depends on x, so it runs on the side stream next to the base GEMM of the same input."""
         box = {}
 
         def run():
-            T = ops.linear(x, self._packed[f"model.layers.{layer}.{gname}.A_in"], auto_split=True)
+            aname = f"model.layers.{layer}.{gname}.A_in"
+            if self.p > 0:
+                lins = dict(GROUPS)[gname]
+                T = torch.empty(x.shape[0], len(lins) * self.R, dtype=BF16, device=self.dev)
+                xds = []
+                for j, (blk, lin) in enumerate(lins):
+                    xd = ops.dropout(x, self.p, self._seed, self._stream_id(layer, lin))
+                    ops.linear(xd, self._packed[f"{aname}.{j}"], out=T[:, j * self.R:(j + 1) * self.R], auto_split=True)
+                    xds.append(xd)
+                box["xd"] = xds
+            else:
+                T = ops.linear(x, self._packed[aname], auto_split=True)
             ops.lora_mask_rows(T, row_adapter, self.r, self.nA)
             box["T"] = T
         done = self._on_side(run, x)
+        self._xd[(layer, gname)] = box.get("xd")
         return box["T"], done
 
     def _lora_fwd_end(self, T, done, ys, layer, gname, saved):
@@ -299,11 +340,21 @@ class MultimodalTrainStep:
         if done is not None:
             torch.cuda.current_stream().wait_event(done)
             dT.record_stream(torch.cuda.current_stream())
-        ops.linear(dT, self._packed[aname + ".T"], residual=dx, out=dx, alpha=self.scale)
         bnames = [f"model.layers.{layer}.{blk}.{lin}.B_cat" for blk, lin in lins]
         self._wgrad(list(dys), [T[:, j * self.R:(j + 1) * self.R] for j in range(len(lins))], [self.view(self.G, bn) for bn in bnames],
                     alpha=self.scale)
-        self._wgrad([dT], [x], [self.view(self.G, aname)], alpha=self.scale)
+        xds = self._xd.pop((layer, gname), None)
+        if xds is None:
+            ops.linear(dT, self._packed[aname + ".T"], residual=dx, out=dx, alpha=self.scale)
+            self._wgrad([dT], [x], [self.view(self.G, aname)], alpha=self.scale)
+            return
+        # dropout: dx += s * (dT_j A_j) * keep_j / (1 - p) with linear j's own mask (regenerated), dA_j = s dT_j^T (dropped x_j)
+        gA = self.view(self.G, aname)
+        for j, (blk, lin) in enumerate(lins):
+            tmp = ops.linear(dT[:, j * self.R:(j + 1) * self.R], self._packed[f"{aname}.{j}.T"])
+            ops.dropout(tmp, self.p, self._seed, self._stream_id(layer, lin), out=dx, accumulate=True, alpha=self.scale)
+        self._wgrad([dT[:, j * self.R:(j + 1) * self.R] for j in range(len(lins))], xds, [gA[j * self.R:(j + 1) * self.R] for j in range(len(lins))],
+                    alpha=self.scale)
 
     # ------------------------------------------------------------------ one step
     def forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
@@ -323,12 +374,16 @@ class MultimodalTrainStep:
         Hd, I, Hh, D, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size
         HD = Hh * D
         eps = cfg.rms_norm_eps
-        if attention_mask is not None and not bool(torch.as_tensor(attention_mask).all()):
-            raise NotImplementedError("padded batches are not implemented in the training step (equal-length samples only)")
+        # Philox key of this step's dropout masks: (step counter, seed x rank) - every rank and every step draws fresh masks
+        self._seed = ((self.dropout_seed * 4096 + self.rank) << 32) | (self.step_count & 0xFFFFFFFF)
+        self._xd = {}
         # ---- encoders (frozen, no gradient) + trainable projector forward with saved pre-activations
         saved: Dict[str, torch.Tensor] = {}
         feats = self._encode(modal_inputs, saved)
-        plan = model._plan(input_ids, None, labels, modal_inputs, feats)
+        plan = model._plan(input_ids, attention_mask, labels, modal_inputs, feats)
+        if not plan.mask_is_suffix:
+            raise NotImplementedError("attention_mask with zeros before the last attended token (left padding / holes) is not implemented: "
+                                      "right-pad the batch as the reference's collator does")
         # modalities without a block in this batch get no gradient; their slices of G still hold the previous step's values (every kernel
         # overwrites, nothing accumulates), so clear them before they can reach the all-reduce
         self._present = [m for m in plan.modal_order if m in self.aux_params]
@@ -336,9 +391,11 @@ class MultimodalTrainStep:
             if m not in self._present:
                 for p_ in plist:
                     self.G[p_.off:p_.off + p_.n].zero_()
-        if not (plan.lens == plan.Lmax).all():
-            raise NotImplementedError("ragged spliced lengths are not implemented in the training step")
         B, L = plan.B, plan.Lmax
+        # padded layout [B, Lmax] as in the reference (multimodal_arch.py:390-430): slots behind a sample's spliced length are zero rows;
+        # keys at or behind the attended length (those slots and right-padding text tokens) are masked by kv_lens
+        ragged = not bool((plan.valid_lens == L).all())
+        kv_lens = torch.from_numpy(np.ascontiguousarray(plan.valid_lens, dtype=np.int32)).to(dev) if ragged else None
         M = B * L
         Mp = ops.ceil_to(M, 64)
         bb, tt = np.divmod(np.arange(M), L)
@@ -366,7 +423,7 @@ class MultimodalTrainStep:
             ops.rope_kv(qkv, row_b, row_t, row_t, self.cos, self.sin, q_seq, kc, vc, Hh, Hh, D, L, L)
             attn = torch.empty(M, HD, dtype=BF16, device=dev)
             lse = torch.empty(B * Hh * L, dtype=F32, device=dev)
-            ops.attn_prefill_lse(q_seq, kc, vc, attn, lse, B, Hh, L, L, D, st_q, st_kv, st_kv, HD, True)
+            ops.attn_prefill_lse(q_seq, kc, vc, attn, lse, B, Hh, L, L, D, st_q, st_kv, st_kv, HD, True, kv_lens=kv_lens)
             T, ev = self._lora_fwd_begin(attn, l, "attn_out", row_adapter)
             x1 = ops.linear(attn, W["o"], residual=x)
             self._lora_fwd_end(T, ev, [x1], l, "attn_out", saved)
@@ -414,7 +471,7 @@ class MultimodalTrainStep:
             dqkv = torch.empty(M, 3 * HD, dtype=BF16, device=dev)
             st3 = (L * 3 * HD, 3 * HD, D)
             ops.attn_bwd(a["q"], a["kc"], a["vc"], a["attn"], d_attn, a["lse"], dqkv, dqkv[:, HD:], dqkv[:, 2 * HD:], B, Hh, L, L, D,
-                         st_q, st_kv, st_kv, st_q, st3, st3, st3, True)
+                         st_q, st_kv, st_kv, st_q, st3, st3, st3, True, kv_lens=kv_lens)
             ops.rope_inplace(dqkv, row_t, self.cos, self.sin, 2 * Hh, D, -1.0)
             dqs = [dqkv[:, j * HD:(j + 1) * HD] for j in range(3)]
             dT, ev = self._lora_bwd_begin(dqs, l, "attn_in", row_adapter)

@@ -1,0 +1,183 @@
+"""Oracle (TEST INFRASTRUCTURE): the composed-Vicuna backbone with the HIP path's rounding points, torch CPU fp32.
+
+`oracle/llm.py` restates the REFERENCE (branch form, fp32 / optional storage rounding).  This file restates what
+`libmc_hip.so` computes for the same function, so that device-vs-oracle comparisons can be held to the tolerance
+BASELINE.json names (1e-3 of the logit scale, greedy ids bit-exact) instead of to "one bf16 rounding per op":
+
+  * weights: one dense matrix per routed adapter, W' = bf16((W + sum_m s_m B_m A_m) diag(g)) with the preceding RMSNorm's
+    weight g folded into q|k|v and gate|up (csrc/compose.hip; reference: LocalLoraLinear.forward
+    modelcompose/model/language_model/multimodal_llama.py:130-157 + LlamaRMSNorm :405-406, dense form
+    scripts/evaluate_delta_weights.py:8-15);
+  * every token multiplies against the weight of ITS adapter only (one-hot modal masks, multimodal_arch.py:452-453;
+    the reference's stack-mask-sum :262-268 adds exact zeros);
+  * RMSNorm = per-row fp32 factor applied to the fp32 accumulator (GEMM epilogue), the normalised activations are never rounded;
+  * values are rounded to bf16 exactly where the kernels store them: q|k|v, rotated q / k, attention output, both residual
+    sums, gate and up (before SiLU), silu(gate)*up, the final norm output;
+  * prefill attention: P = bf16(exp(s - rowmax)) multiplies V and normalises with the sum of the ROUNDED P (csrc/attention.hip);
+    decode attention: fp32 softmax, no rounding of P (attn_decode_kernel);
+  * decode steps use the 'default' adapter only (multimodal_llama.py:435-438).
+What is NOT reproduced: fp32 summation order inside the kernels (MFMA tiling, split reductions) and the online-softmax's
+running maximum (P is rounded relative to the final row maximum here).  Both perturb results far below one bf16 step.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import llm
+
+BF = torch.bfloat16
+
+
+def bf(x: torch.Tensor) -> torch.Tensor:
+    return x.to(BF).to(torch.float32)
+
+
+class DeviceWeights:
+    """Per layer and routed adapter: q|k|v (norm folded), o, gate / up (norm folded), down as fp32 tensors holding bf16 values.
+    Adapters without any LoRA term share the base tensors (as the device path shares their storage)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: llm.LLMConfig):
+        self.cfg = cfg
+        self.layers: List[Dict[str, Dict[str, torch.Tensor]]] = []
+        names = list(cfg.modal_names)
+        for i in range(cfg.num_hidden_layers):
+            p = f"model.layers.{i}"
+            g_in = sd[f"{p}.input_layernorm.weight"].float()
+            g_post = sd[f"{p}.post_attention_layernorm.weight"].float()
+            per = {}
+            cache = {}
+            for ad in names:
+                w = {}
+                for blk, lins in (("self_attn", llm.LINEARS_ATTN), ("mlp", llm.LINEARS_MLP)):
+                    for lin in lins:
+                        pre = f"{p}.{blk}.{lin}"
+                        key = (lin, self._terms_key(sd, pre, cfg, ad))
+                        if key not in cache:
+                            m = llm.merged_weight(sd, pre, cfg, ad)
+                            if lin in ("q_proj", "k_proj", "v_proj"):
+                                m = m * g_in[None, :]
+                            elif lin in ("gate_proj", "up_proj"):
+                                m = m * g_post[None, :]
+                            cache[key] = bf(m)
+                        w[lin] = cache[key]
+                per[ad] = w
+            self.layers.append(per)
+        self.final_norm = sd["model.norm.weight"].float()
+        self.lm_head = bf(sd["lm_head.weight"].float())
+        self.embed = bf(sd["model.embed_tokens.weight"].float())
+
+    @staticmethod
+    def _terms_key(sd, pre, cfg, ad):
+        names, scaling, default_names, merge = llm.adapter_plan(cfg)
+        if f"{pre}.lora_A.{ad}.weight" not in sd or ad not in names:
+            return "base"
+        return ad
+
+
+def _routed(x2d: torch.Tensor, weights: Dict[str, Dict[str, torch.Tensor]], lin: str, groups) -> torch.Tensor:
+    """x2d [M, K]; groups = [(adapter_name, row_index_tensor)]: every row against its adapter's dense weight, fp32 accumulate."""
+    if len(groups) == 1:
+        return F.linear(x2d, weights[groups[0][0]][lin])
+    out = None
+    for ad, rows in groups:
+        y = F.linear(x2d[rows], weights[ad][lin])
+        if out is None:
+            out = torch.empty(x2d.shape[0], y.shape[1], dtype=torch.float32)
+        out[rows] = y
+    return out
+
+
+def _rs(x2d: torch.Tensor, eps: float) -> torch.Tensor:
+    return torch.rsqrt(x2d.pow(2).mean(-1, keepdim=True) + eps)
+
+
+def _rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """x (B, L, H, D) fp32; cos / sin (B, L, D/2): rope_kv_kernel's pairing (i, i + D/2), rounded to bf16."""
+    half = x.shape[-1] // 2
+    a, b = x[..., :half], x[..., half:]
+    c, s = cos[:, :, None, :], sin[:, :, None, :]
+    return bf(torch.cat([a * c - b * s, b * c + a * s], dim=-1))
+
+
+def forward(dw: DeviceWeights, x: torch.Tensor, adapter_masks: Optional[Dict[str, torch.Tensor]], past_kv=None, last_only=False,
+            trace: Optional[dict] = None):
+    """x (B, L, hidden) fp32 holding bf16 values (spliced embeddings, or the embedding rows of one decode token).
+    adapter_masks: {adapter: bool (B, L)} one-hot over the routed adapters, or None (= every token 'default').
+    Returns (logits fp32 (B, L or 1, vocab), present_kv)."""
+    cfg = dw.cfg
+    B, L, Hd = x.shape
+    H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    eps = cfg.rms_norm_eps
+    decode = past_kv is not None
+    past_len = past_kv[0][0].shape[2] if decode else 0
+    if decode or adapter_masks is None:
+        groups = [("default", None)]
+    else:
+        flat = {k: v.reshape(-1) for k, v in adapter_masks.items()}
+        groups = [(k, torch.nonzero(m).squeeze(1)) for k, m in flat.items() if bool(m.any())]
+        cover = torch.zeros(B * L, dtype=torch.long)
+        for _, rows in groups:
+            cover[rows] += 1
+        assert bool((cover == 1).all()), "adapter masks must be one-hot per token"
+        if len(groups) == 1:
+            groups = [(groups[0][0], None)]
+    cos_t, sin_t = llm.rope_tables(D, max(cfg.max_position_embeddings, past_len + L), cfg.rope_theta)
+    half = D // 2
+    pos = torch.arange(past_len, past_len + L)
+    cos = cos_t[pos][:, :half][None].expand(B, L, half)
+    sin = sin_t[pos][:, :half][None].expand(B, L, half)
+    h = x.reshape(B * L, Hd)
+    presents = []
+    scale = 1.0 / math.sqrt(D)
+    for i in range(cfg.num_hidden_layers):
+        W = dw.layers[i]
+        rs = _rs(h, eps)
+        q = bf(_routed(h, W, "q_proj", groups) * rs).view(B, L, H, D)
+        k = bf(_routed(h, W, "k_proj", groups) * rs).view(B, L, Hkv, D)
+        v = bf(_routed(h, W, "v_proj", groups) * rs).view(B, L, Hkv, D)
+        if trace is not None:
+            trace[f"{i}.rs"] = rs.clone()
+            trace[f"{i}.qkv"] = torch.cat([q.reshape(B * L, -1), k.reshape(B * L, -1), v.reshape(B * L, -1)], 1)
+        q, k = _rope(q, cos, sin), _rope(k, cos, sin)
+        if trace is not None:
+            trace[f"{i}.q_rot"] = q.reshape(B * L, -1).clone()
+        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)            # (B, H, L, D)
+        if decode:
+            k = torch.cat([past_kv[i][0], k], dim=2)
+            v = torch.cat([past_kv[i][1], v], dim=2)
+        presents.append((k, v))
+        rep = H // Hkv
+        kk = k if rep == 1 else k.repeat_interleave(rep, dim=1)
+        vv = v if rep == 1 else v.repeat_interleave(rep, dim=1)
+        s = torch.matmul(q, kk.transpose(2, 3)) * scale
+        if decode:
+            p = torch.softmax(s, dim=-1)
+            o = torch.matmul(p, vv)
+        else:
+            causal = torch.ones(L, L, dtype=torch.bool).tril()
+            s = s.masked_fill(~causal, float("-inf"))
+            m = s.max(dim=-1, keepdim=True).values
+            p = bf(torch.exp(s - m))
+            o = torch.matmul(p, vv) / p.sum(-1, keepdim=True)
+        o = bf(o).transpose(1, 2).reshape(B * L, H * D)
+        h = bf(h + _routed(o, W, "o_proj", groups))
+        if trace is not None:
+            trace[f"{i}.attn"] = o.clone()
+            trace[f"{i}.x1"] = h.clone()
+        rs = _rs(h, eps)
+        g = bf(_routed(h, W, "gate_proj", groups) * rs)
+        u = bf(_routed(h, W, "up_proj", groups) * rs)
+        inter = bf(g / (1.0 + torch.exp(-g)) * u)
+        h = bf(h + _routed(inter, W, "down_proj", groups))
+        if trace is not None:
+            trace[f"{i}.inter"] = inter.clone()
+            trace[f"{i}.x2"] = h.clone()
+    hid = h.view(B, L, Hd)
+    if last_only:
+        hid = hid[:, -1:]
+    nl = bf(hid * _rs(hid, eps) * dw.final_norm)
+    return F.linear(nl, dw.lm_head), tuple(presents)

@@ -105,9 +105,17 @@ def adapter_plan(cfg: LLMConfig) -> Tuple[List[str], Dict[str, float], Optional[
     return names, scaling, default_names, merge
 
 
+# training only: nn.Dropout on the LoRA input (multimodal_llama.py:133, :150-153).  DROPOUT_FN(prefix, adapter, x) -> dropped x; None in
+# eval mode.  The reference draws an independent mask per adapter module; a token only ever uses its own adapter's branch
+# (one-hot routing), so one mask per (linear, token) is the same distribution - oracle/train.py passes explicit masks.
+DROPOUT_FN = None
+
+
 def _lora_branch(x, sd, prefix, adapter, scale):
     a = sd.get(f"{prefix}.lora_A.{adapter}.weight")
     b = sd.get(f"{prefix}.lora_B.{adapter}.weight")
+    if DROPOUT_FN is not None:
+        x = DROPOUT_FN(prefix, adapter, x)
     return F.linear(F.linear(x, a), b) * scale
 
 

@@ -13,6 +13,7 @@ from typing import Dict, Optional
 
 import torch
 
+from . import device_path
 from . import encoders as enc
 from . import llm, splice
 
@@ -23,6 +24,9 @@ class OracleModel:
         self.modals = [m for m in cfg.modal_names if m != "default"]
         self.prefix = {k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("prefix_tokens.")} or None
         self.suffix = {k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("suffix_tokens.")} or None
+        # emulate == "device": the backbone follows the HIP path's rounding points (oracle/device_path.py) instead of the reference's
+        # branch form; encoders stay fp32 - pass the device's own feature blocks (feats_blocks) to isolate the backbone
+        self._dw = None
 
     @classmethod
     def from_state_dict(cls, sd, meta, emulate=None):
@@ -52,18 +56,33 @@ class OracleModel:
         return ex.encode(self, modal, x)
 
     # -- forward ------------------------------------------------------------
-    def prepare(self, input_ids, modal_inputs, attention_mask=None, labels=None):
+    def prepare(self, input_ids, modal_inputs, attention_mask=None, labels=None, feats_blocks=None):
+        """feats_blocks: {modal: (n_items, T, hidden)} already projected and wrapped in prefix / suffix tokens (what
+        encode_modal_inputs returns); replaces the encoders for the modalities it names."""
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
-        fns = {m: (lambda x, m=m: self.encode_modal(m, x)) for m in self.modals}
-        feats, fmask = splice.encode_modal_inputs(modal_inputs, self.modals, fns, self.prefix, self.suffix, skip_absent=True)
+        if feats_blocks is not None:
+            fns = {m: (lambda x, m=m: feats_blocks[m].float()) for m in self.modals}
+            feats, fmask = splice.encode_modal_inputs(modal_inputs, self.modals, fns, None, None, skip_absent=True)
+        else:
+            fns = {m: (lambda x, m=m: self.encode_modal(m, x)) for m in self.modals}
+            feats, fmask = splice.encode_modal_inputs(modal_inputs, self.modals, fns, self.prefix, self.suffix, skip_absent=True)
         return splice.prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, list(modal_inputs), feats,
                                                            fmask, self.sd["model.embed_tokens.weight"])
 
-    def prefill(self, input_ids, modal_inputs, attention_mask=None, last_only=False):
-        am, emb, _, mam = self.prepare(input_ids, modal_inputs, attention_mask)
+    def device_weights(self):
+        if self._dw is None:
+            self._dw = device_path.DeviceWeights(self.sd, self.cfg)
+        return self._dw
+
+    def prefill(self, input_ids, modal_inputs, attention_mask=None, last_only=False, feats_blocks=None):
+        am, emb, _, mam = self.prepare(input_ids, modal_inputs, attention_mask, feats_blocks=feats_blocks)
         if self.cfg.lora_strategy not in ("modal", "modal+language"):          # multimodal_llama.py:703-704
             mam = None
+        if self.emulate == "device":
+            assert bool(am.all()), "the device-path restatement takes unpadded batches"
+            logits, kv = device_path.forward(self.device_weights(), device_path.bf(emb.float()), mam, last_only=last_only)
+            return logits, kv, am
         h, kv = llm.model_forward(self.sd, self.cfg, inputs_embeds=emb, attention_mask=am, modal_attention_mask=mam,
                                   emulate=self.emulate)
         if last_only:
@@ -72,14 +91,18 @@ class OracleModel:
 
     def decode_step(self, token_ids, kv, am):
         am = torch.ones((am.shape[0], kv[-1][-1].shape[-2] + 1), dtype=am.dtype)  # multimodal_arch.py:290-293
+        if self.emulate == "device":
+            dw = self.device_weights()
+            logits, kv = device_path.forward(dw, dw.embed[token_ids][:, None], None, past_kv=kv, last_only=True)
+            return logits[:, -1], kv, am
         h, kv = llm.model_forward(self.sd, self.cfg, input_ids=token_ids[:, None], attention_mask=am, past_key_values=kv,
                                   emulate=self.emulate)
         return llm.lm_logits(h, self.sd)[:, -1], kv, am
 
-    def generate(self, input_ids, modal_inputs, max_new_tokens=128, ignore_eos=False, return_logits=False):
+    def generate(self, input_ids, modal_inputs, max_new_tokens=128, ignore_eos=False, return_logits=False, feats_blocks=None):
         """Greedy; returns the NEW ids (B, n).  With ignore_eos=False rows that hit EOS emit pad afterwards
         and the loop stops once every row has finished (transformers 4.31 greedy_search)."""
-        logits, kv, am = self.prefill(input_ids, modal_inputs, last_only=True)
+        logits, kv, am = self.prefill(input_ids, modal_inputs, last_only=True, feats_blocks=feats_blocks)
         last = logits[:, -1]
         B = input_ids.shape[0]
         unfinished = torch.ones(B, dtype=torch.long)

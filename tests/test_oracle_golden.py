@@ -366,3 +366,18 @@ def test_sampling_oracle_against_installed_transformers_warpers():
     ids = sampling.pick(pr, u)
     assert (pr[torch.arange(6), ids] > 0).all()
     assert ids[0] == (pr[0] > 0).float().argmax()            # u = 0 -> first kept token in index order
+
+
+def test_philox4x32_10_known_answers():
+    """oracle/philox.py against the known-answer vectors published with Random123 (kat_vectors: philox4x32 10): the pin of the dropout
+    masks' generator (the reference's nn.Dropout uses torch's own Philox stream, which is implementation-defined; the distribution, not the
+    stream, is the contract)."""
+    from oracle.philox import dropout_keep, philox4x32_10
+    h = lambda x: [int(v[0]) for v in x]
+    assert h(philox4x32_10([0], [0], [0], [0], 0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert h(philox4x32_10([0xffffffff], [0xffffffff], [0xffffffff], [0xffffffff], 0xffffffff, 0xffffffff)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert h(philox4x32_10([0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344], 0xa4093822, 0x299f31d0)) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    k = dropout_keep(64, 256, 0.05, 1234, 7)
+    assert k.shape == (64, 256) and abs(k.mean() - 0.95) < 0.01
+    assert not (k == dropout_keep(64, 256, 0.05, 1234, 8)).all() and (k == dropout_keep(64, 256, 0.05, 1234, 7)).all()
+    assert dropout_keep(8, 8, 0.0, 1, 1).all()

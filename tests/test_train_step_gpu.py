@@ -70,3 +70,158 @@ def test_forward_with_labels_returns_the_reference_loss():
     lab = torch.full_like(a["labels"], -100)
     out = model.forward(a["input_ids"].cuda(), labels=lab.cuda(), modal_inputs={"vision": a["pixels"].cuda()})
     assert torch.isnan(out.loss)
+
+
+def _check_grads(got, ref, tol=6e-2, min_cos=0.995):
+    assert sorted(got) == sorted(ref)
+    worst = 0.0
+    for k, g in ref.items():
+        x = got[k].float().cpu().reshape(g.shape)
+        scale, err = g.abs().max().item(), (x - g).abs().max().item()
+        if scale == 0.0:
+            assert err == 0.0, (k, err)
+            continue
+        cos = torch.nn.functional.cosine_similarity(x.flatten(), g.flatten(), dim=0).item()
+        worst = max(worst, err / scale)
+        assert err <= tol * scale, (k, err, scale)
+        assert cos > min_cos, (k, cos)
+    return worst
+
+
+def test_lora_dropout_matches_the_oracle_with_the_same_masks():
+    """configs[4] as the reference runs it (run_finetune_vision_damc.sh: lora_dropout 0.05; nn.Dropout on the LoRA input,
+    multimodal_llama.py:133-148).  The step's Philox masks are regenerated independently on the CPU (oracle/philox.py), checked against
+    the device's own mask bit for bit, and handed to the autograd oracle: same loss, same gradients."""
+    import numpy as np
+    from modelcompose_amd.model.builder import build_from_state_dict
+    from modelcompose_amd.train import MultimodalTrainStep
+    from oracle import philox, train as otrain
+    a, meta, sd = load_golden("g9_train_step")
+    p = 0.25                                                       # far from 0 so that a missing / misplaced mask cannot hide in the tolerance
+    meta = dict(meta, lora_dropout=p)
+    model = build_from_state_dict(meta, sd)
+    st = MultimodalTrainStep(model, lr=1e-3, dropout_seed=1234)
+    ids, labels, px = a["input_ids"], a["labels"], a["pixels"]
+    loss = st.forward_backward(ids.cuda(), labels.cuda(), {"vision": px.cuda()})
+    B = ids.shape[0]
+    Hd, I = meta["hidden_size"], meta["intermediate_size"]
+    om_probe = otrain.pipeline.OracleModel.from_state_dict({k: v.float() for k, v in sd.items()}, meta)
+    _, emb, _, _ = om_probe.prepare(ids, {"vision": px}, None, labels)
+    L = emb.shape[1]
+    masks = {}
+    for layer in range(meta["num_hidden_layers"]):
+        for blk, lin, K in (("self_attn", "q_proj", Hd), ("self_attn", "k_proj", Hd), ("self_attn", "v_proj", Hd), ("self_attn", "o_proj", Hd),
+                            ("mlp", "gate_proj", Hd), ("mlp", "up_proj", Hd), ("mlp", "down_proj", I)):
+            keep = philox.dropout_keep(B * L, K, p, st._seed, st._stream_id(layer, lin))
+            dev = st.dropout_keep_scale(layer, lin, B * L, K).cpu()
+            assert torch.equal(dev != 0, torch.from_numpy(keep)), (layer, lin)            # Philox on the device == numpy restatement
+            masks[f"model.layers.{layer}.{blk}.{lin}"] = (torch.from_numpy(keep).float() / (1.0 - p)).view(B, L, K)
+    frac = float(np.mean([m.ne(0).float().mean().item() for m in masks.values()]))
+    assert abs(frac - (1 - p)) < 0.01
+    ref_loss, _, ref_grads = otrain.loss_and_grads(sd, meta, ids, labels, {"vision": px}, dropout_masks=masks)
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
+    worst = _check_grads(st.named_gradients(), {k: v for k, v in ref_grads.items()})
+    # and the masks matter: the no-dropout gradients are NOT within tolerance of the dropout reference
+    ref0_loss, _, ref0 = otrain.loss_and_grads(sd, meta, ids, labels, {"vision": px})
+    k = "model.layers.0.mlp.down_proj.lora_A.default.weight"
+    assert (ref0[k] - ref_grads[k]).abs().max() > 0.2 * ref_grads[k].abs().max()
+    # a new step draws new masks; the same step index reproduces its masks exactly
+    g1 = st.G.clone()
+    st.forward_backward(ids.cuda(), labels.cuda(), {"vision": px.cuda()})
+    assert torch.equal(g1, st.G)
+    st.step_count += 1
+    st.forward_backward(ids.cuda(), labels.cuda(), {"vision": px.cuda()})
+    assert not torch.equal(g1, st.G)
+    print("worst relative gradient error with dropout", worst)
+
+
+def test_padded_ragged_batch_matches_the_oracle():
+    """The collator right-pads ids (pad id) / labels (-100) and passes attention_mask = ids != pad (multimodal_dataset.py:148-214); one
+    sample is text only, so the spliced lengths are ragged as well (multimodal_arch.py:390-430).  Loss and gradients against the autograd
+    oracle on the same padded batch."""
+    from modelcompose_amd.model.builder import build_from_state_dict
+    from modelcompose_amd.train import MultimodalTrainStep
+    from oracle import train as otrain
+    a, meta, sd = load_golden("g9_train_step")
+    meta = dict(meta, lora_dropout=0.0)
+    model = build_from_state_dict(meta, sd)
+    st = MultimodalTrainStep(model, lr=1e-3)
+    V, pad = -200, meta.get("pad_token_id", 0) or 0
+    g = torch.Generator().manual_seed(11)
+    r = lambda n: torch.randint(3, meta["vocab_size"] - 1, (n,), generator=g).tolist()
+    rows = [[1] + r(5) + [V, 13] + r(9), [1] + r(3) + [V, 13] + r(4), [1] + r(12)]          # image, shorter + image, text only
+    Lt = max(len(x) for x in rows)
+    ids = torch.tensor([x + [pad] * (Lt - len(x)) for x in rows])
+    am = torch.tensor([[True] * len(x) + [False] * (Lt - len(x)) for x in rows])
+    labels = ids.clone()
+    labels[~am] = -100
+    labels[:, :4] = -100
+    labels[ids == V] = -100
+    px = torch.cat([a["pixels"][:1], a["pixels"][:1] * 0.7])
+    loss = st.forward_backward(ids.cuda(), labels.cuda(), {"vision": px.cuda()}, attention_mask=am.cuda())
+    ref_loss, _, ref_grads = otrain.loss_and_grads(sd, meta, ids, labels, {"vision": px}, attention_mask=am)
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
+    _check_grads(st.named_gradients(), ref_grads)
+    with pytest.raises(NotImplementedError):
+        st.forward_backward(ids.cuda(), labels.cuda(), {"vision": px.cuda()}, attention_mask=am.flip(1).cuda())
+
+
+def test_absent_modality_gets_no_gradient_and_no_optimizer_update():
+    """a text-only batch after an image batch must not re-apply the image batch's projector / prefix / suffix gradients
+    (the reference leaves .grad None and AdamW skips those tensors)."""
+    from modelcompose_amd.model.builder import build_from_state_dict
+    from modelcompose_amd.train import MultimodalTrainStep
+    a, meta, sd = load_golden("g9_train_step")
+    model = build_from_state_dict(dict(meta, lora_dropout=0.0), sd)
+    st = MultimodalTrainStep(model, lr=1e-3)
+    st.step(a["input_ids"].cuda(), a["labels"].cuda(), {"vision": a["pixels"].cuda()})
+    lo = st.aux_lo
+    assert st.G[lo:].abs().max().item() > 0
+    p_before, m_before = st.P[lo:].clone(), st.m1[lo:].clone()
+    g = torch.Generator().manual_seed(2)
+    ids = torch.cat([torch.ones(2, 1, dtype=torch.long), torch.randint(3, meta["vocab_size"] - 1, (2, 11), generator=g)], 1)
+    labels = ids.clone()
+    labels[:, :3] = -100
+    st.step(ids.cuda(), labels.cuda(), {})
+    assert st.G[lo:].abs().max().item() == 0.0
+    assert torch.equal(st.P[lo:], p_before) and torch.equal(st.m1[lo:], m_before)
+    assert st._aux_steps["vision"] == 1 and st.step_count == 2
+
+
+def test_gradient_exchange_and_id_gather_over_rccl_in_a_world_of_one(tmp_path):
+    """The N > 1 code path - RCCL process group, bucketed gradient all-reduce overlapped with the backward, all-gather of generated ids -
+    forced in a world of one rank so that a single-GPU box exercises it (a separate process: the process group is global state)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch.distributed as dist
+from conftest import load_golden
+from modelcompose_amd.dist import gather_ids
+from modelcompose_amd.model.builder import build_from_state_dict
+from modelcompose_amd.train import MultimodalTrainStep
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+a, meta, sd = load_golden("g9_train_step")
+model = build_from_state_dict(dict(meta, lora_dropout=0.0), sd)
+args = (a["input_ids"].cuda(), a["labels"].cuda(), {"vision": a["pixels"].cuda()})
+ref = MultimodalTrainStep(model, lr=1e-3)
+l0 = ref.forward_backward(*args); g0 = ref.G.clone()
+st = MultimodalTrainStep(model, lr=1e-3, force_exchange=True, bucket_layers=1)
+assert st._exchange and len(st._buckets) >= 2
+l1 = st.forward_backward(*args)
+torch.cuda.synchronize()
+assert l0.item() == l1.item() and torch.equal(g0, st.G), "all-reduce over one rank must be the identity"
+ids = model.generate(a["input_ids"].cuda(), modal_inputs={"vision": a["pixels"].cuda()}, max_new_tokens=4, ignore_eos=True)[:, a["input_ids"].shape[1]:]
+out = gather_ids(ids, 1, force=True)
+assert torch.equal(out, ids)
+dist.destroy_process_group()
+print("RCCL_WORLD_OF_ONE_OK")
+''' % (root, root)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert "RCCL_WORLD_OF_ONE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -116,6 +116,20 @@ def main():
                 gemm_case(8192, 8192, 8192, rot=1)
                 gemm_case(10928, 4096, 4096, rot=1)
         L.mc_gemm_debug(0)
+    if "raster" in which:
+        # A/B of the XCD tile order of the 256x256 kernel at the metric workload's prefill shapes (M = 16 x 2793 rows): debug bit 16 = every
+        # XCD owns a contiguous eighth of the tile order, bit 17 = 32-tile blocks dealt round-robin (all XCDs on the same m-group)
+        from modelcompose_amd import _lib
+        L = _lib.lib()
+        Ms = [int(a) for a in which if a.isdigit()] or [44688]
+        for rep in range(2):
+            for d, nm in ((65536, "raster 0: contiguous chunk per XCD"), (131072, "raster 1: blocks round-robin over XCDs")):
+                L.mc_gemm_debug(d)
+                print(nm)
+                for M in Ms:
+                    for (N, K) in ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)):
+                        gemm_case(M, N, K, rot=1)
+        L.mc_gemm_debug(0)
     if "blas" in which:
         # context only (not on the product path): the vendor library GEMM torch.matmul dispatches to (hipBLASLt / rocBLAS) on the same
         # shapes and random data, next to the hand-written 256x256 kernel

@@ -29,7 +29,10 @@ def main():
     for l in open(sys.argv[3]):
         if l.startswith("{") and "roofline" in l:
             line = json.loads(l)
-    out = {"round": 1, "kernel": KERNEL, "dispatches_fetch_pass": nf, "dispatches_write_pass": nw,
+    import datetime
+    cfg = (line or {}).get("config", {})
+    out = {"round": 2, "date": datetime.date.today().isoformat(), "workload": cfg.get("workload_name"), "per_gpu_batch": cfg.get("per_gpu_batch"),
+           "kernel": KERNEL, "dispatches_fetch_pass": nf, "dispatches_write_pass": nw,
            "gemm_tile256_kernel_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
            "fetch_size_kib_avg": fetch, "write_size_kib_avg": write,
            "algorithmic_bytes_per_launch": line["roofline"].get("avg_algorithmic_bytes_per_launch") if line else None,

@@ -5,14 +5,14 @@
 #   3. tools/pmc_traffic.py -> profiles/traffic.json (copied to gpurun_out/ for the merge back)
 # The program itself follows `--` (no env / shell hop): the profiler initialises the GPU before the program starts.
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o run -- python3 bench.py --no-cpu-baseline > gpurun_out/bench_prof_$tag.log 2>&1
 grep '^{' gpurun_out/bench_prof_$tag.log | tail -1 | cut -c1-300
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${tag}_$c -o run -- python3 bench.py --steps 1 --warmup 0 --new-tokens 1 --no-cpu-baseline > gpurun_out/pmc_${tag}_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${tag}_$c -o run -- python3 bench.py --steps 1 --warmup 0 --new-tokens 1 --no-cpu-baseline --no-profile > gpurun_out/pmc_${tag}_$c.log 2>&1
   echo "pmc $c rc=$?"
 done
 f=$(find gpurun_out/pmc_${tag}_FETCH_SIZE -name '*counter_collection.csv' | head -1)
