@@ -33,5 +33,6 @@ def run():
     om = pipeline.OracleModel.from_state_dict(sd, meta)
     ids_o, lg_o = om.generate(a["input_ids"], {"vision": a["pixels"]}, max_new_tokens=4, ignore_eos=True, return_logits=True)
     err = (lg.float().cpu() - lg_o).abs().max().item() / lg_o.abs().max().item()
-    assert err < 3e-2, f"smoke: logits differ from the oracle by {err:.3e} of the logit scale"
+    assert err < 1e-2, f"smoke: logits differ from the oracle by {err:.3e} of the logit scale (measured 5.0e-3 on MI355X)"
+    assert torch.equal(res[:, ids.shape[1]:].cpu(), ids_o), "smoke: greedy ids differ from the oracle"
     print(f"smoke ok: rel logit err {err:.2e}; ids {res[:, ids.shape[1]:].tolist()} oracle {ids_o.tolist()}")

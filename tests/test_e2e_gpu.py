@@ -22,6 +22,13 @@ def rel_err(got, ref):
     return (got.float().cpu() - ref.float()).abs().max().item() / ref.float().abs().max().item()
 
 
+def within(tag, got, ref, bound):
+    """max |got - ref| / max |ref| < bound; the measured value is printed (pytest -s) so that bounds can be kept at ~2x of it."""
+    e = rel_err(got, ref)
+    print(f"[err] {tag}: {e:.3e} (bound {bound:.1e})")
+    assert e < bound, (tag, e, bound)
+
+
 def test_clip_tower_matches_golden():
     from modelcompose_amd.model.clip import ClipVisionConfig, HipClipVisionTower
     a, meta, sd = load_golden("g5_clip")
@@ -29,9 +36,9 @@ def test_clip_tower_matches_golden():
     tower.load_state_dict(sd)
     f = tower(a["pixels"].cuda())
     # bf16 storage through 2 transformer layers vs the fp32 reference: 2^-6 of the feature scale
-    assert rel_err(f, a["features"]) < 2 ** -6
+    within("1 clip features", f, a["features"], 2 ** -6)
     tower.select_layer, tower.select_feature = -1, "cls_patch"
-    assert rel_err(tower(a["pixels"].cuda()), a["features_last_cls"]) < 2 ** -6
+    within("2 clip last layer cls_patch", tower(a["pixels"].cuda()), a["features_last_cls"], 2 ** -6)
 
 
 def test_g4_prefill_logits_and_greedy_ids(g4_model):
@@ -40,45 +47,41 @@ def test_g4_prefill_logits_and_greedy_ids(g4_model):
     px = a["pixels"].cuda()
     out = model.forward(input_ids=ids, modal_inputs={"vision": px})
     assert out.logits.shape == a["logits_prefill"].shape
-    # tolerance: bf16 weights/activations vs the fp32 reference over 2 layers -> 2% of the logit scale
-    assert rel_err(out.logits, a["logits_prefill"]) < 2e-2
+    # tolerances: 2x the error measured on MI355X in round 2 (bf16 storage vs the fp32 reference over 2 layers), of the logit scale
+    within("3 g4 prefill logits", out.logits, a["logits_prefill"], 1.2e-2)
     n_new = a["gen_ids"].shape[1]
     res, step_logits = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=n_new, ignore_eos=True,
                                       return_step_logits=True)
     assert res.shape == (ids.shape[0], ids.shape[1] + n_new)
     assert torch.equal(res[:, :ids.shape[1]].cpu(), a["input_ids"])
-    assert rel_err(step_logits, a["step_logits"]) < 3e-2
-    # greedy ids: bit-exact wherever the reference's top-2 margin exceeds the bf16 error bound
-    ref_l = a["step_logits"]
-    top2 = ref_l.topk(2, dim=-1).values
-    margin = (top2[..., 0] - top2[..., 1])
-    safe = margin > 6e-2 * ref_l.abs().max()
+    within("4 g4 step logits", step_logits, a["step_logits"], 1e-2)          # measured 5.0e-3
+    # greedy ids: equal to the reference's on every row and every step (the fixture's margins: see the assertion message on failure)
     got = res[:, ids.shape[1]:].cpu()
-    # compare up to the first unsafe step per row (later steps depend on earlier choices)
-    for b in range(got.shape[0]):
-        n = n_new if bool(safe[b].all()) else int((~safe[b]).float().argmax())
-        assert torch.equal(got[b, :n], a["gen_ids"][b, :n]), (b, got[b], a["gen_ids"][b])
-    assert sum(int(safe[b].all()) for b in range(got.shape[0])) >= 1
+    assert got.shape == a["gen_ids"].shape and got.numel() == ids.shape[0] * n_new
+    assert torch.equal(got, a["gen_ids"]), (got, a["gen_ids"], _margins(a["step_logits"]))
 
 
-def test_g4_against_bf16_emulating_oracle_ids_exact(g4_model):
-    """Greedy ids bit-exact against the oracle run with the device path's rounding points (bf16 storage, pre-merged weights)."""
+def _margins(ref_logits):
+    top2 = ref_logits.topk(2, dim=-1).values
+    return ((top2[..., 0] - top2[..., 1]) / ref_logits.abs().max()).tolist()
+
+
+def test_g4_against_the_device_rounding_oracle_ids_exact(g4_model):
+    """Greedy ids equal on every row and step against the oracle run with the device path's rounding points (bf16 storage, pre-merged
+    norm-folded weights: oracle/device_path.py), fed the device's own feature block; logits no further from it than from the fp32 reference."""
     from oracle import pipeline
     model, a, meta, sd = g4_model
     sd16 = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in sd.items()}
-    om = pipeline.OracleModel.from_state_dict(sd16, meta, emulate="bf16")
+    om = pipeline.OracleModel.from_state_dict(sd16, meta, emulate="device")
     n_new = 8
-    ids_o, lg_o = om.generate(a["input_ids"], {"vision": a["pixels"].to(torch.bfloat16).float()}, max_new_tokens=n_new,
-                              ignore_eos=True, return_logits=True)
-    res, lg = model.generate(a["input_ids"].cuda(), modal_inputs={"vision": a["pixels"].cuda()}, max_new_tokens=n_new,
-                             ignore_eos=True, return_step_logits=True)
-    assert rel_err(lg, lg_o) < 2e-2
-    top2 = lg_o.topk(2, dim=-1).values
-    safe = (top2[..., 0] - top2[..., 1]) > 4e-2 * lg_o.abs().max()
+    mi = {"vision": a["pixels"].cuda()}
+    feats, _ = model.encode_modal_inputs(mi, model.prefix_tokens, model.suffix_tokens)
+    ids_o, lg_o = om.generate(a["input_ids"], {"vision": a["pixels"]}, max_new_tokens=n_new, ignore_eos=True, return_logits=True,
+                              feats_blocks={m: f.float().cpu() for m, f in feats.items()})
+    res, lg = model.generate(a["input_ids"].cuda(), modal_inputs=mi, max_new_tokens=n_new, ignore_eos=True, return_step_logits=True)
+    within("5 g4 vs device-rounding oracle", lg, lg_o, 1e-2)
     got = res[:, a["input_ids"].shape[1]:].cpu()
-    for b in range(got.shape[0]):
-        n = n_new if bool(safe[b].all()) else int((~safe[b]).float().argmax())
-        assert torch.equal(got[b, :n], ids_o[b, :n])
+    assert got.numel() == a["input_ids"].shape[0] * n_new and torch.equal(got, ids_o), (got, ids_o, _margins(lg_o))
 
 
 def test_generate_eos_padding_and_reference_shape(g4_model):
@@ -149,26 +152,17 @@ def test_g8_four_modality_composed_model_matches_reference():
     for m in ("vision", "audio", "video", "point"):
         assert feats[m].shape == a[f"feat_{m}"].shape
         # bf16 encoders (2-3 layers) + projector vs the fp32 reference; point: bf16 rounding of the coordinates on top
-        assert rel_err(feats[m], a[f"feat_{m}"]) < (2 ** -4 if m == "point" else 2 ** -5), m
+        within(f"6 feats[{m}]", feats[m], a[f"feat_{m}"], 2e-2)       # measured: audio 1.0e-2, video 8.9e-3, point 9.2e-3
     ids = a["input_ids"].cuda()
     out = model.forward(input_ids=ids, modal_inputs=mi)
     assert out.logits.shape == a["logits_prefill"].shape
-    assert rel_err(out.logits, a["logits_prefill"]) < 3e-2
+    within("7 g8 prefill logits", out.logits, a["logits_prefill"], 2.5e-2)      # measured 1.2e-2
     n_new = a["gen_ids"].shape[1]
     res, step_logits = model.generate(ids, modal_inputs=mi, max_new_tokens=n_new, ignore_eos=True, return_step_logits=True)
-    assert rel_err(step_logits, a["step_logits"]) < 4e-2
-    ref_l = a["step_logits"]
-    top2 = ref_l.topk(2, dim=-1).values
-    safe = (top2[..., 0] - top2[..., 1]) > 8e-2 * ref_l.abs().max()
+    within("8 g8 step logits", step_logits, a["step_logits"], 1.5e-2)           # measured 7.4e-3
     got = res[:, ids.shape[1]:].cpu()
-    for b in range(got.shape[0]):
-        n = n_new if bool(safe[b].all()) else int((~safe[b]).float().argmax())
-        assert torch.equal(got[b, :n], a["gen_ids"][b, :n]), (b, got[b], a["gen_ids"][b])
-
-
-def _margin_ok(ref_logits, frac):
-    top2 = ref_logits.topk(2, dim=-1).values
-    return (top2[..., 0] - top2[..., 1]) > frac * ref_logits.abs().max()
+    assert got.numel() == ids.shape[0] * n_new
+    assert torch.equal(got, a["gen_ids"]), (got, a["gen_ids"], _margins(a["step_logits"]))
 
 
 def test_ragged_and_text_only_batch_equals_per_sample_oracle(g4_model):
@@ -190,14 +184,12 @@ def test_ragged_and_text_only_batch_equals_per_sample_oracle(g4_model):
     got = res[:, ids.shape[1]:].cpu()
     for b, (row, mi) in enumerate(((s0, {"vision": px}), (s1, {}))):
         ids_o, lg_o = om.generate(torch.tensor([row]), mi, max_new_tokens=n_new, ignore_eos=True, return_logits=True)
-        assert rel_err(lg[b:b + 1], lg_o) < 4e-2, b
-        safe = _margin_ok(lg_o, 8e-2)[0]
-        n = n_new if bool(safe.all()) else int((~safe).float().argmax())
-        assert torch.equal(got[b, :n], ids_o[0, :n]), (b, got[b], ids_o[0])
+        within(f"9 ragged row {b}", lg[b:b + 1], lg_o, 1.1e-2)      # measured 5.4e-3
+        assert torch.equal(got[b], ids_o[0]), (b, got[b], ids_o[0], _margins(lg_o))           # all 5 ids, no margin gate
     # text-only batch: no modal inputs at all (modal_inputs={} -> no routing, multimodal_llama.py:703-704)
     res2, lg2 = model.generate(torch.tensor([s1]).cuda(), modal_inputs={}, max_new_tokens=3, ignore_eos=True, return_step_logits=True)
     _, lg_o2 = om.generate(torch.tensor([s1]), {}, max_new_tokens=3, ignore_eos=True, return_logits=True)
-    assert rel_err(lg2, lg_o2) < 4e-2
+    within("10 text only", lg2, lg_o2, 1.1e-2)
 
 
 def test_limits_raise_like_the_reference(g4_model):
