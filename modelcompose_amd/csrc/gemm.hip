@@ -143,6 +143,54 @@ __device__ __forceinline__ void epilogue_store4_swiglu(const Epilogue& e, int m,
     *(bf16x4*)((bf16_t*)e.out + (int64_t)m * e.ldo + n_out) = o;
 }
 
+// ---- wide epilogue of the 256x256 kernel ------------------------------------------------------------------------------------------
+// A lane of the 16x16x32 accumulator layout owns 4 consecutive columns of a 16-column block (lane = q4*16 + c16: row c16, columns
+// 4*q4 .. 4*q4+3), i.e. 8 bytes of bf16 - an 8-byte store per block, 32 per wave.  v_permlane16_swap exchanges the packed halves of
+// two neighbouring blocks between the lane pairs (q4 = 0,1) and (q4 = 2,3) of a row, after which every lane holds 8 consecutive
+// columns of ONE block: a 16-byte store per block PAIR (half the store instructions, same bytes; the tail of a tile is store-issue
+// bound, cdna_hip_programming.md T21).  The values are computed exactly as epilogue_store4 / _swiglu compute them.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// the four epilogue values of one accumulator fragment; a = alpha * row_scale[m] (hoisted by the caller), res = the residual's 4 values
+__device__ __forceinline__ bf16x4 epilogue_vals4(const Epilogue& e, float a, int n, f32x4 v, bool has_res, bf16x4 res) {
+    float r[4] = {v[0] * a, v[1] * a, v[2] * a, v[3] * a};
+    if (e.bias) {
+        bf16x4 b = *(const bf16x4*)(e.bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] += (float)b[i];
+    }
+    if (e.act != MC_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = mc_act(r[i], e.act);
+    }
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] += e.beta * (float)res[i];
+    }
+    return (bf16x4){(bf16_t)r[0], (bf16_t)r[1], (bf16_t)r[2], (bf16_t)r[3]};
+}
+
+__device__ __forceinline__ bf16x4 swiglu_vals4(float a, f32x4 g, f32x4 u) {
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float gg = (float)(bf16_t)(g[i] * a), uu = (float)(bf16_t)(u[i] * a);
+        o[i] = (bf16_t)(gg / (1.0f + __expf(-gg)) * uu);
+    }
+    return o;
+}
+
+// lo = this lane's 4 columns of block b, hi = of block b+1 (both for row m).  Stores 16 bytes: lanes with even q4 the columns
+// 8*(q4>>1) .. +7 of block b, odd q4 the same columns of block b+1.  row = &out[m][first column of block b]; blocks are 16 columns apart.
+__device__ __forceinline__ void store_pair16(bf16_t* row, int q4, bf16x4 lo, bf16x4 hi) {
+    u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+    auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+    *(u32x4*)(row + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
+}
+
 // ------------------------------------------------------------------------------------------
 // large-M kernel
 // ------------------------------------------------------------------------------------------
@@ -543,12 +591,67 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     }
     if (wave_n == 0) __builtin_amdgcn_s_barrier();
 
+    // Epilogue.  bf16 outputs whose tile lies inside N take the wide path (16-byte stores of block pairs, the row factor loaded once per
+    // row, ALL residual values of the lane requested before the first store: one exposed memory latency per tile instead of one per row -
+    // a workgroup owns its CU, so nothing else runs while its epilogue waits); everything else the 8-byte path.
+    const bool wide = !ep.out_f32 && (n0 + NT <= N) && (ep.ldo % 8 == 0) && ((uintptr_t)ep.out % 16 == 0) && (NI % 2 == 0);
+    const bool has_res = wide && !ep.swiglu && ep.residual != nullptr;
+    bf16x4 res[2][2][2][NI];
+    if (has_res) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int mc = min(m0 + wave_m * 64 + mh * 32 + jj * 16 + c16, M - 1);
+                const bf16_t* rrow = ep.residual + (int64_t)mc * ep.ldr + n0 + wave_n * (2 * NI * 16) + q4 * 4;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) res[mh][jj][nh][i] = *(const bf16x4*)(rrow + nh * (NI * 16) + i * 16);
+            }
+    }
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
-            if (m >= M) continue;
+            const bool live = m < M;                   // depends on c16 only: the lane pairs of a swap are live together
+            const int mc = live ? m : (M - 1);
+            if (wide) {
+                const float a = ep.row_scale ? ep.alpha * ep.row_scale[mc] : ep.alpha;
+                if (ep.swiglu) {
+                    // gate / up blocks alternate along N: input blocks (f, f+1) -> output block f/2; output blocks f/2 and f/2+1 are adjacent
+                    bf16_t* orow = (bf16_t*)ep.out + (int64_t)mc * ep.ldo + ((n0 + wave_n * (2 * NI * 16)) >> 1);
+#pragma unroll
+                    for (int f = 0; f < 2 * NI; f += 4) {
+                        const bf16x4 lo = swiglu_vals4(a, acc[f / NI][f % NI][mh][jj], acc[(f + 1) / NI][(f + 1) % NI][mh][jj]);
+                        const bf16x4 hi = swiglu_vals4(a, acc[(f + 2) / NI][(f + 2) % NI][mh][jj], acc[(f + 3) / NI][(f + 3) % NI][mh][jj]);
+                        u32x2 pa = __builtin_bit_cast(u32x2, lo), pb = __builtin_bit_cast(u32x2, hi);
+                        auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        if (live) *(u32x4*)(orow + (f >> 1) * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
+                    }
+                    continue;
+                }
+                const int nw = n0 + wave_n * (2 * NI * 16);
+                bf16_t* orow = (bf16_t*)ep.out + (int64_t)mc * ep.ldo + nw;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int i = 0; i < NI; i += 2) {
+                        const int nb = nh * (NI * 16) + i * 16;
+                        const bf16x4 lo = epilogue_vals4(ep, a, nw + nb + q4 * 4, acc[nh][i][mh][jj], has_res, res[mh][jj][nh][i]);
+                        const bf16x4 hi = epilogue_vals4(ep, a, nw + nb + 16 + q4 * 4, acc[nh][i + 1][mh][jj], has_res, res[mh][jj][nh][i + 1]);
+                        u32x2 pa = __builtin_bit_cast(u32x2, lo), pb = __builtin_bit_cast(u32x2, hi);
+                        auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        if (live) *(u32x4*)(orow + nb + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
+                    }
+                continue;
+            }
+            if (!live) continue;
             if (ep.swiglu) {
                 // gate / up blocks alternate along N: consecutive block pairs of this wave's 2*NI blocks (a pair may straddle the nh halves
                 // when NI is odd; both halves are this lane's registers)

@@ -116,6 +116,22 @@ def main():
                 gemm_case(8192, 8192, 8192, rot=1)
                 gemm_case(10928, 4096, 4096, rot=1)
         L.mc_gemm_debug(0)
+    if "epi" in which:
+        # cost of the epilogue variants of the 256x256 kernel at the headline's prefill shapes: plain store, + residual (o / down), + row_scale (q|k|v)
+        M = 44656
+        for (N, K) in ((4096, 4096), (4096, 11008), (12288, 4096)):
+            w = ops.pack_weight((torch.randn(N, K, device="cuda") * K ** -0.5).to(BF))
+            x = torch.randn(M, K, device="cuda").to(BF)
+            res = torch.randn(M, N, device="cuda").to(BF)
+            rs = torch.rand(M, device="cuda") + 0.5
+            out = torch.empty(M, N, dtype=BF, device="cuda")
+            fl = 2.0 * M * N * K
+            for rep in range(2):
+                for nm, f in (("plain", lambda: ops.linear(x, w, out=out)), ("residual", lambda: ops.linear(x, w, residual=res, out=out)),
+                              ("residual in place", lambda: ops.linear(x, w, residual=out, out=out)),
+                              ("row_scale", lambda: ops.linear_ex(x, w, row_scale=rs, out=out))):
+                    t = timeit(f)
+                    print(f"epilogue {nm:18s} M={M} N={N} K={K}: {t*1e6:8.1f} us {fl/t/1e12:7.1f} TFLOP/s")
     if "raster" in which:
         # A/B of the XCD tile order of the 256x256 kernel at the metric workload's prefill shapes (M = 16 x 2793 rows): debug bit 16 = every
         # XCD owns a contiguous eighth of the tile order, bit 17 = 32-tile blocks dealt round-robin (all XCDs on the same m-group)

@@ -1,0 +1,53 @@
+"""The four routed prefill GEMMs of one decoder layer at the headline workload's shapes, standalone - for rocprofv3 PMC passes
+(FETCH_SIZE / WRITE_SIZE / MFMA counters) of gemm_tile256_kernel when the profiler cannot run the whole bench.py process
+(ROCm 7.2's rocprofv3 --pmc aborts with SIGSEGV inside the profiler on the img+audio+video bench process; `--workload vision` is fine).
+
+    python tools/gemm_layer_pmc.py [reps]
+
+Rows: B = 16 samples x (97 text | 42 audio | 586 vision | 2066 video) tokens = 44656 rows in 4 adapter groups (default, audio, vision,
+video), exactly the row groups mc_llm_prefill hands to mc_gemm_grouped_bf16; q|k|v (N 12288, row_scale epilogue), o (N 4096, residual),
+gate|up (N 22016, SwiGLU epilogue), down (K 11008, residual).  Prints the algorithmic bytes / flops per launch in launch order."""
+import json
+import sys
+
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from modelcompose_amd import ops  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    B, Hd, I = 16, 4096, 11008
+    rows = [B * 97, B * 42, B * 586, B * 2066]
+    gs = [0]
+    for r in rows:
+        gs.append(gs[-1] + r)
+    M = gs[-1]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    W = lambda n, k: [ops.pack_weight((rnd(n, k) * k ** -0.5).to(BF)) for _ in range(4)]
+    wqkv, wo, wgu, wd = W(3 * Hd, Hd), W(Hd, Hd), W(2 * I, Hd), W(Hd, I)
+    x = rnd(M, Hd).to(BF)
+    rs = torch.rand(M, device="cuda") + 0.5
+    qkv = torch.empty(M, 3 * Hd, dtype=BF, device="cuda")
+    attn = rnd(M, Hd).to(BF)
+    inter = torch.empty(M, I, dtype=BF, device="cuda")
+    launches = []
+    for _ in range(reps):
+        ops.linear_grouped(x, wqkv, gs, row_scale=rs, out=qkv)
+        ops.linear_grouped(attn, wo, gs, residual=x, out=x)
+        ops.linear_grouped(x, wgu, gs, row_scale=rs, swiglu=True, out=inter)
+        ops.linear_grouped(inter, wd, gs, residual=x, out=x)
+        x.mul_(0.25)
+    torch.cuda.synchronize()
+    for name, N, K, nout, res in (("qkv", 3 * Hd, Hd, 3 * Hd, 0), ("o", Hd, Hd, Hd, 1), ("gate_up", 2 * I, Hd, I, 0), ("down", Hd, I, Hd, 1)):
+        launches.append({"gemm": name, "M": M, "N": N, "K": K, "flops": 2.0 * M * N * K,
+                         "algorithmic_bytes": 2.0 * (M * K + 4 * N * K + M * nout + res * M * Hd)})
+    print(json.dumps({"reps": reps, "launch_order": launches}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,22 @@
+#!/bin/bash
+# PMC evidence for gemm_tile256_kernel at the headline workload's prefill shapes (run through gpurun):  tools/pmc_gemm_layer.sh <tag>
+# Three separate rocprofv3 passes (kernel trace + counters only): FETCH_SIZE, WRITE_SIZE, MFMA/wait counters -> gpurun_out/pmc_<tag>_*.csv
+set -u
+tag=${1:-r02}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcg_${tag}_$c -o run -- python3 tools/gemm_layer_pmc.py 2 > gpurun_out/pmcg_${tag}_$c.log 2>&1
+  echo "pmc $c rc=$?"
+  src=$(find gpurun_out/pmcg_${tag}_$c -name '*counter_collection.csv' | head -1)
+  (head -1 "$src"; grep gemm_tile256_kernel "$src") > gpurun_out/pmcg_${tag}_${c}_gemm_tile256.csv
+  rm -rf gpurun_out/pmcg_${tag}_$c
+done
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcg_${tag}_mfma -o run -- python3 tools/gemm_layer_pmc.py 2 > gpurun_out/pmcg_${tag}_mfma.log 2>&1
+echo "pmc mfma rc=$?"
+cc=$(find gpurun_out/pmcg_${tag}_mfma -name '*counter_collection.csv' | head -1)
+kt=$(find gpurun_out/pmcg_${tag}_mfma -name '*kernel_trace.csv' | head -1)
+python3 tools/pmc_mfma.py "$cc" "$kt" gpurun_out/mfma_util_gemm_layer_$tag.json $tag
+rm -rf gpurun_out/pmcg_${tag}_mfma
+grep launch_order gpurun_out/pmcg_${tag}_FETCH_SIZE.log > gpurun_out/pmcg_${tag}_launches.json

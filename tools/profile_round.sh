@@ -27,3 +27,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${tag}_$c
 done
 rm -f gpurun_out/prof_$tag/*kernel_trace.csv
+# 4. MFMA utilisation: one PMC pass (SQ + GRBM counters; kernel trace only) over one prefill + one decode step -> gpurun_out/mfma_util_<tag>.json
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_${tag}_mfma -o run -- python3 bench.py --steps 1 --warmup 0 --new-tokens 2 --no-cpu-baseline --no-profile > gpurun_out/pmc_${tag}_mfma.log 2>&1
+echo "pmc mfma rc=$?"
+cc=$(find gpurun_out/pmc_${tag}_mfma -name '*counter_collection.csv' | head -1)
+kt=$(find gpurun_out/pmc_${tag}_mfma -name '*kernel_trace.csv' | head -1)
+python3 tools/pmc_mfma.py "$cc" "$kt" gpurun_out/mfma_util_$tag.json $tag
+rm -rf gpurun_out/pmc_${tag}_mfma
