@@ -264,6 +264,31 @@ int mc_sample_step_f32(const float* logits, int64_t ld, int64_t* next_ids, int64
                        int step_const, const uint32_t* seed_ptr, unsigned long long seed_const, int M, int N, float temperature, int top_k,
                        float top_p, const float* uniform_in, float* probs_out, int64_t ldp, void* stream);
 
+/* ---- checkpoint files (csrc/ckpt_reader.cpp) --------------------------------------------------------------------------------
+ * Replaces torch.load / safetensors in load_pretrained_model (model/builder.py:148, :157-168): adapter_model.bin, non_lora_trainables.bin,
+ * mm_projector.bin, the base model's (sharded) pytorch_model-*.bin or *.safetensors, encoder checkpoints.  mc_ckpt_open maps the file and
+ * indexes its tensors: torch zip archives (STORED zip / zip64 + a protocol-2 pickle read by a restricted interpreter that never calls
+ * anything) and safetensors.  Every tensor is (name, dtype code, shape, strides in elements, pointer into the mapping); nested containers
+ * are flattened with '.'-joined names.  Pointers stay valid until mc_ckpt_close.  Legacy non-zip torch files are refused (error 1).     */
+#define MC_CKPT_F32 0
+#define MC_CKPT_F16 1
+#define MC_CKPT_BF16 2
+#define MC_CKPT_F64 3
+#define MC_CKPT_I64 4
+#define MC_CKPT_I32 5
+#define MC_CKPT_I16 6
+#define MC_CKPT_I8 7
+#define MC_CKPT_U8 8
+#define MC_CKPT_BOOL 9
+int mc_ckpt_open(const char* path, void** handle);
+int mc_ckpt_close(void* handle);
+int mc_ckpt_count(void* handle, int* n_tensors);
+/* storage_bytes = bytes from `data` to the end of the tensor's storage record (strided views may touch all of them) */
+int mc_ckpt_entry(void* handle, int index, const char** name, int* dtype, int* ndim, const int64_t** shape, const int64_t** strides,
+                  const void** data, int64_t* storage_bytes);
+/* contiguous tensors only: hipMemcpyAsync from the mapped file to dst_device (numel * element size bytes) on `stream` */
+int mc_ckpt_copy_to_device(void* handle, int index, void* dst_device, void* stream);
+
 /* ---- composed Vicuna backbone runtime (csrc/llm_runtime.cpp) -------------------------------------------
  * Replaces MultimodalLlamaModel.forward + lm_head (model/language_model/multimodal_llama.py:488-619, :720) and the
  * greedy loop driven by model.generate (eval/model_multimodal_qa_loader.py:94-102).  The handle owns only host

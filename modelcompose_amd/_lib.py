@@ -127,6 +127,12 @@ _SIGS.update({
     "mc_llm_decode": [c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "mc_llm_get_option": [c_p, C.c_char_p, C.POINTER(c_i)],
     "mc_llm_profile_kinds": [],
+    "mc_ckpt_open": [C.c_char_p, C.POINTER(c_p)],
+    "mc_ckpt_close": [c_p],
+    "mc_ckpt_count": [c_p, C.POINTER(c_i)],
+    "mc_ckpt_entry": [c_p, c_i, C.POINTER(C.c_char_p), C.POINTER(c_i), C.POINTER(c_i), C.POINTER(C.POINTER(c_l)), C.POINTER(C.POINTER(c_l)),
+                      C.POINTER(c_p), C.POINTER(c_l)],
+    "mc_ckpt_copy_to_device": [c_p, c_i, c_p, c_p],
     "mc_llm_profile_read": [c_p, c_i, C.POINTER(C.c_double), C.POINTER(c_l)],
 })
 # optional symbols added by later ABI revisions are bound if present

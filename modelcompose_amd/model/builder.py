@@ -20,10 +20,7 @@ from .projector import build_projector, projector_type_for
 
 
 def _load_file(path: str) -> Dict[str, torch.Tensor]:
-    if path.endswith(".safetensors"):
-        from safetensors.torch import load_file
-        return load_file(path)
-    return load_tensors(path)
+    return load_tensors(path)            # native reader: torch zip checkpoints and safetensors alike (checkpoint_io.py)
 
 
 def load_base_state_dict(path: str) -> Dict[str, torch.Tensor]:

@@ -89,11 +89,7 @@ class HipClipVisionTower:
         for fn in ("model.safetensors", "pytorch_model.bin"):
             p = os.path.join(path, fn)
             if os.path.exists(p):
-                if fn.endswith(".safetensors"):
-                    from safetensors.torch import load_file
-                    sd = load_file(p)
-                else:
-                    sd = load_tensors(p)
+                sd = load_tensors(p)               # native reader: safetensors and torch zip alike
                 break
         if sd is None:
             raise FileNotFoundError(f"no CLIP weights (model.safetensors / pytorch_model.bin) under {path}")
