@@ -54,9 +54,9 @@ class MappedCheckpoint:
                 t = torch.empty(shape, dtype=dtype)
             else:
                 buf = (C.c_char * (numel_storage * es)).from_address(data.value)
+                buf._mc_owner = self                                 # tensor -> buffer object -> this mapping: the views keep the file mapped
                 flat = torch.frombuffer(buf, dtype=dtype, count=numel_storage)
                 t = flat.as_strided(shape, stride)
-            t._mc_ckpt = self                                       # the view keeps the mapping alive
             out[name.value.decode()] = t
         return out
 
