@@ -36,6 +36,22 @@ struct AttnParams {
 // expands to (compare, scale, ldexp: ~4 extra VALU instructions per call, 17 calls per K/V tile) is dead weight
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// max / sum over the four 16-lane rows of a wave (lanes c, c+16, c+32, c+48 share a query column).  v_permlane16_swap / v_permlane32_swap
+// are VALU instructions; __shfl_xor(x, 16 / 32) compiles to ds_bpermute_b32, an LDS round trip (~150 cycles each) on the critical path of
+// the online softmax: four dependent ones per tile and query block.
+__device__ __forceinline__ float rows4_max(float t) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    t = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows4_sum(float t) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    t = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KiB at the wave-uniform LDS address).  Issued from inline asm on purpose: hipcc
 // otherwise orders every later ds_read behind it with s_waitcnt vmcnt(0) (it cannot prove the read does not alias the DMA
 // destination), which serialises the prefetch of the next K/V tile with the MFMAs of the current one.  The kernel waits for these
@@ -54,9 +70,13 @@ __device__ __forceinline__ void dma16s(const void* base_uniform, uint32_t off, c
 
 // REL: gated relative-position bias of BEATs compiled in (a separate instantiation keeps its per-score loads and branches out of the
 // common kernel)
-// QW: waves per workgroup (4 or 8).  Every wave owns 16 query rows whatever QW is (same registers); 8 waves share each staged K/V tile
-// between 128 queries, which halves the LDS fills, DMA issues and barriers per query and puts 4 waves on every SIMD at two workgroups per CU.
-template <int D, bool REL, int QW>
+// QW: waves per workgroup (4 or 8).  8 waves share each staged K/V tile between twice the queries, which halves the LDS fills, DMA issues
+// and barriers per query and puts 4 waves on every SIMD at two workgroups per CU.
+// NQ: 16-query blocks per wave (1 or 2).  A wave reads the WHOLE staged K and V tile from LDS (16 KiB each at D = 128) for every tile; with
+// one query block that is 32 KiB of LDS reads behind 32 MFMAs (512 cycles): four computing waves per CU ask for 256 B/clk, the LDS's peak
+// - the kernel is LDS-bandwidth bound at ~25 % MFMA utilisation.  With NQ = 2 every K / V fragment read feeds two MFMAs (one per query
+// block): half the LDS bytes per MFMA.
+template <int D, bool REL, int QW, int NQ>
 __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) {
     constexpr int ROWB = D * 2;              // bytes per K/V row
     constexpr int CH = ROWB / 16;            // 16-byte chunks per row
@@ -66,7 +86,8 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
     constexpr int RPI = 1024 / ROWB;         // rows written by one 1-KiB LDS-DMA wave instruction
     constexpr int WROWS = 64 / QW;           // rows of a K/V tile staged by one wave
     constexpr int NDMA = WROWS / RPI;        // DMA instructions per wave per operand per tile
-    constexpr int QB = 16 * QW;              // query rows per workgroup
+    constexpr int WQ = 16 * NQ;              // query rows per wave
+    constexpr int QB = WQ * QW;              // query rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char lds[];               // 2 * 2 * 64 * ROWB bytes: [buffer][K | V]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -88,34 +109,48 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
         b = v / (nx * ny);
     }
     const int hk = h / (p.H / p.Hkv);
-    const int q0 = qblk * QB + wave * 16;
+    const int q0 = qblk * QB + wave * WQ;
     const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
 
     // Q fragments (B operand: col = query c, k = d)
-    bf16x8 qf[KS];
-    {
-        const int t = min(q0 + c, p.Lq - 1);
+    bf16x8 qf[NQ][KS];
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) {
+        const int t = min(q0 + nq * 16 + c, p.Lq - 1);
         const bf16_t* qp = p.q + b * p.q_sb + t * p.q_st + h * p.q_sh + g * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
-        // retire the Q loads here: left to the compiler, their s_waitcnt vmcnt lands on the first MFMA INSIDE the tile loop and
-        // drains the K/V prefetch DMA on every iteration
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+        for (int ks = 0; ks < KS; ++ks) qf[nq][ks] = *(const bf16x8*)(qp + ks * 32);
     }
-    const int q_abs = q0 + c + p.q_offset;   // absolute position of this lane's query
-    const float* relrow = nullptr;
-    float gate = 0.f;
+    // retire the Q loads here: left to the compiler, their s_waitcnt vmcnt lands on the first MFMA INSIDE the tile loop and
+    // drains the K/V prefetch DMA on every iteration
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[nq][ks]));
+    int q_abs[NQ];                           // absolute position of this lane's queries
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) q_abs[nq] = q0 + nq * 16 + c + p.q_offset;
+    const float* relrow[NQ];
+    float gate[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) { relrow[nq] = nullptr; gate[nq] = 0.f; }
     if (REL && p.rel_table) {
-        const int tq_ = min(q0 + c, p.Lq - 1);
-        relrow = p.rel_table + (int64_t)h * p.rel_stride + (p.rel_off - tq_);
-        gate = (p.q_gate ? p.q_gate[((int64_t)b * p.H + h) * p.Lq + tq_] : 1.0f) * 1.4426950408889634f;
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) {
+            const int tq_ = min(q0 + nq * 16 + c, p.Lq - 1);
+            relrow[nq] = p.rel_table + (int64_t)h * p.rel_stride + (p.rel_off - tq_);
+            gate[nq] = (p.q_gate ? p.q_gate[((int64_t)b * p.H + h) * p.Lq + tq_] : 1.0f) * 1.4426950408889634f;
+        }
     }
 
-    f32x4 oacc[DB];
+    f32x4 oacc[NQ][DB];
+    float m_run[NQ], l_run[NQ];
 #pragma unroll
-    for (int i = 0; i < DB; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = NEG_BIG, l_run = 0.f;
+    for (int nq = 0; nq < NQ; ++nq) {
+#pragma unroll
+        for (int i = 0; i < DB; ++i) oacc[nq][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m_run[nq] = NEG_BIG; l_run[nq] = 0.f;
+    }
 
     // number of key tiles this workgroup needs
     int last_key = kvlen;                    // exclusive
@@ -135,10 +170,10 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
         const int row = wave * WROWS + i * RPI + srow;
-        int sw;
-        if (CH == 16) sw = sch ^ (row & 15); else sw = sch ^ ((row >> 1) & 7);
+        int sw, swv;
+        if (CH == 16) { sw = sch ^ (row & 15); swv = sch ^ ((row & 7) << 1); } else { sw = sch ^ ((row >> 1) & 7); swv = sw; }
         koff[i] = (uint32_t)(((int64_t)row * p.k_st + sw * 8) * 2);
-        voff[i] = (uint32_t)(((int64_t)row * p.v_st + sw * 8) * 2);
+        voff[i] = (uint32_t)(((int64_t)row * p.v_st + swv * 8) * 2);
     }
     auto stage = [&](int kt, int buf) {
         char* kb_ = lds + buf * (2 * TILE);
@@ -157,14 +192,16 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
         for (int i = 0; i < NDMA; ++i) {
             const int row = wave * WROWS + i * RPI + srow;
             const int key = min(kt * 64 + row, p.S - 1);
-            int sw;
-            if (CH == 16) sw = sch ^ (row & 15); else sw = sch ^ ((row >> 1) & 7);
+            int sw, swv;
+            if (CH == 16) { sw = sch ^ (row & 15); swv = sch ^ ((row & 7) << 1); } else { sw = sch ^ ((row >> 1) & 7); swv = sw; }
             dma16(kbase + (int64_t)key * p.k_st + sw * 8, kb_ + (wave * WROWS + i * RPI) * ROWB);
-            dma16(vbase + (int64_t)key * p.v_st + sw * 8, vb_ + (wave * WROWS + i * RPI) * ROWB);      // V swizzled like K
+            dma16(vbase + (int64_t)key * p.v_st + swv * 8, vb_ + (wave * WROWS + i * RPI) * ROWB);
         }
     };
     if (ntiles > 0) stage(0, 0);
 
+    // (a three-deep ring with two tiles in flight behind a counted vmcnt was measured and rejected: -6 %, the wait at the top of a tile is
+    // not DMA latency)
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = kt & 1;
         const char* kl = lds + buf * (2 * TILE);
@@ -172,15 +209,16 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
         __builtin_amdgcn_s_barrier();                          // ... and everyone's; all reads of the other buffer (tile kt-1) are done
         if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1);
-        // causal: a tile that starts after this wave's last query contributes nothing (only the upper waves of a 128-query block reach
+        // causal: a tile that starts after this wave's last query contributes nothing (only the upper waves of a block reach
         // the block's last key tile); the wave still took part in the staging and the barrier above
-        if (p.causal && kt * 64 > q0 + 15 + p.q_offset) continue;
+        if (p.causal && kt * 64 > q0 + WQ - 1 + p.q_offset) continue;
 
-        // ---- S^T[key][query] = K · Q^T
-        f32x4 s[4];
+        // ---- S^T[key][query] = K · Q^T : every K fragment feeds the MFMAs of all NQ query blocks
+        f32x4 s[NQ][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nq = 0; nq < NQ; ++nq) s[nq][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int row = kb * 16 + c;     // A operand row = key
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -188,71 +226,85 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                 int sw;
                 if (CH == 16) sw = ch ^ (row & 15); else sw = ch ^ ((row >> 1) & 7);
                 const bf16x8 kf = *(const bf16x8*)(kl + row * ROWB + sw * 16);
-                s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+#pragma unroll
+                for (int nq = 0; nq < NQ; ++nq) s[nq][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[nq][ks], s[nq][kb], 0, 0, 0);
             }
         }
-        // ---- mask, online softmax (lane owns query column c; keys 16kb + 4g + r).  Only the diagonal tile (causal) and a partial last
-        // tile need the per-score index tests; every other tile takes the mask-free path (wave-uniform branch).
-        const bool need_mask = (kt * 64 + 63 >= kvlen) || (p.causal && kt * 64 + 63 > q0 + p.q_offset);
-        float tmax = NEG_BIG;
-        float lsum = 0.f;
-        bf16x8 pf[2];
-        float alpha;
-        if (need_mask || REL) {
-            bool valid[4][4];
+        // ---- mask, online softmax (lane owns query column c of each block; keys 16kb + 4g + r).  Only the diagonal tile (causal) and a
+        // partial last tile need the per-score index tests; every other tile takes the mask-free path (wave-uniform branch per block).
+        // (s_setprio(1) around the two MFMA clusters was measured: -3 %)
+        // The running maximum is only raised (and the accumulators rescaled) when some query of the wave's block gained more than 2^RESC
+        // over it; otherwise P is formed against the old maximum (values up to 2^RESC, exact in bf16's range) and the 8*DB accumulator
+        // multiplies are skipped - the usual case after the first few tiles.  l and O always see the same factor.
+        constexpr float RESC = 8.0f;
+        bf16x8 pf[NQ][2];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+        for (int nq = 0; nq < NQ; ++nq) {
+            const bool need_mask = (kt * 64 + 63 >= kvlen) || (p.causal && kt * 64 + 63 > q0 + nq * 16 + p.q_offset);
+            float tmax = NEG_BIG;
+            float lsum = 0.f;
+            if (need_mask || REL) {
+                bool valid[4][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 64 + kb * 16 + g * 4 + r;
-                    const bool ok = key < kvlen && (!p.causal || key <= q_abs);
-                    valid[kb][r] = ok;
-                    float sv = s[kb][r] * p.scale_log2e;
-                    if (REL && relrow && ok) sv += gate * relrow[key];
-                    s[kb][r] = sv;
-                    tmax = ok ? fmaxf(tmax, sv) : tmax;
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + kb * 16 + g * 4 + r;
+                        const bool ok = key < kvlen && (!p.causal || key <= q_abs[nq]);
+                        valid[kb][r] = ok;
+                        float sv = s[nq][kb][r] * p.scale_log2e;
+                        if (REL && relrow[nq] && ok) sv += gate[nq] * relrow[nq][key];
+                        s[nq][kb][r] = sv;
+                        tmax = ok ? fmaxf(tmax, sv) : tmax;
+                    }
+                tmax = rows4_max(tmax);
+                if (__builtin_amdgcn_ballot_w64(tmax > m_run[nq] + RESC) != 0) {
+                    const float m_new = fmaxf(m_run[nq], tmax);
+                    const float alpha = fast_exp2(m_run[nq] - m_new);
+                    m_run[nq] = m_new;
+                    l_run[nq] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < DB; ++i) oacc[nq][i] *= alpha;
                 }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
-            alpha = fast_exp2(m_run - m_new);
-            m_run = m_new;
+                const float mm = m_run[nq];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = valid[kb][r] ? fast_exp2(s[kb][r] - m_new) : 0.f;
-                    const bf16_t pb = (bf16_t)pv;
-                    lsum += (float)pb;           // normalise with the rounded probabilities actually multiplied
-                    pf[kb >> 1][(kb & 1) * 4 + r] = pb;
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = valid[kb][r] ? fast_exp2(s[nq][kb][r] - mm) : 0.f;
+                        lsum += pv;
+                        pf[nq][kb >> 1][(kb & 1) * 4 + r] = (bf16_t)pv;
+                    }
+            } else {
+                // raw scores: the scale is positive, so the maximum commutes with it and exp2(s*c - m) is one FMA per score
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[nq][kb][r]);
+                tmax = rows4_max(tmax);
+                tmax *= p.scale_log2e;
+                if (__builtin_amdgcn_ballot_w64(tmax > m_run[nq] + RESC) != 0) {
+                    const float m_new = fmaxf(m_run[nq], tmax);
+                    const float alpha = fast_exp2(m_run[nq] - m_new);
+                    m_run[nq] = m_new;
+                    l_run[nq] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < DB; ++i) oacc[nq][i] *= alpha;
                 }
-        } else {
+                const float nm = -m_run[nq];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[kb][r] *= p.scale_log2e;
-                    tmax = fmaxf(tmax, s[kb][r]);
-                }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
-            alpha = fast_exp2(m_run - m_new);
-            m_run = m_new;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bf16_t pb = (bf16_t)fast_exp2(s[kb][r] - m_new);
-                    lsum += (float)pb;
-                    pf[kb >> 1][(kb & 1) * 4 + r] = pb;
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = fast_exp2(fmaf(s[nq][kb][r], p.scale_log2e, nm));
+                        lsum += pv;
+                        pf[nq][kb >> 1][(kb & 1) * 4 + r] = (bf16_t)pv;
+                    }
+            }
+            l_run[nq] += lsum;
         }
-        l_run = l_run * alpha + lsum;
-#pragma unroll
-        for (int i = 0; i < DB; ++i) oacc[i] *= alpha;
 
-        // ---- O^T[d][query] += V^T · P^T ; V fragments through the transposing LDS read
+        // ---- O^T[d][query] += V^T · P^T ; V fragments through the transposing LDS read, each feeding all NQ query blocks
         const int tq = (lane & 15) >> 2, tp = lane & 3;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
@@ -260,11 +312,13 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
             const int key_hi = (2 * pr + 1) * 16 + g * 4 + tq;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                // 8 bytes at logical column (db*16 + tp*4) of row key: 16-byte chunk db*2 + (tp>>1), XOR-swizzled per row (without it the
-                // 16 rows of one instruction sit on the same banks: 256-byte rows = one full bank line each)
+                // 8 bytes at logical column (db*16 + tp*4) of row key: 16-byte chunk db*2 + (tp>>1), XOR-swizzled per row (256-byte rows = one
+                // full bank line each).  A transposing read is served in two groups of 32 lanes = 8 rows x 2 chunks x 2 halves: with
+                // chunk ^ (2 * (row & 7)) the 16 (row, chunk) pairs of a group land on 16 different chunk slots = all 64 banks once
+                // (chunk ^ (row & 15), K's swizzle, puts rows k and k^1 on the same slot: 2-way conflicts, 30 % of the LDS cycles measured)
                 const int chv = db * 2 + (tp >> 1);
-                const int sw_lo = (CH == 16) ? (chv ^ (key_lo & 15)) : (chv ^ ((key_lo >> 1) & 7));
-                const int sw_hi = (CH == 16) ? (chv ^ (key_hi & 15)) : (chv ^ ((key_hi >> 1) & 7));
+                const int sw_lo = (CH == 16) ? (chv ^ ((key_lo & 7) << 1)) : (chv ^ ((key_lo >> 1) & 7));
+                const int sw_hi = (CH == 16) ? (chv ^ ((key_hi & 7) << 1)) : (chv ^ ((key_hi >> 1) & 7));
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                     (__attribute__((address_space(3))) bf16x4*)(char*)(vl + key_lo * ROWB + sw_lo * 16 + (tp & 1) * 8));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
@@ -272,26 +326,28 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                 bf16x8 vf;
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                 vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[pr], oacc[db], 0, 0, 0);
+#pragma unroll
+                for (int nq = 0; nq < NQ; ++nq) oacc[nq][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nq][pr], oacc[nq][db], 0, 0, 0);
             }
         }
     }
     // ---- finalize: total row sum over the 4 lane groups that share query c
-    float l = l_run;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    const int t = q0 + c;
-    if (p.lse && t < p.Lq && g == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + t] = l > 0.f ? m_run + log2f(l) : NEG_BIG;
-    if (t < p.Lq) {
-        const int64_t row = p.out_map ? p.out_map[b * p.Lq + t] : (int64_t)b * p.Lq + t;
-        if (row >= 0) {
-            bf16_t* op = p.o + row * p.o_row_stride + h * D;
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                bf16x4 ov = {(bf16_t)(oacc[db][0] * inv), (bf16_t)(oacc[db][1] * inv), (bf16_t)(oacc[db][2] * inv),
-                             (bf16_t)(oacc[db][3] * inv)};
-                *(bf16x4*)(op + db * 16 + g * 4) = ov;
+    for (int nq = 0; nq < NQ; ++nq) {
+        const float l = rows4_sum(l_run[nq]);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int t = q0 + nq * 16 + c;
+        if (p.lse && t < p.Lq && g == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + t] = l > 0.f ? m_run[nq] + log2f(l) : NEG_BIG;
+        if (t < p.Lq) {
+            const int64_t row = p.out_map ? p.out_map[b * p.Lq + t] : (int64_t)b * p.Lq + t;
+            if (row >= 0) {
+                bf16_t* op = p.o + row * p.o_row_stride + h * D;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    bf16x4 ov = {(bf16_t)(oacc[nq][db][0] * inv), (bf16_t)(oacc[nq][db][1] * inv), (bf16_t)(oacc[nq][db][2] * inv),
+                                 (bf16_t)(oacc[nq][db][3] * inv)};
+                    *(bf16x4*)(op + db * 16 + g * 4) = ov;
+                }
             }
         }
     }
@@ -498,26 +554,37 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
                  (bf16_t*)o, o_row_stride, out_map, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
                  scale * 1.4426950408889634f, rel_table, q_gate, rel_stride, rel_off, lse};
     hipStream_t s = (hipStream_t)stream;
-    // 128-query workgroups (8 waves) for long sequences (measured on MI355X, causal, D = 128: L = 2792 426 vs 475 us, 599 TFLOP/s; at
-    // L = 682 the coarser causal diagonal costs more than the sharing saves, 204 vs 190 us), 64-query ones otherwise
+    // Workgroup shape: QW waves x NQ 16-query blocks per wave.  D = 128 without the relative-position bias (the LLM prefill, training):
+    // two query blocks per wave (half the LDS bytes per MFMA, see the kernel); 4 waves = 128 queries per workgroup, 8 waves = 256 for long
+    // sequences where the coarser causal diagonal is cheap.  Everything else keeps one block per wave: 8 waves (128 queries) for
+    // Lq >= 1024, 4 waves (64 queries) below.  debug word: bit 0 forces <4 waves, 1 block>, bit 1 allows the 8-wave shapes at any
+    // length, bit 2 disables the two-block kernels.
+    const bool two = D == 128 && !rel_table && !(g_attn_dbg & (1 | 4)) && Lq > 64;
+    if (two) {
+        const bool w8 = ((g_attn_dbg & 2) || Lq >= 2048) && (int64_t)((Lq + 255) / 256) * H * B >= 512;
+        if (w8) attn_prefill_kernel<128, false, 8, 2><<<dim3((Lq + 255) / 256, H, B), 512, 4 * 64 * 256, s>>>(p);
+        else attn_prefill_kernel<128, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+        MC_CHECK_LAUNCH();
+        return 0;
+    }
     const bool wide = ((g_attn_dbg & 2) || Lq >= 1024) && (int64_t)((Lq + 127) / 128) * H * B >= 512 && !(g_attn_dbg & 1);
     if (wide) {
         dim3 grid((Lq + 127) / 128, H, B);
         if (rel_table) {
-            if (D == 128) attn_prefill_kernel<128, true, 8><<<grid, 512, 4 * 64 * 256, s>>>(p);
-            else attn_prefill_kernel<64, true, 8><<<grid, 512, 4 * 64 * 128, s>>>(p);
+            if (D == 128) attn_prefill_kernel<128, true, 8, 1><<<grid, 512, 4 * 64 * 256, s>>>(p);
+            else attn_prefill_kernel<64, true, 8, 1><<<grid, 512, 4 * 64 * 128, s>>>(p);
         } else {
-            if (D == 128) attn_prefill_kernel<128, false, 8><<<grid, 512, 4 * 64 * 256, s>>>(p);
-            else attn_prefill_kernel<64, false, 8><<<grid, 512, 4 * 64 * 128, s>>>(p);
+            if (D == 128) attn_prefill_kernel<128, false, 8, 1><<<grid, 512, 4 * 64 * 256, s>>>(p);
+            else attn_prefill_kernel<64, false, 8, 1><<<grid, 512, 4 * 64 * 128, s>>>(p);
         }
     } else {
         dim3 grid((Lq + 63) / 64, H, B);
         if (rel_table) {
-            if (D == 128) attn_prefill_kernel<128, true, 4><<<grid, 256, 4 * 64 * 256, s>>>(p);
-            else attn_prefill_kernel<64, true, 4><<<grid, 256, 4 * 64 * 128, s>>>(p);
+            if (D == 128) attn_prefill_kernel<128, true, 4, 1><<<grid, 256, 4 * 64 * 256, s>>>(p);
+            else attn_prefill_kernel<64, true, 4, 1><<<grid, 256, 4 * 64 * 128, s>>>(p);
         } else {
-            if (D == 128) attn_prefill_kernel<128, false, 4><<<grid, 256, 4 * 64 * 256, s>>>(p);
-            else attn_prefill_kernel<64, false, 4><<<grid, 256, 4 * 64 * 128, s>>>(p);
+            if (D == 128) attn_prefill_kernel<128, false, 4, 1><<<grid, 256, 4 * 64 * 256, s>>>(p);
+            else attn_prefill_kernel<64, false, 4, 1><<<grid, 256, 4 * 64 * 128, s>>>(p);
         }
     }
     MC_CHECK_LAUNCH();

@@ -13,7 +13,7 @@ BASELINE.json names (1e-3 of the logit scale, greedy ids bit-exact) instead of t
   * RMSNorm = per-row fp32 factor applied to the fp32 accumulator (GEMM epilogue), the normalised activations are never rounded;
   * values are rounded to bf16 exactly where the kernels store them: q|k|v, rotated q / k, attention output, both residual
     sums, gate and up (before SiLU), silu(gate)*up, the final norm output;
-  * prefill attention: P = bf16(exp(s - rowmax)) multiplies V and normalises with the sum of the ROUNDED P (csrc/attention.hip);
+  * prefill attention: P = bf16(exp(s - rowmax)) multiplies V, the row sum that normalises is taken over the fp32 P (csrc/attention.hip);
     decode attention: fp32 softmax, no rounding of P (attn_decode_kernel);
   * decode steps use the 'default' adapter only (multimodal_llama.py:435-438).
 What is NOT reproduced: fp32 summation order inside the kernels (MFMA tiling, split reductions) and the online-softmax's
@@ -161,8 +161,8 @@ def forward(dw: DeviceWeights, x: torch.Tensor, adapter_masks: Optional[Dict[str
             causal = torch.ones(L, L, dtype=torch.bool).tril()
             s = s.masked_fill(~causal, float("-inf"))
             m = s.max(dim=-1, keepdim=True).values
-            p = bf(torch.exp(s - m))
-            o = torch.matmul(p, vv) / p.sum(-1, keepdim=True)
+            p = torch.exp(s - m)
+            o = torch.matmul(bf(p), vv) / p.sum(-1, keepdim=True)
         o = bf(o).transpose(1, 2).reshape(B * L, H * D)
         h = bf(h + _routed(o, W, "o_proj", groups))
         if trace is not None:
