@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
     for (int i = 0; i < NDMA; ++i) {
         const int row = wave * WROWS + i * RPI + srow;
         int sw, swv;
-        if (CH == 16) { sw = sch ^ (row & 15); swv = sch ^ ((row & 7) << 1); } else { sw = sch ^ ((row >> 1) & 7); swv = sw; }
+        if (CH == 16) { sw = sch ^ (row & 15); swv = sch ^ ((row & 7) << 1); } else { sw = sch ^ ((row >> 1) & 7); swv = sch ^ (((row >> 1) & 3) << 1); }
         koff[i] = (uint32_t)(((int64_t)row * p.k_st + sw * 8) * 2);
         voff[i] = (uint32_t)(((int64_t)row * p.v_st + swv * 8) * 2);
     }
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
             const int row = wave * WROWS + i * RPI + srow;
             const int key = min(kt * 64 + row, p.S - 1);
             int sw, swv;
-            if (CH == 16) { sw = sch ^ (row & 15); swv = sch ^ ((row & 7) << 1); } else { sw = sch ^ ((row >> 1) & 7); swv = sw; }
+            if (CH == 16) { sw = sch ^ (row & 15); swv = sch ^ ((row & 7) << 1); } else { sw = sch ^ ((row >> 1) & 7); swv = sch ^ (((row >> 1) & 3) << 1); }
             dma16(kbase + (int64_t)key * p.k_st + sw * 8, kb_ + (wave * WROWS + i * RPI) * ROWB);
             dma16(vbase + (int64_t)key * p.v_st + swv * 8, vb_ + (wave * WROWS + i * RPI) * ROWB);
         }
@@ -317,8 +317,9 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                 // chunk ^ (2 * (row & 7)) the 16 (row, chunk) pairs of a group land on 16 different chunk slots = all 64 banks once
                 // (chunk ^ (row & 15), K's swizzle, puts rows k and k^1 on the same slot: 2-way conflicts, 30 % of the LDS cycles measured)
                 const int chv = db * 2 + (tp >> 1);
-                const int sw_lo = (CH == 16) ? (chv ^ ((key_lo & 7) << 1)) : (chv ^ ((key_lo >> 1) & 7));
-                const int sw_hi = (CH == 16) ? (chv ^ ((key_hi & 7) << 1)) : (chv ^ ((key_hi >> 1) & 7));
+                // (128-byte rows, D = 64: two rows per bank line, 8 rows x 2 chunks of a group -> chunk ^ (2 * ((row >> 1) & 3)))
+                const int sw_lo = (CH == 16) ? (chv ^ ((key_lo & 7) << 1)) : (chv ^ (((key_lo >> 1) & 3) << 1));
+                const int sw_hi = (CH == 16) ? (chv ^ ((key_hi & 7) << 1)) : (chv ^ (((key_hi >> 1) & 3) << 1));
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                     (__attribute__((address_space(3))) bf16x4*)(char*)(vl + key_lo * ROWB + sw_lo * 16 + (tp & 1) * 8));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
@@ -350,6 +351,86 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tiny sequences (Lq, S <= 8): the temporal attention of LanguageBind-Video (languagebind/video/modeling_video.py:105-130: every patch
+// position attends over its t = 8 frames - 4112 sequences x 16 heads of 8 x 8 scores per clip batch).  The flash kernel above spends a
+// 64 x 64 MFMA tile and two 64-row LDS stages on each of them (4 TFLOP/s, 260 us per layer); this is a memory-bound problem: q, k, v read
+// once, o written once.  One thread = (sequence, head, query, half of head_dim): its 8 scores are dot products over its half, summed with
+// the partner lane, fp32 softmax, then its half of the output row.
+template <int D>
+__global__ __launch_bounds__(256) void attn_tiny_kernel(AttnParams p) {
+    constexpr int HALF = D / 2, NV = HALF / 8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int half = (int)(gid & 1);
+    const int t = (int)((gid >> 1) & 7);
+    const int64_t bh = gid >> 4;
+    if (bh >= (int64_t)p.B * p.H) return;
+    const int b = (int)(bh / p.H), h = (int)(bh % p.H);
+    const int hk = h / (p.H / p.Hkv);
+    const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
+    const int tq = min(t, p.Lq - 1);
+    const bf16_t* qp = p.q + b * p.q_sb + (int64_t)tq * p.q_st + h * p.q_sh + half * HALF;
+    float qv[HALF];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const bf16x8 x = *(const bf16x8*)(qp + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[i * 8 + j] = (float)x[j];
+    }
+    float sc[8];
+    float m = NEG_BIG;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int key = min(j, p.S - 1);
+        const bf16_t* kp = p.k + b * p.k_sb + (int64_t)key * p.k_st + hk * p.k_sh + half * HALF;
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bf16x8 x = *(const bf16x8*)(kp + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d = fmaf(qv[i * 8 + e], (float)x[e], d);
+        }
+        d += __shfl_xor(d, 1, 64);                          // the other half of head_dim
+        const bool ok = j < kvlen && (!p.causal || j <= tq + p.q_offset);
+        sc[j] = ok ? d * p.scale_log2e : NEG_BIG;
+        m = fmaxf(m, sc[j]);
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = sc[j] > NEG_BIG * 0.5f ? fast_exp2(sc[j] - m) : 0.f; l += sc[j]; }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float o[HALF];
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int key = min(j, p.S - 1);
+        const bf16_t* vp = p.v + b * p.v_sb + (int64_t)key * p.v_st + hk * p.v_sh + half * HALF;
+        // P is rounded to bf16 before it multiplies V, as in the flash kernel (and normalised by the fp32 sum)
+        const float pj = (float)(bf16_t)sc[j];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bf16x8 x = *(const bf16x8*)(vp + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[i * 8 + e] = fmaf(pj, (float)x[e], o[i * 8 + e]);
+        }
+    }
+    if (t < p.Lq) {
+        const int64_t row = p.out_map ? p.out_map[b * p.Lq + t] : (int64_t)b * p.Lq + t;
+        if (row >= 0) {
+            bf16_t* op = p.o + row * p.o_row_stride + h * D + half * HALF;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                bf16x8 x;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = (bf16_t)(o[i * 8 + e] * inv);
+                *(bf16x8*)(op + i * 8) = x;
+            }
+        }
+        if (p.lse && half == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + t] = l > 0.f ? m + log2f(l) : NEG_BIG;
     }
 }
 
@@ -559,6 +640,18 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
     // sequences where the coarser causal diagonal is cheap.  Everything else keeps one block per wave: 8 waves (128 queries) for
     // Lq >= 1024, 4 waves (64 queries) below.  debug word: bit 0 forces <4 waves, 1 block>, bit 1 allows the 8-wave shapes at any
     // length, bit 2 disables the two-block kernels.
+    if (Lq <= 8 && S <= 8 && !rel_table && !(g_attn_dbg & 32)) {
+        const int64_t threads = (int64_t)B * H * 16;
+        if (D == 128) attn_tiny_kernel<128><<<(int)((threads + 255) / 256), 256, 0, s>>>(p);
+        else attn_tiny_kernel<64><<<(int)((threads + 255) / 256), 256, 0, s>>>(p);
+        MC_CHECK_LAUNCH();
+        return 0;
+    }
+    if (D == 64 && !rel_table && (g_attn_dbg & 16) && Lq > 64) {          // A/B: two query blocks per wave at head_dim 64 (encoders)
+        attn_prefill_kernel<64, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 128, s>>>(p);
+        MC_CHECK_LAUNCH();
+        return 0;
+    }
     const bool two = D == 128 && !rel_table && !(g_attn_dbg & (1 | 4)) && Lq > 64;
     if (two) {
         const bool w8 = ((g_attn_dbg & 2) || Lq >= 2048) && (int64_t)((Lq + 255) / 256) * H * B >= 512;
