@@ -174,6 +174,10 @@ int mc_dropout_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int M, i
                     unsigned int stream_id, int accumulate, float alpha, void* stream);
 int mc_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* g, const void* dy, int64_t ldy, const void* dres, int64_t ldr,
                         void* dx, int64_t ldd, int M, int D, float eps, void* stream);
+/* LayerNorm backward (Q-Former projector, multimodal_projector/Qformer.py:112-130): dx, and t = dy * xhat whose column sums are dgamma
+ * (dbeta = column sums of dy: mc_colsum_bf16); t_out may be NULL */
+int mc_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* g, const void* dy, int64_t ldy, void* dx, int64_t ldd, void* t_out,
+                          int64_t ldt, int M, int D, float eps, void* stream);
 int mc_swiglu_bwd_bf16(const void* gate_up, int64_t ld, const void* dinter, int64_t ldi, void* dgate_up, int64_t ldg, int M, int I,
                        void* stream);
 int mc_act_bf16(const void* pre, const void* dy, void* out, int64_t n, int act, void* stream);   /* dy NULL: act(pre); else dy*act'(pre) */

@@ -103,6 +103,7 @@ _SIGS.update({
     "mc_rope_inplace_bf16": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "mc_adamw_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p],
     "mc_cast_f32_bf16": [c_p, c_p, c_l, c_p],
+    "mc_layernorm_bwd_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_dropout_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_f, C.c_uint64, C.c_uint32, c_i, c_f, c_p],
     "mc_add_rows_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_p],
     "mc_zero_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],

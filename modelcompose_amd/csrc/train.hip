@@ -53,6 +53,46 @@ extern "C" int mc_lora_mask_rows_bf16(void* t, int64_t ld, const int32_t* row_ad
 }
 
 // ------------------------------------------------------------------------------------------
+// LayerNorm backward (the Q-Former projector's BertLayer norms, multimodal_projector/Qformer.py:112-130, trained in the audio stage-2
+// recipe): y = xhat * g + b, xhat = (x - mean) * rstd.
+//   dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));   t = dy * xhat  (dgamma = column sums of t, dbeta = column sums of dy)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ g,
+                                                            const bf16_t* __restrict__ dy, int64_t ldy, bf16_t* __restrict__ dx, int64_t ldd,
+                                                            bf16_t* __restrict__ t_out, int64_t ldt, int D, float eps) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const bf16_t* xr = x + (int64_t)row * ldx;
+    const bf16_t* dyr = dy + (int64_t)row * ldy;
+    float s1 = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) s1 += (float)xr[i];
+    const float mean = block_sum(s1, red) / D;
+    float sv = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) { const float d = (float)xr[i] - mean; sv += d * d; }
+    const float rstd = rsqrtf(block_sum(sv, red) / D + eps);
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float xh = ((float)xr[i] - mean) * rstd, dg = (float)dyr[i] * (float)g[i];
+        a += dg; b += dg * xh;
+    }
+    a = block_sum(a, red) / D;
+    b = block_sum(b, red) / D;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float xh = ((float)xr[i] - mean) * rstd, dyv = (float)dyr[i];
+        dx[(int64_t)row * ldd + i] = (bf16_t)(rstd * (dyv * (float)g[i] - a - xh * b));
+        if (t_out) t_out[(int64_t)row * ldt + i] = (bf16_t)(dyv * xh);
+    }
+}
+
+extern "C" int mc_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* g, const void* dy, int64_t ldy, void* dx, int64_t ldd, void* t_out,
+                                     int64_t ldt, int M, int D, float eps, void* stream) {
+    MC_CHECK_ARG(x && g && dy && dx && M > 0 && D > 0, "mc_layernorm_bwd_bf16: bad arguments");
+    layernorm_bwd_kernel<<<M, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, (const bf16_t*)g, (const bf16_t*)dy, ldy, (bf16_t*)dx, ldd,
+                                                             (bf16_t*)t_out, ldt, D, eps);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // nn.Dropout on the LoRA input (LocalLoraLinear.forward, multimodal_llama.py:133-148: lora_A(lora_dropout(x)), p = 0.05 in the stage-2
 // scripts).  Counter-based mask: element e = m*K + k of stream `stream_id` is kept iff word (e & 3) of
 // Philox4x32-10(counter = (e >> 2 lo, e >> 2 hi, stream_id, 0), key = (seed_lo, seed_hi)) >= p * 2^32, so the backward pass (and the

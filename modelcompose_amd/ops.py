@@ -490,6 +490,16 @@ def adamw(p32, g32, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
                "mc_adamw_f32")
 
 
+def layernorm_bwd(x, g, dy, eps, want_t=True):
+    """-> (dx, t = dy * xhat or None): LayerNorm backward w.r.t. the input; dgamma = colsum(t), dbeta = colsum(dy)."""
+    M, D = x.shape
+    dx = torch.empty(M, D, dtype=BF16, device=x.device)
+    t = torch.empty(M, D, dtype=BF16, device=x.device) if want_t else None
+    _lib.check(_lib.lib().mc_layernorm_bwd_bf16(_p(x), x.stride(0), _p(g), _p(dy), dy.stride(0), _p(dx), dx.stride(0), _p(t),
+                                                0 if t is None else t.stride(0), M, D, float(eps), _stream()), "mc_layernorm_bwd_bf16")
+    return dx, t
+
+
 def dropout(x, p: float, seed: int, stream_id: int, out=None, accumulate: bool = False, alpha: float = 1.0):
     """out = (accumulate ? out : 0) + alpha * x * keep / (1 - p); keep from Philox4x32-10 keyed by (seed, stream_id, element index)."""
     M, K = x.shape

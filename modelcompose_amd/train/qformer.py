@@ -1,0 +1,172 @@
+"""Forward-with-saved-activations and backward of the Q-Former projector for the stage-2 finetune step (audio recipe:
+scripts/model_composition/train/run_finetune_audio_damc.sh:37-38 trains `qformer_32N_2L` on BEATs features).
+
+Mirrors VideoLlamaAudioQformer.forward (modelcompose/model/multimodal_projector/builder.py:130-155) over BLIP-2's BertLayer
+(multimodal_projector/Qformer.py:112-277, 403-475 - text FFN removed, cross-attention in every layer): learned position embedding on
+the encoder tokens, learned queries -> LayerNorm -> [self-attention, cross-attention to the encoder tokens, query FFN] x L -> Linear.
+Every parameter of the projector is trainable (train_multimodal.py:436-465 unfreezes the modal projectors).  All arithmetic is kernels
+of libmc_hip.so: bf16 GEMMs (forward, input gradients through transposed packs, weight gradients by the TN kernel), flash attention
+forward with LSE + its backward, LayerNorm / GELU backward, column sums for biases."""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from .. import ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+class QformerTrainable:
+    def __init__(self, step, modal: str, proj, raw: Dict[str, torch.Tensor]):
+        """Registers every parameter of `proj` (a HipQformerProjector) in the step's flat master buffer under the reference's names."""
+        self.step, self.modal, self.proj = step, modal, proj
+        self.pre = f"model.modal_projectors.{modal}."
+        self.names: List[str] = []
+        Dm = proj.hidden
+        if Dm % 64 or proj.width % 64 or proj.inter % 64 or (Dm // proj.heads) not in (64, 128):
+            raise NotImplementedError("Q-Former backward needs hidden / encoder width / FFN width multiples of 64 and head_dim 64 or 128")
+
+        def reg(suffix):
+            k = self.pre + suffix
+            if k not in raw:
+                raise ValueError(f"state dict lacks {k}")
+            step._register(k, raw[k])
+            self.names.append(k)
+        reg("audio_query_tokens")
+        reg("audio_position_embedding.weight")
+        for s in ("weight", "bias"):
+            reg("audio_Qformer.bert.embeddings.LayerNorm." + s)
+        for i in range(proj.nl):
+            p = f"audio_Qformer.bert.encoder.layer.{i}."
+            for att in ("attention", "crossattention"):
+                for lin in ("self.query", "self.key", "self.value", "output.dense"):
+                    for s in ("weight", "bias"):
+                        reg(f"{p}{att}.{lin}.{s}")
+                for s in ("weight", "bias"):
+                    reg(f"{p}{att}.output.LayerNorm.{s}")
+            for lin in ("intermediate_query.dense", "output_query.dense"):
+                for s in ("weight", "bias"):
+                    reg(f"{p}{lin}.{s}")
+            for s in ("weight", "bias"):
+                reg(f"{p}output_query.LayerNorm.{s}")
+        for s in ("weight", "bias"):
+            reg("audio_llama_proj." + s)
+
+    # ------------------------------------------------------------------ helpers over the step's buffers
+    def w16(self, suffix):
+        return self.step.view(self.step.P16, self.pre + suffix)
+
+    def g32(self, suffix):
+        return self.step.view(self.step.G, self.pre + suffix)
+
+    def _lin(self, x, name):
+        return ops.linear(x, ops.pack_weight(self.w16(name + ".weight"), self.w16(name + ".bias")))
+
+    def _lin_bwd(self, x, dy, name, need_dx=True):
+        """dW = dy^T x, db = colsum(dy) into the gradient buffer; returns dx = dy W."""
+        self.step._wgrad([dy], [x], [self.g32(name + ".weight")])
+        ops.colsum(dy, out=self.g32(name + ".bias"))
+        return ops.linear(dy, ops.pack_weight_t(self.w16(name + ".weight"))) if need_dx else None
+
+    def _ln(self, x, name):
+        return ops.layernorm(x, self.w16(name + ".weight"), self.w16(name + ".bias"), self.proj.eps)
+
+    def _ln_bwd(self, x, dy, name):
+        dx, t = ops.layernorm_bwd(x, self.w16(name + ".weight"), dy, self.proj.eps)
+        ops.colsum(t, out=self.g32(name + ".weight"))
+        ops.colsum(dy, out=self.g32(name + ".bias"))
+        return dx
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x (B, T, width) encoder tokens (frozen encoder: no gradient needed) -> (B, nq, llm hidden)."""
+        pj, dev = self.proj, self.step.dev
+        Dm, H, N = pj.hidden, pj.heads, pj.nq
+        d = Dm // H
+        B, T, W = x.shape
+        sv = self.saved = {"B": B, "T": T}
+        xe = x.to(dev, BF16).reshape(B * T, W).contiguous()
+        idx = torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
+        xe = ops.add_rows(xe, self.w16("audio_position_embedding.weight"), idx)            # builder.py:136-140
+        sv["xe"] = xe
+        q0 = self.w16("audio_query_tokens").reshape(N, Dm).repeat(B, 1).contiguous()
+        sv["q0"] = q0
+        h = self._ln(q0, "audio_Qformer.bert.embeddings.LayerNorm")
+        M = B * N
+        for i in range(pj.nl):
+            p = f"audio_Qformer.bert.encoder.layer.{i}."
+            L = sv[i] = {"h_in": h}
+            # self-attention among the queries
+            q, k, v = (self._lin(h, p + "attention.self." + n) for n in ("query", "key", "value"))
+            a = torch.empty(M, Dm, dtype=BF16, device=dev)
+            lse = torch.empty(B * H * N, dtype=F32, device=dev)
+            st = (N * Dm, Dm, d)
+            ops.attn_prefill_lse(q, k, v, a, lse, B, H, N, N, d, st, st, st, Dm, False)
+            s1 = ops.linear(a, ops.pack_weight(self.w16(p + "attention.output.dense.weight"), self.w16(p + "attention.output.dense.bias")), residual=h)
+            h1 = self._ln(s1, p + "attention.output.LayerNorm")
+            L.update(q=q, k=k, v=v, a=a, lse=lse, s1=s1, h1=h1)
+            # cross-attention to the encoder tokens
+            cq = self._lin(h1, p + "crossattention.self.query")
+            ck, cv = (self._lin(xe, p + "crossattention.self." + n) for n in ("key", "value"))
+            ca = torch.empty(M, Dm, dtype=BF16, device=dev)
+            clse = torch.empty(B * H * N, dtype=F32, device=dev)
+            stk = (T * Dm, Dm, d)
+            ops.attn_prefill_lse(cq, ck, cv, ca, clse, B, H, N, T, d, st, stk, stk, Dm, False)
+            s2 = ops.linear(ca, ops.pack_weight(self.w16(p + "crossattention.output.dense.weight"), self.w16(p + "crossattention.output.dense.bias")), residual=h1)
+            h2 = self._ln(s2, p + "crossattention.output.LayerNorm")
+            L.update(cq=cq, ck=ck, cv=cv, ca=ca, clse=clse, s2=s2, h2=h2)
+            # query FFN
+            fpre = self._lin(h2, p + "intermediate_query.dense")
+            f = ops.act(fpre, "gelu")
+            s3 = ops.linear(f, ops.pack_weight(self.w16(p + "output_query.dense.weight"), self.w16(p + "output_query.dense.bias")), residual=h2)
+            h = self._ln(s3, p + "output_query.LayerNorm")
+            L.update(fpre=fpre, f=f, s3=s3)
+        sv["h_out"] = h
+        return self._lin(h, "audio_llama_proj").view(B, N, -1)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dout: torch.Tensor):
+        """dout (B * nq, llm hidden) bf16: gradient of the loss w.r.t. this projector's output rows."""
+        pj, dev, sv = self.proj, self.step.dev, self.saved
+        Dm, H, N = pj.hidden, pj.heads, pj.nq
+        d = Dm // H
+        B, T = sv["B"], sv["T"]
+        M = B * N
+        st, stk = (N * Dm, Dm, d), (T * Dm, Dm, d)
+        dh = self._lin_bwd(sv["h_out"], dout.contiguous(), "audio_llama_proj")
+        dxe = None                                                             # gradient w.r.t. the position-embedded encoder tokens
+        for i in reversed(range(pj.nl)):
+            p = f"audio_Qformer.bert.encoder.layer.{i}."
+            L = sv[i]
+            # h = LN(s3), s3 = fc2(gelu(fc1(h2))) + h2
+            ds3 = self._ln_bwd(L["s3"], dh, p + "output_query.LayerNorm")
+            df = self._lin_bwd(L["f"], ds3, p + "output_query.dense")
+            dfpre = ops.act(L["fpre"], "gelu", dy=df)
+            dh2 = ops.add(self._lin_bwd(L["h2"], dfpre, p + "intermediate_query.dense"), ds3)
+            # h2 = LN(s2), s2 = o(ca) + h1
+            ds2 = self._ln_bwd(L["s2"], dh2, p + "crossattention.output.LayerNorm")
+            dca = self._lin_bwd(L["ca"], ds2, p + "crossattention.output.dense")
+            dcq = torch.empty(M, Dm, dtype=BF16, device=dev)
+            dck, dcv = (torch.empty(B * T, Dm, dtype=BF16, device=dev) for _ in range(2))
+            ops.attn_bwd(L["cq"], L["ck"], L["cv"], L["ca"], dca, L["clse"], dcq, dck, dcv, B, H, N, T, d, st, stk, stk, st, st, stk, stk, False)
+            dh1 = ops.add(self._lin_bwd(L["h1"], dcq, p + "crossattention.self.query"), ds2)
+            for n_, g_ in (("key", dck), ("value", dcv)):
+                dx_ = self._lin_bwd(sv["xe"], g_, p + "crossattention.self." + n_)
+                dxe = dx_ if dxe is None else ops.add(dxe, dx_)
+            # h1 = LN(s1), s1 = o(a) + h_in
+            ds1 = self._ln_bwd(L["s1"], dh1, p + "attention.output.LayerNorm")
+            da = self._lin_bwd(L["a"], ds1, p + "attention.output.dense")
+            dq, dk, dv = (torch.empty(M, Dm, dtype=BF16, device=dev) for _ in range(3))
+            ops.attn_bwd(L["q"], L["k"], L["v"], L["a"], da, L["lse"], dq, dk, dv, B, H, N, N, d, st, st, st, st, st, st, st, False)
+            dh = ds1
+            for n_, g_ in (("query", dq), ("key", dk), ("value", dv)):
+                dh = ops.add(dh, self._lin_bwd(L["h_in"], g_, p + "attention.self." + n_))
+        dq0 = self._ln_bwd(sv["q0"], dh, "audio_Qformer.bert.embeddings.LayerNorm")
+        # the learned queries are shared by the B samples (.expand): sum over the batch; likewise the position rows
+        self.g32("audio_query_tokens").copy_(ops.colsum(dq0.view(B, N * Dm)).view(1, N, Dm))
+        gpos = self.g32("audio_position_embedding.weight")
+        gpos.zero_()
+        gpos[:T].copy_(ops.colsum(dxe.view(B, T * pj.width)).view(T, pj.width))

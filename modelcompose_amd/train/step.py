@@ -22,7 +22,8 @@ Restructuring that keeps the function:
   * padded / ragged batches (collator: multimodal_dataset.py:148-214; splice padding: multimodal_arch.py:390-430): rows keep the
     reference's padded [B, Lmax] layout - pad slots are zero embeddings, masked as attention keys by a per-sample length, ignored by
     the loss (-100) - so they contribute exactly zero to every gradient, as in the reference.
-Limits of this version (raise, never fall back): MLP / linear projectors only (no Q-Former backward), right padding only."""
+  * projectors: MLP / linear (vision, video, point) and the Q-Former of the audio recipe (train/qformer.py).
+Limits of this version (raise, never fall back): right padding only."""
 from __future__ import annotations
 
 import math
@@ -35,6 +36,7 @@ from .. import ops
 from ..constants import IGNORE_INDEX
 from ..model.config import MultimodalConfig, adapter_plan, infer_modals
 from ..model.multimodal_llama import MultimodalLlamaForCausalLM
+from ..model.encoders_extra import HipQformerProjector
 from ..model.projector import HipMlpProjector
 from .buckets import bucket_ranges
 
@@ -141,6 +143,7 @@ class MultimodalTrainStep:
             params.append(_Param(name, off, tensor.shape))
             init.append(tensor.reshape(-1).to(self.dev, F32))
             off += tensor.numel()
+        self._register = add
 
         for l in reversed(range(Ln)):
             for gname, lins in reversed(GROUPS):
@@ -158,9 +161,14 @@ class MultimodalTrainStep:
         self.proj_modals = []
         self.aux_lo = off                                          # projector / prefix / suffix parameters live in [aux_lo, n_params)
         n_before = len(params)
+        self.qformers = {}
         for m, proj in self.model.model.modal_projectors.items():
+            if isinstance(proj, HipQformerProjector):               # audio stage-2 recipe (run_finetune_audio_damc.sh:37-38)
+                from .qformer import QformerTrainable
+                self.qformers[m] = QformerTrainable(self, m, proj, raw)
+                continue
             if not isinstance(proj, HipMlpProjector):
-                raise NotImplementedError(f"projector of modality '{m}' is not an MLP/linear projector: its backward is not implemented")
+                raise NotImplementedError(f"projector of modality '{m}' is neither an MLP / linear nor a Q-Former projector: its backward is not implemented")
             self.proj_modals.append(m)
             keys = ["weight"] if proj.depth == 0 else [f"{2 * i}.weight" for i in range(proj.depth)]
             for k in keys:
@@ -503,16 +511,23 @@ class MultimodalTrainStep:
             if modal not in modal_inputs:
                 continue
             enc = model.model.get_modal_encoder(modal)
-            f = enc(modal_inputs[modal])
+            xin = modal_inputs[modal]
+            f = enc(**xin) if isinstance(xin, dict) else enc(xin)   # BEATs takes audio_inputs / audio_padding_mask (multimodal_arch.py:233-235)
+            f = f[0] if isinstance(f, tuple) else f
             if modal == "video":
                 b, t, n, d = f.shape
                 f = f.reshape(b, t * n, d)
             f = f.to(BF16).contiguous()
             nI, T, Dm = f.shape
             proj = model.model.modal_projectors[modal]
-            h = f.view(nI * T, Dm)
+            if modal in self.qformers:
+                out_q = self.qformers[modal].forward(f)              # (nI, n_queries, hidden)
+                T = out_q.shape[1]
+                h = out_q.reshape(nI * T, -1)
+            else:
+                h = f.view(nI * T, Dm)
             saved[f"proj.{modal}.in"] = h
-            keys = ["weight"] if proj.depth == 0 else [f"{2 * i}.weight" for i in range(proj.depth)]
+            keys = [] if modal in self.qformers else (["weight"] if proj.depth == 0 else [f"{2 * i}.weight" for i in range(proj.depth)])
             for i, k in enumerate(keys):
                 w16 = self.view(self.P16, f"model.modal_projectors.{modal}.{k}")
                 b16 = self.view(self.P16, f"model.modal_projectors.{modal}.{k.replace('weight', 'bias')}")
@@ -557,6 +572,9 @@ class MultimodalTrainStep:
                 if n_suf:
                     self.view(self.G, suf.name).copy_(tok[Tb - n_suf:])
             dout = dblk.view(nI, Tb, Hd)[:, n_pre:Tb - n_suf].reshape(nI * T, Hd).contiguous() if (n_pre or n_suf) else dblk
+            if modal in self.qformers:
+                self.qformers[modal].backward(dout)
+                continue
             proj = self.model.model.modal_projectors[modal]
             keys = ["weight"] if proj.depth == 0 else [f"{2 * k}.weight" for k in range(proj.depth)]
             Mf = nI * T

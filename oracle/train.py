@@ -18,8 +18,8 @@ from . import llm, pipeline
 
 
 def trainable_keys(sd: Dict[str, torch.Tensor]):
-    return [k for k in sd if ".lora_A." in k or ".lora_B." in k or k.startswith("model.modal_projectors.")
-            or k.startswith("prefix_tokens.") or k.startswith("suffix_tokens.")]
+    return [k for k in sd if (".lora_A." in k or ".lora_B." in k or k.startswith("model.modal_projectors.")
+                              or k.startswith("prefix_tokens.") or k.startswith("suffix_tokens.")) and sd[k].is_floating_point()]
 
 
 def loss_and_grads(sd: Dict[str, torch.Tensor], meta: dict, input_ids, labels, modal_inputs, attention_mask=None, dropout_masks=None):

@@ -32,10 +32,10 @@ SENT = {"vision": -200, "audio": -203, "video": -204, "point": -205}
 
 CASES = {
     # BASELINE configs[1]: vision-only LocalLoRA Vicuna (adapters default + vision)
-    "configs1_vision": dict(modals=("vision",), reset=None, inputs=("vision",), seed=11, row_seeds=[105, 109], extra_rows=[100, 101, 103, 104, 106, 107]),
+    "configs1_vision": dict(modals=("vision",), reset=None, inputs=("vision",), seed=11, row_seeds=[449, 470], extra_rows=[100, 101, 103, 104, 106, 107]),
     # configs[2]: online-merge-reset 3-way composed model fed image + audio; the video adapter / encoder are present, the input absent
     "configs2_image_audio_video_absent": dict(modals=("vision", "audio", "video"), reset="default-vision=0.333,default-audio=0.333,default-video=0.333",
-                                              inputs=("vision", "audio"), seed=21, row_seeds=[207, 210], extra_rows=[200, 201, 202, 203, 204, 205]),
+                                              inputs=("vision", "audio"), seed=21, row_seeds=[519, 547], extra_rows=[200, 201, 202, 203, 204, 205]),
     # configs[3]: 4-modality composed model, MCUB-4-shaped inputs (spliced length 3337)
     "configs3_mcub4": dict(modals=("vision", "audio", "video", "point"),
                            reset="default-vision=0.25,default-audio=0.25,default-video=0.25,default-point=0.25",

@@ -75,11 +75,17 @@ def test_forward_with_labels_returns_the_reference_loss():
 def _check_grads(got, ref, tol=6e-2, min_cos=0.995):
     assert sorted(got) == sorted(ref)
     worst = 0.0
+    top = max(g.abs().max().item() for g in ref.values())
     for k, g in ref.items():
         x = got[k].float().cpu().reshape(g.shape)
         scale, err = g.abs().max().item(), (x - g).abs().max().item()
         if scale == 0.0:
             assert err == 0.0, (k, err)
+            continue
+        if scale < 1e-6 * top:
+            # a gradient that is zero in exact arithmetic (the bias of attention KEYS: softmax is invariant to a per-query constant) - the
+            # reference holds fp32 cancellation noise there, the device bf16 cancellation noise; neither has a direction to compare
+            assert err <= 1e-3 * top, (k, err, top)
             continue
         cos = torch.nn.functional.cosine_similarity(x.flatten(), g.flatten(), dim=0).item()
         worst = max(worst, err / scale)
@@ -225,3 +231,49 @@ print("RCCL_WORLD_OF_ONE_OK")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert "RCCL_WORLD_OF_ONE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_audio_recipe_qformer_projector_backward_matches_the_oracle():
+    """Audio stage-2 recipe (run_finetune_audio_damc.sh:37-38: BEATs encoder frozen, qformer projector + LoRA trained): loss and every
+    gradient - incl. all Q-Former parameters (queries, position embedding, LayerNorms, self- / cross-attention, FFN, output projection) -
+    against the autograd oracle.  Base weights, BEATs and the Q-Former come from the reference fixture g8; the LoRA pair is new (r = 32)."""
+    import math
+    from modelcompose_amd.model.builder import build_from_state_dict
+    from modelcompose_amd.train import MultimodalTrainStep
+    from oracle import train as otrain
+    a, meta8, sd8 = load_golden("g8_e2e_4modal")
+    keep = lambda k: not (".lora_" in k or k.startswith("model.modal_encoders.") and not k.startswith("model.modal_encoders.audio.")
+                          or k.startswith("model.modal_projectors.") and not k.startswith("model.modal_projectors.audio.")
+                          or (k.startswith("prefix_tokens.") or k.startswith("suffix_tokens.")) and not k.endswith(".audio"))
+    sd = {k: v for k, v in sd8.items() if keep(k)}
+    meta = {k: v for k, v in meta8.items() if k not in ("clip", "video", "point", "mm_vision_encoder", "mm_video_encoder", "mm_point_encoder")}
+    meta.update(modal_names=["default", "audio"], reset_scaling_weights=None, lora_r=32, lora_alpha=64, lora_dropout=0.0)
+    g = torch.Generator().manual_seed(5)
+    Hd, I = meta["hidden_size"], meta["intermediate_size"]
+    for l in range(meta["num_hidden_layers"]):
+        for blk, lin, n, k in (("self_attn", "q_proj", Hd, Hd), ("self_attn", "k_proj", Hd, Hd), ("self_attn", "v_proj", Hd, Hd), ("self_attn", "o_proj", Hd, Hd),
+                               ("mlp", "gate_proj", I, Hd), ("mlp", "up_proj", I, Hd), ("mlp", "down_proj", Hd, I)):
+            for ad in ("default", "audio"):
+                p = f"model.layers.{l}.{blk}.{lin}"
+                sd[f"{p}.lora_A.{ad}.weight"] = (torch.rand(32, k, generator=g) * 2 - 1) / math.sqrt(k)
+                sd[f"{p}.lora_B.{ad}.weight"] = torch.randn(n, 32, generator=g) * 0.02
+    model = build_from_state_dict(meta, sd)
+    st = MultimodalTrainStep(model, lr=1e-3)
+    A = -203
+    r = lambda n: torch.randint(3, meta["vocab_size"] - 1, (n,), generator=g).tolist()
+    ids = torch.tensor([[1] + r(4) + [A, 13] + r(7), [1] + r(2) + [A, 13] + r(9)])
+    labels = ids.clone()
+    labels[:, :5] = -100
+    labels[ids == A] = -100
+    mi = {"audio": {"audio_inputs": a["fbank"], "audio_padding_mask": a["padding_mask"]}}
+    mid = {"audio": {"audio_inputs": a["fbank"].cuda(), "audio_padding_mask": a["padding_mask"].cuda()}}
+    loss = st.forward_backward(ids.cuda(), labels.cuda(), mid)
+    ref_loss, _, ref_grads = otrain.loss_and_grads(sd, meta, ids, labels, mi)
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
+    got = st.named_gradients()
+    qf = [k for k in ref_grads if k.startswith("model.modal_projectors.audio.")]
+    assert len(qf) >= 40 and all(k in got for k in qf)
+    worst = _check_grads({k: got[k] for k in ref_grads}, ref_grads, tol=8e-2, min_cos=0.99)
+    print("worst relative gradient error (audio recipe)", worst)
+    st.step(ids.cuda(), labels.cuda(), mid)                       # the optimizer path over the Q-Former's parameter group
+    assert st._aux_steps["audio"] == 1

@@ -2,9 +2,9 @@
 (FETCH_SIZE / WRITE_SIZE / MFMA counters) of gemm_tile256_kernel when the profiler cannot run the whole bench.py process
 (ROCm 7.2's rocprofv3 --pmc aborts with SIGSEGV inside the profiler on the img+audio+video bench process; `--workload vision` is fine).
 
-    python tools/gemm_layer_pmc.py [reps]
+    python tools/gemm_layer_pmc.py [reps] [batch]
 
-Rows: B = 16 samples x (97 text | 42 audio | 586 vision | 2066 video) tokens = 44656 rows in 4 adapter groups (default, audio, vision,
+Rows: B (default: bench.py's per-GPU batch of the headline workload) samples x (97 text | 42 audio | 586 vision | 2066 video) tokens in 4 adapter groups (default, audio, vision,
 video), exactly the row groups mc_llm_prefill hands to mc_gemm_grouped_bf16; q|k|v (N 12288, row_scale epilogue), o (N 4096, residual),
 gate|up (N 22016, SwiGLU epilogue), down (K 11008, residual).  Prints the algorithmic bytes / flops per launch in launch order."""
 import json
@@ -20,7 +20,9 @@ BF = torch.bfloat16
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    B, Hd, I = 16, 4096, 11008
+    import bench
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else bench.WORKLOADS["iav"][2]
+    Hd, I = 4096, 11008
     rows = [B * 97, B * 42, B * 586, B * 2066]
     gs = [0]
     for r in rows:
@@ -46,7 +48,7 @@ def main():
     for name, N, K, nout, res in (("qkv", 3 * Hd, Hd, 3 * Hd, 0), ("o", Hd, Hd, Hd, 1), ("gate_up", 2 * I, Hd, I, 0), ("down", Hd, I, Hd, 1)):
         launches.append({"gemm": name, "M": M, "N": N, "K": K, "flops": 2.0 * M * N * K,
                          "algorithmic_bytes": 2.0 * (M * K + 4 * N * K + M * nout + res * M * Hd)})
-    print(json.dumps({"reps": reps, "launch_order": launches}))
+    print(json.dumps({"reps": reps, "per_gpu_batch": B, "launch_order": launches}))
 
 
 if __name__ == "__main__":

@@ -20,3 +20,5 @@ kt=$(find gpurun_out/pmcg_${tag}_mfma -name '*kernel_trace.csv' | head -1)
 python3 tools/pmc_mfma.py "$cc" "$kt" gpurun_out/mfma_util_gemm_layer_$tag.json $tag
 rm -rf gpurun_out/pmcg_${tag}_mfma
 grep launch_order gpurun_out/pmcg_${tag}_FETCH_SIZE.log > gpurun_out/pmcg_${tag}_launches.json
+python3 tools/pmc_gemm_traffic.py gpurun_out/pmcg_${tag}_FETCH_SIZE_gemm_tile256.csv gpurun_out/pmcg_${tag}_WRITE_SIZE_gemm_tile256.csv gpurun_out/pmcg_${tag}_launches.json $tag
+cp profiles/traffic.json gpurun_out/traffic_$tag.json
