@@ -672,182 +672,6 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
         }
 }
 
-// ------------------------------------------------------------------------------------------
-// EXPERIMENTAL large-M kernel with dedicated loader waves (debug word bit 12): 256 x 128 x 64 tiles, 8 waves = 4 MFMA waves (one per
-// SIMD, 128 x 64 outputs each) + 4 loader waves (one per SIMD) that issue every LDS-DMA piece.  gemm_tile256_kernel's MFMA waves spend the
-// load half of each phase issuing two DMA pieces at 100-185 cycles apiece; here an MFMA wave's instruction stream is only
-// fragment reads (slotted between MFMAs) and MFMAs.  Three 48-KiB LDS stages; ONE workgroup barrier per K-tile, placed in the middle of
-// the tile's MFMAs:   consumer, tile t:  [MFMA kk=0 | read kk=1 of t]  lgkmcnt(0)  barrier(t)  [MFMA kk=1 | read kk=0 of t+1]
-//                      loader,   tile t:  vmcnt(tile t+1 landed)  barrier(t)  issue tile t+3 into stage t % 3  (nobody reads tile t after
-//                      barrier(t): its kk=1 fragments were waited for before the barrier)
-#define G3_STAGE 49152
-#define G3_XOFF 16384
-
-__device__ __forceinline__ void g3_dma(const void* base_uniform, uint32_t off, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base_uniform), "s"(lds_addr) : "memory");
-}
-
-// 4 bytes per lane into a scratch LDS line: an L2 prefetch (one lane per 128-byte line) that needs no destination register
-__device__ __forceinline__ void g3_touch(const void* base_uniform, uint32_t off, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base_uniform), "s"(lds_addr) : "memory");
-}
-
-__global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, int M, int N,
-                                                           int K, Epilogue ep, int tiles_m, int tiles_n, int abl) {
-    // abl (timing only, wrong results): 1 = loaders issue nothing after the prologue, 2 = MFMA waves skip reads and MFMAs
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-
-    // XCD-aware tile order: contiguous chunk per XCD, 8 m-tiles per n-tile column
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int per_group = 8 * tiles_n;
-    const int first_m = (bid / per_group) * 8;
-    const int gsz = min(tiles_m - first_m, 8);
-    const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
-    const int m0 = tm * 256, n0 = tn * 128;
-    const int kblocks = K >> 5, nblocks = (N + 15) >> 4, nt = K >> 6;
-
-    if (wave >= 4) {
-        // ------------------------------------------------------------------ loader wave l: 4 W blocks + 8 X row groups per K-tile
-        const int l = wave - 4;
-        uint32_t xo[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (l * 8 + i) * 8 + (lane >> 3);
-            const int gch = (lane & 7) ^ (row & 7);                       // the reader XORs the chunk with row & 7: swizzle via the source
-            xo[i] = (uint32_t)(((int64_t)(min(m0 + row, M - 1) - m0) * ldx + gch * 8) * 2);
-        }
-        const char* xbase = (const char*)(x + (int64_t)m0 * ldx);
-        const char* wb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int bl = l * 4 + i, nbl = bl >> 1, kk = bl & 1;
-            const int nb = min((n0 >> 4) + nbl, nblocks - 1);
-            wb[i] = (const char*)wp + ((int64_t)nb * kblocks + kk) * 1024;
-        }
-        const uint32_t woff = lane * 16;
-        // L2 prefetch, PFD K-tiles ahead of the DMA front: with ~100 KiB in flight per CU a DMA that misses L2 (2 us) caps the stream at
-        // ~50 GB/s per CU (measured: loaders alone 1.1-1.5 PFLOP/s-equivalent from memory, 2.0-2.5 from cache-hot sources); touching one
-        // lane per line early turns the real DMAs into L2 hits.  X: one line per row (64 rows per loader); W: 2 KiB per 16-row block
-        const uint32_t scratch = smem_base + 3 * G3_STAGE + l * 256;
-        const uint32_t xpo = (uint32_t)(((int64_t)(min(m0 + l * 64 + lane, M - 1) - m0) * ldx) * 2);
-        const int pnb = min((n0 >> 4) + l * 2 + ((lane >> 4) & 1), nblocks - 1);
-        const uint32_t wpo = (uint32_t)(((int64_t)(pnb - (n0 >> 4)) * kblocks) * 1024 + (lane & 15) * 128);      // relative to block row n0/16
-        const char* wpbase = (const char*)wp + (int64_t)(n0 >> 4) * kblocks * 1024;
-        // MEASURED AND DISABLED (kPrefetch = false): the touches share the wave's in-order vector-memory queue with the real DMAs, so a touch
-        // that misses to HBM delays every younger DMA's completion count: 1.07-1.27 -> 0.75-0.96 PFLOP/s.  A prefetch has to come from a wave
-        // (or a scalar-cache path) whose waits nobody depends on.
-        constexpr bool kPrefetch = false;
-        constexpr int PFD = 3;
-        auto prefetch = [&](int tt) {
-            if (!kPrefetch) return;
-            tt = min(tt, nt - 1);                                      // always two instructions: the counted waits below rely on it
-            g3_touch(xbase + (int64_t)tt * 128, xpo, scratch);
-            g3_touch(wpbase + (int64_t)tt * 2048, wpo, scratch);
-        };
-        auto issue = [&](int t) {
-            const uint32_t st = smem_base + (t % 3) * G3_STAGE;
-            const int ts = abl == 3 ? t % 3 : t;                          // abl 3: sources stay on K-tiles 0..2 (cache-hot), MFMA waves idle
-#pragma unroll
-            for (int i = 0; i < 4; ++i) g3_dma(wb[i] + (int64_t)ts * 2048, woff, st + (l * 4 + i) * 1024);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) g3_dma(xbase + (int64_t)ts * 128, xo[i], st + G3_XOFF + (l * 8 + i) * 1024);
-        };
-        issue(0);
-        issue(1);
-        issue(2);                                                     // (nt >= 3: the launcher sends shorter K to the other kernels)
-#pragma unroll
-        for (int i = 3; i < 3 + PFD; ++i) prefetch(i);
-        // tile 0 landed -> prologue barrier
-        if (kPrefetch) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");   // 24 tile DMAs + 6 touches younger than tile 0
-        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int t = 0; t < nt; ++t) {
-            // tile t+1 must have landed before barrier(t); tile t+2's 12 DMAs and the 2 touches issued just before them may stay in flight
-            if (t + 2 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (kPrefetch) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 3 < nt && abl != 1) { prefetch(t + 3 + PFD); issue(t + 3); }
-        }
-        return;
-    }
-    // ---------------------------------------------------------------------- MFMA wave: 128 rows x 64 columns
-    const int wave_m = wave >> 1, wave_n = wave & 1;
-    const int c16 = lane & 15, q4 = lane >> 4;
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int wrd = (wave_n * 4) * 2048 + lane * 16;                      // + i * 2048 + kk * 1024
-    int xrd[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xrd[j] = G3_XOFF + (wave_m * 128 + j * 16 + c16) * 128;
-    const int xsw = c16 & 7;                                                // row & 7 of every row this lane reads
-    bf16x8 wa[4], xa[8], wb_[4], xb[8];
-    auto read = [&](int t, int kk, bf16x8 (&wf)[4], bf16x8 (&xf)[8]) {
-        const char* st = smem + (t % 3) * G3_STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(st + wrd + i * 2048 + kk * 1024);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(st + xrd[j] + (((kk * 4 + q4) ^ xsw) * 16));
-    };
-    auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[8]) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    };
-    // 12 fragment reads slotted between 32 MFMAs: 8 x (1 read, 3 MFMA) + 4 x (1 read, 2 MFMA)
-    auto interleave = [&]() {
-#pragma unroll
-        for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
-    };
-    __builtin_amdgcn_s_barrier();                                           // prologue: tile 0 is in LDS
-    read(0, 0, wa, xa);
-    if (abl & 2) {
-        for (int t = 0; t < nt; ++t) __builtin_amdgcn_s_barrier();
-    } else
-    for (int t = 0; t < nt; ++t) {
-        read(t, 1, wb_, xb);
-        mma(wa, xa);
-        interleave();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's reads of tile t are done: its stage may be refilled
-        __builtin_amdgcn_s_barrier();
-        read(t + 1 < nt ? t + 1 : t, 0, wa, xa);                            // unconditional (same basic block as the MFMAs it is slotted into)
-        mma(wb_, xb);
-        interleave();
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int m = m0 + wave_m * 128 + j * 16 + c16;
-        if (m >= M) continue;
-        if (ep.swiglu) {
-#pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                const int n = n0 + wave_n * 64 + i * 16;
-                if (n + 16 < N) epilogue_store4_swiglu(ep, m, (n >> 1) + q4 * 4, acc[i][j], acc[i + 1][j]);
-            }
-            continue;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wave_n * 64 + i * 16 + q4 * 4;
-            if (n < N) epilogue_store4(ep, m, n, acc[i][j]);
-        }
-    }
-}
-
 #define SK_WAVES 8
 
 // ------------------------------------------------------------------------------------------
@@ -1295,11 +1119,6 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
             case 3: launch_skinny2<3>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
             default: launch_skinny2<4>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
         }
-    } else if ((g_gemm_dbg & 4096) && K >= 192) {
-        const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128;
-        static bool attr3 = false;
-        if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G3_STAGE + 1024); attr3 = true; }
-        gemm_ring_kernel<<<tiles_m * tiles_n, 512, 3 * G3_STAGE + 1024, s>>>((const bf16_t*)x, ldx, (const bf16_t*)w_packed, M, N, K, ep, tiles_m, tiles_n, (g_gemm_dbg >> 13) & 3);
     } else if (use_tile256(M, N, K)) {
         G2Groups grp{};
         grp.n = 1; grp.tile_start[0] = 0; grp.tile_start[1] = (M + 255) / 256; grp.row_start[0] = 0; grp.row_start[1] = M;

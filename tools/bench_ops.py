@@ -192,25 +192,6 @@ def main():
                 for (M, N, K) in ((10928, 12288, 4096), (10928, 4096, 4096), (10928, 22016, 4096), (10928, 4096, 11008), (8192, 8192, 8192)):
                     gemm_case(M, N, K, rot=1)
         L.mc_gemm_debug(0)
-    if "ring" in which:
-        # experimental loader/consumer kernel (debug bit 12) vs the production 256x256 kernel, same device
-        from modelcompose_amd import _lib
-        L = _lib.lib()
-        for (M, N, K) in ((512, 256, 256), (300, 520, 192), (3000, 4096, 1024)):
-            x = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
-            pw = ops.pack_weight(w)
-            L.mc_gemm_debug(2); a = ops.linear(x, pw)
-            L.mc_gemm_debug(4096); b = ops.linear(x, pw)
-            L.mc_gemm_debug(0)
-            print(f"ring check M={M} N={N} K={K}: bit-identical to the 128x128 kernel = {torch.equal(a, b)}  max diff {(a.float()-b.float()).abs().max().item():.3e}")
-        for rep in range(2):
-            for d, nm in ((4 + 2048, "256x256 ping-pong kernel"), (4096, "256x128 loader/consumer kernel"), (4096 + 8192, "  ... loaders idle after the prologue"),
-                          (4096 + 16384, "  ... MFMA waves idle (loaders + barriers only)"), (4096 + 8192 + 16384, "  ... MFMA waves idle, DMA sources cache-hot")):
-                L.mc_gemm_debug(d)
-                print(nm)
-                for (M, N, K) in ((10928, 12288, 4096), (10928, 4096, 4096), (10928, 22016, 4096), (10928, 4096, 11008), (8192, 8192, 8192), (2728, 4096, 4096)):
-                    gemm_case(M, N, K, rot=1)
-        L.mc_gemm_debug(0)
     if "t192" in which:
         # 256-column vs 192-column tiles of the large-M kernel on the under-filled shapes of the finetune step / small-batch prefill
         from modelcompose_amd import _lib
