@@ -133,6 +133,14 @@ int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgro
 /* library-wide GEMM policy: "tile192" (default 1) lets the large-M kernel use 192-column tiles when they fill the 256 CUs better than
  * 256-column ones (under-filled launches); 0 = callers that run other work beside such launches keep the wider tile */
 int mc_gemm_set_option(const char* name, int value);
+/* M <= 64 launches with more than 16 rows run gemm_rows_kernel (activations through LDS, K split over workgroups, fp32 slabs folded by the
+ * last-arriving workgroup).  Its workspaces (8 x 50 MiB, one per launching stream so that concurrent streams share nothing) are allocated
+ * at the first such launch made outside stream capture; a launch that finds no workspace (first launch ever is inside a capture, or a
+ * ninth live stream) keeps the older skinny kernel, whose fp32 summation order differs.  Call this once before capturing when the process may
+ * capture before it has launched eagerly (mc_llm_create does).  Options "rows_kernel" (default 1) and "rows_min_mb" (default 2 = more
+ * than 16 rows) of mc_gemm_set_option switch the kernel off / move the threshold. */
+int mc_gemm_reserve_rows(void* stream);
+int mc_gemm_release_rows(void* stream);   /* before destroying a stream that launched GEMMs: gives its workspace slot back */
 int mc_gemm_profile_enable(int on);
 int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches);
 int mc_gemm_profile_read_bytes(double* total_bytes);   /* algorithmic HBM bytes (operands read once, output written once) of the same launches */

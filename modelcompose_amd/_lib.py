@@ -33,6 +33,8 @@ _SIGS = {
     "mc_gemm_clock_read": [c_i, C.POINTER(C.c_double)],
     "mc_attn_debug": [c_i],
     "mc_gemm_set_option": [C.c_char_p, c_i],
+    "mc_gemm_reserve_rows": [C.c_void_p],
+    "mc_gemm_release_rows": [C.c_void_p],
     "mc_gemm_tn_workspace_floats": [c_i, c_i, c_i, c_i, C.POINTER(C.c_int64)],
     "mc_gemm_tn_bf16": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p],
     "mc_pack_weight_strided_bf16": [c_p, c_l, c_l, c_p, c_i, c_i, c_p],

@@ -686,7 +686,11 @@ template <int MB, int R>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_t* __restrict__ x, int64_t ldx,
                                                                      const bf16_t* __restrict__ wp, int M, int N, int K,
                                                                      Epilogue ep, int partial) {
-    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][R][MB][64][4];
+    // cross-wave reduction buffer: one slot per wave up to R * MB = 8 (64 KiB); above that the upper four waves hand their sums to the
+    // lower four first (FOLD), so the buffer stays at 4 slots (48 KiB at R * MB = 12) and two workgroups still share a CU
+    constexpr bool FOLD = R * MB > 8;
+    constexpr int RW = FOLD ? SK_WAVES / 2 : SK_WAVES;
+    __shared__ __attribute__((aligned(16))) float red[RW][R][MB][64][4];
     constexpr int U = (R * MB >= 8) ? 1 : ((R * MB >= 4) ? 2 : (R * MB >= 2 ? 4 : 8));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb0 = blockIdx.x * R;
@@ -704,6 +708,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
     const bf16_t* xptr[MB];
 #pragma unroll
     for (int b = 0; b < MB; ++b) xptr[b] = x + (int64_t)min(b * 16 + c16, M - 1) * ldx + kb0 * 32 + q4 * 8;
+    constexpr int xstep = 32;
     f32x4 acc[R][MB];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int b = 0; b < MB; ++b) xf[u][b] = *(const bf16x8*)(xptr[b] + u * 32);
+            for (int b = 0; b < MB; ++b) xf[u][b] = *(const bf16x8*)(xptr[b] + u * xstep);
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -742,12 +747,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
 #pragma unroll
         for (int r = 0; r < R; ++r) wptr[r] += U * 512;
 #pragma unroll
-        for (int b = 0; b < MB; ++b) xptr[b] += U * 32;
+        for (int b = 0; b < MB; ++b) xptr[b] += U * xstep;
     }
     for (; kb < kb1; ++kb) {
         bf16x8 xf[MB];
 #pragma unroll
-        for (int b = 0; b < MB; ++b) { xf[b] = *(const bf16x8*)(xptr[b]); xptr[b] += 32; }
+        for (int b = 0; b < MB; ++b) { xf[b] = *(const bf16x8*)(xptr[b]); xptr[b] += xstep; }
 #pragma unroll
         for (int b = 0; b < MB; ++b) sumsq(xf[b], ss[b]);
 #pragma unroll
@@ -758,10 +763,28 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
             for (int b = 0; b < MB; ++b) acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[b], acc[r][b], 0, 0, 0);
         }
     }
+    if constexpr (FOLD) {
+        if (wave >= RW) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave][r][b][lane][0] = acc[r][b];
+                for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave - RW][r][b][lane][0] = acc[r][b];
+        }
+        __syncthreads();
+        if (wave < RW) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int b = 0; b < MB; ++b) acc[r][b] += *(f32x4*)&red[wave][r][b][lane][0];
+        }
+        __syncthreads();
+    }
+    if (wave < RW) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave][r][b][lane][0] = acc[r][b];
+    }
     __shared__ float redss[SK_WAVES][MB][16];
     if (ep.rms_eps > 0.f) {
 #pragma unroll
@@ -792,7 +815,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
             const int c = nl & 15;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < SK_WAVES; ++w) v += red[w][nl >> 4][m >> 4][((c >> 2) << 4) | (m & 15)][c & 3];
+            for (int w = 0; w < RW; ++w) v += red[w][nl >> 4][m >> 4][((c >> 2) << 4) | (m & 15)][c & 3];
             const float a = ep.row_scale ? ep.alpha * ep.row_scale[m] : ep.alpha;
             ((float*)ep.out)[((int64_t)blockIdx.y * M + m) * ep.ldo + n] = v * a;
         }
@@ -803,7 +826,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
             const int rp = p / MB, b = p - rp * MB;
             f32x4 g = *(f32x4*)&red[0][2 * rp][b][lane][0], u = *(f32x4*)&red[0][2 * rp + 1][b][lane][0];
 #pragma unroll
-            for (int w = 1; w < SK_WAVES; ++w) {
+            for (int w = 1; w < RW; ++w) {
                 g += *(f32x4*)&red[w][2 * rp][b][lane][0];
                 u += *(f32x4*)&red[w][2 * rp + 1][b][lane][0];
             }
@@ -819,12 +842,207 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
         const int r = p / MB, b = p - r * MB;
         f32x4 s = *(f32x4*)&red[0][r][b][lane][0];
 #pragma unroll
-        for (int w = 1; w < SK_WAVES; ++w) s += *(f32x4*)&red[w][r][b][lane][0];
+        for (int w = 1; w < RW; ++w) s += *(f32x4*)&red[w][r][b][lane][0];
         const int m = b * 16 + c16;
         const int n = (nb0 + r) * 16 + q4 * 4;
         Epilogue e2 = ep;
         e2.alpha = ep.alpha * row_factor(b);
         if (m < M && n < N) epilogue_store4(e2, m, n, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rows kernel (16 < M <= 64): activations shared through LDS, one weight block-row stream per wave, K split over workgroups
+// ------------------------------------------------------------------------------------------
+// The skinny kernel above gives every workgroup the whole of x: with 256 workgroups that is 256 x M x K x 2 bytes of L2 -> CU traffic on
+// the SAME lines at the same time (three times the weight bytes at M = 48 for o_proj, all of it queued on the few L2 channels that hold
+// the current k range), and its K-split over waves leaves each wave a handful of dependent round trips: measured 1.7 - 3.0 TB/s at M = 48
+// against 3.4 - 5.2 TB/s at M = 16.  Here a workgroup owns 8 RW block-rows (wave w: rows RW (8 g + w) ...) and one K slice of the grid's
+// S: the slice's x tiles (128 columns at a time) are loaded once per workgroup with whole-line reads, kept in LDS in MFMA fragment order
+// (double buffered, one barrier per tile) and read by all 8 waves, while every wave streams its own weight fragments with 4 RW KiB in
+// flight (each register is reloaded for the next tile right after its MFMAs).  x traffic drops to 1/S of the skinny kernel's and different
+// slices read different lines.  With S > 1 the fp32 partial sums go to slabs [S][M][N] and rows_reduce_kernel adds them in slice order
+// (deterministic) and applies the epilogue.  The RMS factor (rms_eps) comes from the x tiles as they are staged: each element is squared
+// once per workgroup; with S > 1 the slice sums are combined by the reduce kernel, in slice order.
+template <int MB, int RW, int KT>
+__global__ __launch_bounds__(512) void gemm_rows_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, int M, int N,
+                                                        int K, Epilogue ep, float* __restrict__ slabs, float* __restrict__ ssp) {
+    __shared__ __attribute__((aligned(16))) bf16x8 xs[2][KT][MB][64];
+    __shared__ float rowss[MB * 16];
+    constexpr int CH = KT * 4;                             // 16-byte chunks per tile row (KT k-blocks of 32 columns)
+    constexpr int RPP = 512 / CH;                          // rows per staging pass
+    constexpr int XP = (MB * 16 + RPP - 1) / RPP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int kblocks = K >> 5, nblocks = (N + 15) >> 4;
+    const int S = gridDim.y, y = blockIdx.y;
+    const int tiles = kblocks / KT;
+    const int t0 = (int)((int64_t)tiles * y / S), t1 = (int)((int64_t)tiles * (y + 1) / S);
+    const int nb0 = (blockIdx.x * 8 + wave) * RW;
+
+    // staging role: row srow (+ RPP per pass), 16-byte chunk sch of the tile's row segment (k-block sch >> 2, quarter sch & 3).
+    // slot of (k-block kb, quarter q, row c) inside its 64-slot fragment block: 16 q + ((c + 4 q + kb) & 15) - a bijection per block, so
+    // the fragment read below (lane (q4, c16) takes the slot of (kb, q4, c16)) touches every bank once per 16 lanes, and so does the
+    // staging write (the 16 chunks of a row differ in 4 q + kb)
+    const int srow = tid / CH, sch = tid % CH;
+    const int skb = sch >> 2, sq = sch & 3;
+    const bf16_t* xsrc[XP];
+    int sdst[XP];
+    bool sact[XP];
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+        const int row = p * RPP + srow;
+        sact[p] = row < MB * 16;
+        xsrc[p] = x + (int64_t)min(row, M - 1) * ldx + (int64_t)t0 * (KT * 32) + sch * 8;
+        sdst[p] = (skb * MB + (row >> 4)) * 64 + sq * 16 + (((row & 15) + 4 * sq + skb) & 15);
+    }
+    float ssl[XP];
+#pragma unroll
+    for (int p = 0; p < XP; ++p) ssl[p] = 0.f;
+    int rslot[KT];
+#pragma unroll
+    for (int kb = 0; kb < KT; ++kb) rslot[kb] = q4 * 16 + ((c16 + 4 * q4 + kb) & 15);
+
+    const bf16_t* wptr[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) wptr[r] = wp + ((int64_t)min(nb0 + r, nblocks - 1) * kblocks + (int64_t)t0 * KT) * 512 + lane * 8;
+
+    f32x4 acc[RW][MB];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[r][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 xr[XP];
+    auto stage_load = [&]() {
+#pragma unroll
+        for (int p = 0; p < XP; ++p)
+            if (sact[p]) { xr[p] = *(const bf16x8*)xsrc[p]; xsrc[p] += KT * 32; }
+    };
+    auto stage_store = [&](int buf) {
+        bf16x8* dst = &xs[buf][0][0][0];
+#pragma unroll
+        for (int p = 0; p < XP; ++p)
+            if (sact[p]) {
+                dst[sdst[p]] = xr[p];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)xr[p][j]; ssl[p] = fmaf(f, f, ssl[p]); }
+            }
+    };
+    bf16x8 wf[KT][RW];
+    if (t0 < t1) {
+#pragma unroll
+        for (int kb = 0; kb < KT; ++kb)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) wf[kb][r] = __builtin_nontemporal_load((const bf16x8*)(wptr[r] + kb * 512));
+        stage_load();
+        stage_store(0);
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        const bool more = t + 1 < t1;
+        if (more) stage_load();
+#pragma unroll
+        for (int r = 0; r < RW; ++r) wptr[r] += KT * 512;
+#pragma unroll
+        for (int kb = 0; kb < KT; ++kb) {
+            bf16x8 xf[MB];
+#pragma unroll
+            for (int b = 0; b < MB; ++b) xf[b] = xs[buf][kb][b][rslot[kb]];
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int b = 0; b < MB; ++b) acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kb][r], xf[b], acc[r][b], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r) wf[kb][r] = __builtin_nontemporal_load((const bf16x8*)(wptr[r] + kb * 512));
+            }
+        }
+        if (more) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // sum of squares of this slice's part of every row: the 16 chunk lanes of a row sit in one 16-lane group
+    const bool want_rms = ep.rms_eps > 0.f;
+    if (want_rms) {
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            float v = ssl[p];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (CH == 32) v += __shfl_xor(v, 16, 64);
+            if (sact[p] && sch == 0) rowss[p * RPP + srow] = v;
+        }
+    }
+    if (S > 1) {
+        // partial sums of slice y into slab y (16 floats per lane quarter and row); rows_reduce_kernel adds the slabs in slice order and
+        // applies the epilogue.  (A last-arriver fold inside this kernel was measured 2 - 10x slower: device-scope release / acquire
+        // fences write back and invalidate the XCD's whole L2 on this multi-die part.)
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+                const int m = b * 16 + c16, n = (nb0 + r) * 16 + q4 * 4;
+                if (m < M && n < N) *(f32x4*)(slabs + ((int64_t)y * M + m) * N + n) = acc[r][b];
+            }
+        if (want_rms && blockIdx.x == 0) {                 // every row group squares the same x slice: group 0 reports it
+            __syncthreads();
+            if (tid < MB * 16) ssp[y * 64 + tid] = rowss[tid];
+        }
+        return;
+    }
+    __syncthreads();
+    float fac[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) fac[b] = want_rms ? rsqrtf(rowss[b * 16 + c16] / (float)K + ep.rms_eps) : 1.0f;
+    if (ep.swiglu) {
+        if constexpr (RW % 2 == 0) {
+#pragma unroll
+            for (int r = 0; r < RW; r += 2)
+#pragma unroll
+                for (int b = 0; b < MB; ++b) {
+                    const int m = b * 16 + c16, nb = nb0 + r;
+                    Epilogue e2 = ep;
+                    e2.alpha = ep.alpha * fac[b];
+                    if (m < M && (nb + 1) * 16 < N) epilogue_store4_swiglu(e2, m, (nb >> 1) * 16 + q4 * 4, acc[r][b], acc[r + 1][b]);
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            const int m = b * 16 + c16, n = (nb0 + r) * 16 + q4 * 4;
+            Epilogue e2 = ep;
+            e2.alpha = ep.alpha * fac[b];
+            if (m < M && n < N) epilogue_store4(e2, m, n, acc[r][b]);
+        }
+}
+
+// second stage of the rows kernel: out = epilogue(sum over slices of slabs[k][M][N]) with the RMS factor from the slice sums of squares
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ ssp, int S, int M, int N,
+                                                          int K, Epilogue ep) {
+    const int nq = (ep.swiglu ? N >> 1 : N) >> 2;
+    const int64_t total = (int64_t)M * nq;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / nq), j = (int)(i % nq) * 4;
+        const int n = ep.swiglu ? ((j >> 4) << 5) + (j & 15) : j;
+        const float* p = slabs + (int64_t)m * N + n;
+        f32x4 v = *(const f32x4*)p, u = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ep.swiglu) u = *(const f32x4*)(p + 16);
+        for (int k = 1; k < S; ++k) {
+            v += *(const f32x4*)(p + (int64_t)k * M * N);
+            if (ep.swiglu) u += *(const f32x4*)(p + (int64_t)k * M * N + 16);
+        }
+        Epilogue e2 = ep;
+        if (ep.rms_eps > 0.f) {
+            float t = 0.f;
+            for (int k = 0; k < S; ++k) t += ssp[k * 64 + m];
+            e2.alpha = ep.alpha * rsqrtf(t / (float)K + ep.rms_eps);
+        }
+        if (ep.swiglu) epilogue_store4_swiglu(e2, m, j, v, u);
+        else epilogue_store4(e2, m, n, v);
     }
 }
 
@@ -879,6 +1097,8 @@ static float* splitk_workspace(size_t floats) {
 // fill 69 % of the CUs, 242 tiles of 192 fill 95 %.  debug word bit 10 forces 192, bit 11 forces 256.
 static bool g_tile192 = true;
 static bool g_raster_auto = true;          // "raster_shared" option
+static bool g_rows_on = true;              // "rows_kernel" option: M <= 64 launches with ceil(M / 16) >= "rows_min_mb" take gemm_rows_kernel
+static int g_rows_min_mb = 2;
 static int g_raster_min_tiles = 1024;      // launches with at least this many tiles deal their 32-tile blocks round-robin over the XCDs
 // "tile192" = 0 keeps the large-M kernel on 256-column tiles: for callers that fill the idle CUs of an under-filled launch themselves
 // (the finetune step runs its rank-projection and weight-gradient GEMMs on a second stream next to the base GEMMs: measured on one
@@ -887,6 +1107,8 @@ extern "C" int mc_gemm_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tile192")) { g_tile192 = value != 0; return 0; }
     if (name && !strcmp(name, "raster_shared")) { g_raster_auto = value != 0; return 0; }
     if (name && !strcmp(name, "raster_min_tiles")) { g_raster_min_tiles = value; return 0; }
+    if (name && !strcmp(name, "rows_kernel")) { g_rows_on = value != 0; return 0; }
+    if (name && !strcmp(name, "rows_min_mb")) { g_rows_min_mb = value; return 0; }
     mc_set_error("mc_gemm_set_option: unknown option '%s'", name ? name : "(null)");
     return 1;
 }
@@ -1004,7 +1226,7 @@ extern "C" int mc_unpack_weight_bf16(const void* packed, void* w, int N, int K, 
 template <int MB, int R>
 static void launch_skinny2_r(dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K,
                              const Epilogue& ep, int partial) {
-    if constexpr (R * MB <= 8) gemm_skinny2_kernel<MB, R><<<grid, SK_WAVES * 64, 0, s>>>(x, ldx, w, M, N, K, ep, partial);
+    if constexpr (R * MB <= 12) gemm_skinny2_kernel<MB, R><<<grid, SK_WAVES * 64, 0, s>>>(x, ldx, w, M, N, K, ep, partial);
 }
 
 template <int MB>
@@ -1020,7 +1242,7 @@ static void launch_skinny2(int R, dim3 grid, hipStream_t s, const bf16_t* x, int
     }
 }
 
-// block-rows per workgroup for the skinny kernel: the largest R in {8,6,4,3,2,1} (R * MB <= 8, even for swiglu) whose grid
+// block-rows per workgroup for the skinny kernel: the largest R in {8,6,4,3,2,1} (R * MB <= 12, even for swiglu) whose grid
 // still covers >= ~85 % of the CUs in its last round
 static int skinny_rows(int nblocks, int mb, int split_k, bool swiglu) {
     static const int cand[6] = {8, 6, 4, 3, 2, 1};
@@ -1028,7 +1250,7 @@ static int skinny_rows(int nblocks, int mb, int split_k, bool swiglu) {
     double best_cost = 1e30;
     for (int i = 0; i < 6; ++i) {
         const int R = cand[i];
-        if (R * mb > 8) continue;
+        if (R * mb > 12) continue;
         if (swiglu && (R & 1)) continue;
         const int64_t wgs = (int64_t)((nblocks + R - 1) / R) * split_k;
         const int64_t rounds = (wgs + 255) / 256;
@@ -1037,6 +1259,91 @@ static int skinny_rows(int nblocks, int mb, int split_k, bool swiglu) {
         if (cost < best_cost - 1e-9) { best_cost = cost; best = R; }
     }
     return best;
+}
+
+// ---- rows kernel: workspace (per stream: concurrent streams must not share slabs), shape policy, launcher
+namespace {
+struct RowsWs { hipStream_t stream; char* base; };
+constexpr size_t kRowsSlabFloats = (size_t)12 << 20;          // 48 MiB of fp32 slabs: S x M x N <= 12 Mi (8 x 64 x 22016 fits)
+constexpr int kRowsMaxSplit = 8;
+constexpr size_t kRowsSsBytes = (size_t)kRowsMaxSplit * 64 * sizeof(float);
+std::vector<RowsWs> g_rows_ws;
+constexpr int kRowsPool = 8;
+char* g_rows_pool = nullptr;
+}  // namespace
+
+// The workspace of a stream: a pool of kRowsPool equal workspaces is allocated at the first rows launch (or mc_gemm_reserve_rows) made
+// while the calling stream is not capturing; every stream that launches the kernel is given its own slot then (host bookkeeping only, so a
+// stream met for the first time during capture still gets one).  Concurrent streams never share slabs; a ninth stream, or a
+// first launch inside a capture, keeps the skinny kernel.
+static char* rows_workspace(hipStream_t s) {
+    for (auto& w : g_rows_ws) if (w.stream == s) return w.base;
+    const size_t bytes = kRowsSsBytes + kRowsSlabFloats * sizeof(float);
+    if (!g_rows_pool) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+        char* base = nullptr;
+        if (hipMalloc((void**)&base, bytes * kRowsPool) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_rows_pool = base;
+    }
+    for (int i = 0; i < kRowsPool; ++i) {
+        char* base = g_rows_pool + bytes * i;
+        bool used = false;
+        for (auto& w : g_rows_ws) used = used || w.base == base;
+        if (!used) { g_rows_ws.push_back({s, base}); return base; }
+    }
+    return nullptr;
+}
+
+// a destroyed stream gives its slot back (its launches have completed: the caller synchronised before destroying it)
+extern "C" int mc_gemm_release_rows(void* stream) {
+    for (size_t i = 0; i < g_rows_ws.size(); ++i)
+        if (g_rows_ws[i].stream == (hipStream_t)stream) { g_rows_ws.erase(g_rows_ws.begin() + i); break; }
+    return 0;
+}
+
+extern "C" int mc_gemm_reserve_rows(void* stream) {
+    if (!rows_workspace((hipStream_t)stream)) { mc_set_error("mc_gemm_reserve_rows: no workspace (allocation failed, first call inside a capture, or more than %d streams)", kRowsPool); return 2; }
+    return 0;
+}
+
+// Split count S of the rows kernel for `groups` row groups (workgroups = groups x S).  Measured on MI355X (tools/rows_kernel_check.py): a
+// CU moves ~47 GB/s through this kernel whatever the number of resident workgroups, the chip ~5.2 TB/s, a launch costs ~2 us to start and
+// the reduce launch ~3.5 us + the slab round trip; a grid of more than 256 workgroups therefore behaves like two rounds.
+static int rows_split(int groups, int rw, int nblocks, int kblocks, int kt, int mb, int M, int N) {
+    const int tiles = kblocks / kt;
+    double best = 1e30;
+    int bs = 1;
+    for (int S = 1; S <= kRowsMaxSplit; ++S) {
+        if (S == 7) continue;
+        if (S > 1 && (S > tiles / 2 || (size_t)S * M * N > kRowsSlabFloats)) continue;
+        const int64_t wgs = (int64_t)groups * S;
+        const double kslice = (double)kblocks * 32 / S;
+        const double wg_bytes = (8.0 * rw * 16 + mb * 16) * kslice * 2;
+        const double t_cu = (double)((wgs + 255) / 256) * wg_bytes / 47e3;
+        const double t_hbm = (double)nblocks * 16 * kblocks * 32 * 2 / 5.2e6;
+        const double t = 2.0 + (t_cu > t_hbm ? t_cu : t_hbm) + (S > 1 ? 3.5 + (double)S * M * N * 4 / 4.0e6 : 0.0);
+        if (t < best - 1e-9) { best = t; bs = S; }
+    }
+    return bs;
+}
+
+template <int MB>
+static void launch_rows(int RW, int kt, dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K, const Epilogue& ep,
+                        char* ws) {
+    float* ssp = (float*)ws;
+    float* slabs = (float*)(ws + kRowsSsBytes);
+    if (kt == 8) {
+        if (RW == 2) gemm_rows_kernel<MB, 2, 8><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
+        else gemm_rows_kernel<MB, 1, 8><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
+    } else {
+        if (RW == 2) gemm_rows_kernel<MB, 2, 4><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
+        else gemm_rows_kernel<MB, 1, 4><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
+    }
+    if (grid.y > 1) {
+        const int64_t total = (int64_t)M * ((ep.swiglu ? N >> 1 : N) >> 2);
+        rows_reduce_kernel<<<(int)min((int64_t)1024, (total + 255) / 256), 256, 0, s>>>(slabs, ssp, (int)grid.y, M, N, K, ep);
+    }
 }
 
 // one launch of the 256x256 kernel over the m-tiles of all groups (M_total = rows over all groups, for the live profile)
@@ -1107,10 +1414,35 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
     Epilogue ep{(const bf16_t*)a->bias, (const bf16_t*)a->residual, a->ldr, a->out, a->ldo, a->act, a->out_f32, a->alpha, a->beta,
                 a->row_scale, a->swiglu, a->rms_eps > 0.f ? a->rms_eps : 0.f};
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 64) {
+    const int mb_rows = (M + 15) / 16;
+    char* rows_ws = nullptr;
+    // rows kernel geometry: RW = 2 block-rows per wave for SwiGLU (a gate / up pair), else 1; tiles of 8 k-blocks (8 RW KiB of weights in
+    // flight per wave) when K allows and the register file does (RW = 2 with more than 16 rows needs > 128 VGPRs at depth 8), else 4.
+    // debug word: bits 24-27 force S, bit 28 forces RW = 2, bit 30 forces depth 4 (tools/rows_kernel_check.py sweeps)
+    const int RW = (a->swiglu || (g_gemm_dbg & (1 << 28))) ? 2 : 1;
+    const int kt = ((K >> 5) % 8 == 0 && (K >> 5) >= 32 && !(g_gemm_dbg & (1 << 30)) && !(RW == 2 && mb_rows >= 2)) ? 8 : 4;
+    const bool rows_ok = M <= 64 && g_rows_on && mb_rows >= g_rows_min_mb && split_k == 1 && (K >> 5) % kt == 0 && (K >> 5) >= 2 * kt &&
+                         !(g_gemm_dbg & 524288) && (rows_ws = rows_workspace(s)) != nullptr;
+    if (rows_ok) {
+        const int nblocks = (N + 15) / 16;
+        const int groups = (nblocks + 8 * RW - 1) / (8 * RW);
+        int S = rows_split(groups, RW, nblocks, K >> 5, kt, mb_rows, M, N);
+        const int fs = (g_gemm_dbg >> 24) & 15;
+        if (fs && fs <= kRowsMaxSplit && fs <= (K >> 5) / kt / 2 + (fs == 1) && (size_t)fs * M * N <= kRowsSlabFloats) S = fs;
+        dim3 grid((nblocks + 8 * RW - 1) / (8 * RW), S);
+        const bf16_t* xb = (const bf16_t*)x; const bf16_t* wb = (const bf16_t*)w_packed;
+        switch (mb_rows) {
+            case 1: launch_rows<1>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws); break;
+            case 2: launch_rows<2>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws); break;
+            case 3: launch_rows<3>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws); break;
+            default: launch_rows<4>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws); break;
+        }
+    } else if (M <= 64) {
         const int mb = (M + 15) / 16;
         const int nblocks = (N + 15) / 16;
-        const int R = (g_gemm_dbg & 256) ? (a->swiglu ? 2 : 1) : skinny_rows(nblocks, mb, split_k, a->swiglu != 0);
+        int R = (g_gemm_dbg & 256) ? (a->swiglu ? 2 : 1) : skinny_rows(nblocks, mb, split_k, a->swiglu != 0);
+        const int forced = (g_gemm_dbg >> 20) & 15;             // debug word bits 20-23: force R (tools/skinny_m_bench.py sweeps)
+        if (forced && forced * mb <= 12 && (forced <= 4 || forced == 6 || forced == 8) && !(a->swiglu && (forced & 1))) R = forced;
         dim3 grid((nblocks + R - 1) / R, split_k);
         const bf16_t* xb = (const bf16_t*)x; const bf16_t* wb = (const bf16_t*)w_packed;
         switch (mb) {

@@ -217,6 +217,9 @@ extern "C" int mc_llm_create(const mc_llm_config* cfg, void** handle) {
     Llm* m = new Llm();
     m->cfg = *cfg;
     *handle = m;
+    // decode batches of more than 16 sequences run the rows GEMM kernel: make sure its workspace pool exists before the first graph capture
+    // (best effort: without it those launches keep the skinny kernel)
+    (void)mc_gemm_reserve_rows(nullptr);
     return 0;
 }
 
@@ -225,7 +228,7 @@ extern "C" int mc_llm_destroy(void* handle) {
     if (!m) return 0;
     for (int i = 0; i < Llm::kGraphs; ++i)
         if (m->graph_exec[i]) (void)hipGraphExecDestroy(m->graph_exec[i]);
-    if (m->own_stream) { (void)hipStreamSynchronize(m->own_stream); (void)hipStreamDestroy(m->own_stream); }
+    if (m->own_stream) { (void)hipStreamSynchronize(m->own_stream); (void)mc_gemm_release_rows(m->own_stream); (void)hipStreamDestroy(m->own_stream); }
     if (m->ev_in) (void)hipEventDestroy(m->ev_in);
     if (m->ev_out) (void)hipEventDestroy(m->ev_out);
     for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
