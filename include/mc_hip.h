@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 5
+#define MC_ABI_VERSION 6
 
 /* activation codes for mc_gemm_bf16 */
 #define MC_ACT_NONE 0
@@ -119,7 +119,21 @@ typedef struct mc_gemm_args {
     const void* x; int64_t ldx; const void* w_packed; const void* bias; const void* residual; int64_t ldr;
     void* out; int64_t ldo; int M, N, K; int act; int out_f32; float alpha, beta;
     const float* row_scale; int swiglu; int split_k; float rms_eps;
+    const struct mc_rope_scatter* rope;   /* non-null: the launch is the q|k|v projection of a prefill and its epilogue does what mc_rope_kv_bf16
+                                           * would do next (below); `out` is then scratch ([M, ldo], may or may not be written) */
 } mc_gemm_args;
+/* RoPE + scatter fused into the q|k|v projection (LlamaAttention.forward, multimodal_llama.py:281-312: rotate q and k, append k / v to the
+ * cache): output row r (absolute row index of the launch, as in mc_rope_kv_bf16) belongs to sequence row_b[r] (< 0: padding, skipped), is
+ * query row_t[r] of this call and sits at cache position row_pos[r].  N must be (H + 2 Hkv) D.  With D = 128, an even head count and a
+ * launch large enough for the 256x256 kernel, the rotation happens on the accumulators' bf16 values in registers and q / K / V go
+ * straight to q_out [(b Lq + t)][H D] and the caches [B][Hkv][Smax][D]; otherwise the GEMM writes `out` and mc_rope_kv_bf16 runs after it.
+ * Both routes round identically. */
+typedef struct mc_rope_scatter {
+    const int32_t* row_b; const int32_t* row_pos; const int32_t* row_t;
+    const float* cos_table; const float* sin_table;      /* [max_pos][D / 2] fp32 */
+    void* q_out; void* k_cache; void* v_cache;
+    int H, Hkv, D, Lq, Smax;
+} mc_rope_scatter;
 int mc_gemm_ex_bf16(const mc_gemm_args* args, void* stream);
 
 /* The same linear over rows grouped by routed adapter (multimodal_llama.py:262-268 made dense): rows

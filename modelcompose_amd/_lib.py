@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -61,7 +61,13 @@ class GemmArgsC(C.Structure):
     """struct mc_gemm_args (include/mc_hip.h)."""
     _fields_ = [("x", c_p), ("ldx", c_l), ("w_packed", c_p), ("bias", c_p), ("residual", c_p), ("ldr", c_l), ("out", c_p), ("ldo", c_l),
                 ("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i), ("out_f32", c_i), ("alpha", c_f), ("beta", c_f),
-                ("row_scale", c_p), ("swiglu", c_i), ("split_k", c_i), ("rms_eps", c_f)]
+                ("row_scale", c_p), ("swiglu", c_i), ("split_k", c_i), ("rms_eps", c_f), ("rope", c_p)]
+
+
+class RopeScatterC(C.Structure):
+    """struct mc_rope_scatter (include/mc_hip.h)."""
+    _fields_ = [("row_b", c_p), ("row_pos", c_p), ("row_t", c_p), ("cos_table", c_p), ("sin_table", c_p), ("q_out", c_p), ("k_cache", c_p),
+                ("v_cache", c_p), ("H", c_i), ("Hkv", c_i), ("D", c_i), ("Lq", c_i), ("Smax", c_i)]
 
 
 class AttnBwdArgsC(C.Structure):

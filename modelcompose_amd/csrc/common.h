@@ -29,6 +29,13 @@ __device__ __forceinline__ float mc_act(float x, int act) {
     }
 }
 
+// RoPE of one pair (a, b) = (x[d], x[d + D/2]) with cos / sin of (position, d) (apply_rotary_pos_emb, multimodal_llama.py:281-295: x cos +
+// rotate_half(x) sin).  Explicit FMAs: rope_kv_kernel and the q|k|v GEMM epilogue that replaces it round identically.
+__device__ __forceinline__ void mc_rope_pair(float a, float b, float c, float s, float& o1, float& o2) {
+    o1 = fmaf(a, c, -(b * s));
+    o2 = fmaf(b, c, a * s);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

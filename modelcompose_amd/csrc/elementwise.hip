@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const bf16_t* __restrict__
             for (int j = 0; j < 8; ++j) {
                 const float c = cr[ch * 8 + j], s = sr[ch * 8 + j];
                 const float a = (float)x1[j], bb = (float)x2[j];
-                o1[j] = (bf16_t)(a * c - bb * s);
-                o2[j] = (bf16_t)(bb * c + a * s);
+                float r1, r2;
+                mc_rope_pair(a, bb, c, s, r1, r2);
+                o1[j] = (bf16_t)r1;
+                o2[j] = (bf16_t)r2;
             }
             bf16_t* dst;
             if (hh < H) dst = q_out + ((int64_t)(b * Lq + t) * H + hh) * D + ch * 8;

@@ -101,6 +101,14 @@ struct Epilogue {
     int swiglu;              // 16-row weight blocks alternate gate/up: out[m][16*(nb/2) + c] = silu(gate) * up (LocalLoraMLP :381-388)
     float rms_eps;           // > 0 (skinny kernel only): row m is scaled by rsqrt(mean_k x[m][k]^2 + rms_eps), computed from the x fragments the
                              // kernel streams anyway (LlamaRMSNorm factor without a separate pass; replaces row_scale)
+    // q_out != null (256x256 kernel, 256-column tiles, D = 128): the launch is a prefill's q|k|v projection; a wave's 128 columns are one
+    // head, whose halves d / d + 64 sit in the same lane (acc[0][i] / acc[1][i]): rotate in registers and scatter to q_out / the caches
+    struct Rope {
+        const int32_t* row_b; const int32_t* row_pos; const int32_t* row_t;
+        const float* cosT; const float* sinT;
+        bf16_t* q_out; bf16_t* k_cache; bf16_t* v_cache;
+        int H, Hkv, Lq, Smax;
+    } rope;
 };
 
 __device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n, f32x4 v) {
@@ -595,6 +603,65 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     // row, ALL residual values of the lane requested before the first store: one exposed memory latency per tile instead of one per row -
     // a workgroup owns its CU, so nothing else runs while its epilogue waits); everything else the 8-byte path.
     const bool wide = !ep.out_f32 && (n0 + NT <= N) && (ep.ldo % 8 == 0) && ((uintptr_t)ep.out % 16 == 0) && (NI % 2 == 0);
+    if constexpr (NI == 4) {
+        if (wide && ep.rope.q_out) {
+            // RoPE + scatter (what rope_kv_kernel does to the stored q|k|v row): the values are rounded to bf16 first, exactly as the unfused
+            // route stores them, then rotated in fp32 and rounded again.  A wave's 128 columns are one head.
+            const Epilogue::Rope& rp = ep.rope;
+            const int nw = n0 + wave_n * 128;
+            const int head = nw >> 7;
+            const bool rot = head < rp.H + rp.Hkv;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
+                    const bool live = m < M;
+                    const int mc = live ? m : (M - 1);
+                    const float a = ep.row_scale ? ep.alpha * ep.row_scale[mc] : ep.alpha;
+                    const int b = rp.row_b[mc], pos = rp.row_pos[mc], tq = rp.row_t[mc];
+                    const bool put = live && b >= 0;
+                    bf16_t* drow;
+                    if (head < rp.H) drow = rp.q_out + ((int64_t)(b * rp.Lq + tq) * rp.H + head) * 128;
+                    else if (rot) drow = rp.k_cache + (((int64_t)b * rp.Hkv + (head - rp.H)) * rp.Smax + pos) * 128;
+                    else drow = rp.v_cache + (((int64_t)b * rp.Hkv + (head - rp.H - rp.Hkv)) * rp.Smax + pos) * 128;
+                    const float* cr = rp.cosT + (int64_t)pos * 64 + q4 * 4;
+                    const float* sr = rp.sinT + (int64_t)pos * 64 + q4 * 4;
+                    bf16x4 v1[4], v2[4];                   // block i: first-half / second-half values of d = 16 i + 4 q4 ..
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v1[i] = epilogue_vals4(ep, a, nw + i * 16 + q4 * 4, acc[0][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
+                        v2[i] = epilogue_vals4(ep, a, nw + 64 + i * 16 + q4 * 4, acc[1][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
+                    }
+                    if (rot) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 c = *(const f32x4*)(cr + i * 16), sn = *(const f32x4*)(sr + i * 16);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float r1, r2;
+                                mc_rope_pair((float)v1[i][j], (float)v2[i][j], c[j], sn[j], r1, r2);
+                                v1[i][j] = (bf16_t)r1; v2[i][j] = (bf16_t)r2;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        u32x2 pa = __builtin_bit_cast(u32x2, v1[i]), pb = __builtin_bit_cast(u32x2, v1[i + 1]);
+                        auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                        const u32x4 o1 = {r0[0], r1[0], r0[1], r1[1]};
+                        if (put) *(u32x4*)(drow + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o1;
+                        pa = __builtin_bit_cast(u32x2, v2[i]); pb = __builtin_bit_cast(u32x2, v2[i + 1]);
+                        r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                        r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                        const u32x4 o2 = {r0[0], r1[0], r0[1], r1[1]};
+                        if (put) *(u32x4*)(drow + 64 + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o2;
+                    }
+                }
+            return;
+        }
+    }
     const bool has_res = wide && !ep.swiglu && ep.residual != nullptr;
     bf16x4 res[2][2][2][NI];
     if (has_res) {
@@ -1360,7 +1427,7 @@ static void launch_rows(int RW, int kt, dim3 grid, hipStream_t s, const bf16_t* 
 // one launch of the 256x256 kernel over the m-tiles of all groups (M_total = rows over all groups, for the live profile)
 static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_total, const Epilogue& ep, hipStream_t s) {
     const int N = a->N, K = a->K;
-    const int ni = tile_ni(grp.tile_start[grp.n], N, a->swiglu != 0);
+    const int ni = tile_ni(grp.tile_start[grp.n], N, a->swiglu != 0 || a->rope != nullptr);
     const int tiles_m = grp.tile_start[grp.n], tiles_n = ni == 3 ? (N + 191) / 192 : (N + 255) / 256;
     static bool attr256_set = false;
     const int lds = 2 * G2_STAGE;
@@ -1404,6 +1471,29 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
 }
 
+// ---- RoPE + scatter epilogue of the q|k|v projection (mc_gemm_args.rope)
+static bool rope_args_ok(const mc_gemm_args* a) {
+    const mc_rope_scatter* r = a->rope;
+    return r->row_b && r->row_pos && r->row_t && r->cos_table && r->sin_table && r->q_out && r->k_cache && r->v_cache && r->H > 0 && r->Hkv > 0 &&
+           r->D % 16 == 0 && a->N == (r->H + 2 * r->Hkv) * r->D && !a->out_f32 && !a->swiglu && !a->residual && a->act == MC_ACT_NONE &&
+           a->split_k <= 1 && a->ldo % 8 == 0;
+}
+// the register route: a wave's 128 columns of a 256-column tile must be one head.  debug word bit 31 keeps the separate launch (A/B)
+static bool rope_in_epilogue(const mc_gemm_args* a) {
+    const mc_rope_scatter* r = a->rope;
+    return r && r->D == 128 && a->N % 256 == 0 && !(g_gemm_dbg & (1u << 31));
+}
+static void rope_fill(Epilogue& ep, const mc_rope_scatter* r, int64_t row0) {
+    ep.rope = Epilogue::Rope{r->row_b + row0, r->row_pos + row0, r->row_t + row0, r->cos_table, r->sin_table, (bf16_t*)r->q_out,
+                             (bf16_t*)r->k_cache, (bf16_t*)r->v_cache, r->H, r->Hkv, r->Lq, r->Smax};
+}
+// the separate route over rows [row0, row0 + M) of the stored projection
+static int rope_after(const mc_gemm_args* a, int64_t row0, int M, void* stream) {
+    const mc_rope_scatter* r = a->rope;
+    return mc_rope_kv_bf16((const char*)a->out + row0 * a->ldo * 2, a->ldo, r->row_b + row0, r->row_pos + row0, r->row_t + row0, r->cos_table,
+                           r->sin_table, r->q_out, r->k_cache, r->v_cache, M, r->H, r->Hkv, r->D, r->Lq, r->Smax, stream);
+}
+
 extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
     MC_CHECK_ARG(a, "mc_gemm_ex_bf16: null argument block");
     const void* x = a->x; const int64_t ldx = a->ldx; const void* w_packed = a->w_packed;
@@ -1422,9 +1512,11 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
                  "mc_gemm_ex_bf16: split_k accumulates raw fp32 partial sums (M <= 64, out_f32, no bias/act/residual)");
     MC_CHECK_ARG(!(a->rms_eps > 0.f) || (M <= 64 && !a->row_scale && split_k == 1),
                  "mc_gemm_ex_bf16: rms_eps (in-kernel RMS factor) needs M <= 64, no row_scale and no split_k");
+    MC_CHECK_ARG(!a->rope || rope_args_ok(a), "mc_gemm_ex_bf16: rope needs N = (H + 2 Hkv) D, a plain bf16 output (ldo %% 8 == 0) and every pointer");
     Epilogue ep{(const bf16_t*)a->bias, (const bf16_t*)a->residual, a->ldr, a->out, a->ldo, a->act, a->out_f32, a->alpha, a->beta,
                 a->row_scale, a->swiglu, a->rms_eps > 0.f ? a->rms_eps : 0.f};
     hipStream_t s = (hipStream_t)stream;
+    bool rope_pending = a->rope != nullptr;
     const int mb_rows = (M + 15) / 16;
     char* rows_ws = nullptr;
     // rows kernel geometry: RW = 2 block-rows per wave for SwiGLU (a gate / up pair), else 1; tiles of 8 k-blocks (8 RW KiB of weights in
@@ -1466,6 +1558,7 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
         G2Groups grp{};
         grp.n = 1; grp.tile_start[0] = 0; grp.tile_start[1] = (M + 255) / 256; grp.row_start[0] = 0; grp.row_start[1] = M;
         grp.wp[0] = (const bf16_t*)w_packed;
+        if (rope_in_epilogue(a)) { rope_fill(ep, a->rope, 0); rope_pending = false; }
         launch_tile256(a, grp, M, ep, s);
     } else {
         const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
@@ -1497,6 +1590,7 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
         }
     }
     MC_CHECK_LAUNCH();
+    if (rope_pending) return rope_after(a, 0, M, stream);
     return 0;
 }
 
@@ -1506,7 +1600,7 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = w_packed; a.bias = bias; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = act; a.out_f32 = out_f32; a.alpha = alpha; a.beta = beta;
-    a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1; a.rms_eps = 0.f;
+    a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1; a.rms_eps = 0.f; a.rope = nullptr;
     return mc_gemm_ex_bf16(&a, stream);
 }
 
@@ -1539,6 +1633,12 @@ extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, cons
             if (args->residual) a.residual = (const char*)args->residual + (int64_t)r0 * args->ldr * 2;
             if (args->row_scale) a.row_scale = args->row_scale + r0;
             a.w_packed = w_packed[g]; a.M = mg;
+            mc_rope_scatter rg;
+            if (args->rope) {
+                rg = *args->rope;
+                rg.row_b += r0; rg.row_pos += r0; rg.row_t += r0;
+                a.rope = &rg;
+            }
             const int rc = mc_gemm_ex_bf16(&a, stream);
             if (rc) return rc;
         }
@@ -1556,7 +1656,10 @@ extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, cons
     a.out = (char*)args->out + (int64_t)base * args->ldo * (args->out_f32 ? 4 : 2);
     if (args->residual) a.residual = (const char*)args->residual + (int64_t)base * args->ldr * 2;
     if (args->row_scale) a.row_scale = args->row_scale + base;
+    MC_CHECK_ARG(!args->rope || rope_args_ok(args), "mc_gemm_grouped_bf16: rope needs N = (H + 2 Hkv) D, a plain bf16 output (ldo %% 8 == 0) and every pointer");
     Epilogue ep{(const bf16_t*)a.bias, (const bf16_t*)a.residual, a.ldr, a.out, a.ldo, a.act, a.out_f32, a.alpha, a.beta, a.row_scale, a.swiglu, 0.f};
+    const bool rope_fused = rope_in_epilogue(args);
+    if (rope_fused) rope_fill(ep, args->rope, base);
     G2Groups grp{};
     int t = 0, k = 0;
     for (int g = 0; g < n_groups; ++g) {
@@ -1570,5 +1673,6 @@ extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, cons
     grp.n = k; grp.tile_start[k] = t;
     launch_tile256(&a, grp, M_total, ep, (hipStream_t)stream);
     MC_CHECK_LAUNCH();
+    if (args->rope && !rope_fused) return rope_after(args, base, M_total, stream);
     return 0;
 }

@@ -124,16 +124,17 @@ int gemm_ex(const void* x, int64_t ldx, const void* w, const void* residual, int
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = w; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = out_f32; a.alpha = 1.0f; a.beta = 1.0f;
-    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = split_k; a.rms_eps = 0.f;
+    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = split_k; a.rms_eps = 0.f; a.rope = nullptr;
     return mc_gemm_ex_bf16(&a, stream);
 }
 
 int gemm_grouped(const void* x, int64_t ldx, const void* residual, int64_t ldr, void* out, int64_t ldo, int N, int K, const float* row_scale,
-                 int swiglu, int n_groups, const int32_t* gstart, const void* const* weights, void* stream, float rms_eps = 0.f) {
+                 int swiglu, int n_groups, const int32_t* gstart, const void* const* weights, void* stream, float rms_eps = 0.f,
+                 const mc_rope_scatter* rope = nullptr) {
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = nullptr; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = 0; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = 0; a.alpha = 1.0f; a.beta = 1.0f;
-    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = 1; a.rms_eps = rms_eps;
+    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = 1; a.rms_eps = rms_eps; a.rope = rope;
     return mc_gemm_grouped_bf16(&a, n_groups, gstart, weights, stream);
 }
 
@@ -165,15 +166,17 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     };
     const int ph = decode ? 1 : 0;
     // q|k|v = (x / rms) . (W_qkv diag(g_in))^T                                                  (:440-443, :262-268)
-    RUNP(m, ph, PK_QKV, stream, gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in));
+    // prefill: RoPE, the q re-ordering and the cache append are the projection's epilogue (mc_rope_scatter; a separate mc_rope_kv_bf16
+    // launch inside the library when the launch is too small for the 256x256 kernel or the head size is not 128)            (:281-312)
+    mc_rope_scatter rope{row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, (int)H, (int)Hkv, (int)D, Lq, Smax};
+    RUNP(m, ph, PK_QKV, stream, gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in,
+                                             decode ? nullptr : &rope));
     if (decode) {
         // one token per sequence (row b = sequence b): RoPE, the cache append and the attention are one launch (:281-312)
         RUNP(m, ph, PK_ATTN, stream, mc_attn_decode_rope_bf16(w.qkv, qkvd, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
                                      Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit,
                                      scale, stream));
     } else {
-        RUNP(m, ph, PK_ROPE, stream, mc_rope_kv_bf16(w.qkv, qkvd, row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, M, (int)H, (int)Hkv,
-                                     (int)D, Lq, Smax, stream));
         RUNP(m, ph, PK_ATTN, stream, mc_attn_prefill_bf16(w.qseq, (int64_t)Lq * H * D, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
                                      Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, out_map, kv_lens, B, (int)H, (int)Hkv, Lq, Smax,
                                      (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, stream));

@@ -205,17 +205,32 @@ def test_first_layer_stages_are_exact_to_rounding(name):
     mid = fc.to_dev(mi)
     feats, _ = model.encode_modal_inputs(mid, model.prefix_tokens, model.suffix_tokens)
     plan = model._plan(ids.cuda(), None, None, mid, feats)
-    st = model._prefill(plan, feats, 0, want_hidden=False, want_logits=True)
-    torch.cuda.synchronize()
-    lay, cfg = st["layout"], model.config
-    M, B, Lq = lay.M, plan.B, plan.Lmax
+    from modelcompose_amd import _lib
+    cfg = model.config
     Hd, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
     al = lambda v: (v + 255) // 256 * 256
-    ws, off = st["ws"], 0
-    views = {}
-    for tag, rows, cols in (("qkv", M, 3 * H * D), ("q_rot", B * Lq, H * D), ("attn", M, Hd)):     # carve() of csrc/llm_runtime.cpp
-        views[tag] = ws[off:off + rows * cols * 2].view(torch.bfloat16).view(rows, cols).float().cpu()
-        off += al(rows * cols * 2)
+
+    def stages(debug):
+        # the shipped route rotates q / k in the q|k|v projection's epilogue and never stores the un-rotated projection; debug bit 31 keeps
+        # the GEMM -> mc_rope_kv_bf16 sequence (bit-identical results, tests/test_ops_gpu.py), whose workspace still holds q|k|v
+        _lib.lib().mc_gemm_debug(debug)
+        try:
+            st_ = model._prefill(plan, feats, 0, want_hidden=False, want_logits=True)
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().mc_gemm_debug(0)
+        lay_ = st_["layout"]
+        ws, off, v = st_["ws"], 0, {}
+        for tag, rows, cols in (("qkv", lay_.M, 3 * H * D), ("q_rot", plan.B * plan.Lmax, H * D), ("attn", lay_.M, Hd)):     # carve() of csrc/llm_runtime.cpp
+            v[tag] = ws[off:off + rows * cols * 2].view(torch.bfloat16).view(rows, cols).float().cpu()
+            off += al(rows * cols * 2)
+        return st_, v
+    _, separate = stages(-2147483648)
+    st, views = stages(0)
+    assert torch.equal(views["q_rot"], separate["q_rot"]) and torch.equal(views["attn"], separate["attn"]), "fused RoPE epilogue != separate launch"
+    views["qkv"] = separate["qkv"]
+    lay = st["layout"]
+    M, B, Lq = lay.M, plan.B, plan.Lmax
     sdf = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
     od = pipeline.OracleModel.from_state_dict(sdf, meta, emulate="device")
     fb = {m: f.float().cpu() for m, f in feats.items()}

@@ -551,3 +551,65 @@ def test_rows_gemm_kernel_every_split_and_epilogue(M, N, K):
         assert (old - f32_by_split[1]).abs().max().item() <= 1e-5 * plain.abs().max().item()
     finally:
         L.mc_gemm_debug(0)
+
+
+@pytest.mark.parametrize("D,H,Hkv,sizes", [(128, 8, 8, (700, 1300)), (128, 4, 2, (2100,)), (64, 8, 8, (900, 1200)), (128, 8, 8, (40, 30)), (128, 8, 8, (1700, 0, 1500))])
+def test_qkv_projection_with_rope_scatter_epilogue(ops, D, H, Hkv, sizes):
+    """mc_gemm_args.rope: the q|k|v projection's epilogue rotates q / k and scatters q, K, V (register route of the 256x256 kernel for
+    D = 128 and large launches; GEMM + mc_rope_kv_bf16 inside the library otherwise).  Both routes must equal, BIT for bit, the separate
+    GEMM -> mc_rope_kv_bf16 sequence the runtime used before, incl. padding rows (row_b < 0), several adapter groups and ragged positions;
+    untouched cache slots stay untouched."""
+    from modelcompose_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(D + H + sum(sizes))
+    K, N = 1024, (H + 2 * Hkv) * D
+    M = sum(sizes)
+    Bq, Lq, Smax = 3, (M + 2) // 3 + 5, (M + 2) // 3 + 40
+    x = torch.randn(M, K, generator=g).to(BF).cuda()
+    ws = [ops.pack_weight((torch.randn(N, K, generator=g) * 0.05).to(BF).cuda()) for _ in sizes]
+    starts = [0]
+    for sz in sizes:
+        starts.append(starts[-1] + sz)
+    # rows dealt to (sequence, query index) slots in a shuffled order; every 17th row is padding
+    slots = torch.randperm(Bq * Lq, generator=g)[:M]
+    row_b = (slots // Lq).to(torch.int32)
+    row_t = (slots % Lq).to(torch.int32)
+    row_pos = (row_t + 7 * row_b).to(torch.int32)           # per-sequence offset: position != query index
+    row_b[::17] = -1
+    row_b, row_t, row_pos = row_b.cuda(), row_t.cuda(), row_pos.cuda()
+    half = D // 2
+    ang = torch.arange(Smax + 32, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(half, dtype=torch.float32) / half))[None]
+    cos, sin = ang.cos().cuda().contiguous(), ang.sin().cuda().contiguous()
+
+    def buffers():
+        return (torch.full((Bq * Lq, H * D), 3.0, dtype=BF, device="cuda"), torch.full((Bq, Hkv, Smax, D), 5.0, dtype=BF, device="cuda"),
+                torch.full((Bq, Hkv, Smax, D), 7.0, dtype=BF, device="cuda"))
+    # automatic route; bit 2: the 256x256 kernel whatever the size (register route when D = 128); bit 31: GEMM + separate launch
+    for dbg in (0, 4, -2147483648):
+        L.mc_gemm_debug(dbg)
+        try:
+            # reference sequence with the same GEMM kernel choice: grouped GEMM, then the RoPE / scatter launch
+            q0, k0, v0 = buffers()
+            qkv = ops.linear_grouped(x, ws, starts)
+            ops.rope_kv(qkv, row_b, row_pos, row_t, cos, sin, q0, k0, v0, H, Hkv, D, Lq, Smax)
+            q1, k1, v1 = buffers()
+            rope = ops.rope_scatter(row_b, row_pos, row_t, cos, sin, q1, k1, v1, H, Hkv, D, Lq, Smax)
+            scratch = torch.full((M, N), 9.0, dtype=BF, device="cuda")
+            ops.linear_grouped(x, ws, starts, rope=rope, out=scratch)
+            if dbg == 4 and M > 64:
+                # the register route never stores the un-rotated projection; the other route does
+                assert bool((scratch == 9.0).all()) == (D == 128), "unexpected route"
+            if len(sizes) == 1:
+                q2, k2, v2 = buffers()
+                rope2 = ops.rope_scatter(row_b, row_pos, row_t, cos, sin, q2, k2, v2, H, Hkv, D, Lq, Smax)
+                ops.linear_ex(x, ws[0], rope=rope2)
+                assert torch.equal(q2, q0) and torch.equal(k2, k0) and torch.equal(v2, v0)
+        finally:
+            L.mc_gemm_debug(0)
+        assert torch.equal(q1, q0), f"q differs (debug {dbg})"
+        assert torch.equal(k1, k0), f"K cache differs (debug {dbg})"
+        assert torch.equal(v1, v0), f"V cache differs (debug {dbg})"
+    assert (q0 == 3.0).any() and (k0 == 5.0).any() and (q0 != 3.0).any()      # padding / unused slots exist and stay untouched
+    with pytest.raises(Exception):
+        bad = ops.rope_scatter(row_b, row_pos, row_t, cos, sin, q0, k0, v0, H + 1, Hkv, D, Lq, Smax)       # N != (H + 2 Hkv) D
+        ops.linear_grouped(x, ws, starts, rope=bad)
