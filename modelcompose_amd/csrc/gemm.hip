@@ -1088,40 +1088,32 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const bf16_t* __restrict
 }
 
 // second stage of the rows kernel: out = epilogue(sum over slices of slabs[k][M][N]) with the RMS factor from the slice sums of squares.
-// One output quad per thread; the S slab loads are issued together (S <= 8, compile-time bound) and added in slice order.
+// (A variant with one output quad per thread and the S slab loads issued together as nontemporal loads measured 18.8 us per launch inside
+// the decode graph against 6.4 us for this grid-stride loop - profiles/r02d vs r02c kernel stats - although both time the same in
+// back-to-back replays of one shape.)
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ ssp, int S, int M, int N,
                                                           int K, Epilogue ep) {
     const int nq = (ep.swiglu ? N >> 1 : N) >> 2;
-    const int64_t i = blockIdx.x * 256LL + threadIdx.x;
-    if (i >= (int64_t)M * nq) return;
-    const int m = (int)(i / nq), j = (int)(i % nq) * 4;
-    const int n = ep.swiglu ? ((j >> 4) << 5) + (j & 15) : j;
-    const float* p = slabs + (int64_t)m * N + n;
-    const int64_t slab = (int64_t)M * N;
-    f32x4 pv[8], pu[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (k < S) pv[k] = __builtin_nontemporal_load((const f32x4*)(p + k * slab));
-        if (k < S && ep.swiglu) pu[k] = __builtin_nontemporal_load((const f32x4*)(p + k * slab + 16));
-    }
-    float ssq[8];
-    const bool rms = ep.rms_eps > 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) ssq[k] = (rms && k < S) ? ssp[k * 64 + m] : 0.f;
-    f32x4 v = pv[0], u = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (ep.swiglu) u = pu[0];
-    float t = ssq[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k)
-        if (k < S) {
-            v += pv[k];
-            if (ep.swiglu) u += pu[k];
-            t += ssq[k];
+    const int64_t total = (int64_t)M * nq;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / nq), j = (int)(i % nq) * 4;
+        const int n = ep.swiglu ? ((j >> 4) << 5) + (j & 15) : j;
+        const float* p = slabs + (int64_t)m * N + n;
+        f32x4 v = *(const f32x4*)p, u = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ep.swiglu) u = *(const f32x4*)(p + 16);
+        for (int k = 1; k < S; ++k) {
+            v += *(const f32x4*)(p + (int64_t)k * M * N);
+            if (ep.swiglu) u += *(const f32x4*)(p + (int64_t)k * M * N + 16);
         }
-    Epilogue e2 = ep;
-    if (rms) e2.alpha = ep.alpha * rsqrtf(t / (float)K + ep.rms_eps);
-    if (ep.swiglu) epilogue_store4_swiglu(e2, m, j, v, u);
-    else epilogue_store4(e2, m, n, v);
+        Epilogue e2 = ep;
+        if (ep.rms_eps > 0.f) {
+            float t = 0.f;
+            for (int k = 0; k < S; ++k) t += ssp[k * 64 + m];
+            e2.alpha = ep.alpha * rsqrtf(t / (float)K + ep.rms_eps);
+        }
+        if (ep.swiglu) epilogue_store4_swiglu(e2, m, j, v, u);
+        else epilogue_store4(e2, m, n, v);
+    }
 }
 
 // Split-K second stage for the 128x128 kernel: sums the fp32 slabs [S][M][N] in fixed order and applies the real epilogue.
@@ -1420,7 +1412,7 @@ static void launch_rows(int RW, int kt, dim3 grid, hipStream_t s, const bf16_t* 
     }
     if (grid.y > 1) {
         const int64_t total = (int64_t)M * ((ep.swiglu ? N >> 1 : N) >> 2);
-        rows_reduce_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(slabs, ssp, (int)grid.y, M, N, K, ep);
+        rows_reduce_kernel<<<(int)min((int64_t)1024, (total + 255) / 256), 256, 0, s>>>(slabs, ssp, (int)grid.y, M, N, K, ep);
     }
 }
 

@@ -5,7 +5,7 @@
     python tools/gemm_layer_pmc.py [reps] [batch]
 
 Rows: B (default: bench.py's per-GPU batch of the headline workload) samples x (97 text | 42 audio | 586 vision | 2066 video) tokens in 4 adapter groups (default, audio, vision,
-video), exactly the row groups mc_llm_prefill hands to mc_gemm_grouped_bf16; q|k|v (N 12288, row_scale epilogue), o (N 4096, residual),
+video), exactly the row groups mc_llm_prefill hands to mc_gemm_grouped_bf16; q|k|v (N 12288, row_scale + RoPE / cache-scatter epilogue), o (N 4096, residual),
 gate|up (N 22016, SwiGLU epilogue), down (K 11008, residual).  Prints the algorithmic bytes / flops per launch in launch order."""
 import json
 import sys
@@ -37,9 +37,24 @@ def main():
     qkv = torch.empty(M, 3 * Hd, dtype=BF, device="cuda")
     attn = rnd(M, Hd).to(BF)
     inter = torch.empty(M, I, dtype=BF, device="cuda")
+    # the q|k|v launch carries the RoPE + scatter epilogue of the prefill (mc_rope_scatter): rows of sample b, position t
+    L, H, D = 97 + 42 + 586 + 2066, 32, 128
+    Smax = (L + 32 + 63) // 64 * 64
+    row_b = torch.cat([torch.arange(B, device="cuda").repeat_interleave(n) for n in (97, 42, 586, 2066)]).to(torch.int32)
+    offs, parts = 0, []
+    for n in (97, 42, 586, 2066):
+        parts.append((torch.arange(n, device="cuda") + offs).repeat(B))
+        offs += n
+    row_t = torch.cat(parts).to(torch.int32)
+    ang = torch.arange(Smax, dtype=torch.float32, device="cuda")[:, None] * (10000.0 ** (-torch.arange(64, dtype=torch.float32, device="cuda") / 64))[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    q_out = torch.empty(B * L, H * D, dtype=BF, device="cuda")
+    kc = torch.empty(B, H, Smax, D, dtype=BF, device="cuda")
+    vc = torch.empty(B, H, Smax, D, dtype=BF, device="cuda")
+    rope = ops.rope_scatter(row_b, row_t, row_t, cos, sin, q_out, kc, vc, H, H, D, L, Smax)
     launches = []
     for _ in range(reps):
-        ops.linear_grouped(x, wqkv, gs, row_scale=rs, out=qkv)
+        ops.linear_grouped(x, wqkv, gs, row_scale=rs, out=qkv, rope=rope)
         ops.linear_grouped(attn, wo, gs, residual=x, out=x)
         ops.linear_grouped(x, wgu, gs, row_scale=rs, swiglu=True, out=inter)
         ops.linear_grouped(inter, wd, gs, residual=x, out=x)
