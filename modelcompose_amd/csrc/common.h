@@ -19,11 +19,15 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
+// 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the IEEE division sequence (~10 VALU instructions per element:
+// measured +34 % on a CLIP fc1 launch with the QuickGELU epilogue, K = 1024).  Every caller rounds its result to bf16, 2^-15 coarser.
+__device__ __forceinline__ float mc_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
 __device__ __forceinline__ float mc_act(float x, int act) {
     switch (act) {
         case MC_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-        case MC_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
-        case MC_ACT_SILU: return x / (1.0f + __expf(-x));
+        case MC_ACT_QUICK_GELU: return x * mc_sigmoid(1.702f * x);
+        case MC_ACT_SILU: return x * mc_sigmoid(x);
         case MC_ACT_RELU: return fmaxf(x, 0.0f);
         default: return x;
     }

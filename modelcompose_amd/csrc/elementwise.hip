@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gf = (float)g[j];
-            o[j] = (bf16_t)(gf / (1.0f + __expf(-gf)) * (float)u[j]);
+            o[j] = (bf16_t)(gf * mc_sigmoid(gf) * (float)u[j]);
         }
         *(bf16x8*)(out + (int64_t)m * ldo + c * 8) = o;
     }

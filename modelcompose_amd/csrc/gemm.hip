@@ -16,6 +16,7 @@
 // MFMA roles: A = weight fragment (rows = n), B = activation fragment (cols = m) so that a lane
 // ends up with 4 consecutive n for one token m  ->  8-byte packed bf16 stores.
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // weight packing
@@ -146,7 +147,7 @@ __device__ __forceinline__ void epilogue_store4_swiglu(const Epilogue& e, int m,
         // gate and up are rounded to the storage dtype as the unfused path stores them (the reference's projections return
         // the model dtype, :381-388); act(gate) * up is evaluated in fp32 and rounded once
         const float gg = (float)(bf16_t)(g[i] * a), uu = (float)(bf16_t)(u[i] * a);
-        o[i] = (bf16_t)(gg / (1.0f + __expf(-gg)) * uu);
+        o[i] = (bf16_t)(gg * mc_sigmoid(gg) * uu);
     }
     *(bf16x4*)((bf16_t*)e.out + (int64_t)m * e.ldo + n_out) = o;
 }
@@ -161,16 +162,25 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // the four epilogue values of one accumulator fragment; a = alpha * row_scale[m] (hoisted by the caller), res = the residual's 4 values
-__device__ __forceinline__ bf16x4 epilogue_vals4(const Epilogue& e, float a, int n, f32x4 v, bool has_res, bf16x4 res) {
+// ACTC: how the activation is evaluated - 0 none, 1 the sigmoid family x sigmoid(k x) (QuickGELU k = 1.702, SiLU k = 1), 2 the generic
+// per-element switch.  The caller picks the class once per row: with the switch inside the element loops every element walked a scalar
+// branch tree (a CLIP fc1 launch, K = 1024: +34 % over the same launch without activation; +13 % with the class hoisted).
+template <int ACTC = 2>
+__device__ __forceinline__ bf16x4 epilogue_vals4(const Epilogue& e, float a, int n, f32x4 v, bool has_res, bf16x4 res, float act_k = 1.0f) {
     float r[4] = {v[0] * a, v[1] * a, v[2] * a, v[3] * a};
     if (e.bias) {
         bf16x4 b = *(const bf16x4*)(e.bias + n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] += (float)b[i];
     }
-    if (e.act != MC_ACT_NONE) {
+    if constexpr (ACTC == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = mc_act(r[i], e.act);
+        for (int i = 0; i < 4; ++i) r[i] = r[i] * mc_sigmoid(act_k * r[i]);
+    } else if constexpr (ACTC == 2) {
+        if (e.act != MC_ACT_NONE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = mc_act(r[i], e.act);
+        }
     }
     if (has_res) {
 #pragma unroll
@@ -184,7 +194,7 @@ __device__ __forceinline__ bf16x4 swiglu_vals4(float a, f32x4 g, f32x4 u) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float gg = (float)(bf16_t)(g[i] * a), uu = (float)(bf16_t)(u[i] * a);
-        o[i] = (bf16_t)(gg / (1.0f + __expf(-gg)) * uu);
+        o[i] = (bf16_t)(gg * mc_sigmoid(gg) * uu);
     }
     return o;
 }
@@ -476,6 +486,37 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
     mma(1, 0);
 }
 
+// wide epilogue of the 256x256 kernel for plain bf16 outputs (bias / activation / residual), one instantiation per activation class so
+// that no element walks a branch tree: every lane stores 16 bytes per block pair (v_permlane16_swap, see above)
+template <int ACTC, int NI>
+__device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc)[2][4][2][2], bf16x4 (&res)[2][2][2][NI], bool has_res, int m0,
+                                                 int n0, int M, int wave_m, int wave_n, int c16, int q4, float act_k) {
+    const int nw = n0 + wave_n * (2 * NI * 16);
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
+            const bool live = m < M;                   // depends on c16 only: the lane pairs of a swap are live together
+            const int mc = live ? m : (M - 1);
+            const float a = ep.row_scale ? ep.alpha * ep.row_scale[mc] : ep.alpha;
+            bf16_t* orow = (bf16_t*)ep.out + (int64_t)mc * ep.ldo + nw;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int i = 0; i < NI; i += 2) {
+                    const int nb = nh * (NI * 16) + i * 16;
+                    const bf16x4 lo = epilogue_vals4<ACTC>(ep, a, nw + nb + q4 * 4, acc[nh][i][mh][jj], has_res, res[mh][jj][nh][i], act_k);
+                    const bf16x4 hi = epilogue_vals4<ACTC>(ep, a, nw + nb + 16 + q4 * 4, acc[nh][i + 1][mh][jj], has_res, res[mh][jj][nh][i + 1], act_k);
+                    u32x2 pa = __builtin_bit_cast(u32x2, lo), pb = __builtin_bit_cast(u32x2, hi);
+                    auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                    if (live) *(u32x4*)(orow + nb + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
+                }
+        }
+}
+
 // rows of one launch may belong to several adapter groups (routed LocalLoRA order): group g owns rows [row_start[g], row_start[g+1])
 // = m-tiles [tile_start[g], tile_start[g+1]) and multiplies against its own composed weight
 struct G2Groups {
@@ -663,6 +704,8 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
         }
     }
     const bool has_res = wide && !ep.swiglu && ep.residual != nullptr;
+    const int actc = ep.act == MC_ACT_NONE ? 0 : ((ep.act == MC_ACT_QUICK_GELU || ep.act == MC_ACT_SILU) ? 1 : 2);
+    const float act_k = ep.act == MC_ACT_QUICK_GELU ? 1.702f : 1.0f;
     bf16x4 res[2][2][2][NI];
     if (has_res) {
 #pragma unroll
@@ -676,6 +719,14 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
 #pragma unroll
                     for (int i = 0; i < NI; ++i) res[mh][jj][nh][i] = *(const bf16x4*)(rrow + nh * (NI * 16) + i * 16);
             }
+    }
+    if constexpr (NI % 2 == 0) {
+        if (wide && !ep.swiglu) {
+            if (actc == 0) g2_epilogue_wide<0, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
+            else if (actc == 1) g2_epilogue_wide<1, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
+            else g2_epilogue_wide<2, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
+            return;
+        }
     }
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
         bf16x8 og, ou;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float gf = (float)g[j], sg = 1.0f / (1.0f + __expf(-gf)), df = (float)d[j];
+            const float gf = (float)g[j], sg = mc_sigmoid(gf), df = (float)d[j];
             ou[j] = (bf16_t)(df * gf * sg);
             og[j] = (bf16_t)(df * (float)u[j] * sg * (1.0f + gf * (1.0f - sg)));
         }
@@ -236,8 +236,8 @@ __device__ __forceinline__ float act_grad(float x, int act) {
             const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
             return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
         }
-        case MC_ACT_QUICK_GELU: { const float s = 1.0f / (1.0f + __expf(-1.702f * x)); return s * (1.0f + 1.702f * x * (1.0f - s)); }
-        case MC_ACT_SILU: { const float s = 1.0f / (1.0f + __expf(-x)); return s * (1.0f + x * (1.0f - s)); }
+        case MC_ACT_QUICK_GELU: { const float s = mc_sigmoid(1.702f * x); return s * (1.0f + 1.702f * x * (1.0f - s)); }
+        case MC_ACT_SILU: { const float s = mc_sigmoid(x); return s * (1.0f + x * (1.0f - s)); }
         case MC_ACT_RELU: return x > 0.f ? 1.0f : 0.f;
         default: return 1.0f;
     }
