@@ -165,10 +165,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // ACTC: how the activation is evaluated - 0 none, 1 the sigmoid family x sigmoid(k x) (QuickGELU k = 1.702, SiLU k = 1), 2 the generic
 // per-element switch.  The caller picks the class once per row: with the switch inside the element loops every element walked a scalar
 // branch tree (a CLIP fc1 launch, K = 1024: +34 % over the same launch without activation; +13 % with the class hoisted).
-template <int ACTC = 2>
+// BIASC / RESC: 1 / 0 = known present / absent (the branch is hoisted by the caller), -1 = decided here per call.
+template <int ACTC = 2, int BIASC = -1, int RESC = -1>
 __device__ __forceinline__ bf16x4 epilogue_vals4(const Epilogue& e, float a, int n, f32x4 v, bool has_res, bf16x4 res, float act_k = 1.0f) {
     float r[4] = {v[0] * a, v[1] * a, v[2] * a, v[3] * a};
-    if (e.bias) {
+    if (BIASC == 1 || (BIASC == -1 && e.bias)) {
         bf16x4 b = *(const bf16x4*)(e.bias + n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] += (float)b[i];
@@ -182,7 +183,7 @@ __device__ __forceinline__ bf16x4 epilogue_vals4(const Epilogue& e, float a, int
             for (int i = 0; i < 4; ++i) r[i] = mc_act(r[i], e.act);
         }
     }
-    if (has_res) {
+    if (RESC == 1 || (RESC == -1 && has_res)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] += e.beta * (float)res[i];
     }
@@ -488,7 +489,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
 
 // wide epilogue of the 256x256 kernel for plain bf16 outputs (bias / activation / residual), one instantiation per activation class so
 // that no element walks a branch tree: every lane stores 16 bytes per block pair (v_permlane16_swap, see above)
-template <int ACTC, int NI>
+template <int ACTC, int BIASC, int RESC, int NI>
 __device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc)[2][4][2][2], bf16x4 (&res)[2][2][2][NI], bool has_res, int m0,
                                                  int n0, int M, int wave_m, int wave_n, int c16, int q4, float act_k) {
     const int nw = n0 + wave_n * (2 * NI * 16);
@@ -506,8 +507,8 @@ __device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc
 #pragma unroll
                 for (int i = 0; i < NI; i += 2) {
                     const int nb = nh * (NI * 16) + i * 16;
-                    const bf16x4 lo = epilogue_vals4<ACTC>(ep, a, nw + nb + q4 * 4, acc[nh][i][mh][jj], has_res, res[mh][jj][nh][i], act_k);
-                    const bf16x4 hi = epilogue_vals4<ACTC>(ep, a, nw + nb + 16 + q4 * 4, acc[nh][i + 1][mh][jj], has_res, res[mh][jj][nh][i + 1], act_k);
+                    const bf16x4 lo = epilogue_vals4<ACTC, BIASC, RESC>(ep, a, nw + nb + q4 * 4, acc[nh][i][mh][jj], has_res, res[mh][jj][nh][i], act_k);
+                    const bf16x4 hi = epilogue_vals4<ACTC, BIASC, RESC>(ep, a, nw + nb + 16 + q4 * 4, acc[nh][i + 1][mh][jj], has_res, res[mh][jj][nh][i + 1], act_k);
                     u32x2 pa = __builtin_bit_cast(u32x2, lo), pb = __builtin_bit_cast(u32x2, hi);
                     auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
                     auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
@@ -722,9 +723,17 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     }
     if constexpr (NI % 2 == 0) {
         if (wide && !ep.swiglu) {
-            if (actc == 0) g2_epilogue_wide<0, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
-            else if (actc == 1) g2_epilogue_wide<1, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
-            else g2_epilogue_wide<2, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
+            // the common combinations get their own straight-line instantiation; the rest decide bias / residual per call
+#define G2_EPI(A, B, R) g2_epilogue_wide<A, B, R, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k)
+            const bool hb = ep.bias != nullptr;
+            if (actc == 0 && !hb && !has_res) G2_EPI(0, 0, 0);            // LLM q|k|v (without the RoPE route), plain projections
+            else if (actc == 0 && !hb && has_res) G2_EPI(0, 0, 1);        // LLM o / down
+            else if (actc == 0 && hb && !has_res) G2_EPI(0, 1, 0);        // encoder q|k|v
+            else if (actc == 0 && hb && has_res) G2_EPI(0, 1, 1);         // encoder out / fc2
+            else if (actc == 1 && hb && !has_res) G2_EPI(1, 1, 0);        // encoder fc1 (QuickGELU)
+            else if (actc == 1) G2_EPI(1, -1, -1);
+            else G2_EPI(2, -1, -1);
+#undef G2_EPI
             return;
         }
     }

@@ -30,3 +30,9 @@ o5 = torch.empty(M5, N5 // 2, device="cuda", dtype=torch.bfloat16)
 dt = t(lambda: ops.linear_ex(x5, w5, row_scale=rs, swiglu=True, out=o5), 5); print("gate|up swiglu", f"{dt*1e6:.0f} us  {2*M5*N5*K5/dt/1e12:.0f} TFLOP/s")
 o6 = torch.empty(M5, N5, device="cuda", dtype=torch.bfloat16)
 dt = t(lambda: ops.linear_ex(x5, w5, row_scale=rs, out=o6), 5); print("gate|up plain", f"{dt*1e6:.0f} us  {2*M5*N5*K5/dt/1e12:.0f} TFLOP/s")
+M7, N7, K7 = 44656, 4096, 4096
+x7 = torch.randn(M7, K7, device="cuda", dtype=torch.bfloat16)
+w7 = ops.pack_weight(torch.randn(N7, K7, device="cuda", dtype=torch.bfloat16) * 0.02)
+h7 = torch.randn(M7, N7, device="cuda", dtype=torch.bfloat16)
+dt = t(lambda: ops.linear_ex(x7, w7, residual=h7, out=h7), 10); print("o_proj residual", f"{dt*1e6:.0f} us  {2*M7*N7*K7/dt/1e12:.0f} TFLOP/s")
+dt = t(lambda: ops.linear_ex(x7, w7, out=h7), 10); print("o_proj plain", f"{dt*1e6:.0f} us  {2*M7*N7*K7/dt/1e12:.0f} TFLOP/s")
