@@ -119,7 +119,7 @@ def test_gemm_argument_errors(ops):
 
 
 def test_rmsnorm_layernorm(ops):
-    for (M, D) in [(5, 4096), (130, 1024), (3, 384), (2, 16384)]:
+    for (M, D) in [(5, 4096), (130, 1024), (3, 384), (2, 16384), (7, 768), (9, 2048), (1, 1408), (6, 2056)]:
         x = dev(rand_bf(M, D, seed=7))
         w = dev((1 + 0.1 * torch.randn(D)).to(BF))
         b = dev((0.1 * torch.randn(D)).to(BF))
