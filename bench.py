@@ -68,8 +68,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (roofline objects become null)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--pipeline", action="store_true", help="two generation pipelines on two HIP streams (decode of batch i beside the prefill of "
-                    "batch i+1, MultimodalLlamaForCausalLM.generate_pipelined); every step still is one full batch")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=None,
+                    help="the eval loop's throughput mode (default for the iav / vision workloads): two generation pipelines on two HIP streams, the "
+                    "decode of batch i - HBM-bound - beside the encoders + prefill of batch i+1 - MFMA-bound "
+                    "(MultimodalLlamaForCausalLM.generate_pipelined, eval/model_multimodal_qa_loader.py --pipeline); every step still is one full "
+                    "batch, all K batches start and finish inside the timed region")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one generate() call per step, nothing overlapped")
     ap.add_argument("--no-overlap", action="store_true", help="debug only (train): weight-gradient / rank-projection GEMMs on the main stream")
     ap.add_argument("--gemm-debug", type=int, default=0, help="debug only: mc_gemm_debug word (A/B of kernel variants)")
     ap.add_argument("--workload", default="iav", choices=["iav", "vision", "generate", "mcub4", "train"],
@@ -299,6 +303,8 @@ def generate_main(args, world, rank, local):
     from modelcompose_amd.model.builder import build_from_state_dict
     name = args.workload
     modals, sentinels, defB, msuffix, desc = WORKLOADS[name]
+    if args.pipeline is None:
+        args.pipeline = name in ("iav", "vision")
     dev = torch.device("cuda", local)
     meta = workload_meta(name, args.layers)
     sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
@@ -360,25 +366,30 @@ def generate_main(args, world, rank, local):
         "roofline": None, "roofline_decode": None,
     }
     del feats
-    if not args.no_profile and not args.pipeline:
+    if not args.no_profile:
+        # per-kernel evidence: a separate pass of sequential generate() calls with one HIP-event bracket per launch on the launch stream
+        # (overlapped launches of the pipelined loop would inflate each other's durations)
         cfgd = dict(hidden=meta["hidden_size"], inter=meta["intermediate_size"], vocab=meta["vocab_size"], layers=args.layers,
                     heads=meta["num_attention_heads"], head_dim=meta["hidden_size"] // meta["num_attention_heads"], workload_name=name)
         roofline, dec, stages, pre = profiled_pass(model, step, cfgd, B, args.new_tokens, min(args.steps, 3))
         line["roofline"], line["roofline_decode"], line["stages_ms"] = roofline, dec, stages
         line["prefill_kernel_classes_ms"] = pre
         line["config"]["decode_graph"] = dec["graph_active"]
-    if world == 1 and not args.pipeline and not args.no_profile and name != "mcub4":
-        # informational, outside the timed region and outside the contract's fields: the same K batches through generate_pipelined
-        args.pipeline = True
+    if world == 1 and not args.no_profile and name != "mcub4":
+        # informational, outside the timed region and outside the contract's fields: the same K batches through the other eval loop
+        was = args.pipeline
+        args.pipeline = not was
         run_steps(2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_steps(args.steps)
         torch.cuda.synchronize()
         dtp = time.perf_counter() - t0
-        args.pipeline = False
-        line["pipelined"] = {"value": round(B * args.steps / dtp, 4), "unit": "samples/s", "ms_per_step": round(dtp / args.steps * 1e3, 3),
-                             "note": "bench.py --pipeline: decode of batch i overlapped with encoders + prefill of batch i+1; same tokens"}
+        args.pipeline = was
+        line["sequential" if was else "pipelined"] = {
+            "value": round(B * args.steps / dtp, 4), "unit": "samples/s", "ms_per_step": round(dtp / args.steps * 1e3, 3),
+            "note": ("bench.py --no-pipeline: one generate() call per batch, nothing overlapped; same tokens" if was else
+                     "bench.py --pipeline: decode of batch i overlapped with encoders + prefill of batch i+1; same tokens")}
     if world == 1 and not args.no_cpu_baseline:
         del model
         torch.cuda.empty_cache()
