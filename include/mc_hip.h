@@ -121,6 +121,11 @@ typedef struct mc_gemm_args {
     const float* row_scale; int swiglu; int split_k; float rms_eps;
     const struct mc_rope_scatter* rope;   /* non-null: the launch is the q|k|v projection of a prefill and its epilogue does what mc_rope_kv_bf16
                                            * would do next (below); `out` is then scratch ([M, ldo], may or may not be written) */
+    float* rms_out; float rms_out_eps;    /* rms_out non-null (bf16 output, no SwiGLU): after the launch rms_out[m] = rsqrt(mean_n out[m][n]^2 +
+                                           * rms_out_eps) of the STORED rows - the factor of the RMSNorm that reads the new hidden state
+                                           * (LlamaRMSNorm, multimodal_llama.py:405-406), without the separate mc_rms_scale_bf16 pass: the
+                                           * 256x256 kernel's epilogue leaves one sum of squares per row and 128-column chunk, a small
+                                           * launch adds them in column order; other routes run mc_rms_scale_bf16 after the GEMM */
 } mc_gemm_args;
 /* RoPE + scatter fused into the q|k|v projection (LlamaAttention.forward, multimodal_llama.py:281-312: rotate q and k, append k / v to the
  * cache): output row r (absolute row index of the launch, as in mc_rope_kv_bf16) belongs to sequence row_b[r] (< 0: padding, skipped), is

@@ -61,7 +61,7 @@ class GemmArgsC(C.Structure):
     """struct mc_gemm_args (include/mc_hip.h)."""
     _fields_ = [("x", c_p), ("ldx", c_l), ("w_packed", c_p), ("bias", c_p), ("residual", c_p), ("ldr", c_l), ("out", c_p), ("ldo", c_l),
                 ("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i), ("out_f32", c_i), ("alpha", c_f), ("beta", c_f),
-                ("row_scale", c_p), ("swiglu", c_i), ("split_k", c_i), ("rms_eps", c_f), ("rope", c_p)]
+                ("row_scale", c_p), ("swiglu", c_i), ("split_k", c_i), ("rms_eps", c_f), ("rope", c_p), ("rms_out", c_p), ("rms_out_eps", c_f)]
 
 
 class RopeScatterC(C.Structure):

@@ -110,6 +110,8 @@ struct Epilogue {
         bf16_t* q_out; bf16_t* k_cache; bf16_t* v_cache;
         int H, Hkv, Lq, Smax;
     } rope;
+    float* ss_parts;         // non-null (256x256 kernel, wide plain epilogue): ss_parts[m * ss_chunks + n / 128] = sum of squares of the stored
+    int ss_chunks;           // bf16 values of row m in that 128-column chunk (mc_gemm_args.rms_out)
 };
 
 __device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n, f32x4 v) {
@@ -489,7 +491,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
 
 // wide epilogue of the 256x256 kernel for plain bf16 outputs (bias / activation / residual), one instantiation per activation class so
 // that no element walks a branch tree: every lane stores 16 bytes per block pair (v_permlane16_swap, see above)
-template <int ACTC, int BIASC, int RESC, int NI>
+template <int ACTC, int BIASC, int RESC, int NI, bool SS = false>
 __device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc)[2][4][2][2], bf16x4 (&res)[2][2][2][NI], bool has_res, int m0,
                                                  int n0, int M, int wave_m, int wave_n, int c16, int q4, float act_k) {
     const int nw = n0 + wave_n * (2 * NI * 16);
@@ -502,6 +504,7 @@ __device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc
             const int mc = live ? m : (M - 1);
             const float a = ep.row_scale ? ep.alpha * ep.row_scale[mc] : ep.alpha;
             bf16_t* orow = (bf16_t*)ep.out + (int64_t)mc * ep.ldo + nw;
+            float ss = 0.f;
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -509,12 +512,26 @@ __device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc
                     const int nb = nh * (NI * 16) + i * 16;
                     const bf16x4 lo = epilogue_vals4<ACTC, BIASC, RESC>(ep, a, nw + nb + q4 * 4, acc[nh][i][mh][jj], has_res, res[mh][jj][nh][i], act_k);
                     const bf16x4 hi = epilogue_vals4<ACTC, BIASC, RESC>(ep, a, nw + nb + 16 + q4 * 4, acc[nh][i + 1][mh][jj], has_res, res[mh][jj][nh][i + 1], act_k);
+                    if constexpr (SS) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float f0 = (float)lo[e], f1 = (float)hi[e];
+                            ss = fmaf(f0, f0, ss);
+                            ss = fmaf(f1, f1, ss);
+                        }
+                    }
                     u32x2 pa = __builtin_bit_cast(u32x2, lo), pb = __builtin_bit_cast(u32x2, hi);
                     auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
                     auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
                     const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
                     if (live) *(u32x4*)(orow + nb + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
                 }
+            if constexpr (SS) {
+                // this wave's 128 columns of row m: the four column quarters (q4) of the row, then one store per row
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                if (live && q4 == 0) ep.ss_parts[(int64_t)m * ep.ss_chunks + (nw >> 7)] = ss;
+            }
         }
 }
 
@@ -672,8 +689,8 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
                     bf16x4 v1[4], v2[4];                   // block i: first-half / second-half values of d = 16 i + 4 q4 ..
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        v1[i] = epilogue_vals4(ep, a, nw + i * 16 + q4 * 4, acc[0][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
-                        v2[i] = epilogue_vals4(ep, a, nw + 64 + i * 16 + q4 * 4, acc[1][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
+                        v1[i] = epilogue_vals4<0, -1, 0>(ep, a, nw + i * 16 + q4 * 4, acc[0][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
+                        v2[i] = epilogue_vals4<0, -1, 0>(ep, a, nw + 64 + i * 16 + q4 * 4, acc[1][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
                     }
                     if (rot) {
 #pragma unroll
@@ -726,7 +743,9 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
             // the common combinations get their own straight-line instantiation; the rest decide bias / residual per call
 #define G2_EPI(A, B, R) g2_epilogue_wide<A, B, R, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k)
             const bool hb = ep.bias != nullptr;
-            if (actc == 0 && !hb && !has_res) G2_EPI(0, 0, 0);            // LLM q|k|v (without the RoPE route), plain projections
+            if (ep.ss_parts && NI == 4 && actc == 0 && !hb && has_res) g2_epilogue_wide<0, 0, 1, NI, true>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);   // LLM o / down + next norm's factor
+            else if (ep.ss_parts && NI == 4 && actc == 0) g2_epilogue_wide<0, -1, -1, NI, true>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
+            else if (actc == 0 && !hb && !has_res) G2_EPI(0, 0, 0);            // LLM q|k|v (without the RoPE route), plain projections
             else if (actc == 0 && !hb && has_res) G2_EPI(0, 0, 1);        // LLM o / down
             else if (actc == 0 && hb && !has_res) G2_EPI(0, 1, 0);        // encoder q|k|v
             else if (actc == 0 && hb && has_res) G2_EPI(0, 1, 1);         // encoder out / fc2
@@ -1479,7 +1498,7 @@ static void launch_rows(int RW, int kt, dim3 grid, hipStream_t s, const bf16_t* 
 // one launch of the 256x256 kernel over the m-tiles of all groups (M_total = rows over all groups, for the live profile)
 static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_total, const Epilogue& ep, hipStream_t s) {
     const int N = a->N, K = a->K;
-    const int ni = tile_ni(grp.tile_start[grp.n], N, a->swiglu != 0 || a->rope != nullptr);
+    const int ni = tile_ni(grp.tile_start[grp.n], N, a->swiglu != 0 || a->rope != nullptr || ep.ss_parts != nullptr);
     const int tiles_m = grp.tile_start[grp.n], tiles_n = ni == 3 ? (N + 191) / 192 : (N + 255) / 256;
     static bool attr256_set = false;
     const int lds = 2 * G2_STAGE;
@@ -1521,6 +1540,70 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         default: G2_LAUNCH(0); break;
     }
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+}
+
+// ---- mc_gemm_args.rms_out: 1/rms of the stored output rows
+__global__ __launch_bounds__(256) void rms_parts_kernel(const float* __restrict__ parts, int chunks, int M, int N, float eps, float* __restrict__ rs) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* p = parts + (int64_t)m * chunks;
+    float t = 0.f;
+    for (int c = 0; c < chunks; ++c) t += p[c];            // column order: deterministic
+    rs[m] = rsqrtf(t / (float)N + eps);
+}
+// The same per-chunk sums from a STORED output (routes other than the 256x256 epilogue), in exactly the epilogue's order - a lane's 32
+// values of its column quarter by (half, block pair, element) FMAs, then (q0 + q1) + (q2 + q3) - so that the factor of a row does not
+// depend on which kernel produced the row (batch invariance: small launches take other kernels).  4 lanes per (row, chunk).
+__global__ __launch_bounds__(256) void rms_chunk_parts_kernel(const bf16_t* __restrict__ out, int64_t ldo, int M, int chunks, float* __restrict__ parts) {
+    const int64_t t = blockIdx.x * 256LL + threadIdx.x;
+    const int q4 = (int)(t & 3);
+    const int64_t rc = t >> 2;
+    const bool on = rc < (int64_t)M * chunks;
+    const int m = on ? (int)(rc / chunks) : 0, c = on ? (int)(rc % chunks) : 0;
+    const bf16_t* p = out + (int64_t)m * ldo + c * 128 + q4 * 4;
+    float ss = 0.f;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const bf16x4 lo = *(const bf16x4*)(p + nh * 64 + i * 16), hi = *(const bf16x4*)(p + nh * 64 + i * 16 + 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float f0 = (float)lo[e], f1 = (float)hi[e];
+                ss = fmaf(f0, f0, ss);
+                ss = fmaf(f1, f1, ss);
+            }
+        }
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    if (on && q4 == 0) parts[(int64_t)m * chunks + c] = ss;
+}
+static bool rms_out_args_ok(const mc_gemm_args* a) { return !a->out_f32 && !a->swiglu && !a->rope && a->split_k <= 1 && a->rms_out_eps > 0.f; }
+// the epilogue route needs whole 256-column tiles of the 256x256 kernel, no activation, and the partial sums to fit the stream's workspace
+static float* rms_parts_buffer(const mc_gemm_args* a, int64_t M_total, hipStream_t s) {
+    if (a->N % 128 || a->ldo % 4 || ((uintptr_t)a->out % 8) || (size_t)M_total * (a->N / 128) > kRowsSlabFloats) return nullptr;
+    char* ws = rows_workspace(s);
+    return ws ? (float*)(ws + kRowsSsBytes) : nullptr;
+}
+static float* rms_out_parts(const mc_gemm_args* a, int64_t M_total, hipStream_t s) {
+    if (!a->rms_out || a->N % 256 || a->act != MC_ACT_NONE || a->ldo % 8 || ((uintptr_t)a->out % 16) || (g_gemm_dbg & (1 << 29))) return nullptr;
+    return rms_parts_buffer(a, M_total, s);
+}
+// parts: what the epilogue left (null: another route ran).  Without a workspace (first launch inside a capture) or for N that is not a
+// multiple of 128 the plain row pass computes the factor (other fp32 summation order).
+static int rms_out_after(const mc_gemm_args* a, int64_t row0, int M, float* parts, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = a->N / 128;
+    if (!parts && (parts = rms_parts_buffer(a, M, s)) != nullptr) {
+        const int64_t threads = (int64_t)M * chunks * 4;
+        rms_chunk_parts_kernel<<<(int)((threads + 255) / 256), 256, 0, s>>>((const bf16_t*)a->out + row0 * a->ldo, a->ldo, M, chunks, parts);
+    }
+    if (parts) {
+        rms_parts_kernel<<<(M + 255) / 256, 256, 0, s>>>(parts, chunks, M, a->N, a->rms_out_eps, a->rms_out + row0);
+        MC_CHECK_LAUNCH();
+        return 0;
+    }
+    return mc_rms_scale_bf16((const char*)a->out + row0 * a->ldo * 2, a->ldo, a->rms_out + row0, M, a->N, a->rms_out_eps, stream);
 }
 
 // ---- RoPE + scatter epilogue of the q|k|v projection (mc_gemm_args.rope)
@@ -1567,8 +1650,10 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
     MC_CHECK_ARG(!a->rope || rope_args_ok(a), "mc_gemm_ex_bf16: rope needs N = (H + 2 Hkv) D, a plain bf16 output (ldo %% 8 == 0) and every pointer");
     Epilogue ep{(const bf16_t*)a->bias, (const bf16_t*)a->residual, a->ldr, a->out, a->ldo, a->act, a->out_f32, a->alpha, a->beta,
                 a->row_scale, a->swiglu, a->rms_eps > 0.f ? a->rms_eps : 0.f};
+    MC_CHECK_ARG(!a->rms_out || rms_out_args_ok(a), "mc_gemm_ex_bf16: rms_out needs a bf16 output without SwiGLU / rope / split_k and rms_out_eps > 0");
     hipStream_t s = (hipStream_t)stream;
     bool rope_pending = a->rope != nullptr;
+    float* ss_parts = nullptr;
     const int mb_rows = (M + 15) / 16;
     char* rows_ws = nullptr;
     // rows kernel geometry: RW = 2 block-rows per wave for SwiGLU (a gate / up pair), else 1; tiles of 8 k-blocks (8 RW KiB of weights in
@@ -1611,6 +1696,7 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
         grp.n = 1; grp.tile_start[0] = 0; grp.tile_start[1] = (M + 255) / 256; grp.row_start[0] = 0; grp.row_start[1] = M;
         grp.wp[0] = (const bf16_t*)w_packed;
         if (rope_in_epilogue(a)) { rope_fill(ep, a->rope, 0); rope_pending = false; }
+        if ((ss_parts = rms_out_parts(a, M, s)) != nullptr) { ep.ss_parts = ss_parts; ep.ss_chunks = N / 128; }
         launch_tile256(a, grp, M, ep, s);
     } else {
         const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
@@ -1643,6 +1729,7 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
     }
     MC_CHECK_LAUNCH();
     if (rope_pending) return rope_after(a, 0, M, stream);
+    if (a->rms_out) return rms_out_after(a, 0, M, ss_parts, stream);
     return 0;
 }
 
@@ -1652,7 +1739,7 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = w_packed; a.bias = bias; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = act; a.out_f32 = out_f32; a.alpha = alpha; a.beta = beta;
-    a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1; a.rms_eps = 0.f; a.rope = nullptr;
+    a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1; a.rms_eps = 0.f; a.rope = nullptr; a.rms_out = nullptr; a.rms_out_eps = 0.f;
     return mc_gemm_ex_bf16(&a, stream);
 }
 
@@ -1685,6 +1772,7 @@ extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, cons
             if (args->residual) a.residual = (const char*)args->residual + (int64_t)r0 * args->ldr * 2;
             if (args->row_scale) a.row_scale = args->row_scale + r0;
             a.w_packed = w_packed[g]; a.M = mg;
+            if (args->rms_out) a.rms_out = args->rms_out + r0;
             mc_rope_scatter rg;
             if (args->rope) {
                 rg = *args->rope;
@@ -1712,6 +1800,9 @@ extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, cons
     Epilogue ep{(const bf16_t*)a.bias, (const bf16_t*)a.residual, a.ldr, a.out, a.ldo, a.act, a.out_f32, a.alpha, a.beta, a.row_scale, a.swiglu, 0.f};
     const bool rope_fused = rope_in_epilogue(args);
     if (rope_fused) rope_fill(ep, args->rope, base);
+    MC_CHECK_ARG(!args->rms_out || rms_out_args_ok(args), "mc_gemm_grouped_bf16: rms_out needs a bf16 output without SwiGLU / rope / split_k and rms_out_eps > 0");
+    float* ss_parts = rms_out_parts(&a, M_total, (hipStream_t)stream);
+    if (ss_parts) { ep.ss_parts = ss_parts; ep.ss_chunks = N / 128; }
     G2Groups grp{};
     int t = 0, k = 0;
     for (int g = 0; g < n_groups; ++g) {
@@ -1726,5 +1817,6 @@ extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, cons
     launch_tile256(&a, grp, M_total, ep, (hipStream_t)stream);
     MC_CHECK_LAUNCH();
     if (args->rope && !rope_fused) return rope_after(args, base, M_total, stream);
+    if (args->rms_out) return rms_out_after(args, base, M_total, ss_parts, stream);
     return 0;
 }

@@ -124,17 +124,17 @@ int gemm_ex(const void* x, int64_t ldx, const void* w, const void* residual, int
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = w; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = out_f32; a.alpha = 1.0f; a.beta = 1.0f;
-    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = split_k; a.rms_eps = 0.f; a.rope = nullptr;
+    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = split_k; a.rms_eps = 0.f; a.rope = nullptr; a.rms_out = nullptr; a.rms_out_eps = 0.f;
     return mc_gemm_ex_bf16(&a, stream);
 }
 
 int gemm_grouped(const void* x, int64_t ldx, const void* residual, int64_t ldr, void* out, int64_t ldo, int N, int K, const float* row_scale,
                  int swiglu, int n_groups, const int32_t* gstart, const void* const* weights, void* stream, float rms_eps = 0.f,
-                 const mc_rope_scatter* rope = nullptr) {
+                 const mc_rope_scatter* rope = nullptr, float* rms_out = nullptr, float rms_out_eps = 0.f) {
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = nullptr; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = 0; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = 0; a.alpha = 1.0f; a.beta = 1.0f;
-    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = 1; a.rms_eps = rms_eps; a.rope = rope;
+    a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = 1; a.rms_eps = rms_eps; a.rope = rope; a.rms_out = rms_out; a.rms_out_eps = rms_out_eps;
     return mc_gemm_grouped_bf16(&a, n_groups, gstart, weights, stream);
 }
 
@@ -182,13 +182,14 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
                                      (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, stream));
     }
     // x += o_proj(attn)  (:447);  then 1/rms of the new x for post_attention_layernorm (:462)
-    RUNP(m, ph, PK_O, stream, gemm_grouped(w.attn, hd, x, hd, x, hd, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream));
-    if (!skinny) RUNP(m, ph, PK_RMS, stream, mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
+    // (prefill: the factor of post_attention_layernorm comes out of the same launch - rms_out - instead of a pass over the new x)
+    RUNP(m, ph, PK_O, stream, gemm_grouped(w.attn, hd, x, hd, x, hd, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream, 0.f, nullptr,
+                                           skinny ? nullptr : w.rs, c.rms_eps));
     // inter = silu(gate) * up with gate|up = (x / rms) . (W_gu diag(g_post))^T                 (:380-390)
     RUNP(m, ph, PK_GATE_UP, stream, gemm_grouped(x, hd, nullptr, 0, w.inter, I, (int)(2 * I), (int)hd, rs_in, 1, n_groups, gstart, W_all(2), stream, eps_in));
     // x += down_proj(inter)  (:466);  then 1/rms for the next layer's input_layernorm / the final norm
-    RUNP(m, ph, PK_DOWN, stream, gemm_grouped(w.inter, I, x, hd, x, hd, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream));
-    if (!skinny) RUNP(m, ph, PK_RMS, stream, mc_rms_scale_bf16(x, hd, w.rs, M, (int)hd, c.rms_eps, stream));
+    RUNP(m, ph, PK_DOWN, stream, gemm_grouped(w.inter, I, x, hd, x, hd, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream, 0.f, nullptr,
+                                              skinny ? nullptr : w.rs, c.rms_eps));
     return 0;
 }
 

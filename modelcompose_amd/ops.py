@@ -133,7 +133,7 @@ def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.
 
 def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor] = None, swiglu: bool = False, split_k: int = 1,
               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False, rms_eps: float = 0.0,
-              rope=None) -> torch.Tensor:
+              rope=None, rms_out: Optional[torch.Tensor] = None, rms_out_eps: float = 0.0) -> torch.Tensor:
     """mc_gemm_ex_bf16: row_scale fp32 [M] (1/rms of a folded RMSNorm), swiglu (gate/up interleaved per 16 rows -> [M, N/2]),
     split_k > 1 (M <= 64): fp32 partial slabs [split_k, M, N]; rope = rope_scatter(...): the launch is a prefill's q|k|v projection, RoPE and
     the q / KV-cache scatter happen in its epilogue (the returned buffer is scratch then)."""
@@ -150,7 +150,8 @@ def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor
     a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), w.data.data_ptr(), 0, 0 if residual is None else residual.data_ptr(),
                        0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(-2), M, w.N, w.Kp, 0,
                        1 if (out_f32 or split_k > 1) else 0, 1.0, 1.0, 0 if row_scale is None else row_scale.data_ptr(),
-                       1 if swiglu else 0, split_k, float(rms_eps), 0 if rope is None else C.addressof(rope[0]))
+                       1 if swiglu else 0, split_k, float(rms_eps), 0 if rope is None else C.addressof(rope[0]),
+                       0 if rms_out is None else rms_out.data_ptr(), float(rms_out_eps))
     _lib.check(_lib.lib().mc_gemm_ex_bf16(C.byref(a), _stream()), "mc_gemm_ex_bf16")
     return out
 
@@ -162,7 +163,8 @@ def rope_scatter(row_b, row_pos, row_t, cos, sin, q_out, k_cache, v_cache, H, Hk
 
 
 def linear_grouped(x: torch.Tensor, weights: Sequence[PackedWeight], group_start: Sequence[int], row_scale: Optional[torch.Tensor] = None,
-                   swiglu: bool = False, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, rope=None) -> torch.Tensor:
+                   swiglu: bool = False, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, rope=None,
+                   rms_out: Optional[torch.Tensor] = None, rms_out_eps: float = 0.0) -> torch.Tensor:
     """mc_gemm_grouped_bf16: rows [group_start[g], group_start[g+1]) of x use weights[g] (routed LocalLoRA linear)."""
     _req(x, BF16, "x")
     w0 = weights[0]
@@ -172,7 +174,8 @@ def linear_grouped(x: torch.Tensor, weights: Sequence[PackedWeight], group_start
         out = torch.empty(M, n_out, dtype=BF16, device=x.device)
     a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), 0, 0, 0 if residual is None else residual.data_ptr(),
                        0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), 0, w0.N, w0.Kp, 0, 0, 1.0, 1.0,
-                       0 if row_scale is None else row_scale.data_ptr(), 1 if swiglu else 0, 1, 0.0, 0 if rope is None else C.addressof(rope[0]))
+                       0 if row_scale is None else row_scale.data_ptr(), 1 if swiglu else 0, 1, 0.0, 0 if rope is None else C.addressof(rope[0]),
+                       0 if rms_out is None else rms_out.data_ptr(), float(rms_out_eps))
     gs = (C.c_int32 * len(group_start))(*group_start)
     wp = (C.c_void_p * len(weights))(*[w.data.data_ptr() for w in weights])
     _lib.check(_lib.lib().mc_gemm_grouped_bf16(C.byref(a), len(weights), gs, wp, _stream()), "mc_gemm_grouped_bf16")

@@ -613,3 +613,43 @@ def test_qkv_projection_with_rope_scatter_epilogue(ops, D, H, Hkv, sizes):
     with pytest.raises(Exception):
         bad = ops.rope_scatter(row_b, row_pos, row_t, cos, sin, q0, k0, v0, H + 1, Hkv, D, Lq, Smax)       # N != (H + 2 Hkv) D
         ops.linear_grouped(x, ws, starts, rope=bad)
+
+
+@pytest.mark.parametrize("sizes,N,K", [((700, 1300), 4096, 512), ((9000,), 1024, 256), ((40, 30), 4096, 256), ((3000, 2500, 600), 4096, 1024), ((300,), 520, 128)])
+def test_gemm_rms_out_factor_of_the_stored_rows(ops, sizes, N, K):
+    """mc_gemm_args.rms_out: the launch also leaves rsqrt(mean(out_row^2) + eps) of the rows it STORED (the next RMSNorm's factor): from the
+    256x256 kernel's epilogue (per-chunk sums of squares + a small reduce) or, on other routes, mc_rms_scale_bf16 inside the library.
+    Either way it must equal the separate pass over the stored output to fp32 summation order (2e-6), with residual, groups and ragged rows;
+    the output itself is bit-identical to the launch without rms_out."""
+    from modelcompose_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(sum(sizes) + N)
+    M = sum(sizes)
+    x = torch.randn(M, K, generator=g).to(BF).cuda()
+    ws = [ops.pack_weight((torch.randn(N, K, generator=g) * 0.05).to(BF).cuda()) for _ in sizes]
+    res = torch.randn(M, N, generator=g).to(BF).cuda()
+    starts = [0]
+    for sz in sizes:
+        starts.append(starts[-1] + sz)
+    by_route = {}
+    for dbg in (0, 4, 1 << 29):                     # automatic; 256x256 kernel forced (epilogue route); bit 29: separate pass inside the library
+        L.mc_gemm_debug(dbg)
+        try:
+            ref = ops.linear_grouped(x, ws, starts, residual=res)
+            rs = torch.full((M,), -1.0, dtype=torch.float32, device="cuda")
+            got = ops.linear_grouped(x, ws, starts, residual=res, rms_out=rs, rms_out_eps=1e-5)
+            if len(sizes) == 1:
+                rs1 = torch.full((M,), -1.0, dtype=torch.float32, device="cuda")
+                got1 = ops.linear_ex(x, ws[0], residual=res, rms_out=rs1, rms_out_eps=1e-5)
+                assert torch.equal(got1, ref) and torch.equal(rs1, rs)
+        finally:
+            L.mc_gemm_debug(0)
+        assert torch.equal(got, ref)
+        by_route[dbg] = rs
+        want = ops.rms_scale(got, 1e-5)
+        assert (rs - want).abs().max().item() <= 2e-6 * want.abs().max().item(), (dbg, (rs - want).abs().max().item())
+        exact = torch.rsqrt(got.float().pow(2).mean(-1) + 1e-5)
+        assert (rs - exact).abs().max().item() <= 2e-6 * exact.abs().max().item()
+    if N % 128 == 0:
+        # the factor does not depend on the route (the stored-output pass sums in the epilogue's order): batch invariance
+        assert torch.equal(by_route[0], by_route[4]) and torch.equal(by_route[0], by_route[1 << 29])
