@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const bf16_t* __restrict
 // second stage of the rows kernel: out = epilogue(sum over slices of slabs[k][M][N]) with the RMS factor from the slice sums of squares.
 // (A variant with one output quad per thread and the S slab loads issued together as nontemporal loads measured 18.8 us per launch inside
 // the decode graph against 6.4 us for this grid-stride loop - profiles/r02d vs r02c kernel stats - although both time the same in
-// back-to-back replays of one shape.)
+// back-to-back replays of one shape; a version templated on S with all slab loads of a quad issued together: 11-13 us.)
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ ssp, int S, int M, int N,
                                                           int K, Epilogue ep) {
     const int nq = (ep.swiglu ? N >> 1 : N) >> 2;
@@ -1471,7 +1471,10 @@ static int rows_split(int groups, int rw, int nblocks, int kblocks, int kt, int 
         const double wg_bytes = (8.0 * rw * 16 + mb * 16) * kslice * 2;
         const double t_cu = (double)((wgs + 255) / 256) * wg_bytes / 47e3;
         const double t_hbm = (double)nblocks * 16 * kblocks * 32 * 2 / 5.2e6;
-        const double t = 2.0 + (t_cu > t_hbm ? t_cu : t_hbm) + (S > 1 ? 3.5 + (double)S * M * N * 4 / 4.0e6 : 0.0);
+        double t = 2.0 + (t_cu > t_hbm ? t_cu : t_hbm) + (S > 1 ? 3.5 + (double)S * M * N * 4 / 4.0e6 : 0.0);
+        // a grid that leaves more than a third of the CUs idle does not reach the chip rate the estimate assumes (down_proj at S = 5, 160
+        // workgroups: 29 us against 27 at S = 8): grids of 172-256 workgroups go first
+        if (wgs < 172 || wgs > 256) t += 1000.0;
         if (t < best - 1e-9) { best = t; bs = S; }
     }
     return bs;

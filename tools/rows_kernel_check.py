@@ -62,7 +62,7 @@ def timeit(fn, n=200):
     return (time.perf_counter() - t0) / (n // 20 * 20)
 
 L.mc_gemm_reserve_rows(torch.cuda.current_stream().cuda_stream)
-for M in (16, 32, 48, 64) if "--all" in sys.argv else (32, 48):
+for M in (16, 32, 48, 64) if "--all" in sys.argv else ((48,) if "--m48" in sys.argv else (32, 48)):
     for (N, K, name, kw) in ((4096, 4096, "o_proj", dict(res=True)), (4096, 11008, "down_proj", dict(res=True)), (12288, 4096, "qkv", dict(eps=1e-5)),
                              (22016, 4096, "gate|up", dict(eps=1e-5, sw=True)), (32000, 4096, "lm_head", dict(f32=True))):
         ws = [ops.pack_weight(torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.02) for _ in range(8)]
