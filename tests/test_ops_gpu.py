@@ -495,7 +495,7 @@ def test_prefill_attention_128_query_workgroups_match_64_query_ones(causal):
 
 
 @pytest.mark.parametrize("M", [17, 33, 48, 64])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (1000, 256), (4096, 11008), (2048, 4096)])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (1000, 256), (4096, 11008), (2048, 4096), (12288, 1024), (22016, 512), (11008, 1024)])
 def test_rows_gemm_kernel_every_split_and_epilogue(M, N, K):
     """gemm_rows_kernel (decode batches of more than 16 rows: x through LDS, K split over workgroups, slabs folded by rows_reduce_kernel):
     every epilogue at every forced split count and tile depth agrees with the fp32 product to bf16 output rounding (2^-7 of the output
@@ -514,7 +514,8 @@ def test_rows_gemm_kernel_every_split_and_epilogue(M, N, K):
     cases = [("plain", {}, plain), ("residual", dict(residual=res), plain + res.float()), ("rms", dict(rms_eps=1e-5), plain * fac),
              ("f32", dict(out_f32=True), plain)]
     if N % 32 == 0:
-        gu = (plain * fac).view(M, N // 32, 2, 16)
+        # gate and up are rounded to bf16 before silu(gate) * up, as the unfused path stores them (epilogue_store4_swiglu)
+        gu = (plain * fac).to(torch.bfloat16).float().view(M, N // 32, 2, 16)
         cases.append(("swiglu", dict(swiglu=True, rms_eps=1e-5), (torch.nn.functional.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(M, N // 2)))
     f32_by_split = {}
     try:
