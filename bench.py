@@ -324,6 +324,10 @@ def generate_main(args, world, rank, local):
         out = model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True, **kw)
         return gather_ids(out[:, ids.shape[1]:], world, force=DIST)
 
+    def step_local(**kw):
+        # rank 0's evidence passes run after the other ranks have left: no collective in them
+        return model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True, **kw)
+
     def barrier():
         if DIST or world > 1:
             torch.distributed.barrier()
@@ -371,7 +375,7 @@ def generate_main(args, world, rank, local):
         # (overlapped launches of the pipelined loop would inflate each other's durations)
         cfgd = dict(hidden=meta["hidden_size"], inter=meta["intermediate_size"], vocab=meta["vocab_size"], layers=args.layers,
                     heads=meta["num_attention_heads"], head_dim=meta["hidden_size"] // meta["num_attention_heads"], workload_name=name)
-        roofline, dec, stages, pre = profiled_pass(model, step, cfgd, B, args.new_tokens, min(args.steps, 3))
+        roofline, dec, stages, pre = profiled_pass(model, step_local, cfgd, B, args.new_tokens, min(args.steps, 3))
         line["roofline"], line["roofline_decode"], line["stages_ms"] = roofline, dec, stages
         line["prefill_kernel_classes_ms"] = pre
         line["config"]["decode_graph"] = dec["graph_active"]
