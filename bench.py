@@ -268,7 +268,7 @@ def profiled_pass(model, step_fn, cfg, B, new_tokens, n_steps):
     kv_bytes_layer = kv_keys * H * D * 2 * 2.0
     step_bytes = Ln * (wbytes["qkv_gemm"] + wbytes["o_gemm"] + wbytes["gate_up_gemm"] + wbytes["down_gemm"] + kv_bytes_layer) + wbytes["lm_head_gemm"]
     step_ms = stages["decode"] / max(n_dec, 1)
-    dec = {"bound": "hbm", "kernel": "decode step (5 launches per layer + lm_head + argmax, hipGraph replay)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+    dec = {"bound": "hbm", "kernel": "decode step (5 launches per layer - plus one slab-reduce launch behind each split GEMM at batches above 16 - + lm_head + argmax, hipGraph replay)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
            "achieved": round(step_bytes / max(step_ms, 1e-9) / 1e6, 1), "frac": round(step_bytes / max(step_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
            "bytes_per_step": step_bytes, "ms_per_step": round(step_ms, 4), "graph_active": bool(graph_active),
            "avg_keys_per_sequence": round(kv_keys / B, 1)}

@@ -152,7 +152,8 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     char* vcl = vc + (size_t)layer * kv_layer;
     const float scale = 1.0f / sqrtf((float)D);
     // skinny decode shapes (M <= 64): no normalisation pass at all - the GEMMs that read the hidden state compute its 1/rms from the x
-    // fragments they stream (rms_eps), o_proj / down_proj add the residual in their epilogue: 5 launches per layer
+    // fragments they stream (rms_eps), o_proj / down_proj add the residual in their epilogue: 5 launches per layer (batches above 16 rows: the rows
+    // kernel splits K over workgroups where that fills the chip, each such GEMM is followed by its slab-reduce launch)
     const bool skinny = decode && M <= 64;
     const float* rs_in = skinny ? nullptr : w.rs;
     const float eps_in = skinny ? c.rms_eps : 0.f;
