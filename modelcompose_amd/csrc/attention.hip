@@ -654,7 +654,7 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
     }
     const bool two = D == 128 && !rel_table && !(g_attn_dbg & (1 | 4)) && Lq > 64;
     if (two) {
-        const bool w8 = ((g_attn_dbg & 2) || Lq >= 2048) && (int64_t)((Lq + 255) / 256) * H * B >= 512;
+        const bool w8 = ((g_attn_dbg & 2) || Lq >= 2048) && (int64_t)((Lq + 255) / 256) * H * B >= 512 && !(g_attn_dbg & 8);      // bit 3: 4 waves at any length (A/B)
         if (w8) attn_prefill_kernel<128, false, 8, 2><<<dim3((Lq + 255) / 256, H, B), 512, 4 * 64 * 256, s>>>(p);
         else attn_prefill_kernel<128, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
         MC_CHECK_LAUNCH();
