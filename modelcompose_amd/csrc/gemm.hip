@@ -164,8 +164,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // the four epilogue values of one accumulator fragment; a = alpha * row_scale[m] (hoisted by the caller), res = the residual's 4 values
-// ACTC: how the activation is evaluated - 0 none, 1 the sigmoid family x sigmoid(k x) (QuickGELU k = 1.702, SiLU k = 1), 2 the generic
-// per-element switch.  The caller picks the class once per row: with the switch inside the element loops every element walked a scalar
+// ACTC: how the activation is evaluated - 0 none, 1 the sigmoid family x sigmoid(k x) (QuickGELU k = 1.702, SiLU k = 1), 3 exact GELU, 2 the
+// generic per-element switch.  The caller picks the class once per row: with the switch inside the element loops every element walked a scalar
 // branch tree (a CLIP fc1 launch, K = 1024: +34 % over the same launch without activation; +13 % with the class hoisted).
 // BIASC / RESC: 1 / 0 = known present / absent (the branch is hoisted by the caller), -1 = decided here per call.
 template <int ACTC = 2, int BIASC = -1, int RESC = -1>
@@ -179,6 +179,9 @@ __device__ __forceinline__ bf16x4 epilogue_vals4(const Epilogue& e, float a, int
     if constexpr (ACTC == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = r[i] * mc_sigmoid(act_k * r[i]);
+    } else if constexpr (ACTC == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = mc_gelu(r[i]);
     } else if constexpr (ACTC == 2) {
         if (e.act != MC_ACT_NONE) {
 #pragma unroll
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
         }
     }
     const bool has_res = wide && !ep.swiglu && ep.residual != nullptr;
-    const int actc = ep.act == MC_ACT_NONE ? 0 : ((ep.act == MC_ACT_QUICK_GELU || ep.act == MC_ACT_SILU) ? 1 : 2);
+    const int actc = ep.act == MC_ACT_NONE ? 0 : ((ep.act == MC_ACT_QUICK_GELU || ep.act == MC_ACT_SILU) ? 1 : (ep.act == MC_ACT_GELU ? 3 : 2));
     const float act_k = ep.act == MC_ACT_QUICK_GELU ? 1.702f : 1.0f;
     bf16x4 res[2][2][2][NI];
     if (has_res) {
@@ -751,6 +754,7 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
             else if (actc == 0 && hb && has_res) G2_EPI(0, 1, 1);         // encoder out / fc2
             else if (actc == 1 && hb && !has_res) G2_EPI(1, 1, 0);        // encoder fc1 (QuickGELU)
             else if (actc == 1) G2_EPI(1, -1, -1);
+            else if (actc == 3) G2_EPI(3, -1, -1);                        // BEATs / point-cloud fc1 (exact GELU)
             else G2_EPI(2, -1, -1);
 #undef G2_EPI
             return;
