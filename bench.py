@@ -341,7 +341,10 @@ def generate_main(args, world, rank, local):
         for out in model.generate_pipelined(((ids, mi) for _ in range(n)), max_new_tokens=args.new_tokens, ignore_eos=True):
             gather_ids(out[:, ids.shape[1]:], world, force=DIST)
 
-    run_steps(args.warmup)
+    # the pipelined loop alternates two generation pipelines (own KV cache, workspace, decode graph): both must have run once before the
+    # timed region, whatever W the caller asked for
+    priming = max(0, 2 - args.warmup) if args.pipeline else 0
+    run_steps(priming + args.warmup)
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -366,7 +369,8 @@ def generate_main(args, world, rank, local):
         "config": {"workload": f"{desc}; batch {B} per GPU, {spliced}-token spliced prompt, {args.new_tokens} greedy tokens",
                    "workload_name": name, "per_gpu_batch": B, "new_tokens": args.new_tokens, "layers": args.layers, "spliced_length": spliced,
                    "block_tokens": {m: int(f.shape[1]) for m, f in feats.items()}, "adapters": list(model.modal_names),
-                   "parallelism": f"dp{world}", "decode_graph_requested": not args.no_graph, "pipelined": bool(args.pipeline)},
+                   "parallelism": f"dp{world}", "decode_graph_requested": not args.no_graph, "pipelined": bool(args.pipeline),
+                   "pipeline_priming_steps": priming},
         "roofline": None, "roofline_decode": None,
     }
     del feats

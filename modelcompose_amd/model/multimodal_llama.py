@@ -636,18 +636,39 @@ def _past_len(pkv):
     return pkv[-1][-1].shape[-2]
 
 
+_CAT_IDX = {}
+
+
 def _cat_rows(parts: List[torch.Tensor]) -> torch.Tensor:
-    """cat along dim 1 of (b, T_i, H) bf16 tensors with the device copy kernel."""
+    """cat along dim 1 of (b, T_i, H) bf16 tensors with the device copy kernel: ONE launch per part (row r = i T_p + j of the part goes to
+    row i T + off + j of the result; the index vectors are cached per shape), not one per (part, sample)."""
     b, Hd = parts[0].shape[0], parts[0].shape[-1]
     T = sum(p.shape[1] for p in parts)
-    out = torch.empty(b, T, Hd, dtype=BF16, device=parts[0].device)
+    dev = parts[0].device
+    out = torch.empty(b, T, Hd, dtype=BF16, device=dev)
+    flat = out.view(b * T, Hd)
     off = 0
     for p in parts:
         t = p.shape[1]
-        pc = p if p.is_contiguous() else None
-        for i in range(b):
-            src = (pc[i] if pc is not None else p[i].contiguous())
-            ops.copy_rows(src, out[i, off:off + t], t)
+        if t == 0:
+            continue
+        key = (b, T, off, t, str(dev))
+        idx = _CAT_IDX.get(key)
+        if idx is None:
+            idx = (torch.arange(b, dtype=torch.int32)[:, None] * T + off + torch.arange(t, dtype=torch.int32)[None, :]).reshape(-1).to(dev)
+            if len(_CAT_IDX) > 256:
+                _CAT_IDX.clear()
+            _CAT_IDX[key] = idx
+        if p.stride(0) == 0 and p[0].is_contiguous():             # a block broadcast over the batch (prefix / suffix tokens): gather it
+            skey = ("src", b, t, str(dev))
+            sidx = _CAT_IDX.get(skey)
+            if sidx is None:
+                sidx = torch.arange(t, dtype=torch.int32).repeat(b).to(dev)
+                _CAT_IDX[skey] = sidx
+            ops.copy_rows(p[0], flat, b * t, sidx, idx)
+        else:
+            src = (p if p.is_contiguous() else p.contiguous()).view(b * t, Hd)
+            ops.copy_rows(src, flat, b * t, None, idx)
         off += t
     return out
 
