@@ -255,6 +255,9 @@ int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const float* cos_t
 
 /* ---- row kernels ---------------------------------------------------------------------------------- */
 int mc_silu_mul_bf16(const void* gate_up, int64_t ld, void* out, int64_t ldo, int M, int I, void* stream);   /* :392-394 */
+/* dst[b] = src[b * Lq + lens[b] - 1] (rows of D bf16): the last valid row of every sequence of a [B, Lq, D] tensor (the rotated query of
+ * the last prompt token, for the last-layer tail of mc_llm_prefill) */
+int mc_gather_last_rows_bf16(const void* src, int64_t ld_src, const int32_t* lens, int Lq, void* dst, int64_t ld_dst, int B, int D, void* stream);
 int mc_copy_rows_bf16(const void* src, int64_t ld_src, const int32_t* src_idx, void* dst, int64_t ld_dst,
                       const int32_t* dst_idx, int n_rows, int D, void* stream);       /* splice: multimodal_arch.py:349-378 */
 int mc_embed_rows_bf16(const void* table, int64_t ld_table, const int64_t* ids, void* dst, int64_t ld_dst,

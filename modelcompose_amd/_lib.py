@@ -48,6 +48,7 @@ _SIGS = {
     "mc_attn_decode_bf16": [c_p, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
                             c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "mc_silu_mul_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    "mc_gather_last_rows_bf16": [C.c_void_p, C.c_int64, C.c_void_p, c_i, C.c_void_p, C.c_int64, c_i, c_i, C.c_void_p],
     "mc_copy_rows_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_embed_rows_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_argmax_f32": [c_p, c_l, c_p, c_i, c_i, c_p],

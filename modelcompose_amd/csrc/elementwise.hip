@@ -355,6 +355,24 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
     for (int c = threadIdx.x; c < nv; c += 256) *(bf16x8*)(d + c * 8) = *(const bf16x8*)(s + c * 8);
 }
 
+// dst[b] = src[b * Lq + lens[b] - 1]: the last valid row of every sequence of a [B, Lq, D] tensor (rows of D bf16)
+__global__ __launch_bounds__(256) void gather_last_rows_kernel(const bf16_t* __restrict__ src, int64_t lds_, const int32_t* __restrict__ lens, int Lq,
+                                                               bf16_t* __restrict__ dst, int64_t ldd, int D) {
+    const int b = blockIdx.x;
+    const int t = min(max(lens[b], 1), Lq) - 1;
+    const bf16_t* s = src + ((int64_t)b * Lq + t) * lds_;
+    bf16_t* d = dst + (int64_t)b * ldd;
+    for (int c = threadIdx.x; c < (D >> 3); c += 256) *(bf16x8*)(d + c * 8) = *(const bf16x8*)(s + c * 8);
+}
+
+extern "C" int mc_gather_last_rows_bf16(const void* src, int64_t ld_src, const int32_t* lens, int Lq, void* dst, int64_t ld_dst, int B, int D,
+                                        void* stream) {
+    MC_CHECK_ARG(src && lens && dst && B > 0 && Lq > 0 && D > 0 && D % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, "mc_gather_last_rows_bf16: bad arguments");
+    gather_last_rows_kernel<<<B, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, ld_src, lens, Lq, (bf16_t*)dst, ld_dst, D);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int mc_copy_rows_bf16(const void* src, int64_t ld_src, const int32_t* src_idx, void* dst, int64_t ld_dst,
                                  const int32_t* dst_idx, int n_rows, int D, void* stream) {
     MC_CHECK_ARG(src && dst && n_rows >= 0 && D > 0 && D % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, "mc_copy_rows_bf16: bad arguments");

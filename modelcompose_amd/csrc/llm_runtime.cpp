@@ -43,6 +43,8 @@ struct Llm {
     Key gkey[kGraphs] = {};
     int graph_next = 0;                      // round-robin victim
     bool use_graph = true;
+    int tail_adapter = -1;                   // >= 0: generate()'s prefill runs the last layer's attention + MLP for the last token of every
+                                             // sequence only (all of them routed to this adapter); -1: every row (forward(), mixed adapters)
     // hipStreamBeginCapture is refused on the legacy null stream (torch's default current stream).  Callers that pass stream 0 have their
     // decode graphs captured and replayed on this handle-owned non-blocking stream, ordered against stream 0 by the two events.
     hipStream_t own_stream = nullptr;
@@ -143,7 +145,9 @@ int gemm_grouped(const void* x, int64_t ldx, const void* residual, int64_t ldr, 
 int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t* gstart, const int32_t* gadapter,
                   const Ws& w, const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t, const int32_t* out_map,
                   const int32_t* kv_lens, int B, int Lq, char* kc, char* vc, int Smax, bool decode, int nsplit, void* attn_ws,
-                  void* stream) {
+                  void* stream, int stage = 0) {
+    // stage 0: the whole layer; 1: the q|k|v projection (+ RoPE / cache scatter) only; 2: everything after the attention (w.attn holds its
+    // output) - the two halves of the last prefill layer of generate(), which runs the second half for the last tokens only
     const mc_llm_config& c = m->cfg;
     const int64_t hd = c.hidden, D = c.head_dim, H = c.n_heads, Hkv = c.n_kv_heads, I = c.inter;
     const int64_t qkvd = (H + 2 * Hkv) * D;
@@ -170,9 +174,12 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     // prefill: RoPE, the q re-ordering and the cache append are the projection's epilogue (mc_rope_scatter; a separate mc_rope_kv_bf16
     // launch inside the library when the launch is too small for the 256x256 kernel or the head size is not 128)            (:281-312)
     mc_rope_scatter rope{row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, (int)H, (int)Hkv, (int)D, Lq, Smax};
-    RUNP(m, ph, PK_QKV, stream, gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in,
-                                             decode ? nullptr : &rope));
-    if (decode) {
+    if (stage != 2)
+        RUNP(m, ph, PK_QKV, stream, gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in,
+                                                 decode ? nullptr : &rope));
+    if (stage == 1) return 0;
+    if (stage == 2) {
+    } else if (decode) {
         // one token per sequence (row b = sequence b): RoPE, the cache append and the attention are one launch (:281-312)
         RUNP(m, ph, PK_ATTN, stream, mc_attn_decode_rope_bf16(w.qkv, qkvd, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
                                      Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit,
@@ -264,6 +271,11 @@ extern "C" int mc_llm_set_option(void* handle, const char* name, int value) {
     Llm* m = (Llm*)handle;
     if (!m || !name) { mc_set_error("mc_llm_set_option: null argument"); return 1; }
     if (!strcmp(name, "use_graph")) { m->use_graph = value != 0; return 0; }
+    if (!strcmp(name, "tail_adapter")) {
+        if (value >= m->cfg.n_adapters) { mc_set_error("mc_llm_set_option: tail_adapter %d of %d adapters", value, m->cfg.n_adapters); return 1; }
+        m->tail_adapter = value < 0 ? -1 : value;
+        return 0;
+    }
     if (!strcmp(name, "profile")) {
         if (value && !m->prof_on) {
             for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -347,9 +359,38 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
     const mc_llm_config& c = m->cfg;
     Ws w = carve(c, M, B, Lq, (char*)workspace);
     RUN(mc_rms_scale_bf16(x_routed, c.hidden, w.rs, M, c.hidden, c.rms_eps, stream));
-    for (int l = 0; l < c.n_layers; ++l)
+    // generate() only reads the last token's hidden state of the LAST layer (lm_head on row -1, multimodal_llama.py:720 + greedy_search):
+    // that layer still projects q|k|v for every row (the cache needs all keys), but its attention, o_proj and MLP run for the B last
+    // tokens only - as a decode step would, reading the keys the projection just stored.  Needs all last tokens on one adapter.
+    const bool tail = m->tail_adapter >= 0 && !hidden_out && last_rows && kv_lens && (logits_out || next_ids) && B <= 512;
+    const int full_layers = tail ? c.n_layers - 1 : c.n_layers;
+    for (int l = 0; l < full_layers; ++l)
         RUN(layer_forward(m, l, (char*)x_routed, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
                           Lq, (char*)k_cache, (char*)v_cache, Smax, false, 1, nullptr, stream));
+    if (tail) {
+        const int l = c.n_layers - 1;
+        const int64_t hd = c.hidden, D = c.head_dim, H = c.n_heads, Hkv = c.n_kv_heads;
+        RUN(layer_forward(m, l, (char*)x_routed, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
+                          Lq, (char*)k_cache, (char*)v_cache, Smax, false, 1, nullptr, stream, 1));
+        // last tokens: residual rows, rotated queries (sequence order: row b Lq + len_b - 1 of qseq), attention over the stored keys
+        RUN(mc_copy_rows_bf16(x_routed, hd, last_rows, w.xl, hd, nullptr, B, (int)hd, stream));
+        RUN(mc_gather_last_rows_bf16(w.qseq, H * D, kv_lens, Lq, w.qkv, H * D, B, (int)(H * D), stream));
+        const size_t kv_layer = (size_t)B * Hkv * Smax * D * 2;
+        char* kcl = (char*)k_cache + (size_t)l * kv_layer;
+        char* vcl = (char*)v_cache + (size_t)l * kv_layer;
+        const int nsplit = decode_nsplit(c, B);
+        RUNP(m, 0, PK_ATTN, stream, mc_attn_decode_bf16(w.qkv, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl, Hkv * Smax * D, D,
+                                                        (int64_t)Smax * D, w.attn, hd, (char*)workspace + w.total, kv_lens, B, (int)H, (int)Hkv, Smax,
+                                                        (int)D, nsplit, 1.0f / sqrtf((float)D), stream));
+        const int32_t gs1[2] = {0, B};
+        const int32_t ga1[1] = {m->tail_adapter};
+        RUN(layer_forward(m, l, w.xl, B, 1, gs1, ga1, w, nullptr, nullptr, nullptr, nullptr, kv_lens, B, 1, (char*)k_cache, (char*)v_cache, Smax,
+                          B <= 64, 1, nullptr, stream, 2));
+        float* lg = logits_out ? logits_out : (float*)w.logits;
+        RUN(head_forward(m, w.xl, B, w, lg, stream, 0));
+        if (next_ids) RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, nullptr, 0, nullptr, B, c.vocab, stream));
+        return 0;
+    }
     if (hidden_out)   // final norm over all rows (forward() API: logits for every position, :720)
         RUN(mc_rmsnorm_bf16(x_routed, c.hidden, m->final_norm, hidden_out, c.hidden, M, c.hidden, c.rms_eps, stream));
     if (last_rows && (logits_out || next_ids)) {

@@ -8,6 +8,8 @@ Composition: at load every LocalLoRA linear is expanded into one dense weight pe
 (W + Σ scale·B·A, csrc/compose.hip), so a forward is plain GEMMs over adapter-grouped rows."""
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from typing import Dict, List, Optional
@@ -390,6 +392,16 @@ class MultimodalLlamaForCausalLM:
             self._cache[("next_ids", slot, B)] = next_ids
         gs = np.ascontiguousarray(lay.group_start, dtype=np.int32)
         ga = np.ascontiguousarray(lay.group_adapter, dtype=np.int32)
+        # generate() reads the last layer's output for the last token of every sequence only: when those tokens share one adapter (they are
+        # text tokens of the prompt's tail) the runtime runs that layer's attention + MLP for them alone ("tail_adapter"; forward() needs
+        # every row)
+        tail = -1
+        if not want_hidden and getattr(self, "last_layer_tail", os.environ.get("MC_LAST_LAYER_TAIL", "1") != "0"):
+            g_of_last = np.searchsorted(gs, np.asarray(lay.last_rows), side="right") - 1
+            ads = np.unique(ga[np.clip(g_of_last, 0, len(ga) - 1)])
+            if len(ads) == 1:
+                tail = int(ads[0])
+        _lib.check(_lib.lib().mc_llm_set_option(self._handle, b"tail_adapter", tail), "mc_llm_set_option")
         _lib.check(_lib.lib().mc_llm_prefill(self._handle, _ptr(x), M, len(ga), gs.ctypes.data_as(C.c_void_p), ga.ctypes.data_as(C.c_void_p),
                                              _ptr(row_b), _ptr(row_t), _ptr(row_t), _ptr(out_map), _ptr(kv_lens), _ptr(last_rows), B, Lmax,
                                              _ptr(kc), _ptr(vc), Smax, _ptr(ws), _ptr(hidden), _ptr(logits), _ptr(next_ids), _stream()),

@@ -365,3 +365,37 @@ def test_right_padded_batch_equals_per_sample_and_other_masks_raise(g4_model):
     left = am.flip(1)
     with pytest.raises(NotImplementedError):
         model.generate(ids.cuda(), modal_inputs={"vision": px.cuda()}, attention_mask=left.cuda(), max_new_tokens=2)
+
+
+def test_last_layer_tail_equals_the_full_last_layer(g4_model):
+    """generate()'s prefill runs the last decoder layer's attention + MLP for the last token of every sequence only (mc_llm option
+    "tail_adapter"): the first-step logits agree with the all-rows path to fp32 summation order of one attention row and three small GEMMs
+    (<= 4e-3 of the logit scale - both are within 1e-2 of the reference), the greedy ids are the same, the KV cache of the last layer is
+    BIT-identical (its q|k|v projection still covers every row), and forward() - which needs every row - is untouched; ragged batch too."""
+    model, a, meta, sd = g4_model
+    ids = a["input_ids"].cuda()
+    px = a["pixels"].cuda()
+    n_new = a["gen_ids"].shape[1]
+    outs = {}
+    for flag in (False, True):
+        model.last_layer_tail = flag
+        try:
+            res, lg = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=n_new, ignore_eos=True, return_step_logits=True)
+            torch.cuda.synchronize()
+            kc = [t.clone() for t in model._cache[next(k for k in model._cache if isinstance(k, tuple) and k and k[0] == "kv")]] \
+                if any(isinstance(k, tuple) and k and k[0] == "kv" for k in model._cache) else None
+            fw = model.forward(input_ids=ids, modal_inputs={"vision": px}).logits.clone()
+        finally:
+            del model.last_layer_tail
+        outs[flag] = (res.cpu(), lg.float().cpu(), kc, fw.float().cpu())
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][0][:, ids.shape[1]:], a["gen_ids"])
+    scale = a["step_logits"].abs().max().item()
+    d = (outs[True][1] - outs[False][1]).abs().max().item() / scale
+    print(f"[err] tail vs full last layer, step logits: {d:.3e}")
+    assert d <= 4e-3, d
+    within("tail step logits vs reference", outs[True][1], a["step_logits"], 1e-2)
+    assert torch.equal(outs[True][3], outs[False][3])                     # forward(): every row, never the tail
+    if outs[True][2] is not None:
+        for x, y in zip(outs[True][2], outs[False][2]):
+            assert torch.equal(x, y)

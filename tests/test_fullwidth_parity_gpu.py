@@ -208,6 +208,7 @@ def test_first_layer_stages_are_exact_to_rounding(name):
     meta["num_hidden_layers"] = 1
     sd = {k: v for k, v in sd.items() if not k.startswith("model.layers.1.")}
     model = build_from_state_dict(meta, sd)
+    model.last_layer_tail = False            # this one-layer model's only layer must run for every row: its stages are what is compared
     mid = fc.to_dev(mi)
     feats, _ = model.encode_modal_inputs(mid, model.prefix_tokens, model.suffix_tokens)
     plan = model._plan(ids.cuda(), None, None, mid, feats)
