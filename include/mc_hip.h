@@ -341,7 +341,11 @@ int mc_llm_destroy(void* handle);
  * (LlamaRotaryEmbedding of transformers 4.31, computed in fp32).                                                        */
 int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* final_norm, const void* lm_head_packed,
                        const void* embed_table, const float* cos_table, const float* sin_table);
-int mc_llm_set_option(void* handle, const char* name, int value);        /* "use_graph" */
+/* options: "use_graph" (decode steps replayed from a hipGraph, default 1); "profile" (below); "tail_adapter" (default -1 = off; a >= 0: the
+ * next mc_llm_prefill calls that ask for last-row logits / next ids only - hidden_out null - run the LAST layer's attention, o_proj and
+ * MLP for the last token of every sequence only, with adapter a's weights; the layer's q|k|v projection still covers every row, so the
+ * KV cache is what the all-rows path writes.  The caller guarantees that all last tokens are routed to adapter a) */
+int mc_llm_set_option(void* handle, const char* name, int value);
 /* read back: "use_graph"; "graph_active" = 1 when the last mc_llm_decode replayed a hipGraph (0: one launch per kernel); "graph_captures" /
  * "graph_failures" = decode-step graphs captured / capture attempts that failed since mc_llm_create */
 int mc_llm_get_option(void* handle, const char* name, int* value);
@@ -357,7 +361,8 @@ int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_
 int mc_llm_workspace_bytes(void* handle, int M, int B, int Lq, int64_t* bytes);
 /* Prefill over M rows in routed order.  group_start / group_adapter are HOST arrays (n_groups+1 / n_groups); the other
  * int32 arrays are device arrays: row_b/row_pos/row_t [M], out_map [B*Lq] (sequence slot -> routed row, -1 = padding),
- * kv_lens [B], last_rows [B] (routed row of each sample's last token).  x_routed is updated in place.             */
+ * kv_lens [B], last_rows [B] (routed row of each sample's last token).  x_routed is updated in place (with "tail_adapter" set and
+ * hidden_out null its rows hold the input of the last layer, not its output: only the last tokens' outputs exist, in the workspace). */
 int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups, const int32_t* group_start, const int32_t* group_adapter,
                    const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t, const int32_t* out_map,
                    const int32_t* kv_lens, const int32_t* last_rows, int B, int Lq, void* k_cache, void* v_cache, int Smax,
