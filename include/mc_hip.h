@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 6
+#define MC_ABI_VERSION 7
 
 /* activation codes for mc_gemm_bf16 */
 #define MC_ACT_NONE 0
@@ -303,7 +303,9 @@ int mc_sample_step_f32(const float* logits, int64_t ld, int64_t* next_ids, int64
  * mm_projector.bin, the base model's (sharded) pytorch_model-*.bin or *.safetensors, encoder checkpoints.  mc_ckpt_open maps the file and
  * indexes its tensors: torch zip archives (STORED zip / zip64 + a protocol-2 pickle read by a restricted interpreter that never calls
  * anything) and safetensors.  Every tensor is (name, dtype code, shape, strides in elements, pointer into the mapping); nested containers
- * are flattened with '.'-joined names.  Pointers stay valid until mc_ckpt_close.  Legacy non-zip torch files are refused (error 1).     */
+ * are flattened with '.'-joined names.  Pointers stay valid until mc_ckpt_close.  Legacy non-zip torch files are refused (error 1);
+ * every size, offset and count read from the file is bounds-checked with overflow-safe arithmetic, object trees deeper than 64 levels
+ * (or self-referential through the pickle memo) are refused.                                                                          */
 #define MC_CKPT_F32 0
 #define MC_CKPT_F16 1
 #define MC_CKPT_BF16 2
@@ -322,6 +324,20 @@ int mc_ckpt_entry(void* handle, int index, const char** name, int* dtype, int* n
                   const void** data, int64_t* storage_bytes);
 /* contiguous tensors only: hipMemcpyAsync from the mapped file to dst_device (numel * element size bytes) on `stream` */
 int mc_ckpt_copy_to_device(void* handle, int index, void* dst_device, void* stream);
+/* Non-tensor leaves of the object tree (None / bool / int / float / str): encoder checkpoints keep their configuration next to the
+ * weights - BEATs files are {'cfg': {...}, 'model': state_dict} (beats/BEATs.py:120-148 reads checkpoint['cfg']).  `name` is the
+ * '.'-joined key as for tensors; `path` (also mc_ckpt_entry_path for tensors) joins the levels with 0x1f and marks list / tuple
+ * indices with a leading 0x1e, so a caller can rebuild the exact tree even when keys contain dots.  svalue is NOT NUL-terminated
+ * text in general: use slen.  safetensors files have no scalars.                                                                     */
+#define MC_CKPT_NONE 0
+#define MC_CKPT_BOOLEAN 1
+#define MC_CKPT_INT 2
+#define MC_CKPT_FLOAT 3
+#define MC_CKPT_STR 4
+int mc_ckpt_entry_path(void* handle, int index, const char** path);
+int mc_ckpt_scalar_count(void* handle, int* n_scalars);
+int mc_ckpt_scalar(void* handle, int index, const char** name, const char** path, int* kind, int64_t* ivalue, double* fvalue,
+                   const char** svalue, int64_t* slen);
 
 /* ---- composed Vicuna backbone runtime (csrc/llm_runtime.cpp) -------------------------------------------
  * Replaces MultimodalLlamaModel.forward + lm_head (model/language_model/multimodal_llama.py:488-619, :720) and the

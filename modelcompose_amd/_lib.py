@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -143,6 +143,10 @@ _SIGS.update({
     "mc_ckpt_entry": [c_p, c_i, C.POINTER(C.c_char_p), C.POINTER(c_i), C.POINTER(c_i), C.POINTER(C.POINTER(c_l)), C.POINTER(C.POINTER(c_l)),
                       C.POINTER(c_p), C.POINTER(c_l)],
     "mc_ckpt_copy_to_device": [c_p, c_i, c_p, c_p],
+    "mc_ckpt_entry_path": [c_p, c_i, C.POINTER(C.c_char_p)],
+    "mc_ckpt_scalar_count": [c_p, C.POINTER(c_i)],
+    "mc_ckpt_scalar": [c_p, c_i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(c_i), C.POINTER(c_l), C.POINTER(C.c_double),
+                       C.POINTER(c_p), C.POINTER(c_l)],
     "mc_llm_profile_read": [c_p, c_i, C.POINTER(C.c_double), C.POINTER(c_l)],
 })
 # optional symbols added by later ABI revisions are bound if present

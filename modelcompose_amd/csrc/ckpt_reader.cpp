@@ -31,8 +31,19 @@ void mc_set_error(const char* fmt, ...);
 
 namespace {
 
+// Paths: the levels of the object tree joined by PATH_SEP; a level that is a list / tuple index starts with PATH_IDX (so a rebuilt tree
+// can tell {"0": x} from [x]).  Names ('.'-joined) stay what the flat state-dict readers use.
+constexpr char PATH_SEP = '\x1f', PATH_IDX = '\x1e';
+
+struct Scalar {                     // non-tensor leaf of the object tree (BEATs checkpoints keep their config dict next to the weights)
+    std::string name, path, s;
+    int kind = MC_CKPT_NONE;        // MC_CKPT_NONE / _BOOLEAN / _INT / _FLOAT / _STR
+    int64_t i = 0;
+    double f = 0;
+};
+
 struct Entry {
-    std::string name;
+    std::string name, path;
     int dtype = -1;                 // MC_CKPT_* code
     std::vector<int64_t> shape, stride;
     const uint8_t* data = nullptr;  // first element (storage base + storage_offset)
@@ -44,6 +55,7 @@ struct Ckpt {
     uint8_t* map = nullptr;
     size_t size = 0;
     std::vector<Entry> entries;
+    std::vector<Scalar> scalars;
     ~Ckpt() {
         if (map) munmap(map, size);
         if (fd >= 0) close(fd);
@@ -81,16 +93,18 @@ bool parse_zip(const Ckpt& c, std::map<std::string, ZipRec>& recs, std::string& 
     uint64_t cd_off = rd32(m + eocd + 16), cd_size = rd32(m + eocd + 12), total = rd16(m + eocd + 10);
     if (eocd >= 20 && rd32(m + eocd - 20) == 0x07064b50u) {            // zip64 locator -> zip64 end-of-central-directory record
         const uint64_t e64 = rd64(m + eocd - 20 + 8);
-        if (e64 + 56 > n || rd32(m + e64) != 0x06064b50u) { err = "corrupt zip64 end-of-central-directory record"; return false; }
+        if (e64 > n || n - e64 < 56 || rd32(m + e64) != 0x06064b50u) { err = "corrupt zip64 end-of-central-directory record"; return false; }
         total = rd64(m + e64 + 32); cd_size = rd64(m + e64 + 40); cd_off = rd64(m + e64 + 48);
     }
-    if (cd_off + cd_size > n) { err = "central directory outside the file"; return false; }
+    // every bound below is written as `x > n || y > n - x`: fields of an untrusted file must not wrap a 64-bit sum
+    if (cd_off > n || cd_size > n - cd_off) { err = "central directory outside the file"; return false; }
+    if (total > cd_size / 46) { err = "central directory entry count exceeds its size"; return false; }
     uint64_t p = cd_off;
     for (uint64_t k = 0; k < total; ++k) {
-        if (p + 46 > n || rd32(m + p) != 0x02014b50u) { err = "corrupt central directory entry"; return false; }
+        if (p > n || n - p < 46 || rd32(m + p) != 0x02014b50u) { err = "corrupt central directory entry"; return false; }
         const uint16_t method = rd16(m + p + 10), nlen = rd16(m + p + 28), xlen = rd16(m + p + 30), clen = rd16(m + p + 32);
         uint64_t csize = rd32(m + p + 20), usize = rd32(m + p + 24), lho = rd32(m + p + 42);
-        if (p + 46 + nlen + xlen + clen > n) { err = "corrupt central directory entry"; return false; }
+        if ((uint64_t)nlen + xlen + clen > n - p - 46) { err = "corrupt central directory entry"; return false; }
         std::string name((const char*)m + p + 46, nlen);
         // zip64 extended information: 64-bit fields replace the 0xFFFFFFFF placeholders, in this fixed order
         uint64_t x = p + 46 + nlen;
@@ -105,10 +119,10 @@ bool parse_zip(const Ckpt& c, std::map<std::string, ZipRec>& recs, std::string& 
             }
             x += 4 + sz;
         }
-        if (lho + 30 > n || rd32(m + lho) != 0x04034b50u) { err = "corrupt local file header of '" + name + "'"; return false; }
-        const uint64_t data = lho + 30 + rd16(m + lho + 26) + rd16(m + lho + 28);
+        if (lho > n || n - lho < 30 || rd32(m + lho) != 0x04034b50u) { err = "corrupt local file header of '" + name + "'"; return false; }
+        const uint64_t data = lho + 30 + rd16(m + lho + 26) + rd16(m + lho + 28);            // lho <= n - 30: cannot wrap
         if (method != 0 || csize != usize) { err = "record '" + name + "' is compressed; torch checkpoints are stored uncompressed"; return false; }
-        if (data + usize > n) { err = "record '" + name + "' outside the file"; return false; }
+        if (data > n || usize > n - data) { err = "record '" + name + "' outside the file"; return false; }
         recs[name] = ZipRec{data, usize};
         p += 46 + nlen + xlen + clen;
     }
@@ -319,36 +333,64 @@ struct Unpickler {
     }
 };
 
-bool flatten(const VP& v, const std::string& prefix, Ckpt& c, const std::map<std::string, ZipRec>& recs, const std::string& root, std::string& err) {
+constexpr int MAX_DEPTH = 64;       // of the object tree (a pickle can build a self-referential container through its memo)
+
+bool flatten(const VP& v, const std::string& prefix, const std::string& path, int depth, Ckpt& c, const std::map<std::string, ZipRec>& recs,
+             const std::string& root, std::string& err) {
+    if (depth > MAX_DEPTH) { err = "object tree deeper than 64 levels (or self-referential) at '" + prefix + "'"; return false; }
+    auto join = [](const std::string& a, const std::string& b, char sep) { return a.empty() ? b : a + sep + b; };
     if (v->kind == Val::DICT) {
         for (auto& kv : v->dict) {
             std::string key;
             if (kv.first->kind == Val::STR) key = kv.first->s;
             else if (kv.first->kind == Val::INT) key = std::to_string(kv.first->i);
             else continue;
-            if (!flatten(kv.second, prefix.empty() ? key : prefix + "." + key, c, recs, root, err)) return false;
+            if (!flatten(kv.second, join(prefix, key, '.'), join(path, key, PATH_SEP), depth + 1, c, recs, root, err)) return false;
         }
         return true;
     }
-    if (v->kind != Val::TENSOR) return true;              // scalars / opaque objects carry no tensor data
+    if (v->kind == Val::LIST || v->kind == Val::TUPLE) {
+        for (size_t k = 0; k < v->items.size(); ++k) {
+            const std::string key = std::to_string(k);
+            if (!flatten(v->items[k], join(prefix, key, '.'), join(path, std::string(1, PATH_IDX) + key, PATH_SEP), depth + 1, c, recs, root, err)) return false;
+        }
+        return true;
+    }
+    if (v->kind == Val::NONE || v->kind == Val::BOOL || v->kind == Val::INT || v->kind == Val::FLOAT || v->kind == Val::STR) {
+        Scalar sc;
+        sc.name = prefix; sc.path = path; sc.i = v->i; sc.f = v->f; sc.s = v->s;
+        sc.kind = v->kind == Val::NONE ? MC_CKPT_NONE : v->kind == Val::BOOL ? MC_CKPT_BOOLEAN : v->kind == Val::INT ? MC_CKPT_INT
+                : v->kind == Val::FLOAT ? MC_CKPT_FLOAT : MC_CKPT_STR;
+        c.scalars.push_back(std::move(sc));
+        return true;
+    }
+    if (v->kind != Val::TENSOR) return true;              // opaque objects carry nothing
     auto it = recs.find(root + "data/" + v->storage->s);
     if (it == recs.end()) { err = "storage record '" + v->storage->s + "' of tensor '" + prefix + "' is missing"; return false; }
     const int es = elt_size(v->dtype);
     if (es == 0) { err = "tensor '" + prefix + "' has an unsupported storage type"; return false; }
-    // the furthest element a strided view touches must lie inside its storage record
+    // the furthest element a strided view touches must lie inside its storage record; every product / sum is overflow-checked
+    // (shape, stride and offset come straight from the pickle)
     int64_t span = 1;
     bool empty = false;
     for (size_t d = 0; d < v->shape.size(); ++d) {
         if (v->shape[d] < 0 || v->stride[d] < 0) { err = "tensor '" + prefix + "' has a negative size or stride"; return false; }
         if (v->shape[d] == 0) empty = true;
-        span += (v->shape[d] - 1) * v->stride[d];
     }
-    if (empty) span = 0;
-    if (v->offset < 0 || (uint64_t)(v->offset + span) * es > it->second.size) { err = "tensor '" + prefix + "' reaches outside its storage record"; return false; }
+    const std::string outside = "tensor '" + prefix + "' reaches outside its storage record";
+    if (!empty)
+        for (size_t d = 0; d < v->shape.size(); ++d) {
+            int64_t step;
+            if (__builtin_mul_overflow(v->shape[d] - 1, v->stride[d], &step) || __builtin_add_overflow(span, step, &span)) { err = outside; return false; }
+        }
+    else span = 0;
+    int64_t last, bytes, off_bytes;
+    if (v->offset < 0 || __builtin_add_overflow(v->offset, span, &last) || __builtin_mul_overflow(last, (int64_t)es, &bytes) ||
+        (uint64_t)bytes > it->second.size || __builtin_mul_overflow(v->offset, (int64_t)es, &off_bytes)) { err = outside; return false; }
     Entry e;
-    e.name = prefix; e.dtype = v->dtype; e.shape = v->shape; e.stride = v->stride;
-    e.data = c.map + it->second.off + (uint64_t)v->offset * es;
-    e.storage_bytes_left = (int64_t)(it->second.size - (uint64_t)v->offset * es);
+    e.name = prefix; e.path = path; e.dtype = v->dtype; e.shape = v->shape; e.stride = v->stride;
+    e.data = c.map + it->second.off + (uint64_t)off_bytes;
+    e.storage_bytes_left = (int64_t)(it->second.size - (uint64_t)off_bytes);
     c.entries.push_back(std::move(e));
     return true;
 }
@@ -370,7 +412,7 @@ bool load_torch_zip(Ckpt& c, std::string& err) {
     Unpickler u{c.map + pkl->off, c.map + pkl->off + pkl->size, {}, {}, {}};
     VP top;
     if (!u.run(top)) { err = "data.pkl: " + u.err; return false; }
-    return flatten(top, "", c, recs, root, err);
+    return flatten(top, "", "", 0, c, recs, root, err);
 }
 
 // ------------------------------------------------------------------------------------------------ safetensors
@@ -408,7 +450,8 @@ struct Json {
         ++p;
         return true;
     }
-    bool skip() {                                   // any value
+    bool skip(int depth = 0) {                      // any value
+        if (depth > MAX_DEPTH) { err = "JSON nested deeper than 64 levels"; return false; }
         ws();
         if (p >= end) { err = "unexpected end"; return false; }
         if (*p == '"') { std::string s; return str(s); }
@@ -418,7 +461,7 @@ struct Json {
             if (p < end && *p == close) { ++p; return true; }
             while (true) {
                 if (close == '}') { std::string k; if (!str(k)) return false; ws(); if (p >= end || *p != ':') { err = "expected ':'"; return false; } ++p; }
-                if (!skip()) return false;
+                if (!skip(depth + 1)) return false;
                 ws();
                 if (p < end && *p == ',') { ++p; continue; }
                 if (p < end && *p == close) { ++p; return true; }
@@ -439,7 +482,8 @@ struct Json {
             if (p < end && *p == '-') { neg = true; ++p; }
             if (p >= end || *p < '0' || *p > '9') { err = "expected an integer"; return false; }
             int64_t v = 0;
-            while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+            while (p < end && *p >= '0' && *p <= '9')
+                if (__builtin_mul_overflow(v, (int64_t)10, &v) || __builtin_add_overflow(v, (int64_t)(*p++ - '0'), &v)) { err = "integer out of range"; return false; }
             out.push_back(neg ? -v : v);
             ws();
             if (p < end && *p == ',') { ++p; continue; }
@@ -503,8 +547,14 @@ bool load_safetensors(Ckpt& c, std::string& err) {
             }
             const int es = elt_size(e.dtype);
             int64_t numel = 1;
-            for (int64_t d : e.shape) { if (d < 0) { err = "negative dimension in '" + name + "'"; return false; } numel *= d; }
-            if (es == 0 || offs.size() != 2 || offs[0] < 0 || offs[1] < offs[0] || (uint64_t)offs[1] > data_bytes || offs[1] - offs[0] != numel * es) {
+            bool ovf = false;
+            for (int64_t d : e.shape) {
+                if (d < 0) { err = "negative dimension in '" + name + "'"; return false; }
+                ovf |= __builtin_mul_overflow(numel, d, &numel);
+            }
+            int64_t nbytes = 0;
+            ovf |= __builtin_mul_overflow(numel, (int64_t)es, &nbytes);
+            if (ovf || es == 0 || offs.size() != 2 || offs[0] < 0 || offs[1] < offs[0] || (uint64_t)offs[1] > data_bytes || offs[1] - offs[0] != nbytes) {
                 err = "tensor '" + name + "': dtype / shape / data_offsets are inconsistent"; return false;
             }
             e.stride.assign(e.shape.size(), 1);
@@ -574,6 +624,34 @@ extern "C" int mc_ckpt_entry(void* handle, int index, const char** name, int* dt
     return 0;
 }
 
+extern "C" int mc_ckpt_entry_path(void* handle, int index, const char** path) {
+    Ckpt* c = (Ckpt*)handle;
+    if (!c || index < 0 || index >= (int)c->entries.size() || !path) { mc_set_error("mc_ckpt_entry_path: bad handle or index %d", index); return 1; }
+    *path = c->entries[index].path.c_str();
+    return 0;
+}
+
+extern "C" int mc_ckpt_scalar_count(void* handle, int* n) {
+    if (!handle || !n) { mc_set_error("mc_ckpt_scalar_count: null argument"); return 1; }
+    *n = (int)((Ckpt*)handle)->scalars.size();
+    return 0;
+}
+
+extern "C" int mc_ckpt_scalar(void* handle, int index, const char** name, const char** path, int* kind, int64_t* ivalue, double* fvalue,
+                              const char** svalue, int64_t* slen) {
+    Ckpt* c = (Ckpt*)handle;
+    if (!c || index < 0 || index >= (int)c->scalars.size()) { mc_set_error("mc_ckpt_scalar: bad handle or index %d", index); return 1; }
+    const Scalar& sc = c->scalars[index];
+    if (name) *name = sc.name.c_str();
+    if (path) *path = sc.path.c_str();
+    if (kind) *kind = sc.kind;
+    if (ivalue) *ivalue = sc.i;
+    if (fvalue) *fvalue = sc.f;
+    if (svalue) *svalue = sc.s.data();
+    if (slen) *slen = (int64_t)sc.s.size();
+    return 0;
+}
+
 // Host-to-device copy of a CONTIGUOUS tensor straight from the mapped file (no intermediate host buffer); dst holds numel * element size bytes.
 extern "C" int mc_ckpt_copy_to_device(void* handle, int index, void* dst_device, void* stream) {
     Ckpt* c = (Ckpt*)handle;
@@ -582,11 +660,16 @@ extern "C" int mc_ckpt_copy_to_device(void* handle, int index, void* dst_device,
     int64_t numel = 1, expect = 1;
     for (int d = (int)e.shape.size() - 1; d >= 0; --d) {
         if (e.shape[d] != 1 && e.stride[d] != expect) { mc_set_error("mc_ckpt_copy_to_device: tensor '%s' is not contiguous", e.name.c_str()); return 1; }
-        expect *= e.shape[d];
-        numel *= e.shape[d];
+        if (__builtin_mul_overflow(expect, e.shape[d], &expect) || __builtin_mul_overflow(numel, e.shape[d], &numel)) {
+            mc_set_error("mc_ckpt_copy_to_device: tensor '%s' is too large", e.name.c_str()); return 1;
+        }
     }
     if (numel == 0) return 0;
-    hipError_t err = hipMemcpyAsync(dst_device, e.data, (size_t)numel * elt_size(e.dtype), hipMemcpyHostToDevice, (hipStream_t)stream);
+    int64_t nbytes;
+    if (__builtin_mul_overflow(numel, (int64_t)elt_size(e.dtype), &nbytes) || nbytes > e.storage_bytes_left) {
+        mc_set_error("mc_ckpt_copy_to_device: tensor '%s' reaches outside its storage record", e.name.c_str()); return 1;
+    }
+    hipError_t err = hipMemcpyAsync(dst_device, e.data, (size_t)nbytes, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (err != hipSuccess) { mc_set_error("mc_ckpt_copy_to_device: %s", hipGetErrorString(err)); return 2; }
     return 0;
 }

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from ..checkpoint_io import load_tensors
+from ..checkpoint_io import load_nested, load_tensors
 
 from .. import ops
 from .clip import _strip
@@ -71,7 +71,7 @@ class HipBeatsAudioEncoder:
         except Exception:
             self.audio_processor = None
         if audio_encoder is not None and os.path.isfile(str(audio_encoder)):
-            ck = load_tensors(audio_encoder)
+            ck = self._read_checkpoint(audio_encoder)
             self.cfg = BeatsConfig(ck["cfg"])
             if not delay_load:
                 self.load_state_dict(ck["model"])
@@ -85,9 +85,18 @@ class HipBeatsAudioEncoder:
         return {"audio_inputs": torch.zeros(1, 1024, 128, device=self.device, dtype=self.dtype),
                 "audio_padding_mask": torch.zeros(1, 1024, device=self.device, dtype=torch.bool)}
 
+    @staticmethod
+    def _read_checkpoint(path):
+        """BEATs files are {'cfg': {...scalars...}, 'model': state_dict} (beats/BEATs.py:120-148 reads checkpoint['cfg'] and
+        checkpoint['model']): the tree form of the native reader keeps the config's scalar leaves."""
+        ck = load_nested(path)
+        if not isinstance(ck, dict) or "cfg" not in ck or "model" not in ck:
+            raise KeyError(f"{path}: a BEATs checkpoint holds 'cfg' and 'model'; found {sorted(ck) if isinstance(ck, dict) else type(ck).__name__}")
+        return ck
+
     def load_model(self):
         if not self.is_loaded:
-            ck = load_tensors(self.audio_encoder_name)
+            ck = self._read_checkpoint(self.audio_encoder_name)
             self.cfg = BeatsConfig(ck["cfg"])
             self.load_state_dict(ck["model"])
 

@@ -23,6 +23,10 @@ Groups:
   g12 host callers: length-grouped samplers, LLaVA -> multimodal checkpoint conversion
   g13 prompt helpers of mm_utils.py: placeholder tokenisation, stopping criteria, expand2square
   g14 caller-side data formats: preprocess (conversation -> ids / labels) and the batch collator
+  g15 FULL DEPTH: the metric's model (3-way composed Vicuna-7B, 32 layers, real widths, real-size encoders) on two rows of the metric's
+      inputs, 17 greedy tokens, by the pinned oracle (oracle/pipeline.py, fp32 branch form).  NOT part of the default run: 45 GB of
+      memory and ~15 minutes of CPU; `python -m oracle.gen_golden g15`.  The reference classes themselves cannot be instantiated at
+      this size in 64 GB next to the oracle, so this group is oracle output (pinned by g1-g8), not reference output.
 """
 from __future__ import annotations
 
@@ -1072,11 +1076,44 @@ def g14():
     _save("g14_data", meta=np.array(json.dumps(meta)), **arrays)
 
 
+def g15():
+    """Full-depth parity fixture.  Case definition: tests/fullwidth_cases.py DEPTH_CASES["fulldepth_iav"] (CPU-generator
+    weights and inputs, reproduced bit for bit on the GPU box).  Stored: the new ids, the FULL fp32 logits rows of every step (so any
+    top-k / margin can be derived), the fp32 encoder feature blocks' norms and the per-layer hidden-state scale of the last prompt token
+    (diagnostics of depth-wise growth).  Follows multimodal_llama.py:488-619 (model forward), eval/model_multimodal_qa_loader.py:94-108
+    (greedy generate call)."""
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    import fullwidth_cases as fc
+    from . import pipeline
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name, fname in (("fulldepth_iav", "g15_fulldepth_iav"), ("depth8_iav", "g15_depth8_iav")):
+        t0 = time.time()
+        meta, sd, ids, mi = fc.build_case(name)
+        fc.sd_to_f32_inplace(sd)
+        t1 = time.time()
+        with torch.no_grad():
+            om = pipeline.OracleModel.from_state_dict(sd, meta)
+            new_ids, logits = om.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True)
+        t2 = time.time()
+        print(f"{name}: weights {t1 - t0:.0f}s oracle {t2 - t1:.0f}s ids {new_ids.tolist()} min margin {fc.margins(logits).min().item():.2e}")
+        _save(fname, ids=new_ids, logits=logits.float(), input_ids=ids, margins=fc.margins(logits),
+              meta=np.frombuffer(json.dumps({"case": name, "layers": meta["num_hidden_layers"], "seed": fc.DEPTH_CASES[name]["seed"],
+                                             "row_seeds": fc.DEPTH_CASES[name]["row_seeds"], "oracle_seconds": round(t2 - t1, 1)}).encode(), dtype=np.uint8))
+        del sd, om
+
+
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
           "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14}
+SLOW_GROUPS = {"g15": g15}          # by name only
 
 
 def main(argv):
+    if argv and all(a in SLOW_GROUPS for a in argv):
+        for a in argv:
+            print(f"== {a}")
+            SLOW_GROUPS[a]()
+        return
     refshim.install()
     todo = argv or list(GROUPS)
     for g in todo:

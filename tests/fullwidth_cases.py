@@ -43,11 +43,27 @@ CASES = {
 }
 
 
+# Full DEPTH: the metric's model - 3-way composed Vicuna-7B, all 32 decoder layers, image + audio + video, spliced length
+# 2793 - on two unscreened rows.  The oracle side is a committed fixture (tests/golden/g15_fulldepth_iav.npz, written in the build
+# container by `python -m oracle.gen_golden g15`: ~45 GB of fp32 weights and ~15 minutes of CPU, too much for the GPU box's test run);
+# `depth8` is the same model cut to 8 layers, cheap enough for the oracle to run next to the test (error growth 2 -> 8 -> 32 layers).
+DEPTH_CASES = {
+    "fulldepth_iav": dict(modals=("vision", "audio", "video"), reset="default-vision=0.333,default-audio=0.333,default-video=0.333",
+                          inputs=("vision", "audio", "video"), seed=41, row_seeds=[700, 701], layers=32),
+    "depth8_iav": dict(modals=("vision", "audio", "video"), reset="default-vision=0.333,default-audio=0.333,default-video=0.333",
+                       inputs=("vision", "audio", "video"), seed=41, row_seeds=[700], layers=8),
+}
+
+
+def _case(name):
+    return CASES[name] if name in CASES else DEPTH_CASES[name]
+
+
 def build_weights(name: str, lora_b_std: float = 0.01):
     """-> (meta, sd bf16 on the CPU)."""
     from modelcompose_amd import synthetic
-    c = CASES[name]
-    meta = synthetic.vicuna7b_meta(c["modals"], c["reset"], layers=2)
+    c = _case(name)
+    meta = synthetic.vicuna7b_meta(c["modals"], c["reset"], layers=c.get("layers", 2))
     sd = synthetic.synthetic_state_dict(meta, device="cpu", seed=c["seed"], dtype=torch.bfloat16)
     if lora_b_std != 0.01:
         for k in sd:
@@ -59,7 +75,7 @@ def build_weights(name: str, lora_b_std: float = 0.01):
 def build_rows(name: str, row_seeds=None):
     """-> (input_ids (B, L_text), modal_inputs bf16 on the CPU): row r is drawn from its own generator (seed row_seeds[r])."""
     from modelcompose_amd import synthetic
-    c = CASES[name]
+    c = _case(name)
     row_seeds = c["row_seeds"] if row_seeds is None else row_seeds
     ids, per = [], {m: [] for m in c["inputs"]}
     for rs in row_seeds:
@@ -93,6 +109,16 @@ def build_case(name: str, row_seeds=None, lora_b_std: float = 0.01):
     if "point" in mi:
         meta["fps_start"] = [0] * ids.shape[0]
     return meta, sd, ids, mi
+
+
+def sd_to_f32_inplace(sd):
+    """bf16 -> fp32 one tensor at a time (a 32-layer state dict is 17 GB in bf16 and 35 GB in fp32: never hold both)."""
+    for k in list(sd):
+        v = sd[k]
+        if v.is_floating_point() and v.dtype != torch.float32:
+            sd[k] = v.float()
+            del v
+    return sd
 
 
 def to_f32(x):

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from modelcompose_amd import _lib
-from modelcompose_amd.checkpoint_io import MappedCheckpoint, load_tensors
+from modelcompose_amd.checkpoint_io import MappedCheckpoint, load_nested, load_tensors
 
 
 def same(a: torch.Tensor, b: torch.Tensor):
@@ -67,9 +67,52 @@ def test_nested_containers_are_flattened_and_scalars_skipped(tmp_path):
     p = tmp_path / "ckpt.bin"
     torch.save(obj, p)
     got = load_tensors(str(p))
-    assert set(got) == {"model.a", "model.b.c"}
+    assert set(got) == {"model.a", "model.b.c", "tuple.0"}
     same(got["model.a"], torch.ones(2))
     same(got["model.b.c"], torch.zeros(3, dtype=torch.int64))
+    # the tree form keeps the scalar leaves (BEATs files are {'cfg': {...}, 'model': state_dict})
+    tree = load_nested(str(p))
+    assert tree["step"] == 7 and tree["lr"] == 1e-3 and tree["name"] == "x" and tree["flag"] is True and tree["none"] is None
+    assert tree["list"] == [1, 2, 3] and isinstance(tree["tuple"], list) and torch.equal(tree["tuple"][0], torch.ones(1))
+    same(tree["model"]["b"]["c"], torch.zeros(3, dtype=torch.int64))
+
+
+def test_keys_with_dots_and_numeric_keys_survive_the_tree_form(tmp_path):
+    obj = {"cfg": {"a.b": 1, "neg": -5, "big": 2 ** 40, "f": -0.25, "s": "caf\u00e9", "empty": ""}, "model": {"enc.0.weight": torch.ones(2), "0": torch.zeros(1)},
+           3: {"x": 2.5}}
+    p = tmp_path / "t.bin"
+    torch.save(obj, p)
+    tree = load_nested(str(p))
+    assert tree["cfg"] == {"a.b": 1, "neg": -5, "big": 2 ** 40, "f": -0.25, "s": "caf\u00e9", "empty": ""}
+    assert set(tree["model"]) == {"enc.0.weight", "0"} and isinstance(tree["model"], dict)       # a dict keyed "0" is not a list
+    assert tree["3"] == {"x": 2.5}
+
+
+def test_beats_checkpoint_layout_loads_through_the_encoder_class(tmp_path):
+    """the reference loads BEATs as checkpoint['cfg'] / checkpoint['model'] (beats/BEATs.py:120-148,
+    multimodal_encoder/audio_encoder.py:20-31).  The class must find both in a real-layout file; the state dict is loaded on the GPU only,
+    so here the config half is asserted and the weights half is checked to arrive under their un-prefixed names."""
+    from modelcompose_amd.model.encoders_extra import BeatsConfig, HipBeatsAudioEncoder
+    cfg = {"encoder_layers": 2, "encoder_embed_dim": 64, "encoder_ffn_embed_dim": 128, "encoder_attention_heads": 4, "activation_fn": "gelu",
+           "deep_norm": True, "relative_position_embedding": True, "gru_rel_pos": True, "input_patch_size": 16, "embed_dim": 32,
+           "num_buckets": 320, "max_distance": 800, "conv_pos": 128, "conv_pos_groups": 16, "dropout": 0.1, "layer_norm_first": False, "conv_bias": False}
+    model = {"patch_embedding.weight": torch.randn(32, 1, 16, 16), "layer_norm.weight": torch.ones(32), "layer_norm.bias": torch.zeros(32),
+             "encoder.layers.0.self_attn.k_proj.weight": torch.randn(64, 64)}
+    p = tmp_path / "BEATs_iter3_plus_AS2M_finetuned_on_AS2M_cpt2.pt"
+    torch.save({"cfg": cfg, "model": model}, p)
+    ck = HipBeatsAudioEncoder._read_checkpoint(str(p))
+    assert ck["cfg"] == cfg
+    assert list(ck["model"]) == list(model)
+    for k in model:
+        same(ck["model"][k], model[k])
+    c = BeatsConfig(ck["cfg"])
+    assert c.deep_norm is True and c.gru_rel_pos is True and c.input_patch_size == 16 and c.encoder_layers == 2 and c.max_distance == 800
+    enc = HipBeatsAudioEncoder(str(p), delay_load=True, device="cpu")           # constructor path: config from the file, weights deferred
+    assert enc.cfg.encoder_embed_dim == 64 and enc.hidden_size == 64 and not enc.is_loaded
+    q = tmp_path / "flat.pt"
+    torch.save(model, q)
+    with pytest.raises(KeyError, match="'cfg' and 'model'"):
+        HipBeatsAudioEncoder._read_checkpoint(str(q))
 
 
 def test_sharded_base_checkpoint_through_the_builder(tmp_path):
@@ -128,11 +171,18 @@ def test_hostile_and_malformed_files_are_refused_without_executing(tmp_path):
     assert set(got) == {"w"} and not os.path.exists(marker)
     with pytest.raises(Exception):
         torch.load(p, map_location="cpu", weights_only=True)        # torch's restricted unpickler rejects the same file
-    # legacy (non-zip) torch format
+    # legacy (non-zip) torch format: the native reader refuses it, load_tensors falls back to torch's own restricted unpickler
     q = tmp_path / "legacy.bin"
-    torch.save({"w": torch.ones(2)}, q, _use_new_zipfile_serialization=False)
-    with pytest.raises(ValueError, match="neither a zip"):
-        load_tensors(str(q))
+    torch.save({"w": torch.arange(3.0), "n": {"v": torch.ones(2)}}, q, _use_new_zipfile_serialization=False)
+    h = C.c_void_p(0)
+    assert _lib.lib().mc_ckpt_open(str(q).encode(), C.byref(h)) == 1 and b"neither a zip" in _lib.lib().mc_last_error()
+    leg = load_tensors(str(q))
+    assert set(leg) == {"w", "n.v"} and torch.equal(leg["w"], torch.arange(3.0))
+    q2 = tmp_path / "legacy_evil.bin"
+    torch.save({"w": torch.ones(2), "boom": _Evil()}, q2, _use_new_zipfile_serialization=False)
+    with pytest.raises(Exception):
+        load_tensors(str(q2))
+    assert not os.path.exists(marker)
     # truncated archive
     data = open(p, "rb").read()
     r = tmp_path / "trunc.bin"
@@ -164,3 +214,190 @@ def test_c_abi_enumeration_directly(tmp_path):
     assert list((C.c_int32 * 6).from_address(data.value)) == [0, 1, 2, 3, 4, 5]
     assert L.mc_ckpt_entry(h, 2, None, None, None, None, None, None, None) == 1
     assert L.mc_ckpt_close(h) == 0
+
+
+# ---- crafted files: every size / offset / count of an untrusted file must be checked without wrapping -------------
+def _zip_parts(path):
+    """-> (bytes, eocd offset, [central directory entry offsets])."""
+    b = bytearray(open(path, "rb").read())
+    eocd = b.rfind(b"PK\x05\x06")
+    total, cd_off = struct.unpack_from("<H", b, eocd + 10)[0], struct.unpack_from("<I", b, eocd + 16)[0]
+    offs, p = [], cd_off
+    for _ in range(total):
+        assert b[p:p + 4] == b"PK\x01\x02"
+        nlen, xlen, clen = struct.unpack_from("<HHH", b, p + 28)
+        offs.append(p)
+        p += 46 + nlen + xlen + clen
+    return b, eocd, offs
+
+
+def _entry_name(b, p):
+    return bytes(b[p + 46:p + 46 + struct.unpack_from("<H", b, p + 28)[0]]).decode()
+
+
+def _refused(path, match=None):
+    h = C.c_void_p(0)
+    rc = _lib.lib().mc_ckpt_open(str(path).encode(), C.byref(h))
+    msg = _lib.lib().mc_last_error().decode()
+    assert rc == 1 and not h.value, (rc, msg)
+    if match:
+        assert match in msg, msg
+
+
+@pytest.mark.parametrize("usize", [2 ** 64 - 1, 2 ** 64 - 64, 2 ** 63, 2 ** 40])
+def test_zip64_record_size_near_the_top_of_the_range_is_refused(tmp_path, usize):
+    """A zip64 extended-information field with an uncompressed size of ~2^64: `data + usize` wraps to a small number.  Before the fix the
+    record was accepted with a huge size and every tensor offset inside it passed the storage bound."""
+    p = tmp_path / "ok.bin"
+    torch.save({"w": torch.arange(64, dtype=torch.float32)}, p)
+    b, eocd, offs = _zip_parts(p)
+    tgt = next(o for o in offs if "data/" in _entry_name(b, o))
+    nlen, xlen, clen = struct.unpack_from("<HHH", b, tgt + 28)
+    # rebuild that central-directory entry with 0xFFFFFFFF sizes and a zip64 extra field carrying (usize, csize)
+    head = bytearray(b[tgt:tgt + 46])
+    struct.pack_into("<II", head, 20, 0xFFFFFFFF, 0xFFFFFFFF)
+    extra = struct.pack("<HHQQ", 1, 16, usize, usize)
+    struct.pack_into("<H", head, 30, len(extra))
+    new_entry = bytes(head) + bytes(b[tgt + 46:tgt + 46 + nlen]) + extra + bytes(b[tgt + 46 + nlen + xlen:tgt + 46 + nlen + xlen + clen])
+    grow = len(new_entry) - (46 + nlen + xlen + clen)
+    nb = b[:tgt] + new_entry + b[tgt + 46 + nlen + xlen + clen:]
+    e2 = eocd + grow
+    if struct.unpack_from("<I", nb, e2 + 12)[0] != 0xFFFFFFFF:
+        struct.pack_into("<I", nb, e2 + 12, struct.unpack_from("<I", nb, e2 + 12)[0] + grow)      # central directory size
+    if nb[e2 - 20:e2 - 16] == b"PK\x06\x07":                                                      # torch's writer emits zip64 records
+        e64 = struct.unpack_from("<Q", nb, e2 - 20 + 8)[0] + grow
+        struct.pack_into("<Q", nb, e2 - 20 + 8, e64)
+        assert nb[e64:e64 + 4] == b"PK\x06\x06"
+        struct.pack_into("<Q", nb, e64 + 40, struct.unpack_from("<Q", nb, e64 + 40)[0] + grow)
+    q = tmp_path / "huge.bin"
+    open(q, "wb").write(nb)
+    _refused(q, "outside the file")
+    with pytest.raises(ValueError):
+        load_tensors(str(q))
+
+
+def test_corrupt_zip64_locator_and_directory_fields_are_refused(tmp_path):
+    p = tmp_path / "ok.bin"
+    torch.save({"w": torch.ones(8)}, p)
+    b, eocd, offs = _zip_parts(p)
+    # (1) a zip64 locator in front of the EOCD pointing near 2^64 (e64 + 56 wraps)
+    loc = struct.pack("<IIQI", 0x07064b50, 0, 2 ** 64 - 8, 1)
+    q = tmp_path / "loc.bin"
+    open(q, "wb").write(bytes(b[:eocd]) + loc + bytes(b[eocd:]))
+    _refused(q, "zip64")
+    has64 = b[eocd - 20:eocd - 16] == b"PK\x06\x07"
+    e64 = struct.unpack_from("<Q", b, eocd - 20 + 8)[0] if has64 else None
+    # (2) central directory offset beyond the file / offset + size wrapping 64 bits
+    c = bytearray(b)
+    struct.pack_into("<I", c, eocd + 16, 0xFFFFFF00)
+    if has64:
+        struct.pack_into("<Q", c, e64 + 48, 2 ** 64 - 16)
+    q = tmp_path / "cd.bin"
+    open(q, "wb").write(c)
+    _refused(q, "central directory")
+    # (3) local-header offset beyond the file
+    c = bytearray(b)
+    struct.pack_into("<I", c, offs[0] + 42, 0xFFFFFFF0)
+    q = tmp_path / "lho.bin"
+    open(q, "wb").write(c)
+    _refused(q, "local file header")
+    # (4) entry count far larger than the directory can hold
+    c = bytearray(b)
+    struct.pack_into("<H", c, eocd + 10, 0xFFFF)
+    if has64:
+        struct.pack_into("<Q", c, e64 + 32, 2 ** 63)
+    q = tmp_path / "count.bin"
+    open(q, "wb").write(c)
+    _refused(q)
+
+
+def _save_with_patched_pickle(tmp_path, name, patch):
+    """torch.save a one-tensor dict, then rewrite data.pkl in place (same length) through `patch(bytes) -> bytes`."""
+    p = tmp_path / (name + "_src.bin")
+    torch.save({"w": torch.arange(6, dtype=torch.float32).reshape(2, 3)}, p)
+    b, eocd, offs = _zip_parts(p)
+    tgt = next(o for o in offs if _entry_name(b, o).endswith("data.pkl"))
+    lho = struct.unpack_from("<I", b, tgt + 42)[0]
+    size = struct.unpack_from("<I", b, tgt + 24)[0]
+    data = lho + 30 + struct.unpack_from("<H", b, lho + 26)[0] + struct.unpack_from("<H", b, lho + 28)[0]
+    new = patch(bytes(b[data:data + size]))
+    assert len(new) == size
+    b[data:data + size] = new
+    q = tmp_path / (name + ".bin")
+    open(q, "wb").write(b)
+    return q
+
+
+def test_shapes_and_strides_that_overflow_int64_are_refused(tmp_path):
+    # shape (2, 3) is pickled as K\x02 K\x03 \x86 (BININT1 x2 + TUPLE2); strides (3, 1) follow the same way.  Replace the stride tuple's
+    # two BININT1 by ... not enough room for 8-byte ints, so grow the numbers through the storage offset instead: the offset is the
+    # BININT1 right after the persistent-id tuple ('K\x00').  A same-length patch cannot carry a 2^62 value, so this case builds its
+    # pickle by hand below.
+    import io
+    import zipfile
+
+    def make(shape, stride, offset, numel=6):
+        pk = io.BytesIO()
+        P = pickle.Pickler(pk, protocol=2)          # only used for its opcode constants through dumps of plain objects
+
+        def long1(v):
+            raw = v.to_bytes(8, "little", signed=True)
+            return b"\x8a\x08" + raw
+        body = b"\x80\x02}q\x00X\x01\x00\x00\x00wq\x01ctorch._utils\n_rebuild_tensor_v2\nq\x02("
+        body += b"(X\x07\x00\x00\x00storageq\x03ctorch\nFloatStorage\nq\x04X\x01\x00\x00\x000q\x05X\x03\x00\x00\x00cpuq\x06" + long1(numel) + b"tq\x07Q"
+        body += long1(offset)
+        body += b"(" + b"".join(long1(d) for d in shape) + b"t"
+        body += b"(" + b"".join(long1(d) for d in stride) + b"t"
+        body += b"\x89ccollections\nOrderedDict\nq\x08)Rq\ttq\nRq\x0bs."
+        zb = io.BytesIO()
+        with zipfile.ZipFile(zb, "w", zipfile.ZIP_STORED) as z:
+            z.writestr("archive/data.pkl", body)
+            z.writestr("archive/data/0", struct.pack("<6f", *range(6)))
+            z.writestr("archive/version", b"3\n")
+        return zb.getvalue()
+    ok = tmp_path / "hand_ok.bin"
+    open(ok, "wb").write(make((2, 3), (3, 1), 0))
+    same(load_tensors(str(ok))["w"], torch.arange(6, dtype=torch.float32).reshape(2, 3))          # the hand-built pickle is well-formed
+    for tag, (shape, stride, offset) in {
+            "span_mul": ((2 ** 62, 2 ** 62), (2 ** 62, 1), 0),           # (shape-1)*stride overflows
+            "span_add": ((2 ** 62, 2), (3, 2 ** 62), 0),                 # sum overflows
+            "bytes_mul": ((2 ** 61,), (1,), 2 ** 61),                    # (offset + span) * 4 overflows
+            "offset_big": ((1,), (1,), 2 ** 63 - 1),                     # offset + span overflows
+            "past_end": ((2, 3), (3, 1), 1),                             # plain out-of-record view
+            "neg": ((2, 3), (-3, 1), 0)}.items():
+        q = tmp_path / f"hand_{tag}.bin"
+        open(q, "wb").write(make(shape, stride, offset))
+        _refused(q, "tensor 'w'")
+
+
+def test_self_referential_and_deep_object_trees_are_refused_not_overflowed(tmp_path):
+    import io
+    import zipfile
+
+    def archive(body):
+        zb = io.BytesIO()
+        with zipfile.ZipFile(zb, "w", zipfile.ZIP_STORED) as z:
+            z.writestr("archive/data.pkl", body)
+            z.writestr("archive/version", b"3\n")
+        return zb.getvalue()
+    # d = {}; d['k'] = d  (EMPTY_DICT, BINPUT 0, 'k', BINGET 0, SETITEM, STOP): legal pickle, infinite tree
+    q = tmp_path / "cycle.bin"
+    open(q, "wb").write(archive(b"\x80\x02}q\x00X\x01\x00\x00\x00kh\x00s."))
+    _refused(q, "deeper than 64")
+    # 10 000 nested lists
+    q = tmp_path / "deep.bin"
+    open(q, "wb").write(archive(b"\x80\x02" + b"]" * 10000 + b"a" * 9999 + b"."))
+    _refused(q, "deeper than 64")
+    # safetensors metadata with 100 000 nested arrays
+    s = tmp_path / "deep.safetensors"
+    hdr = (b'{"__metadata__":' + b"[" * 100000 + b"]" * 100000 + b',"w":{"dtype":"F32","shape":[1],"data_offsets":[0,4]}}')
+    open(s, "wb").write(struct.pack("<Q", len(hdr)) + hdr + b"\0" * 4)
+    _refused(s, "nested deeper")
+
+
+def test_safetensors_shape_products_that_overflow_are_refused(tmp_path):
+    for shape in ([2 ** 32, 2 ** 32], [2 ** 62, 4], [99999999999999999999, 1]):
+        s = tmp_path / "ovf.safetensors"
+        hdr = json.dumps({"w": {"dtype": "F32", "shape": shape, "data_offsets": [0, 0]}}).encode()
+        open(s, "wb").write(struct.pack("<Q", len(hdr)) + hdr)
+        _refused(s)
