@@ -322,7 +322,7 @@ def generate_main(args, world, rank, local):
 
     def step(**kw):
         out = model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True, **kw)
-        return gather_ids(out[:, ids.shape[1]:], world, force=DIST)
+        return gather_ids(out[:, ids.shape[1]:], world, force=DIST, equal_shapes=True)
 
     def step_local(**kw):
         # rank 0's evidence passes run after the other ranks have left: no collective in them
@@ -339,7 +339,7 @@ def generate_main(args, world, rank, local):
                 step()
             return
         for out in model.generate_pipelined(((ids, mi) for _ in range(n)), max_new_tokens=args.new_tokens, ignore_eos=True):
-            gather_ids(out[:, ids.shape[1]:], world, force=DIST)
+            gather_ids(out[:, ids.shape[1]:], world, force=DIST, equal_shapes=True)
 
     # the pipelined loop alternates two generation pipelines (own KV cache, workspace, decode graph): both must have run once before the
     # timed region, whatever W the caller asked for

@@ -20,12 +20,42 @@ def get_chunk(lst: Sequence, n: int, k: int):
     return split_list(lst, n)[k]
 
 
-def gather_ids(ids: torch.Tensor, world_size: int, force: bool = False) -> torch.Tensor:
-    """All ranks' generated ids [B, T] -> [world*B, T], rank-major = the order of the reference's `cat` of chunk files.
-    force: run the collective even in a world of one (exercises the RCCL path on a single GPU)."""
+def gather_ids(ids: torch.Tensor, world_size: int, force: bool = False, pad_value: int = 0, equal_shapes: bool = False,
+               return_rows: bool = False):
+    """All ranks' generated ids -> one tensor, rank-major = the order of the reference's `cat` of chunk files
+    (eval/model_multimodal_qa_loader.py:25-33, scripts/model_composition/test/MCUB-4.sh:60-70).
+
+    Ranks may hold DIFFERENT shapes: the last `ceil(n/N)` chunk is shorter (or empty) and a batch stops at its own longest row (EOS), so
+    [B_r, T_r] differs per rank.  One small all-gather exchanges the shapes; if they differ every rank pads to [max B, max T] with
+    `pad_value` (HF pads finished rows with pad_token_id the same way), one all-gather moves the ids, and the padding ROWS are dropped so
+    that the result is [sum_r B_r, max T] in rank order.  `equal_shapes=True` (fixed-shape benchmark loops) skips the shape exchange.
+    force: run the collectives even in a world of one (exercises the RCCL path on a single GPU).
+    return_rows: also return the per-rank row counts (list of int)."""
     if world_size == 1 and not force:
-        return ids
+        return (ids, [int(ids.shape[0])]) if return_rows else ids
     import torch.distributed as dist
-    out = torch.empty((world_size * ids.shape[0],) + tuple(ids.shape[1:]), dtype=ids.dtype, device=ids.device)
-    dist.all_gather_into_tensor(out, ids.contiguous())
-    return out
+    assert ids.dim() == 2, "gather_ids takes [rows, tokens]"
+    ids = ids.contiguous()
+    if equal_shapes:
+        out = torch.empty((world_size * ids.shape[0], ids.shape[1]), dtype=ids.dtype, device=ids.device)
+        dist.all_gather_into_tensor(out, ids)
+        return (out, [int(ids.shape[0])] * world_size) if return_rows else out
+    mine = torch.tensor([ids.shape[0], ids.shape[1]], dtype=torch.int64, device=ids.device)
+    shapes = torch.empty(world_size * 2, dtype=torch.int64, device=ids.device)
+    dist.all_gather_into_tensor(shapes, mine)
+    shapes = shapes.view(world_size, 2).cpu()
+    rows = [int(r) for r in shapes[:, 0]]
+    Bm, Tm = int(shapes[:, 0].max()), int(shapes[:, 1].max())
+    if Bm == 0 or Tm == 0:
+        out = torch.empty((sum(rows), Tm), dtype=ids.dtype, device=ids.device)
+        return (out, rows) if return_rows else out
+    if tuple(ids.shape) != (Bm, Tm):
+        padded = torch.full((Bm, Tm), pad_value, dtype=ids.dtype, device=ids.device)
+        padded[:ids.shape[0], :ids.shape[1]] = ids
+    else:
+        padded = ids
+    out = torch.empty((world_size * Bm, Tm), dtype=ids.dtype, device=ids.device)
+    dist.all_gather_into_tensor(out, padded)
+    if any(r != Bm for r in rows):
+        out = torch.cat([out[k * Bm:k * Bm + r] for k, r in enumerate(rows)], 0)
+    return (out, rows) if return_rows else out

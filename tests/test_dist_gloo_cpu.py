@@ -46,6 +46,86 @@ def test_two_rank_shard_and_gather():
     assert torch.equal(got, exp)
 
 
+def _ragged_ids(sample, rank):
+    """"generated ids" of one sample: its length depends on the sample (EOS at different steps)."""
+    n = 2 + (sample * 3) % 5
+    return [sample * 100 + t for t in range(n)]
+
+
+def _ragged_worker(rank, world, port, ret, n_samples, batch):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from modelcompose_amd.dist import gather_ids, split_list
+    samples = list(range(n_samples))
+    chunks = split_list(samples, world)
+    mine = chunks[rank] if rank < len(chunks) else []               # ceil(n/N) chunks: the last rank's may be shorter or missing
+    got = []
+    n_batches = -(-max(len(c) for c in chunks) // batch)
+    for b in range(n_batches):                                       # every rank makes the same number of collective calls
+        part = mine[b * batch:(b + 1) * batch]
+        rows = [_ragged_ids(s, rank) for s in part]
+        T = max((len(r) for r in rows), default=0)
+        ids = torch.full((len(rows), T), 0, dtype=torch.int64)       # HF pads finished rows with pad_token_id (0)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = torch.tensor(r)
+        allids, nrows = gather_ids(ids, world, return_rows=True)
+        got.append((allids, nrows))
+    if rank == 0:
+        ret.put(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_unequal_chunks_and_lengths():
+    """7 samples on 2 ranks = chunks of 4 and 3 (model_multimodal_qa_loader.py:25-33), batches of 2, rows that stop
+    at different lengths.  The gathered rows, batch by batch, must be the reference's `cat` of the chunk outputs (MCUB-4.sh:60-70):
+    rank-major, every row's own ids followed only by pad."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q, 7, 2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    chunks = [[0, 1, 2, 3], [4, 5, 6]]
+    assert len(got) == 2
+    per_rank = {0: [], 1: []}
+    for b, (allids, nrows) in enumerate(got):
+        exp_rows = [len(c[b * 2:(b + 1) * 2]) for c in chunks]
+        assert nrows == exp_rows and allids.shape[0] == sum(exp_rows)
+        row = 0
+        for r, c in enumerate(chunks):
+            for s in c[b * 2:(b + 1) * 2]:
+                want = _ragged_ids(s, r)
+                assert allids[row, :len(want)].tolist() == want and int(allids[row, len(want):].abs().sum()) == 0, (b, r, s, allids[row])
+                per_rank[r].append(s)
+                row += 1
+    assert per_rank[0] + per_rank[1] == list(range(7))              # concatenating rank 0's answers then rank 1's = the question order
+
+
+def test_gather_with_an_empty_rank():
+    """5 samples on 4 ranks: ceil(5/4) = 2 -> chunks 2, 2, 1 and NO chunk for rank 3 (the reference's split_list returns 3 chunks)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 4, port, q, 5, 2)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (allids, nrows), = got
+    assert nrows == [2, 2, 1, 0] and allids.shape[0] == 5
+    for row, s in enumerate(range(5)):
+        want = _ragged_ids(s, 0)
+        assert allids[row, :len(want)].tolist() == want
+
+
 def _grad_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
