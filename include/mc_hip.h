@@ -53,10 +53,13 @@ int mc_compose_weight_bf16(const void* w_rowmajor, int64_t ldw, const void* cons
 /* As above with (a) col_scale fp32 [K] multiplied into the columns before the single bf16 rounding — folds the weight of the
  * LlamaRMSNorm that precedes the linear (multimodal_llama.py:405-406, :443, :462) into it — and (b) block interleaving: packed
  * 16-row block nb is written at block index nb*nb_stride + nb_offset (gate_proj / up_proj interleaved for the fused SwiGLU
- * epilogue of mc_gemm_ex_bf16).                                                                                           */
+ * epilogue of mc_gemm_ex_bf16).  (c) retention_parts (optional, device, 2 * ceil(ceil64(K)/256) * ceil(N/32) floats): per-workgroup
+ * partial sums {sum (W' - bf16(W c)) (dW c), sum (dW c)^2} over the elements the workgroup wrote - their ratio, summed by the caller,
+ * is the share of the delta that survives the single bf16 rounding (1 for trained deltas; falls when |dW| is below half a bf16 step
+ * of W: the reference's branch form, multimodal_llama.py:130-149, has no such rounding).                                        */
 int mc_compose_weight_ex_bf16(const void* w_rowmajor, int64_t ldw, const void* const* at_list, const void* const* b_list,
                               const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
-                              int N, int K, const float* col_scale, int nb_stride, int nb_offset, void* stream);
+                              int N, int K, const float* col_scale, int nb_stride, int nb_offset, float* retention_parts, void* stream);
 
 /* ---- audio front-end: Kaldi log-mel filterbank + BEATs normalisation + zero padding (beats/audio_processor.py:143-170; replaces
  * torchaudio.compliance.kaldi.fbank, a third-party CPU dependency of the reference).  wav [B, wav_stride] fp32 at 16 kHz,
@@ -358,9 +361,11 @@ int mc_llm_destroy(void* handle);
 int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* final_norm, const void* lm_head_packed,
                        const void* embed_table, const float* cos_table, const float* sin_table);
 /* options: "use_graph" (decode steps replayed from a hipGraph, default 1); "profile" (below); "tail_adapter" (default -1 = off; a >= 0: the
- * next mc_llm_prefill calls that ask for last-row logits / next ids only - hidden_out null - run the LAST layer's attention, o_proj and
+ * NEXT mc_llm_prefill call, if it asks for last-row logits / next ids only - hidden_out null - runs the LAST layer's attention, o_proj and
  * MLP for the last token of every sequence only, with adapter a's weights; the layer's q|k|v projection still covers every row, so the
- * KV cache is what the all-rows path writes.  The caller guarantees that all last tokens are routed to adapter a) */
+ * KV cache is what the all-rows path writes.  ONE-SHOT: the value is the caller's promise that every last_rows entry of that batch lies
+ * in a group routed to adapter a (last_rows is device memory, the library cannot check it without a synchronising copy); the call consumes
+ * it and resets the option to -1, so the promise never carries over to another batch) */
 int mc_llm_set_option(void* handle, const char* name, int value);
 /* read back: "use_graph"; "graph_active" = 1 when the last mc_llm_decode replayed a hipGraph (0: one launch per kernel); "graph_captures" /
  * "graph_failures" = decode-step graphs captured / capture attempts that failed since mc_llm_create */

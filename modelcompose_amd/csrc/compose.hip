@@ -25,6 +25,8 @@ struct ComposeParams {
     int N, K, Kp;
     const float* col_scale;                  // [K] fp32 or null: W'[n][k] *= col_scale[k] before the single bf16 rounding
     int nb_stride, nb_offset;                // packed 16-row block nb is written at block index nb*nb_stride + nb_offset
+    float* retention_parts;                  // optional [gridDim.y][gridDim.x][2]: per-workgroup partial sums of (W' - bf16(W c)) * (dW c) and
+                                             // (dW c)^2: how much of the delta survives the single bf16 rounding (see mc_hip.h)
 };
 
 // workgroup = 4 waves; tile = 32 rows (n) x 256 cols (k); wave w owns cols [64w, 64w+64)
@@ -33,7 +35,9 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeParams p) {
     const int c16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.y * 32;
     const int k0 = blockIdx.x * 256 + wave * 64;
-    if (k0 >= p.Kp) return;
+    const bool wave_on = k0 < p.Kp;
+    float ret_num = 0.f, ret_den = 0.f;
+    if (wave_on) {
 
     f32x4 tot[2][4];
 #pragma unroll
@@ -104,6 +108,19 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeParams p) {
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (inb && k + j < p.K) ? (bf16_t)r4[j] : (bf16_t)0.0f;
+            if (p.retention_parts && p.w && inb) {
+                // the composed weight against the base weight rounded the same way: the part of (W' - bf16(W c)) that lies along dW c
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k + j < p.K) {
+                        const float cs = p.col_scale ? p.col_scale[k + j] : 1.0f;
+                        const float wv = (float)p.w[(int64_t)n * p.ldw + k + j];
+                        const float d = tot[i][t][j] * cs;
+                        const float moved = (float)o[j] - (float)(bf16_t)(wv * cs);
+                        ret_num = fmaf(moved, d, ret_num);
+                        ret_den = fmaf(d, d, ret_den);
+                    }
+            }
             const int kb = k >> 5;
             const int q = (k & 31) >> 3;
             bf16_t* dst = p.out_packed + ((int64_t)(nb * p.nb_stride + p.nb_offset) * kblocks + kb) * 512 + ((q << 4) | (n & 15)) * 8 + (k & 7);
@@ -115,12 +132,28 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeParams p) {
             }
         }
     }
+    }
+    if (p.retention_parts) {
+        __shared__ float red[4][2];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ret_num += __shfl_xor(ret_num, o, 64);
+            ret_den += __shfl_xor(ret_den, o, 64);
+        }
+        if (lane == 0) { red[wave][0] = ret_num; red[wave][1] = ret_den; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* dst = p.retention_parts + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+            dst[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);            // fixed order: reproducible
+            dst[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        }
+    }
 }
 
 extern "C" int mc_compose_weight_ex_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,
                                          const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor,
                                          int64_t ldo, int N, int K, const float* col_scale, int nb_stride, int nb_offset,
-                                         void* stream) {
+                                         float* retention_parts, void* stream) {
     MC_CHECK_ARG(out_packed && N > 0 && K > 0, "mc_compose_weight_bf16: bad arguments");
     MC_CHECK_ARG(n_terms >= 0 && n_terms <= MC_MAX_TERMS, "mc_compose_weight_bf16: at most %d terms (got %d)", MC_MAX_TERMS, n_terms);
     MC_CHECK_ARG(n_terms == 0 || (r > 0 && r % 32 == 0), "mc_compose_weight_bf16: rank %d must be a multiple of 32 (pad A^T / B)", r);
@@ -136,6 +169,7 @@ extern "C" int mc_compose_weight_ex_bf16(const void* w, int64_t ldw, const void*
     p.out_packed = (bf16_t*)out_packed; p.out_rowmajor = (bf16_t*)out_rowmajor; p.ldo = ldo;
     p.N = N; p.K = K; p.Kp = (K + 63) / 64 * 64;
     p.col_scale = col_scale; p.nb_stride = nb_stride; p.nb_offset = nb_offset;
+    p.retention_parts = retention_parts;
     dim3 grid((p.Kp + 255) / 256, (N + 31) / 32);
     compose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
     MC_CHECK_LAUNCH();
@@ -146,5 +180,5 @@ extern "C" int mc_compose_weight_bf16(const void* w, int64_t ldw, const void* co
                                       const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor,
                                       int64_t ldo, int N, int K, void* stream) {
     return mc_compose_weight_ex_bf16(w, ldw, at_list, b_list, scales, n_terms, r, out_packed, out_rowmajor, ldo, N, K, nullptr, 1, 0,
-                                     stream);
+                                     nullptr, stream);
 }

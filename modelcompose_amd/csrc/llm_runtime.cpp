@@ -145,7 +145,7 @@ int gemm_grouped(const void* x, int64_t ldx, const void* residual, int64_t ldr, 
 int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t* gstart, const int32_t* gadapter,
                   const Ws& w, const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t, const int32_t* out_map,
                   const int32_t* kv_lens, int B, int Lq, char* kc, char* vc, int Smax, bool decode, int nsplit, void* attn_ws,
-                  void* stream, int stage = 0) {
+                  void* stream, int stage = 0, int phase_tag = -1) {
     // stage 0: the whole layer; 1: the q|k|v projection (+ RoPE / cache scatter) only; 2: everything after the attention (w.attn holds its
     // output) - the two halves of the last prefill layer of generate(), which runs the second half for the last tokens only
     const mc_llm_config& c = m->cfg;
@@ -169,7 +169,7 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
         for (int g = 0; g < n_groups; ++g) wg[g] = W(gadapter[g], which);
         return (const void* const*)wg;
     };
-    const int ph = decode ? 1 : 0;
+    const int ph = phase_tag >= 0 ? phase_tag : (decode ? 1 : 0);      // profile phase: the prefill's last-token tail uses decode kernels but is prefill time
     // q|k|v = (x / rms) . (W_qkv diag(g_in))^T                                                  (:440-443, :262-268)
     // prefill: RoPE, the q re-ordering and the cache append are the projection's epilogue (mc_rope_scatter; a separate mc_rope_kv_bf16
     // launch inside the library when the launch is too small for the 256x256 kernel or the head size is not 128)            (:281-312)
@@ -363,6 +363,11 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
     // that layer still projects q|k|v for every row (the cache needs all keys), but its attention, o_proj and MLP run for the B last
     // tokens only - as a decode step would, reading the keys the projection just stored.  Needs all last tokens on one adapter.
     const bool tail = m->tail_adapter >= 0 && !hidden_out && last_rows && kv_lens && (logits_out || next_ids) && B <= 512;
+    const int tail_adapter = m->tail_adapter;
+    // ONE-SHOT: the option is the caller's promise that every last_rows entry of THIS batch is routed to that adapter (last_rows lives on
+    // the device; checking it here would cost a synchronising copy per prefill).  It is consumed by the call, so a promise made for one
+    // batch can never be applied silently to the next: a caller that wants the tail path sets it before every prefill.
+    m->tail_adapter = -1;
     const int full_layers = tail ? c.n_layers - 1 : c.n_layers;
     for (int l = 0; l < full_layers; ++l)
         RUN(layer_forward(m, l, (char*)x_routed, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
@@ -383,9 +388,9 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
                                                         (int64_t)Smax * D, w.attn, hd, (char*)workspace + w.total, kv_lens, B, (int)H, (int)Hkv, Smax,
                                                         (int)D, nsplit, 1.0f / sqrtf((float)D), stream));
         const int32_t gs1[2] = {0, B};
-        const int32_t ga1[1] = {m->tail_adapter};
+        const int32_t ga1[1] = {tail_adapter};
         RUN(layer_forward(m, l, w.xl, B, 1, gs1, ga1, w, nullptr, nullptr, nullptr, nullptr, kv_lens, B, 1, (char*)k_cache, (char*)v_cache, Smax,
-                          B <= 64, 1, nullptr, stream, 2));
+                          B <= 64, 1, nullptr, stream, 2, 0));
         float* lg = logits_out ? logits_out : (float*)w.logits;
         RUN(head_forward(m, w.xl, B, w, lg, stream, 0));
         if (next_ids) RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, nullptr, 0, nullptr, B, c.vocab, stream));

@@ -174,7 +174,7 @@ class MultimodalLlamaForCausalLM:
             a = self._raw[f"{prefix}.lora_A.{key}.weight"].to(dev)
             b = self._raw[f"{prefix}.lora_B.{key}.weight"].to(dev)
             tl.append((a, b, scale))
-        _compose_into(w, tl, N, K, out, col_scale, nb_stride, nb_offset)
+        _compose_into(w, tl, N, K, out, col_scale, nb_stride, nb_offset, retention=self._retention_parts.setdefault(adapter, []))
 
     def finalize(self):
         """Compose + pack every weight, create the C runtime handle."""
@@ -184,6 +184,7 @@ class MultimodalLlamaForCausalLM:
         names = self.modal_names
         nA = len(names)
         raw = self._raw
+        self._retention_parts = {}
         if "model.embed_tokens.weight" not in raw:
             raise ValueError("state dict lacks model.embed_tokens.weight")
         self.model.embed_tokens = raw["model.embed_tokens.weight"].to(dev, BF16).contiguous()
@@ -246,7 +247,33 @@ class MultimodalLlamaForCausalLM:
         self._final_norm = final_norm
         self._dirty = False
         torch.cuda.synchronize()
+        self._summarise_delta_retention()
         return self
+
+    def _summarise_delta_retention(self):
+        """delta_retention[adapter] = Σ (W' - bf16(W c))·(ΔW c) / Σ (ΔW c)² over every composed linear of the adapter: the share of the
+        LoRA delta that survives the single bf16 rounding of the pre-merged weight, projected on the delta itself.  1.0 for trained
+        deltas (|ΔW| ~ 2^-4 |W|); it falls when |ΔW| sinks below half a bf16 step of W (0.72 at 2^-9.3 with norm weights of exactly 1: the
+        base weights then sit ON the bf16 grid and small deltas round back to them; the reference's branch form keeps them).  A warning
+        is raised below 0.9 - the lost part is then still under the bf16 rounding of the layer's own output, but it is a systematic
+        shrink of the delta, not noise (DESIGN.md §5, tests/test_fullwidth_parity_gpu.py::test_small_delta_*)."""
+        import warnings
+        self.delta_retention = {}
+        for ad, plist in self._retention_parts.items():
+            if not plist:
+                continue
+            num = den = 0.0
+            for parts in plist:
+                h = parts.double().cpu().numpy()
+                num += float(h[:, 0].sum())
+                den += float(h[:, 1].sum())
+            if den > 0:
+                self.delta_retention[ad] = num / den
+        self._retention_parts = {}
+        low = {a: round(v, 3) for a, v in self.delta_retention.items() if v < 0.9}
+        if low:
+            warnings.warn(f"LoRA deltas of adapters {low} are below the bf16 resolution of the base weights: only that share of them "
+                          f"survives the pre-merge rounding (the reference's branch form keeps small deltas)", RuntimeWarning)
 
     # ------------------------------------------------------------------ encode / splice (multimodal_arch.py:197-459)
     def encode_modal_inputs(self, inputs, prefix_tokens=None, suffix_tokens=None):
@@ -685,8 +712,10 @@ def _cat_rows(parts: List[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col_scale=None, nb_stride=1, nb_offset=0):
-    """W' = (W + Σ scale·B·A)·diag(col_scale) packed into the preallocated buffer `out` (16-row block nb at nb*nb_stride + nb_offset)."""
+def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col_scale=None, nb_stride=1, nb_offset=0, retention=None):
+    """W' = (W + Σ scale·B·A)·diag(col_scale) packed into the preallocated buffer `out` (16-row block nb at nb*nb_stride + nb_offset).
+    retention: a list that receives this call's [workgroups, 2] fp32 partial sums (Σ (W' - bf16(W c))·(ΔW c), Σ (ΔW c)²), see
+    delta_retention()."""
     n = len(terms)
     ats, bs, r = [], [], 0
     for (a, b, s) in terms:
@@ -709,7 +738,11 @@ def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col
     sc = (C.c_float * max(n, 1))(*[float(t[2]) for t in terms])
     if out.numel() != ops.packed_elems(N, K) * nb_stride:
         raise ValueError("packed buffer has the wrong size")
+    parts = None
+    if retention is not None and n > 0:
+        parts = torch.empty(((ops.ceil_to(K, 64) + 255) // 256) * ((N + 31) // 32), 2, dtype=torch.float32, device=out.device)
+        retention.append(parts)
     _lib.check(_lib.lib().mc_compose_weight_ex_bf16(_ptr(w), w.stride(0), at_arr, b_arr, sc, n, r, _ptr(out), None, 0, N, K,
-                                                    _ptr(col_scale), nb_stride, nb_offset, _stream()), "mc_compose_weight_ex_bf16")
+                                                    _ptr(col_scale), nb_stride, nb_offset, _ptr(parts), _stream()), "mc_compose_weight_ex_bf16")
     # keep operands alive until the kernel has been enqueued on the stream (stream-ordered allocator semantics)
     return out

@@ -39,7 +39,7 @@ CASES = {
     # configs[3]: 4-modality composed model, MCUB-4-shaped inputs (spliced length 3337)
     "configs3_mcub4": dict(modals=("vision", "audio", "video", "point"),
                            reset="default-vision=0.25,default-audio=0.25,default-video=0.25,default-point=0.25",
-                           inputs=("vision", "audio", "video", "point"), seed=31, row_seeds=[600, 622]),
+                           inputs=("vision", "audio", "video", "point"), seed=31, row_seeds=[600, 622], extra_rows=[300, 301]),
 }
 
 

@@ -1,0 +1,108 @@
+"""Parity at the DEPTH that is benchmarked: the metric's model - 3-way composed Vicuna-7B (online-merge-reset
+vision / audio / video = 0.333, routed adapters default / audio / vision / video), all 32 decoder layers at the real widths, real-size
+CLIP-L/336 + BEATs/Q-Former + LanguageBind-Video encoders - on two UNSCREENED rows of the metric's inputs (336 px image + 10 s audio +
+8-frame video, spliced length 2793), prefill + 16 greedy decode steps through the C ABI, against the committed output of the pinned
+fp32 branch-form oracle (tests/golden/g15_fulldepth_iav.npz, written in the build container by `python -m oracle.gen_golden g15`:
+35 GB of fp32 weights, ~15 minutes on 8 cores - too much to run beside the test).  A second fixture holds the same model cut to
+8 layers, so the error's growth with depth (2 -> 8 -> 32 layers) is measured, not extrapolated.
+
+Reference: modelcompose/model/language_model/multimodal_llama.py:488-619 (model forward), :676-767 (lm_head / generation inputs),
+eval/model_multimodal_qa_loader.py:94-108 (the greedy generate call the metric times).
+
+What is asserted (tests/test_fullwidth_parity_gpu.py explains why a fixed 1e-3 cannot hold end to end with bf16 storage):
+  * the weights and inputs generated on this box are the ones the fixture was made from (input ids equal, a checksum of the weights);
+  * per-step logits vs the oracle within DEPTH_BOUND = 2x the error measured on MI355X (of the oracle's logit scale), on every step
+    that still sees the oracle's token history;
+  * greedy ids equal to the oracle's up to the first step whose oracle top-2 margin is inside the measured error band; at that step the
+    device's token must be one the oracle itself ranks within the band of its best.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fullwidth_cases as fc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# 2x the max |logit error| / max |oracle logit| measured on MI355X in round 3 (profiles/r03_parity.json)
+DEPTH_BOUND = {"depth8_iav": 4.0e-2, "fulldepth_iav": 8.0e-2}
+REPORT = {}
+
+
+def _fixture(fname):
+    path = os.path.join(GOLD, fname + ".npz")
+    if not os.path.exists(path):
+        pytest.fail(f"{path} is missing: python -m oracle.gen_golden g15 (build container)")
+    z = np.load(path)
+    return {k: z[k] for k in z.files}
+
+
+def _run(name, fname):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from modelcompose_amd.model.builder import build_from_state_dict
+    gold = _fixture(fname)
+    info = json.loads(bytes(gold["meta"]).decode())
+    assert info["case"] == name and info["row_seeds"] == fc.DEPTH_CASES[name]["row_seeds"] and info["seed"] == fc.DEPTH_CASES[name]["seed"]
+    meta, sd, ids, mi = fc.build_case(name)
+    assert meta["num_hidden_layers"] == info["layers"]
+    assert np.array_equal(ids.numpy(), gold["input_ids"]), "this box generated other prompts than the fixture's"
+    model = build_from_state_dict(meta, sd)
+    del sd
+    mid = fc.to_dev(mi)
+    res, lg = model.generate(ids.cuda(), modal_inputs=mid, max_new_tokens=fc.N_NEW, ignore_eos=True, return_step_logits=True)
+    res_graph = model.generate(ids.cuda(), modal_inputs=mid, max_new_tokens=fc.N_NEW, ignore_eos=True)          # shipped path: hipGraph replay
+    graph_active = model.runtime_option("graph_active")
+    got_ids, got_lg = res[:, ids.shape[1]:].cpu(), lg.float().cpu()
+    assert torch.equal(res_graph[:, ids.shape[1]:].cpu(), got_ids) and graph_active == 1
+    del model
+    torch.cuda.empty_cache()
+    ref_ids, ref_lg = torch.from_numpy(gold["ids"]), torch.from_numpy(gold["logits"])
+    assert got_lg.shape == ref_lg.shape == (ids.shape[0], fc.N_NEW, meta["vocab_size"])
+    scale = ref_lg.abs().max()
+    bound = DEPTH_BOUND[name]
+    rows = []
+    worst = 0.0
+    for b in range(ids.shape[0]):
+        neq = (got_ids[b] != ref_ids[b]).nonzero()
+        t = int(neq[0]) if len(neq) else fc.N_NEW
+        upto = min(t + 1, fc.N_NEW)                                 # steps that saw the oracle's token history
+        err = ((got_lg[b, :upto] - ref_lg[b, :upto]).abs().max() / scale).item()
+        err0 = ((got_lg[b, 0] - ref_lg[b, 0]).abs().max() / scale).item()
+        rms = ((got_lg[b, :upto] - ref_lg[b, :upto]).pow(2).mean().sqrt() / ref_lg[b, :upto].pow(2).mean().sqrt()).item()
+        worst = max(worst, err)
+        row = {"row": b, "steps_on_the_oracle_path": t, "max_err_over_those_steps": err, "prefill_step_err": err0, "rms_err_over_rms_logit": rms,
+               "min_oracle_margin_over_those_steps": fc.margins(ref_lg[b:b + 1, :upto]).min().item() if upto else None}
+        if t < fc.N_NEW:
+            top2 = ref_lg[b, t].topk(2)
+            row["departure_margin"] = ((top2.values[0] - top2.values[1]) / scale).item()
+            row["departure_chosen_gap"] = ((top2.values[0] - ref_lg[b, t, int(got_ids[b, t])]) / scale).item()
+        rows.append(row)
+    REPORT[name] = {"layers": info["layers"], "rows": rows, "max_err": worst, "bound": bound, "logit_scale": scale.item(),
+                    "spliced_length": 2793, "oracle": "fp32 branch form (oracle/pipeline.py), fixture " + fname}
+    out = os.path.join(fc.ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(REPORT, open(os.path.join(out, "fulldepth_parity.json"), "w"), indent=1)
+    print(name, json.dumps(REPORT[name]))
+    for row in rows:
+        assert row["max_err_over_those_steps"] <= bound, row
+        if row["steps_on_the_oracle_path"] < fc.N_NEW:
+            # a departure is legitimate only at an oracle near-tie: margin and the chosen token's gap inside the error band of a logit
+            # DIFFERENCE (two logits, each within `bound`/2 typical error)
+            assert row["departure_margin"] < bound and row["departure_chosen_gap"] < bound, row
+    return rows
+
+
+def test_eight_layers_against_the_committed_oracle_fixture():
+    _run("depth8_iav", "g15_depth8_iav")
+
+
+def test_full_depth_32_layers_against_the_committed_oracle_fixture():
+    rows = _run("fulldepth_iav", "g15_fulldepth_iav")
+    # the first generated token (the prefill's argmax over 32 layers x 2793 positions) is the oracle's unless its margin is a near-tie
+    for row in rows:
+        assert row["steps_on_the_oracle_path"] >= 1 or row["departure_margin"] < DEPTH_BOUND["fulldepth_iav"]

@@ -266,11 +266,17 @@ def test_first_layer_stages_are_exact_to_rounding(name):
 
 
 def test_small_delta_composition_against_the_branch_form():
-    """VERDICT r1 #2 / SURVEY §7 "hard parts": W' = bf16(W + sum s B A) drops a delta smaller than half a bf16 step of W.  LoRA B scaled so
-    that |dW| / |W| ~ 2^-10 elementwise (the adversarial regime; trained deltas are ~2^-4): the pre-merged HIP path against the fp32
-    BRANCH-form oracle, which keeps the delta exactly."""
+    """VERDICT r1 #2 / r2 #2 / SURVEY §7 "hard parts": W' = bf16(W + sum s B A) drops a delta smaller than half a bf16 step of W.  LoRA B
+    scaled so that |dW| / |W| ~ 2^-10 elementwise (the adversarial regime; trained deltas are ~2^-4).  The whole delta then moves the
+    logits by less than the path's bf16 noise, so "logits within the bound" cannot tell a kept delta from a dropped one.  What can:
+    the DIFFERENCE the delta makes.  dH = HIP(with delta) - HIP(B = 0) and dO = oracle(with delta) - oracle(B = 0) on the first-step
+    logits (fp32 branch-form oracle, multimodal_llama.py:130-149, which keeps the delta exactly); the projection c = <dH, dO> / <dO, dO>
+    averages the bf16 noise of the two device runs (uncorrelated with dO) over 64 000 logits: c ~ 0 if the composition lost the delta,
+    ~1 if it kept all of it, ~0.7 for RNE rounding of on-grid base weights at this ratio (tests/test_ops_gpu.py::
+    test_compose_small_delta_retention_is_the_rne_value pins that value at the op level)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    import warnings
     from modelcompose_amd.model.builder import build_from_state_dict
     from oracle import pipeline
     name = "configs1_vision"
@@ -279,29 +285,51 @@ def test_small_delta_composition_against_the_branch_form():
     dw = 2.0 * sd["model.layers.0.self_attn.q_proj.lora_B.default.weight"].float() @ sd["model.layers.0.self_attn.q_proj.lora_A.default.weight"].float()
     ratio = (dw.abs().mean() / w.abs().mean()).item()
     assert 2 ** -11.5 < ratio < 2 ** -8.5, ratio
-    model = build_from_state_dict(meta, sd)
     mid = fc.to_dev(mi)
-    feats, _ = model.encode_modal_inputs(mid, model.prefix_tokens, model.suffix_tokens)
-    res, lg = model.generate(ids.cuda(), modal_inputs=mid, max_new_tokens=fc.N_NEW, ignore_eos=True, return_step_logits=True)
-    fb = {m: f.float().cpu() for m, f in feats.items()}
-    del model
-    torch.cuda.empty_cache()
+
+    def hip_first_logits(state):
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            model = build_from_state_dict(meta, state)
+        feats, _ = model.encode_modal_inputs(mid, model.prefix_tokens, model.suffix_tokens)
+        res, lg = model.generate(ids.cuda(), modal_inputs=mid, max_new_tokens=fc.N_NEW, ignore_eos=True, return_step_logits=True)
+        out = (res[:, ids.shape[1]:].cpu(), lg.float().cpu(), {m: f.float().cpu() for m, f in feats.items()}, dict(model.delta_retention),
+               [str(w_.message) for w_ in wlist if issubclass(w_.category, RuntimeWarning)])
+        del model
+        torch.cuda.empty_cache()
+        return out
+    got_ids, lg, fb, retention, warned = hip_first_logits(sd)
+    sd_zero = {k: (torch.zeros_like(v) if ".lora_B." in k else v) for k, v in sd.items()}
+    _, lg_h0, fb0, retention0, _ = hip_first_logits(sd_zero)
+    assert all(torch.equal(fb[m], fb0[m]) for m in fb)            # the encoders do not depend on the LoRA terms: identical feature blocks
     sdf = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
     with torch.no_grad():
         o32 = pipeline.OracleModel.from_state_dict(sdf, meta)
         ids_r, lg_r = o32.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True, feats_blocks=fb)
-        # the same model with the LoRA terms removed: how large the delta's effect on the logits is at all
+        # the same model with the LoRA terms removed
         sd0 = {k: (torch.zeros_like(v) if ".lora_B." in k else v) for k, v in sdf.items()}
         o0 = pipeline.OracleModel.from_state_dict(sd0, meta)
         _, lg_0 = o0.generate(ids, fc.to_f32(mi), max_new_tokens=1, ignore_eos=True, return_logits=True, feats_blocks=fb)
+    dH = (lg[:, :1] - lg_h0[:, :1]).double()
+    dO = (lg_r[:, :1] - lg_0).double()
+    c = ((dH * dO).sum() / (dO * dO).sum()).item()
+    resid = ((dH - c * dO).norm() / dO.norm()).item()             # what is left after the projection: the two device runs' bf16 noise
     err = rel(lg[:, :1], lg_r[:, :1])
     effect = rel(lg_0, lg_r[:, :1])
-    got = res[:, ids.shape[1]:].cpu()
-    agree = int((got == ids_r).sum())
+    agree = int((got_ids == ids_r).sum())
     REPORT["small_delta"] = {"dw_over_w": ratio, "prefill_err_vs_branch_form": err, "delta_effect_on_logits": effect,
+                             "delta_projection_hip_on_oracle": c, "orthogonal_residual_over_effect": resid,
+                             "compose_retention_per_adapter": retention, "warned": warned,
                              "ids_agree": agree, "ids_total": int(ids_r.numel()), "min_margin": fc.margins(lg_r).min().item()}
     out = os.path.join(fc.ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(REPORT, open(os.path.join(out, "fullwidth_parity.json"), "w"), indent=1)
-    # the composed path must stay within the same bound as with ordinary deltas (the dropped part of the delta must not show)
-    assert err <= FP32_BOUND[name], f"pre-merged weights lose a small delta: {err:.2e} of the logit scale (delta effect {effect:.2e})"
+    print("small delta:", REPORT["small_delta"])
+    # (1) the delta is there: its projection on the oracle's delta effect is what RNE rounding of on-grid weights retains (0.6-0.8 at the op
+    #     level), not 0.  (2) the composition itself says so: per-adapter retention reported by the compose kernel, and a warning.
+    assert 0.45 <= c <= 1.25, f"delta effect projection {c:.3f}: the composed weights lost (or inflated) the small delta"
+    assert retention and all(0.5 < v < 0.9 for v in retention.values()), retention
+    assert warned and "below the bf16 resolution" in warned[0]
+    assert not retention0                                            # B = 0: no delta, nothing to retain, no statistic
+    # (3) and the composed path stays within the same bound as with ordinary deltas
+    assert err <= FP32_BOUND[name], f"pre-merged weights: {err:.2e} of the logit scale (delta effect {effect:.2e})"
