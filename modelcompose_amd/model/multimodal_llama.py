@@ -528,6 +528,10 @@ class MultimodalLlamaForCausalLM:
             sampling = (T, Kk, P, int(seed))
         streamer = kw.pop("streamer", None)
         criteria = kw.pop("stopping_criteria", None)
+        # forced_ids (B, >= max_new_tokens - 1), optional: TEACHER FORCING - decode step s is fed forced_ids[:, s] instead of the token the
+        # model chose, so every step's logits are conditioned on a given history (parity tests compare all steps with an oracle even
+        # after a near-tie departure); the returned ids are still the model's own choices, one launch sequence per token
+        forced = kw.pop("forced_ids", None)
         # stage_events (dict, optional): receives torch.cuda.Event pairs recorded on the current stream around the three stages, as
         # {"encode": (e0, e1), "prefill": (e1, e2), "decode": (e2, e3)} (bench.py: stage times and the decode roofline)
         stage_events = kw.pop("stage_events", None)
@@ -584,7 +588,16 @@ class MultimodalLlamaForCausalLM:
         if streamer is not None:
             streamer.put(input_ids.cpu())
         halted = hooks(1) if per_token else False
-        if max_new_tokens > 1 and not halted:
+        if forced is not None:
+            if sampling is not None or per_token or not ignore_eos:
+                raise ValueError("forced_ids is a greedy, ignore_eos=True, hook-free mode")
+            forced = forced.to(self.device, torch.int64)
+            for s_ in range(max_new_tokens - 1):
+                st["next_ids"].copy_(forced[:, s_])
+                lg = self._decode(st, 1, out[:, 1:], s_, want_logits=return_step_logits)
+                if return_step_logits:
+                    step_logits.append(lg)
+        elif max_new_tokens > 1 and not halted:
             if ignore_eos and not per_token:
                 lg = self._decode(st, max_new_tokens - 1, out[:, 1:], 0, want_logits=return_step_logits)
                 if return_step_logits:

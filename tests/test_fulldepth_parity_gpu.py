@@ -9,12 +9,18 @@ fp32 branch-form oracle (tests/golden/g15_fulldepth_iav.npz, written in the buil
 Reference: modelcompose/model/language_model/multimodal_llama.py:488-619 (model forward), :676-767 (lm_head / generation inputs),
 eval/model_multimodal_qa_loader.py:94-108 (the greedy generate call the metric times).
 
-What is asserted (tests/test_fullwidth_parity_gpu.py explains why a fixed 1e-3 cannot hold end to end with bf16 storage):
-  * the weights and inputs generated on this box are the ones the fixture was made from (input ids equal, a checksum of the weights);
-  * per-step logits vs the oracle within DEPTH_BOUND = 2x the error measured on MI355X (of the oracle's logit scale), on every step
-    that still sees the oracle's token history;
-  * greedy ids equal to the oracle's up to the first step whose oracle top-2 margin is inside the measured error band; at that step the
-    device's token must be one the oracle itself ranks within the band of its best.
+What is asserted (tests/test_fullwidth_parity_gpu.py explains why a fixed 1e-3 cannot hold end to end with bf16 storage; measured
+on MI355X the distance from the fp32 oracle grows 1.1e-2 -> 1.8e-2 -> 3.0e-2 of the logit scale over 2 -> 8 -> 32 layers, i.e. like the
+square root of the depth, as independent per-layer rounding noise does):
+  * the inputs generated on this box are the ones the fixture was made from;
+  * TEACHER-FORCED pass (generate(forced_ids = the oracle's ids)): the logits of ALL 17 steps - prefill and 16 cached decode steps, each
+    conditioned on the oracle's own history - within DEPTH_BOUND = 2x the error measured on MI355X (of the oracle's logit scale), and
+    the device's argmax at every step equal to the oracle's token unless the oracle's top-2 margin at that step is inside the band;
+  * FREE pass (the shipped loop, hipGraph replay): greedy ids equal to the oracle's up to the first step whose oracle top-2 margin is
+    inside the band; at that step the device's token must be one the oracle itself ranks within the band of its best.  (With a logit
+    error of 3e-2 against a mean top-2 gap of 4.4e-2 for this random-weight model, a 32-layer row leaves the oracle's path within
+    the first few tokens more often than not - both rows of the fixture do so at token 0, at oracle margins 7.5e-3 and 1.7e-3 - which
+    is why the teacher-forced pass carries the per-step comparison.)
 """
 import json
 import os
@@ -29,7 +35,7 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # 2x the max |logit error| / max |oracle logit| measured on MI355X in round 3 (profiles/r03_parity.json)
-DEPTH_BOUND = {"depth8_iav": 4.0e-2, "fulldepth_iav": 8.0e-2}
+DEPTH_BOUND = {"depth8_iav": 3.6e-2, "fulldepth_iav": 6.0e-2}          # measured 1.76e-2 / 2.97e-2 (first GPU run of round 3)
 REPORT = {}
 
 
@@ -54,14 +60,19 @@ def _run(name, fname):
     model = build_from_state_dict(meta, sd)
     del sd
     mid = fc.to_dev(mi)
+    ref_ids, ref_lg = torch.from_numpy(gold["ids"]), torch.from_numpy(gold["logits"])
     res, lg = model.generate(ids.cuda(), modal_inputs=mid, max_new_tokens=fc.N_NEW, ignore_eos=True, return_step_logits=True)
     res_graph = model.generate(ids.cuda(), modal_inputs=mid, max_new_tokens=fc.N_NEW, ignore_eos=True)          # shipped path: hipGraph replay
     graph_active = model.runtime_option("graph_active")
     got_ids, got_lg = res[:, ids.shape[1]:].cpu(), lg.float().cpu()
     assert torch.equal(res_graph[:, ids.shape[1]:].cpu(), got_ids) and graph_active == 1
+    # teacher forcing: decode step s is fed the oracle's token s
+    res_tf, lg_tf = model.generate(ids.cuda(), modal_inputs=mid, max_new_tokens=fc.N_NEW, ignore_eos=True, return_step_logits=True,
+                                   forced_ids=ref_ids[:, :fc.N_NEW - 1])
+    tf_ids, tf_lg = res_tf[:, ids.shape[1]:].cpu(), lg_tf.float().cpu()
+    assert torch.equal(tf_lg[:, 0], got_lg[:, 0])                    # the prefill step is the same launch sequence in both passes
     del model
     torch.cuda.empty_cache()
-    ref_ids, ref_lg = torch.from_numpy(gold["ids"]), torch.from_numpy(gold["logits"])
     assert got_lg.shape == ref_lg.shape == (ids.shape[0], fc.N_NEW, meta["vocab_size"])
     scale = ref_lg.abs().max()
     bound = DEPTH_BOUND[name]
@@ -82,12 +93,26 @@ def _run(name, fname):
             row["departure_margin"] = ((top2.values[0] - top2.values[1]) / scale).item()
             row["departure_chosen_gap"] = ((top2.values[0] - ref_lg[b, t, int(got_ids[b, t])]) / scale).item()
         rows.append(row)
-    REPORT[name] = {"layers": info["layers"], "rows": rows, "max_err": worst, "bound": bound, "logit_scale": scale.item(),
+    # teacher-forced: every step is comparable
+    tf_err = ((tf_lg - ref_lg).abs().amax(-1) / scale)                                    # (B, 17)
+    tf_rms = ((tf_lg - ref_lg).pow(2).mean(-1).sqrt() / ref_lg.pow(2).mean(-1).sqrt())
+    marg = fc.margins(ref_lg)                                                             # oracle top-2 gaps / logit scale, (B, 17)
+    agree = tf_ids == ref_ids
+    tf = {"max_err": tf_err.max().item(), "max_err_per_step": tf_err.amax(0).tolist(), "rms_err_over_rms_logit": tf_rms.mean().item(),
+          "argmax_agrees": int(agree.sum()), "argmax_total": int(agree.numel()),
+          "disagreements": [{"row": int(b), "step": int(t), "oracle_margin": marg[b, t].item(),
+                             "chosen_gap": ((ref_lg[b, t].max() - ref_lg[b, t, int(tf_ids[b, t])]) / scale).item()}
+                            for b, t in (~agree).nonzero().tolist()]}
+    worst = max(worst, tf["max_err"])
+    REPORT[name] = {"layers": info["layers"], "teacher_forced": tf, "free_rows": rows, "max_err": worst, "bound": bound, "logit_scale": scale.item(),
                     "spliced_length": 2793, "oracle": "fp32 branch form (oracle/pipeline.py), fixture " + fname}
     out = os.path.join(fc.ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(REPORT, open(os.path.join(out, "fulldepth_parity.json"), "w"), indent=1)
     print(name, json.dumps(REPORT[name]))
+    assert tf["max_err"] <= bound, tf
+    for d in tf["disagreements"]:
+        assert d["oracle_margin"] < bound and d["chosen_gap"] < bound, d
     for row in rows:
         assert row["max_err_over_those_steps"] <= bound, row
         if row["steps_on_the_oracle_path"] < fc.N_NEW:
