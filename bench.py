@@ -21,6 +21,9 @@ in a separate profiled pass of the same step:
                     graph-replayed loop, plus every decode kernel class's own HBM fraction from event-bracketed launches
   stages          – encode / prefill / decode milliseconds per step
   cpu_baseline    – the oracle (CPU port of the reference algorithm, torch fp32, host cores) on a bounded sample of the same workload
+                    (one sample, timed with 1 and with 8 of the 32 decoder layers)
+  secondary       – N = 1 only: BASELINE configs[1] / [3] / [4] (`vision`, `mcub4`, `train`) for a few steps each in child processes after
+                    the headline model has been freed: {value, ms_per_step, config} per config (driver-visible, not part of `value`)
 """
 from __future__ import annotations
 
@@ -66,6 +69,7 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configs after the timed region")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (roofline objects become null)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=None,
@@ -118,8 +122,8 @@ def workload_meta(name, layers):
 def cpu_baseline(workload: str, new_tokens: int):
     """Oracle = CPU port of the reference algorithm (branch-form LocalLoRA on all tokens, mask-sum routing, every encoder), torch fp32.
     Bounded sample of the SAME workload: one sample (batch 1, the reference's eval batch), `new_tokens` greedy tokens, timed with 1 and
-    with 3 of the 32 decoder layers; the per-layer cost from the difference is scaled to 32, the fixed cost (encoders,
-    projectors, splice, lm_head) is measured in full."""
+    with 8 of the 32 decoder layers (about a minute of CPU); the per-layer cost from the difference is scaled to 32, the fixed cost
+    (encoders, projectors, splice, lm_head) is measured in full."""
     from modelcompose_amd import synthetic
     from oracle import pipeline
     # torch's intra-op pool degrades badly far beyond ~32 threads on these op sizes (256 threads measured 70x slower)
@@ -128,7 +132,7 @@ def cpu_baseline(workload: str, new_tokens: int):
     modals, sentinels = WORKLOADS[workload][0], WORKLOADS[workload][1]
     times = {}
     gen_dev = "cuda" if torch.cuda.is_available() else "cpu"      # weights are only GENERATED on the GPU, then moved to host fp32
-    lo, hi = 1, 3
+    lo, hi = 1, 8                                                 # the deep point is a quarter of the real depth, not 3 layers
     for nl in (lo, hi):
         meta = workload_meta(workload, nl)
         sd = synthetic.synthetic_state_dict(meta, device=gen_dev, seed=7, dtype=torch.float32)
@@ -154,7 +158,38 @@ def cpu_baseline(workload: str, new_tokens: int):
             "sample": f"oracle (torch fp32 CPU port of the reference path, batch 1 as the reference's eval loop) on one sample of the same "
                       f"workload ({WORKLOADS[workload][3]}, {new_tokens} greedy tokens), timed with {lo} and {hi} of 32 decoder layers "
                       f"({times[lo]:.1f}s, {times[hi]:.1f}s): per-layer cost x32 + measured fixed cost (all encoders, projectors, splice, "
-                      f"lm_head) = {full:.1f}s per sample; a full 32-layer run of this sample in the build container is recorded in DESIGN.md"}
+                      f"lm_head) = {full:.1f}s per sample; a full 32-layer run of this sample in the build container (8 cores) took 352 s, "
+                      f"and two rows x 17 tokens of it 831 s (oracle/gen_golden.py g15)"}
+
+
+# ------------------------------------------------------------------------------------------------------------------- other configs
+def secondary_runs(new_tokens: int):
+    """BASELINE configs[1] (vision, B = 16), configs[3] (mcub4, the 4-modality model) and configs[4] (stage-2 finetune step) for a few
+    steps each, AFTER the timed region of the headline workload and after its model has been freed: one child process per config
+    (`python bench.py --workload X --no-profile --no-cpu-baseline --no-secondary`, i.e. the same timing code path with its own barrier +
+    synchronize bracket), whose JSON line is attached in compact form.  Not part of `value`."""
+    import subprocess
+    out = {}
+    for name, steps, warm in (("vision", 6, 2), ("mcub4", 4, 2), ("train", 10, 3)):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--steps", str(steps), "--warmup", str(warm), "--no-profile",
+               "--no-cpu-baseline", "--no-secondary", "--new-tokens", str(new_tokens)]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MC_BENCH_FORCE_DIST")}
+        try:
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            line = next((l for l in reversed(r.stdout.strip().splitlines()) if l.startswith("{")), None)
+            if r.returncode != 0 or line is None:
+                out[name] = {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+                continue
+            j = json.loads(line)
+            out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                         "warmup": j["warmup"], "n_gpus": j["n_gpus"], "dtype": j["dtype"],
+                         "config": {k: v for k, v in j["config"].items() if k in ("workload", "per_gpu_batch", "new_tokens", "layers", "spliced_length",
+                                                                                 "pipelined", "parallelism", "trainable_params")},
+                         "wall_s_incl_model_build": round(time.perf_counter() - t0, 1)}
+        except Exception as e:                                           # evidence only: never lose the headline line to it
+            out[name] = {"error": repr(e)[:300]}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------- train (configs[4])
@@ -398,9 +433,11 @@ def generate_main(args, world, rank, local):
             "value": round(B * args.steps / dtp, 4), "unit": "samples/s", "ms_per_step": round(dtp / args.steps * 1e3, 3),
             "note": ("bench.py --no-pipeline: one generate() call per batch, nothing overlapped; same tokens" if was else
                      "bench.py --pipeline: decode of batch i overlapped with encoders + prefill of batch i+1; same tokens")}
+    del model
+    torch.cuda.empty_cache()
+    if world == 1 and not DIST and not args.no_secondary and name == "iav" and args.layers == 32:
+        line["secondary"] = secondary_runs(args.new_tokens)
     if world == 1 and not args.no_cpu_baseline:
-        del model
-        torch.cuda.empty_cache()
         line["cpu_baseline"] = cpu_baseline(name, args.new_tokens)
     print(json.dumps(line), flush=True)
     if DIST or world > 1:
