@@ -52,6 +52,13 @@ __device__ __forceinline__ float rows4_sum(float t) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// acc *= alpha IN PLACE (asm with tied operands): the rare rescale branch of the online softmax must leave the accumulators in the
+// registers they live in (see the rescale below)
+__device__ __forceinline__ void scale_inplace(f32x4& a, float alpha) {
+    asm volatile("v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(alpha));
+}
+
 // One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KiB at the wave-uniform LDS address).  Issued from inline asm on purpose: hipcc
 // otherwise orders every later ds_read behind it with s_waitcnt vmcnt(0) (it cannot prove the read does not alias the DMA
 // destination), which serialises the prefetch of the next K/V tile with the MFMAs of the current one.  The kernel waits for these
@@ -188,10 +195,14 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
             }
             return;
         }
+        // rare path (the last tile of a buffer whose row count is not a multiple of 64).  The opaque copy of kt keeps hipcc from hoisting this
+        // path's vector address arithmetic (~50 VALU instructions per operand) above the branch, where every tile of every launch paid for it
+        int kt_c = kt;
+        asm volatile("" : "+s"(kt_c));
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
             const int row = wave * WROWS + i * RPI + srow;
-            const int key = min(kt * 64 + row, p.S - 1);
+            const int key = min(kt_c * 64 + row, p.S - 1);
             int sw, swv;
             if (CH == 16) { sw = sch ^ (row & 15); swv = sch ^ ((row & 7) << 1); } else { sw = sch ^ ((row >> 1) & 7); swv = sch ^ (((row >> 1) & 3) << 1); }
             dma16(kbase + (int64_t)key * p.k_st + sw * 8, kb_ + (wave * WROWS + i * RPI) * ROWB);
@@ -241,10 +252,13 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) {
             const bool need_mask = (kt * 64 + 63 >= kvlen) || (p.causal && kt * 64 + 63 > q0 + nq * 16 + p.q_offset);
+            const bool masked = need_mask || REL;
             float tmax = NEG_BIG;
             float lsum = 0.f;
-            if (need_mask || REL) {
-                bool valid[4][4];
+            bool valid[4][4];
+            // (1) tile maximum per query.  masked: scores scaled (and biased) in place, invalid keys left out; mask-free: the raw scores -
+            // the scale is positive, so the maximum commutes with it and exp2(s*c - m) is one FMA per score
+            if (masked) {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -258,14 +272,27 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                         tmax = ok ? fmaxf(tmax, sv) : tmax;
                     }
                 tmax = rows4_max(tmax);
-                if (__builtin_amdgcn_ballot_w64(tmax > m_run[nq] + RESC) != 0) {
-                    const float m_new = fmaxf(m_run[nq], tmax);
-                    const float alpha = fast_exp2(m_run[nq] - m_new);
-                    m_run[nq] = m_new;
-                    l_run[nq] *= alpha;
+            } else {
 #pragma unroll
-                    for (int i = 0; i < DB; ++i) oacc[nq][i] *= alpha;
-                }
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[nq][kb][r]);
+                tmax = rows4_max(tmax);
+                tmax *= p.scale_log2e;
+            }
+            // (2) the rare rescale, ONE copy of it for both paths, multiplying in place (round 3): with one copy per path the accumulators
+            // came out of the masked and the mask-free path in different registers and the COMMON path paid 16 v_mov_b64 per query block
+            // and tile to merge them (hipcc, ROCm 7.2)
+            if (__builtin_amdgcn_ballot_w64(tmax > m_run[nq] + RESC) != 0) {
+                const float m_new = fmaxf(m_run[nq], tmax);
+                const float alpha = fast_exp2(m_run[nq] - m_new);
+                m_run[nq] = m_new;
+                l_run[nq] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DB; ++i) scale_inplace(oacc[nq][i], alpha);
+            }
+            // (3) probabilities against the (possibly raised) running maximum
+            if (masked) {
                 const float mm = m_run[nq];
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
@@ -276,21 +303,6 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                         pf[nq][kb >> 1][(kb & 1) * 4 + r] = (bf16_t)pv;
                     }
             } else {
-                // raw scores: the scale is positive, so the maximum commutes with it and exp2(s*c - m) is one FMA per score
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[nq][kb][r]);
-                tmax = rows4_max(tmax);
-                tmax *= p.scale_log2e;
-                if (__builtin_amdgcn_ballot_w64(tmax > m_run[nq] + RESC) != 0) {
-                    const float m_new = fmaxf(m_run[nq], tmax);
-                    const float alpha = fast_exp2(m_run[nq] - m_new);
-                    m_run[nq] = m_new;
-                    l_run[nq] *= alpha;
-#pragma unroll
-                    for (int i = 0; i < DB; ++i) oacc[nq][i] *= alpha;
-                }
                 const float nm = -m_run[nq];
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
@@ -654,7 +666,11 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
     }
     const bool two = D == 128 && !rel_table && !(g_attn_dbg & (1 | 4)) && Lq > 64;
     if (two) {
-        const bool w8 = ((g_attn_dbg & 2) || Lq >= 2048) && (int64_t)((Lq + 255) / 256) * H * B >= 512 && !(g_attn_dbg & 8);      // bit 3: 4 waves at any length (A/B)
+        // 8 waves (256 queries per workgroup) only on request (debug bit 1): after the round-3 clean-up of the softmax's instruction stream the
+        // 4-wave workgroups are the faster shape at every length measured (L = 2793, B = 48: 817 vs 800 TFLOP/s; L = 2048: 724 vs 620);
+        // a variant with the two wave groups of an 8-wave workgroup running half a tile apart (MFMA half beside softmax half,
+        // bit-identical results) measured 794 - it is not in the tree
+        const bool w8 = (g_attn_dbg & 2) && (int64_t)((Lq + 255) / 256) * H * B >= 512 && !(g_attn_dbg & 8);
         if (w8) attn_prefill_kernel<128, false, 8, 2><<<dim3((Lq + 255) / 256, H, B), 512, 4 * 64 * 256, s>>>(p);
         else attn_prefill_kernel<128, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
         MC_CHECK_LAUNCH();

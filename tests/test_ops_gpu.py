@@ -548,6 +548,47 @@ def test_prefill_attention_128_query_workgroups_match_64_query_ones(causal):
     assert outs[0].float().abs().sum().item() > 0
 
 
+@pytest.mark.parametrize("causal,L,S,lens", [(True, 2793, 2880, (2793, 2000, 2793, 64)), (True, 2049, 2112, (2049, 1, 700, 2049)),
+                                               (False, 2304, 2304, (2304, 2300, 129, 2304)), (True, 2560, 2560, (2560, 2560, 2560, 2560))])
+def test_long_prefill_attention_shapes_are_bit_identical_and_right(causal, L, S, lens):
+    """The LLM prefill's attention at the headline lengths (head_dim 128, L >= 2048): the shipped shape (4 waves x 2 query blocks), the
+    8-wave shape (debug bit 1) and the one-block-per-wave kernel (bit 2) give BITWISE the same output - every accumulator sees the same
+    MFMAs in the same order whatever the tile ownership - with causal and bidirectional masks, ragged kv_lens (rows shorter than one tile,
+    rows that end inside the diagonal), query counts that are not multiples of the workgroup's, and run to run; and the output is the fp32
+    softmax attention of the bf16 inputs to bf16 rounding.  (Round 3 restructured the online softmax's rescale - one shared in-place
+    copy - and the staging's rare clamped path: same arithmetic, fewer instructions.)"""
+    from modelcompose_amd import _lib, ops
+    B, H, D = 4, 32, 128
+    g = torch.Generator().manual_seed(L)
+    q = torch.randn(B, L, H, D, generator=g).to(torch.bfloat16).cuda()
+    k = torch.randn(B, H, S, D, generator=g).to(torch.bfloat16).cuda()
+    v = torch.randn(B, H, S, D, generator=g).to(torch.bfloat16).cuda()
+    kl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+
+    def run(dbg):
+        _lib.lib().mc_attn_debug(dbg)
+        out = torch.zeros(B * L, H * D, dtype=torch.bfloat16, device="cuda")
+        ops.attn_prefill(q, k, v, out, B, H, H, L, S, D, (L * H * D, H * D, D), (H * S * D, D, S * D), (H * S * D, D, S * D), H * D, causal, kv_lens=kl)
+        _lib.lib().mc_attn_debug(0)
+        return out
+    stag = run(0)
+    assert torch.equal(stag, run(2)), "4-wave != 8-wave kernel"
+    assert torch.equal(stag, run(4)), "two query blocks per wave != one"
+    for _ in range(5):
+        assert torch.equal(stag, run(0)), "not reproducible run to run"
+    # and it is the right function: fp32 softmax attention of the bf16 inputs for one (batch, head)
+    b_, h_ = 1, 7
+    n = int(lens[b_])
+    qs, ks, vs = q[b_, :, h_].float(), k[b_, h_, :n].float(), v[b_, h_, :n].float()
+    sc = qs @ ks.t() / D ** 0.5
+    if causal:
+        sc = sc.masked_fill(torch.arange(n, device="cuda")[None, :] > torch.arange(L, device="cuda")[:, None], float("-inf"))
+    ref = torch.softmax(sc, -1) @ vs
+    got = stag.view(B, L, H, D)[b_, :, h_].float()
+    rows = torch.isfinite(ref).all(-1)
+    assert (got[rows] - ref[rows]).abs().max().item() <= 2 ** -6 * ref[rows].abs().max().item()
+
+
 @pytest.mark.parametrize("M", [17, 33, 48, 64])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (1000, 256), (4096, 11008), (2048, 4096), (12288, 1024), (22016, 512), (11008, 1024)])
 def test_rows_gemm_kernel_every_split_and_epilogue(M, N, K):
