@@ -153,7 +153,11 @@ int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, const int32_t* 
 /* live HIP-event timing of the large-M GEMM kernel on its launch stream (bench.py roofline) */
 int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgroup computes tile (0,0)) */
 /* library-wide GEMM policy: "tile192" (default 1) lets the large-M kernel use 192-column tiles when they fill the 256 CUs better than
- * 256-column ones (under-filled launches); 0 = callers that run other work beside such launches keep the wider tile */
+ * 256-column ones (under-filled launches); 0 = callers that run other work beside such launches keep the wider tile;
+ * "raster_shared" (default 1): launches of >= 1024 tiles deal their 32-tile blocks round-robin over the XCDs (all XCDs on one m-group);
+ * "raster_slab" (default 32, applied to launches of more than 64 tile columns; setting it applies it to every launch wider than the
+ * value; 0 = off): with the shared raster the tile columns go in slabs of that many, slab outermost, so that a slab of W stays in the
+ * Infinity Cache across the sweep over M.  None of these changes results. */
 int mc_gemm_set_option(const char* name, int value);
 /* M <= 64 launches with more than 16 rows run gemm_rows_kernel (activations through LDS, K split over workgroups, fp32 slabs folded by the
  * last-arriving workgroup).  Its workspaces (8 x 50 MiB, one per launching stream so that concurrent streams share nothing) are allocated

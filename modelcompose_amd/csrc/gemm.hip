@@ -568,7 +568,7 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     // once per m-group, stays resident - L2 misses become Infinity-Cache hits instead of HBM round trips.
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
-    if (raster == 1) {
+    if ((raster & 255) == 1) {
         const int full = nwg & ~255;
         if (bid < full) {
             const int xcd = bid & 7, idx = bid >> 3;
@@ -579,12 +579,25 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int GROUP = 8;
-    const int per_group = GROUP * tiles_n;
+    // raster bits 8-15 = SW > 0 (round 3): tile columns in SLABS of SW, slab outermost - all m-groups of a slab before the next slab - so
+    // that the slab of W (SW x 256 x K x 2 bytes: 67 MB at SW = 32, K = 4096) stays in the 256-MiB Infinity Cache across the whole sweep
+    // over M instead of the whole W being re-swept (and, once the activations + outputs exceed the cache, re-fetched from HBM) once per
+    // m-group; with SW = 32 an (m-group, slab) is exactly one 8 x 4 block per XCD
+    int tn_base = 0, tiles_n_eff = tiles_n;
+    const int SW = (raster >> 8) & 255;
+    if (SW > 0) {
+        const int per_slab = tiles_m * SW;
+        const int sidx = bid / per_slab;
+        tn_base = sidx * SW;
+        tiles_n_eff = min(SW, tiles_n - tn_base);
+        bid -= sidx * per_slab;
+    }
+    const int per_group = GROUP * tiles_n_eff;
     const int g = bid / per_group;
     const int first_m = g * GROUP;
     const int gsz = min(tiles_m - first_m, GROUP);
     const int tm = first_m + (bid % per_group) % gsz;
-    const int tn = (bid % per_group) / gsz;
+    const int tn = tn_base + (bid % per_group) / gsz;
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i)
@@ -1252,6 +1265,9 @@ static bool g_tile192 = true;
 static bool g_raster_auto = true;          // "raster_shared" option
 static bool g_rows_on = true;              // "rows_kernel" option: M <= 64 launches with ceil(M / 16) >= "rows_min_mb" take gemm_rows_kernel
 static int g_rows_min_mb = 2;
+static int g_raster_slab = 32;             // "raster_slab" option: tile columns per n-slab of the shared-m-group raster (0 = no slabs)
+static int g_raster_slab_min = 64;         // ... for launches of more than this many tile columns (gate|up: 86; measured, M = 44 656, K = 4096:
+                                           // N = 22 016 1398 -> 1425 TFLOP/s, N = 12 288 1437 -> 1425: q|k|v keeps the slab-less order)
 static int g_raster_min_tiles = 1024;      // launches with at least this many tiles deal their 32-tile blocks round-robin over the XCDs
 // "tile192" = 0 keeps the large-M kernel on 256-column tiles: for callers that fill the idle CUs of an under-filled launch themselves
 // (the finetune step runs its rank-projection and weight-gradient GEMMs on a second stream next to the base GEMMs: measured on one
@@ -1259,6 +1275,7 @@ static int g_raster_min_tiles = 1024;      // launches with at least this many t
 extern "C" int mc_gemm_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tile192")) { g_tile192 = value != 0; return 0; }
     if (name && !strcmp(name, "raster_shared")) { g_raster_auto = value != 0; return 0; }
+    if (name && !strcmp(name, "raster_slab")) { g_raster_slab = value < 0 ? 0 : (value > 255 ? 255 : value); g_raster_slab_min = 0; return 0; }
     if (name && !strcmp(name, "raster_min_tiles")) { g_raster_min_tiles = value; return 0; }
     if (name && !strcmp(name, "rows_kernel")) { g_rows_on = value != 0; return 0; }
     if (name && !strcmp(name, "rows_min_mb")) { g_rows_min_mb = value; return 0; }
@@ -1531,7 +1548,9 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         (void)hipEventRecord(rec.a, s);
     }
     // debug word bit 16 forces raster 0, bit 17 forces raster 1
-    const int raster = (g_gemm_dbg & 65536) ? 0 : ((g_gemm_dbg & 131072) ? 1 : (g_raster_auto && tiles_m * tiles_n >= g_raster_min_tiles ? 1 : 0));
+    int raster = (g_gemm_dbg & 65536) ? 0 : ((g_gemm_dbg & 131072) ? 1 : (g_raster_auto && tiles_m * tiles_n >= g_raster_min_tiles ? 1 : 0));
+    // n-slabs ("raster_slab" option, default 0 = off; see the kernel): only with the shared-m-group raster and when there is more than one slab
+    if (raster == 1 && g_raster_slab > 0 && tiles_n > g_raster_slab && tiles_n > g_raster_slab_min) raster |= g_raster_slab << 8;
 #define G2_LAUNCH(A) gemm_tile256_kernel<A><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster)
     // debug word bits 3-5: timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1;
     // 40 = correct results + clock stamps around the main loop (mc_gemm_clock_read)
