@@ -37,6 +37,51 @@ class CausalLMOutputWithPast:
         return tuple(v for v in (self.loss, self.logits, self.past_key_values) if v is not None)[i]
 
 
+class _PastShape:
+    """What a caller reads from one cached key / value tensor of the reference's tuple cache: its shape (multimodal_arch.py:290-293 and
+    HF's generation loop use past_key_values[-1][-1].shape[-2] = cached length)."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+
+class HipPastKeyValues:
+    """The `past_key_values` of the HIP path (multimodal_llama.py:523, :676-688, :747-767): an opaque handle on the device-resident KV
+    cache of one batch - [layer][B][Hkv][Smax][D] K and V buffers, per-row cached lengths - returned by forward(use_cache=True) and
+    taken back by forward(past_key_values=...).  It is NOT a tuple of tensors (the cache is pre-allocated and appended in place by the
+    attention kernel, never concatenated), but it answers what loops written against the tuple ask of it: len(), cache[i][j].shape
+    (so `past_key_values[-1][-1].shape[-2]` is the cached length), get_seq_length().  Rows may hold different lengths (right-padded
+    prompts): the shape reports the longest."""
+
+    def __init__(self, model, st, lens):
+        self.model, self.st = model, st
+        self.lens = np.asarray(lens, dtype=np.int64).copy()          # tokens cached per row
+        self.steps = 0
+
+    def get_seq_length(self, layer_idx=0):
+        return int(self.lens.max())
+
+    def __len__(self):
+        return self.model.config.num_hidden_layers
+
+    def __getitem__(self, i):
+        c = self.model.config
+        sh = _PastShape((len(self.lens), c.num_key_value_heads, self.get_seq_length(), c.head_dim))
+        return (sh, sh)
+
+    def __iter__(self):
+        return iter(self[i] for i in range(len(self)))
+
+    def __del__(self):
+        try:
+            self.model._release_slot(self.st.get("slot"))
+        except Exception:
+            pass
+
+
 _LlmConfigC = _lib.LlmConfigC
 
 
@@ -469,20 +514,48 @@ class MultimodalLlamaForCausalLM:
 
     # ------------------------------------------------------------------ public API
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
-                output_attentions=None, output_hidden_states=None, modal_inputs=None, return_dict=None):
-        """Prefill forward with logits for every position (multimodal_llama.py:676-745).  Incremental calls with
-        past_key_values are served by generate(); forward() is the full-sequence entry point."""
+                output_attentions=None, output_hidden_states=None, modal_inputs=None, return_dict=None, *, modal_attention_mask=None,
+                cache_reserve=None):
+        """MultimodalLlamaForCausalLM.forward (multimodal_llama.py:676-745) incl. its cached-decoding contract (:676-688, :747-767):
+
+          * no past_key_values: prefill over input_ids (+ modal_inputs spliced in at the sentinels) or over inputs_embeds; logits for
+            every position; with use_cache=True the result carries a HipPastKeyValues handle on the batch's KV cache;
+          * past_key_values given: ONE new token per row (input_ids (B, 1), or (B, n) whose last column is taken, as
+            prepare_inputs_for_generation hands them over) is appended to the cache and its logits (B, 1, V) returned - the step an
+            external loop (HF generate, a server's own scheduler) drives; modal_inputs are ignored then, as in the reference (:290-293).
+
+        inputs_embeds (B, L, hidden): the reference routes by modal_attention_mask, which its ForCausalLM.forward leaves unbound on this
+        entry; here `modal_attention_mask` ({modal: bool (B, L)}, optional) routes the rows, default = every row on
+        the `default` adapter.  cache_reserve: tokens of KV capacity beyond the prompt (default 256; the cache grows when it fills)."""
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention maps / per-layer hidden states are never materialised on the HIP path")
-        if past_key_values is not None or inputs_embeds is not None:
-            raise NotImplementedError("forward() takes input_ids; cached decoding is driven by generate()")
-        if input_ids is None:
+        V = self.config.vocab_size
+        if past_key_values is not None:
+            if not isinstance(past_key_values, HipPastKeyValues) or past_key_values.model is not self:
+                raise TypeError("past_key_values must be the HipPastKeyValues returned by this model's forward(use_cache=True)")
+            if labels is not None or inputs_embeds is not None:
+                raise NotImplementedError("a cached step takes input_ids only")
+            if input_ids is None or input_ids.dim() != 2 or input_ids.shape[0] != len(past_key_values.lens):
+                raise ValueError("a cached step needs input_ids (B, 1) for the cache's B rows")
+            logits = self._cached_step(past_key_values, input_ids[:, -1])
+            return CausalLMOutputWithPast(loss=None, logits=logits.view(-1, 1, V), past_key_values=past_key_values)
+        if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You have to specify either decoder_input_ids or decoder_inputs_embeds")
-        modal_inputs = modal_inputs or {}
-        feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
-        plan = self._plan(input_ids, attention_mask, labels, modal_inputs, feats)
-        st = self._prefill(plan, feats, 0, want_hidden=True, want_logits=False)
-        B, Lmax, V = plan.B, plan.Lmax, self.config.vocab_size
+        reserve = 0
+        slot = 0
+        if use_cache:
+            reserve = 256 if cache_reserve is None else int(cache_reserve)
+            slot = self._new_slot()
+        if inputs_embeds is not None:
+            if labels is not None:
+                raise NotImplementedError("labels with inputs_embeds")
+            plan, feats = self._plan_from_embeds(inputs_embeds, attention_mask, modal_attention_mask)
+        else:
+            modal_inputs = modal_inputs or {}
+            feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
+            plan = self._plan(input_ids, attention_mask, labels, modal_inputs, feats)
+        st = self._prefill(plan, feats, reserve, want_hidden=True, want_logits=False, slot=slot)
+        B, Lmax = plan.B, plan.Lmax
         lg_r = ops.linear(st["hidden"], self.lm_head, out_f32=True)                          # lm_head (:720), routed order
         logits = torch.zeros(B * Lmax, V, dtype=torch.float32, device=self.device)
         valid = st["out_map"] >= 0
@@ -495,7 +568,81 @@ class MultimodalLlamaForCausalLM:
             tgt[:, :-1] = lab[:, 1:]
             rows, _ = ops.ce_loss(logits.view(B * Lmax, V), tgt.view(-1), 1.0, want_grad=False)
             loss = rows.sum() / (tgt != IGNORE_INDEX).sum()                                   # nan when every target is ignored, as torch's CE
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None)
+        pkv = HipPastKeyValues(self, st, plan.valid_lens) if use_cache else None
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv)
+
+    # ---- cached decoding for external loops ----------------------------------------------------------------------------------
+    def _new_slot(self):
+        """A private buffer slot (KV cache, workspace, decode state) for one HipPastKeyValues; generate() keeps slots 0 / 1."""
+        n = self._cache.get(("ext_slots",), 0) + 1
+        self._cache[("ext_slots",)] = n
+        return ("ext", n)
+
+    def _release_slot(self, slot):
+        if isinstance(slot, tuple) and slot and slot[0] == "ext":
+            for k in [k for k in self._cache if isinstance(k, tuple) and len(k) > 1 and k[1] == slot]:
+                del self._cache[k]
+
+    def _plan_from_embeds(self, inputs_embeds, attention_mask, modal_attention_mask):
+        """A splice plan whose rows are the rows of inputs_embeds: every token is a "feature row" b * L + t of its routing group."""
+        E = inputs_embeds.to(self.device, BF16).contiguous()
+        B, L, Hd = E.shape
+        if Hd != self.config.hidden_size:
+            raise ValueError(f"inputs_embeds has width {Hd}, the model {self.config.hidden_size}")
+        am = np.ones((B, L), dtype=bool) if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool)
+        mam = {k: v.detach().cpu().numpy().astype(bool) for k, v in (modal_attention_mask or {}).items() if k != "default"}
+        for k in mam:
+            if k not in self.modal_names:
+                raise ValueError(f"modal_attention_mask names '{k}', the model's adapters are {self.modal_names}")
+        order = [m for m in self.modal_names if m in mam] + ["default"]
+        src_modal = np.full((B, L), len(order) - 1, dtype=np.int8)
+        for i, m in enumerate(order[:-1]):
+            src_modal[mam[m]] = i
+        n_att = am.sum(1)
+        valid_lens = n_att.astype(np.int32)
+        suffix_only = bool(all(am[b, :n_att[b]].all() for b in range(B)))
+        masks = {m: src_modal == i for i, m in enumerate(order)}
+        src_row = (np.arange(B)[:, None] * L + np.arange(L)[None, :]).astype(np.int32)
+        plan = SplicePlan(B, L, np.full(B, L, dtype=np.int32), L, np.full((B, L), -1, dtype=np.int64), src_modal, src_row, None, am, masks,
+                          order, {m: 0 for m in order}, valid_lens, suffix_only)
+        return plan, {m: E for m in order}
+
+    def _cached_step(self, pkv: "HipPastKeyValues", token_ids: torch.Tensor) -> torch.Tensor:
+        """Append one token per row to the cache of `pkv` and return its logits (B, V) fp32: one decode step of the runtime (the launch
+        sequence generate() replays from a graph), driven from outside."""
+        st = pkv.st
+        B = len(pkv.lens)
+        need = int(pkv.lens.max()) + 1
+        if need > st["Smax"]:
+            self._grow_cache(st, need)
+        if need > self.config.max_position_embeddings:
+            raise ValueError(f"sequence length {need} exceeds max_position_embeddings {self.config.max_position_embeddings}")
+        st["next_ids"].copy_(token_ids.to(self.device, torch.int64).reshape(B))
+        scratch = self._cache.get(("step_out", st["slot"], B))
+        if scratch is None:
+            with torch.inference_mode(False):
+                scratch = torch.zeros(B, 1, dtype=torch.int64, device=self.device)
+            self._cache[("step_out", st["slot"], B)] = scratch
+        lg = self._decode(st, 1, scratch, pkv.steps, want_logits=True)
+        pkv.steps += 1
+        pkv.lens += 1
+        return lg[0]
+
+    def _grow_cache(self, st, need):
+        """KV capacity exhausted: a larger cache, the cached keys copied over (device-to-device), the old one dropped."""
+        cfg = self.config
+        old_k, old_v, old_S = st["kc"], st["vc"], st["Smax"]
+        new_S = ops.ceil_to(max(need + 256, old_S + old_S // 2), 64)
+        new_S = min(new_S, ops.ceil_to(cfg.max_position_embeddings, 64))
+        shape = (cfg.num_hidden_layers, old_k.shape[1], cfg.num_key_value_heads, new_S, cfg.head_dim)
+        with torch.inference_mode(False):
+            kc, vc = torch.zeros(shape, dtype=BF16, device=self.device), torch.zeros(shape, dtype=BF16, device=self.device)
+        kc[:, :, :, :old_S].copy_(old_k)
+        vc[:, :, :, :old_S].copy_(old_v)
+        for k in [k for k in self._cache if isinstance(k, tuple) and k[0] == "kv" and k[1] == st["slot"]]:
+            del self._cache[k]
+        self._cache[("kv", st["slot"], old_k.shape[1], new_S)] = (kc, vc)
+        st["kc"], st["vc"], st["Smax"] = kc, vc, new_S
 
     __call__ = forward
 

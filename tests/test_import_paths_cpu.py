@@ -23,6 +23,9 @@ REFERENCE_IMPORT_LINES = [
     "from modelcompose.model.language_model.multimodal_llama import MultimodalLlamaForCausalLM, MultimodalConfig",
     "from modelcompose.train.llava_trainer import LengthGroupedSampler",
     "import modelcompose.eval.model_multimodal_qa_loader",
+    # serve/model_worker.py:20-22 (the model-facing imports of the worker) and the worker's own module path
+    "from modelcompose.mm_utils import process_images, load_image_from_base64, tokenizer_image_token, KeywordsStoppingCriteria",
+    "from modelcompose.serve.model_worker import ModelWorker",
 ]
 
 
@@ -45,8 +48,12 @@ def test_signatures_match_the_reference_surface():
     assert LlavaLlamaForCausalLM is MultimodalLlamaForCausalLM and MultimodalLlamaForCausalLM.config_class is MultimodalConfig
     M = MultimodalLlamaForCausalLM
     # multimodal_llama.py:676-688
-    assert _params(M.forward)[1:] == ["input_ids", "attention_mask", "past_key_values", "inputs_embeds", "labels", "use_cache",
-                                      "output_attentions", "output_hidden_states", "modal_inputs", "return_dict"]
+    fwd = inspect.signature(M.forward).parameters
+    positional = [k for k, v in fwd.items() if v.kind == v.POSITIONAL_OR_KEYWORD]
+    assert positional[1:] == ["input_ids", "attention_mask", "past_key_values", "inputs_embeds", "labels", "use_cache",
+                              "output_attentions", "output_hidden_states", "modal_inputs", "return_dict"]
+    # extensions are keyword-only: a positional call written against the reference means the same thing here
+    assert all(v.kind == v.KEYWORD_ONLY for k, v in fwd.items() if k not in positional)
     # multimodal_arch.py:197, :287
     assert _params(M.encode_modal_inputs)[1:] == ["inputs", "prefix_tokens", "suffix_tokens"]
     assert _params(M.prepare_inputs_labels_for_multimodal)[1:] == ["input_ids", "attention_mask", "past_key_values", "labels", "modal_inputs",
