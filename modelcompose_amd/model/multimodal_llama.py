@@ -554,6 +554,7 @@ class MultimodalLlamaForCausalLM:
             modal_inputs = modal_inputs or {}
             feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
             plan = self._plan(input_ids, attention_mask, labels, modal_inputs, feats)
+        reserve = max(0, min(reserve, self.config.max_position_embeddings - plan.Lmax))       # the rotary table bounds the cache
         st = self._prefill(plan, feats, reserve, want_hidden=True, want_logits=False, slot=slot)
         B, Lmax = plan.B, plan.Lmax
         lg_r = ops.linear(st["hidden"], self.lm_head, out_f32=True)                          # lm_head (:720), routed order

@@ -78,9 +78,12 @@ class ContinuousBatcher:
         self._stop = threading.Event()
         self.steps = 0
         self.tokens_out = 0
+        self.dead: Optional[BaseException] = None                    # set when the background loop has died
 
     # ------------------------------------------------------------------ client side
     def submit(self, req: GenerationRequest) -> GenerationRequest:
+        if self.dead is not None:
+            raise RuntimeError(f"the batching engine has stopped: {self.dead!r}")
         req.t_submit = time.perf_counter()
         self.waiting.put(req)
         return req
@@ -221,11 +224,30 @@ class ContinuousBatcher:
             self._thread = None
 
     def _loop(self):
-        torch.cuda.set_device(self.model.device)
-        with torch.no_grad():
-            while not self._stop.is_set():
-                if self.step() == 0 and self.waiting.empty():
-                    time.sleep(0.001)
+        try:
+            dev = self.model.device
+            torch.cuda.set_device(dev.index if dev.index is not None else torch.cuda.current_device())
+            with torch.no_grad():
+                while not self._stop.is_set():
+                    if self.step() == 0 and self.waiting.empty():
+                        time.sleep(0.001)
+        except BaseException as e:                                   # the engine itself failed: no request may wait for it forever
+            self.dead = e
+            for row in range(self.B):
+                if self.rows[row] is not None:
+                    self._fail(self.rows[row], e)
+                    self.rows[row] = None
+            while not self.waiting.empty():
+                try:
+                    self._fail(self.waiting.get_nowait(), e)
+                except queue.Empty:
+                    break
+
+    @staticmethod
+    def _fail(req, e):
+        req.error = e
+        req.t_done = time.perf_counter()
+        req.finished.set()
 
     def run_until_idle(self, max_iters: int = 1 << 30):
         """Synchronous driver (tests, offline use): iterate until no request is waiting or active."""
@@ -297,6 +319,8 @@ class ModelWorker:
             except queue.Empty:
                 if req.finished.is_set() and q.empty():
                     break
+                if self.engine.dead is not None:
+                    raise RuntimeError(f"the batching engine has stopped: {self.engine.dead!r}")
                 continue
             if tok != eos:
                 ids.append(tok)

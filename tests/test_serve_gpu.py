@@ -164,11 +164,12 @@ def test_model_worker_generate_stream_chunks(g4_model):
         px = a["pixels"][0:1]
         p1 = {"prompt": "describe <image> now please", "images": px, "temperature": 0.0, "max_new_tokens": 5, "stop": "</s>"}
         p2 = {"prompt": "a text only question", "temperature": 0.0, "max_new_tokens": 4, "stop": "</s>"}
-        ths = [threading.Thread(target=run, args=(n, p)) for n, p in (("a", p1), ("b", p2))]
+        ths = [threading.Thread(target=run, args=(n, p), daemon=True) for n, p in (("a", p1), ("b", p2))]
         for t in ths:
             t.start()
         for t in ths:
-            t.join(120)
+            t.join(60)
+        assert not any(t.is_alive() for t in ths) and worker.engine.dead is None, worker.engine.dead
         assert all(c["error_code"] == 0 for c in outs["a"] + outs["b"])
         assert len(outs["a"]) == 5 and len(outs["b"]) == 4
         for name, p in (("a", p1), ("b", p2)):
