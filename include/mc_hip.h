@@ -118,6 +118,7 @@ int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* b
  * fragments it streams anyway and uses it as row_scale - the decode path needs no separate normalisation pass.
  * split_k < 0 (M > 64): "auto" - launches that would leave most CUs idle (few output tiles, long K: the LoRA rank projections of the
  * finetune step) are split along K into library-owned fp32 slabs, summed in fixed order, then given the normal epilogue.          */
+struct mc_slab_ref;
 typedef struct mc_gemm_args {
     const void* x; int64_t ldx; const void* w_packed; const void* bias; const void* residual; int64_t ldr;
     void* out; int64_t ldo; int M, N, K; int act; int out_f32; float alpha, beta;
@@ -129,7 +130,19 @@ typedef struct mc_gemm_args {
                                            * (LlamaRMSNorm, multimodal_llama.py:405-406), without the separate mc_rms_scale_bf16 pass: the
                                            * 256x256 kernel's epilogue leaves one sum of squares per row and 128-column chunk, a small
                                            * launch adds them in column order; other routes run mc_rms_scale_bf16 after the GEMM */
+    struct mc_slab_ref* defer_reduce;     /* non-null (round 3): a launch that the library splits along K into fp32 slabs (16 < M <= 64, plain
+                                           * bf16 output: no bias / activation / residual / SwiGLU) may SKIP its slab-reduce launch and describe
+                                           * the slabs here instead (S > 0); `out` is then NOT written and the consumer folds the slabs itself
+                                           * (mc_attn_decode_rope_bf16 takes the q|k|v projection this way: one launch less per decoder layer
+                                           * and step).  S = 0 on return: the launch wrote `out` as usual.  The slabs belong to the launching
+                                           * stream's workspace and are valid until that stream's next M <= 64 GEMM launch */
 } mc_gemm_args;
+typedef struct mc_slab_ref {
+    const float* slabs;                   /* [S][M][N] fp32 partial sums, slice-major */
+    const float* ssp;                     /* [S][64] per-slice sums of squares of the x rows (rms_eps > 0), else unused */
+    int S, M, N, K;
+    float rms_eps;                        /* > 0: row m of the product is scaled by rsqrt(sum_s ssp[s][m] / K + rms_eps) */
+} mc_slab_ref;
 /* RoPE + scatter fused into the q|k|v projection (LlamaAttention.forward, multimodal_llama.py:281-312: rotate q and k, append k / v to the
  * cache): output row r (absolute row index of the launch, as in mc_rope_kv_bf16) belongs to sequence row_b[r] (< 0: padding, skipped), is
  * query row_t[r] of this call and sits at cache position row_pos[r].  N must be (H + 2 Hkv) D.  With D = 128, an even head count and a
@@ -259,6 +272,13 @@ int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const float* cos_t
                              int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
                              void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
                              int nsplit, float scale, void* stream);
+/* the same step with the q|k|v row given as the UNREDUCED split-K slabs of its projection (mc_gemm_args.defer_reduce, B <= 64): the
+ * kernel folds them in slice order, applies the RMS row factor and rounds to bf16 exactly as the slab-reduce launch would have stored
+ * the row, so the result is bit-identical and the reduce launch between projection and attention disappears */
+int mc_attn_decode_rope_slabs_bf16(const struct mc_slab_ref* qkv_slabs, const float* cos_table, const float* sin_table, void* k_cache,
+                                   int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                   void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
+                                   int nsplit, float scale, void* stream);
 
 /* ---- row kernels ---------------------------------------------------------------------------------- */
 int mc_silu_mul_bf16(const void* gate_up, int64_t ld, void* out, int64_t ldo, int M, int I, void* stream);   /* :392-394 */

@@ -62,7 +62,13 @@ class GemmArgsC(C.Structure):
     """struct mc_gemm_args (include/mc_hip.h)."""
     _fields_ = [("x", c_p), ("ldx", c_l), ("w_packed", c_p), ("bias", c_p), ("residual", c_p), ("ldr", c_l), ("out", c_p), ("ldo", c_l),
                 ("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i), ("out_f32", c_i), ("alpha", c_f), ("beta", c_f),
-                ("row_scale", c_p), ("swiglu", c_i), ("split_k", c_i), ("rms_eps", c_f), ("rope", c_p), ("rms_out", c_p), ("rms_out_eps", c_f)]
+                ("row_scale", c_p), ("swiglu", c_i), ("split_k", c_i), ("rms_eps", c_f), ("rope", c_p), ("rms_out", c_p), ("rms_out_eps", c_f),
+                ("defer_reduce", c_p)]
+
+
+class SlabRefC(C.Structure):
+    """struct mc_slab_ref (include/mc_hip.h)."""
+    _fields_ = [("slabs", c_p), ("ssp", c_p), ("S", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("rms_eps", c_f)]
 
 
 class RopeScatterC(C.Structure):
@@ -99,6 +105,8 @@ _SIGS.update({
     "mc_gemm_grouped_bf16": [C.POINTER(GemmArgsC), c_i, C.POINTER(C.c_int32), C.POINTER(c_p), c_p],
     "mc_attn_bwd_bf16": [C.POINTER(AttnBwdArgsC), c_p],
     "mc_attn_decode_rope_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
+                                 c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "mc_attn_decode_rope_slabs_bf16": [C.POINTER(SlabRefC), c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
                                  c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "mc_attn_prefill_lse_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
                                  c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p, c_p, c_p],

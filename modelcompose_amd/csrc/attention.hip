@@ -464,6 +464,10 @@ struct DecodeParams {
     const bf16_t* qkv; int64_t qkv_ld;
     const float* cosT; const float* sinT;
     bf16_t* k_out; bf16_t* v_out;
+    // round 3: the q|k|v projection as the UNREDUCED fp32 slabs of its split-K GEMM (mc_gemm_args.defer_reduce): [S][B][N] + per-slice
+    // sums of squares; row b of q|k|v = bf16(sum_s slab_s[b] * rsqrt(sum_s ssp[s][b] / K + eps)) - what rows_reduce_kernel would have
+    // stored, slice order and rounding included - so the reduce launch between the projection and this kernel is gone
+    const float* slabs; const float* ssp; int n_slabs, slab_n, slab_k; float slab_eps;
 };
 
 template <int D>
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
 
     float qv[8];
     float knew[8], vnew[8];
-    const bool fused = p.qkv != nullptr;
+    const bool fused = p.qkv != nullptr || p.slabs != nullptr;
     const int cache_len = fused ? kvlen - 1 : kvlen;          // keys read from the cache (fused: the new token's key comes from registers)
     const int per = (cache_len + p.nsplit - 1) / p.nsplit;
     const int j0 = split * per, j1 = min(j0 + per, cache_len);
@@ -502,10 +506,31 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
     if (j < j1) request(j);
     if (fused) {
         const int pos = kvlen - 1;
-        const bf16_t* row = p.qkv + (int64_t)b * p.qkv_ld;
-        const bf16x8 q8 = *(const bf16x8*)(row + h * D + dl);
-        const bf16x8 k8 = *(const bf16x8*)(row + (p.H + hk) * D + dl);
-        const bf16x8 v8 = *(const bf16x8*)(row + (p.H + p.Hkv + hk) * D + dl);
+        bf16x8 q8, k8, v8;
+        if (p.slabs) {
+            float fac = 1.0f;
+            if (p.slab_eps > 0.f) {
+                float t = 0.f;
+                for (int s_ = 0; s_ < p.n_slabs; ++s_) t += p.ssp[s_ * 64 + b];
+                fac = 1.0f * rsqrtf(t / (float)p.slab_k + p.slab_eps);
+            }
+            const int64_t sstride = (int64_t)p.B * p.slab_n;
+            auto fold = [&](int n) {
+                const float* sp = p.slabs + (int64_t)b * p.slab_n + n;
+                f32x4 lo = *(const f32x4*)sp, hi = *(const f32x4*)(sp + 4);
+                for (int s_ = 1; s_ < p.n_slabs; ++s_) { lo += *(const f32x4*)(sp + s_ * sstride); hi += *(const f32x4*)(sp + s_ * sstride + 4); }
+                bf16x8 r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { r[i] = (bf16_t)(lo[i] * fac); r[4 + i] = (bf16_t)(hi[i] * fac); }
+                return r;
+            };
+            q8 = fold(h * D + dl); k8 = fold((p.H + hk) * D + dl); v8 = fold((p.H + p.Hkv + hk) * D + dl);
+        } else {
+            const bf16_t* row = p.qkv + (int64_t)b * p.qkv_ld;
+            q8 = *(const bf16x8*)(row + h * D + dl);
+            k8 = *(const bf16x8*)(row + (p.H + hk) * D + dl);
+            v8 = *(const bf16x8*)(row + (p.H + p.Hkv + hk) * D + dl);
+        }
         // rotate-half: lanes dl < D/2 pair with lane + LPK/2 (dl + D/2)
         const bool lo = dl < D / 2;
         const float* cr = p.cosT + (int64_t)pos * (D / 2) + (lo ? dl : dl - D / 2);
@@ -741,17 +766,20 @@ extern "C" int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, co
 // Decode attention with RoPE and the KV-cache append fused in: qkv [B, (H + 2 Hkv) * D] is the pre-rotary output of the q|k|v linear
 // for the token at position kv_lens[b] - 1 of every sequence (kv_lens counts this token).  Replaces mc_rope_kv_bf16 +
 // mc_attn_decode_bf16 for one-token steps (multimodal_llama.py:281-312): one launch less per layer and no q round trip.
-extern "C" int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const float* cos_table, const float* sin_table, void* k_cache,
-                                        int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
-                                        void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
-                                        int nsplit, float scale, void* stream) {
-    MC_CHECK_ARG(qkv && cos_table && sin_table && k_cache && v_cache && o && kv_lens, "mc_attn_decode_rope_bf16: null pointer");
+static int attn_decode_rope_impl(const void* qkv, int64_t qkv_ld, const mc_slab_ref* sl, const float* cos_table, const float* sin_table, void* k_cache,
+                                 int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                 void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
+                                 int nsplit, float scale, void* stream) {
+    MC_CHECK_ARG((qkv || sl) && cos_table && sin_table && k_cache && v_cache && o && kv_lens, "mc_attn_decode_rope_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_decode_rope_bf16: head_dim %d not supported (64 or 128)", D);
     MC_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || workspace), "mc_attn_decode_rope_bf16: nsplit>1 needs a workspace");
     MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && S > 0 && qkv_ld % 8 == 0, "mc_attn_decode_rope_bf16: bad shape");
+    MC_CHECK_ARG(!sl || (sl->S >= 1 && sl->slabs && sl->M == B && sl->N == (H + 2 * Hkv) * D && B <= 64 && (sl->rms_eps <= 0.f || sl->ssp)),
+                 "mc_attn_decode_rope_slabs_bf16: the slabs must be the [S][B][(H + 2 Hkv) D] partial sums of this batch's q|k|v projection");
     DecodeParams p{nullptr, 0, 0, (const bf16_t*)k_cache, k_sb, k_st, k_sh, (const bf16_t*)v_cache, v_sb, v_st, v_sh,
                    (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
-                   (const bf16_t*)qkv, qkv_ld, cos_table, sin_table, (bf16_t*)k_cache, (bf16_t*)v_cache};
+                   (const bf16_t*)qkv, qkv_ld, cos_table, sin_table, (bf16_t*)k_cache, (bf16_t*)v_cache,
+                   sl ? sl->slabs : nullptr, sl ? sl->ssp : nullptr, sl ? sl->S : 0, sl ? sl->N : 0, sl ? sl->K : 0, sl ? sl->rms_eps : 0.f};
     dim3 grid(B * H, nsplit);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) {
@@ -763,4 +791,23 @@ extern "C" int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const f
     }
     MC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const float* cos_table, const float* sin_table, void* k_cache,
+                                        int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                        void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
+                                        int nsplit, float scale, void* stream) {
+    MC_CHECK_ARG(qkv, "mc_attn_decode_rope_bf16: null pointer");
+    return attn_decode_rope_impl(qkv, qkv_ld, nullptr, cos_table, sin_table, k_cache, k_sb, k_st, k_sh, v_cache, v_sb, v_st, v_sh, o, o_sb, workspace,
+                                 kv_lens, B, H, Hkv, S, D, nsplit, scale, stream);
+}
+
+// The same step with the q|k|v projection handed over as the unreduced split-K slabs of its GEMM (mc_gemm_args.defer_reduce)
+extern "C" int mc_attn_decode_rope_slabs_bf16(const mc_slab_ref* qkv_slabs, const float* cos_table, const float* sin_table, void* k_cache,
+                                              int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                              void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
+                                              int nsplit, float scale, void* stream) {
+    MC_CHECK_ARG(qkv_slabs, "mc_attn_decode_rope_slabs_bf16: null pointer");
+    return attn_decode_rope_impl(nullptr, 0, qkv_slabs, cos_table, sin_table, k_cache, k_sb, k_st, k_sh, v_cache, v_sb, v_st, v_sh, o, o_sb, workspace,
+                                 kv_lens, B, H, Hkv, S, D, nsplit, scale, stream);
 }

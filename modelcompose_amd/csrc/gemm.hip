@@ -1503,7 +1503,7 @@ static int rows_split(int groups, int rw, int nblocks, int kblocks, int kt, int 
 
 template <int MB>
 static void launch_rows(int RW, int kt, dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K, const Epilogue& ep,
-                        char* ws) {
+                        char* ws, bool skip_reduce = false) {
     float* ssp = (float*)ws;
     float* slabs = (float*)(ws + kRowsSsBytes);
     if (kt == 8) {
@@ -1513,7 +1513,7 @@ static void launch_rows(int RW, int kt, dim3 grid, hipStream_t s, const bf16_t* 
         if (RW == 2) gemm_rows_kernel<MB, 2, 4><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
         else gemm_rows_kernel<MB, 1, 4><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
     }
-    if (grid.y > 1) {
+    if (grid.y > 1 && !skip_reduce) {
         const int64_t total = (int64_t)M * ((ep.swiglu ? N >> 1 : N) >> 2);
         rows_reduce_kernel<<<(int)min((int64_t)1024, (total + 255) / 256), 256, 0, s>>>(slabs, ssp, (int)grid.y, M, N, K, ep);
     }
@@ -1680,6 +1680,7 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     bool rope_pending = a->rope != nullptr;
     float* ss_parts = nullptr;
+    if (a->defer_reduce) a->defer_reduce->S = 0;
     const int mb_rows = (M + 15) / 16;
     char* rows_ws = nullptr;
     // rows kernel geometry: RW = 2 block-rows per wave for SwiGLU (a gate / up pair), else 1; tiles of 8 k-blocks (8 RW KiB of weights in
@@ -1697,11 +1698,19 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
         if (fs && fs <= kRowsMaxSplit && fs <= (K >> 5) / kt / 2 + (fs == 1) && (size_t)fs * M * N <= kRowsSlabFloats) S = fs;
         dim3 grid((nblocks + 8 * RW - 1) / (8 * RW), S);
         const bf16_t* xb = (const bf16_t*)x; const bf16_t* wb = (const bf16_t*)w_packed;
+        // mc_gemm_args.defer_reduce: the consumer folds the slabs (plain epilogues only: the fold is sum, row factor, one bf16 rounding)
+        const bool defer = a->defer_reduce && S > 1 && !a->bias && !a->residual && a->act == MC_ACT_NONE && !a->swiglu && !a->out_f32 &&
+                           a->alpha == 1.0f && !a->row_scale && !a->rope && !a->rms_out;
         switch (mb_rows) {
-            case 1: launch_rows<1>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws); break;
-            case 2: launch_rows<2>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws); break;
-            case 3: launch_rows<3>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws); break;
-            default: launch_rows<4>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws); break;
+            case 1: launch_rows<1>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws, defer); break;
+            case 2: launch_rows<2>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws, defer); break;
+            case 3: launch_rows<3>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws, defer); break;
+            default: launch_rows<4>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws, defer); break;
+        }
+        if (defer) {
+            mc_slab_ref* r = a->defer_reduce;
+            r->ssp = (const float*)rows_ws; r->slabs = (const float*)(rows_ws + kRowsSsBytes);
+            r->S = S; r->M = M; r->N = N; r->K = K; r->rms_eps = ep.rms_eps;
         }
     } else if (M <= 64) {
         const int mb = (M + 15) / 16;
@@ -1766,6 +1775,7 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
     a.x = x; a.ldx = ldx; a.w_packed = w_packed; a.bias = bias; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = act; a.out_f32 = out_f32; a.alpha = alpha; a.beta = beta;
     a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1; a.rms_eps = 0.f; a.rope = nullptr; a.rms_out = nullptr; a.rms_out_eps = 0.f;
+    a.defer_reduce = nullptr;
     return mc_gemm_ex_bf16(&a, stream);
 }
 

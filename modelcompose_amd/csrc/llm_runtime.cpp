@@ -43,6 +43,7 @@ struct Llm {
     Key gkey[kGraphs] = {};
     int graph_next = 0;                      // round-robin victim
     bool use_graph = true;
+    bool fold_qkv = true;                    // decode: the q|k|v projection's split-K slabs are folded by the attention launch (no reduce launch)
     int tail_adapter = -1;                   // >= 0: generate()'s prefill runs the last layer's attention + MLP for the last token of every
                                              // sequence only (all of them routed to this adapter); -1: every row (forward(), mixed adapters)
     // hipStreamBeginCapture is refused on the legacy null stream (torch's default current stream).  Callers that pass stream 0 have their
@@ -127,16 +128,18 @@ int gemm_ex(const void* x, int64_t ldx, const void* w, const void* residual, int
     a.x = x; a.ldx = ldx; a.w_packed = w; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = out_f32; a.alpha = 1.0f; a.beta = 1.0f;
     a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = split_k; a.rms_eps = 0.f; a.rope = nullptr; a.rms_out = nullptr; a.rms_out_eps = 0.f;
+    a.defer_reduce = nullptr;
     return mc_gemm_ex_bf16(&a, stream);
 }
 
 int gemm_grouped(const void* x, int64_t ldx, const void* residual, int64_t ldr, void* out, int64_t ldo, int N, int K, const float* row_scale,
                  int swiglu, int n_groups, const int32_t* gstart, const void* const* weights, void* stream, float rms_eps = 0.f,
-                 const mc_rope_scatter* rope = nullptr, float* rms_out = nullptr, float rms_out_eps = 0.f) {
+                 const mc_rope_scatter* rope = nullptr, float* rms_out = nullptr, float rms_out_eps = 0.f, mc_slab_ref* defer = nullptr) {
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = nullptr; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = 0; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = 0; a.alpha = 1.0f; a.beta = 1.0f;
     a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = 1; a.rms_eps = rms_eps; a.rope = rope; a.rms_out = rms_out; a.rms_out_eps = rms_out_eps;
+    a.defer_reduce = defer;
     return mc_gemm_grouped_bf16(&a, n_groups, gstart, weights, stream);
 }
 
@@ -174,13 +177,22 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     // prefill: RoPE, the q re-ordering and the cache append are the projection's epilogue (mc_rope_scatter; a separate mc_rope_kv_bf16
     // launch inside the library when the launch is too small for the 256x256 kernel or the head size is not 128)            (:281-312)
     mc_rope_scatter rope{row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, (int)H, (int)Hkv, (int)D, Lq, Smax};
+    // decode at 16 < B <= 64: the projection's split-K slabs stay unreduced and the attention launch folds them ("fold_qkv", default on)
+    mc_slab_ref qkv_slabs;
+    qkv_slabs.S = 0;
+    const bool fold = skinny && stage == 0 && n_groups == 1 && m->fold_qkv;
     if (stage != 2)
         RUNP(m, ph, PK_QKV, stream, gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in,
-                                                 decode ? nullptr : &rope));
+                                                 decode ? nullptr : &rope, nullptr, 0.f, fold ? &qkv_slabs : nullptr));
     if (stage == 1) return 0;
     if (stage == 2) {
     } else if (decode) {
         // one token per sequence (row b = sequence b): RoPE, the cache append and the attention are one launch (:281-312)
+        if (qkv_slabs.S > 0)
+            RUNP(m, ph, PK_ATTN, stream, mc_attn_decode_rope_slabs_bf16(&qkv_slabs, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
+                                         Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D,
+                                         nsplit, scale, stream));
+        else
         RUNP(m, ph, PK_ATTN, stream, mc_attn_decode_rope_bf16(w.qkv, qkvd, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
                                      Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit,
                                      scale, stream));
@@ -271,6 +283,13 @@ extern "C" int mc_llm_set_option(void* handle, const char* name, int value) {
     Llm* m = (Llm*)handle;
     if (!m || !name) { mc_set_error("mc_llm_set_option: null argument"); return 1; }
     if (!strcmp(name, "use_graph")) { m->use_graph = value != 0; return 0; }
+    if (!strcmp(name, "fold_qkv")) {
+        if (m->fold_qkv != (value != 0)) {                       // captured decode graphs hold the other launch sequence
+            for (int i = 0; i < Llm::kGraphs; ++i) m->gkey[i] = Llm::Key{};
+        }
+        m->fold_qkv = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "tail_adapter")) {
         if (value >= m->cfg.n_adapters) { mc_set_error("mc_llm_set_option: tail_adapter %d of %d adapters", value, m->cfg.n_adapters); return 1; }
         m->tail_adapter = value < 0 ? -1 : value;

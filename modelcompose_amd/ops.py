@@ -133,8 +133,9 @@ def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.
 
 def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor] = None, swiglu: bool = False, split_k: int = 1,
               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False, rms_eps: float = 0.0,
-              rope=None, rms_out: Optional[torch.Tensor] = None, rms_out_eps: float = 0.0) -> torch.Tensor:
+              rope=None, rms_out: Optional[torch.Tensor] = None, rms_out_eps: float = 0.0, defer_reduce=None) -> torch.Tensor:
     """mc_gemm_ex_bf16: row_scale fp32 [M] (1/rms of a folded RMSNorm), swiglu (gate/up interleaved per 16 rows -> [M, N/2]),
+    defer_reduce: a _lib.SlabRefC the library fills when it leaves the split-K slabs of a 17..64-row launch unreduced (S > 0),
     split_k > 1 (M <= 64): fp32 partial slabs [split_k, M, N]; rope = rope_scatter(...): the launch is a prefill's q|k|v projection, RoPE and
     the q / KV-cache scatter happen in its epilogue (the returned buffer is scratch then)."""
     _req(x, BF16, "x")
@@ -151,7 +152,7 @@ def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor
                        0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(-2), M, w.N, w.Kp, 0,
                        1 if (out_f32 or split_k > 1) else 0, 1.0, 1.0, 0 if row_scale is None else row_scale.data_ptr(),
                        1 if swiglu else 0, split_k, float(rms_eps), 0 if rope is None else C.addressof(rope[0]),
-                       0 if rms_out is None else rms_out.data_ptr(), float(rms_out_eps))
+                       0 if rms_out is None else rms_out.data_ptr(), float(rms_out_eps), 0 if defer_reduce is None else C.addressof(defer_reduce))
     _lib.check(_lib.lib().mc_gemm_ex_bf16(C.byref(a), _stream()), "mc_gemm_ex_bf16")
     return out
 
@@ -527,9 +528,15 @@ def cast_bf16(x32, out=None):
 
 
 def attn_decode_rope(qkv, cos, sin, k_cache, v_cache, out, kv_lens, B, H, Hkv, Smax, D, nsplit=1, workspace=None, scale=None):
-    """Decode attention with RoPE + KV append fused (caches [B, Hkv, Smax, D]); kv_lens counts the token being decoded."""
+    """Decode attention with RoPE + KV append fused (caches [B, Hkv, Smax, D]); kv_lens counts the token being decoded.
+    qkv: the [B, (H + 2 Hkv) D] bf16 rows, or a _lib.SlabRefC with S > 0 (the projection's unreduced split-K slabs)."""
     sc = (1.0 / math.sqrt(D)) if scale is None else scale
     st = (Hkv * Smax * D, D, Smax * D)
+    if isinstance(qkv, _lib.SlabRefC):
+        _lib.check(_lib.lib().mc_attn_decode_rope_slabs_bf16(C.byref(qkv), _p(cos), _p(sin), _p(k_cache), *st, _p(v_cache), *st, _p(out),
+                                                             out.stride(0), _p(workspace), _p(kv_lens), B, H, Hkv, Smax, D, nsplit, sc, _stream()),
+                   "mc_attn_decode_rope_slabs_bf16")
+        return out
     _lib.check(_lib.lib().mc_attn_decode_rope_bf16(_p(qkv), qkv.stride(0), _p(cos), _p(sin), _p(k_cache), *st, _p(v_cache), *st, _p(out),
                                                    out.stride(0), _p(workspace), _p(kv_lens), B, H, Hkv, Smax, D, nsplit, sc, _stream()),
                "mc_attn_decode_rope_bf16")

@@ -6,7 +6,13 @@ Mirrors VideoLlamaAudioQformer.forward (modelcompose/model/multimodal_projector/
 the encoder tokens, learned queries -> LayerNorm -> [self-attention, cross-attention to the encoder tokens, query FFN] x L -> Linear.
 Every parameter of the projector is trainable (train_multimodal.py:436-465 unfreezes the modal projectors).  All arithmetic is kernels
 of libmc_hip.so: bf16 GEMMs (forward, input gradients through transposed packs, weight gradients by the TN kernel), flash attention
-forward with LSE + its backward, LayerNorm / GELU backward, column sums for biases."""
+forward with LSE + its backward, LayerNorm / GELU backward, column sums for biases.
+
+KNOWN DEVIATION: the reference builds this Q-Former from a default BertConfig, i.e. hidden_dropout_prob =
+attention_probs_dropout_prob = 0.1, active in model.train() on the embeddings (Qformer.py:108), the attention probabilities (:259) and
+both output dense layers (:288, :374).  This step applies NO dropout inside the projector (the LoRA-input dropout of the decoder layers is
+implemented, train/step.py).  The constructor says so with a RuntimeWarning every time; the step is the reference's with
+`hidden_dropout_prob = attention_probs_dropout_prob = 0` (what the autograd oracle of tests/test_train_step_gpu.py is configured with)."""
 from __future__ import annotations
 
 from typing import Dict, List
@@ -23,6 +29,10 @@ class QformerTrainable:
     def __init__(self, step, modal: str, proj, raw: Dict[str, torch.Tensor]):
         """Registers every parameter of `proj` (a HipQformerProjector) in the step's flat master buffer under the reference's names."""
         self.step, self.modal, self.proj = step, modal, proj
+        import warnings
+        warnings.warn(f"Q-Former projector of modality '{modal}': the reference trains it with dropout 0.1 on the embeddings, the attention "
+                      f"probabilities and the two output dense layers (BertConfig defaults; Qformer.py:108, 259, 288, 374); this step "
+                      f"applies none of them - its regularisation differs from run_finetune_audio_damc.sh", RuntimeWarning, stacklevel=3)
         self.pre = f"model.modal_projectors.{modal}."
         self.names: List[str] = []
         Dm = proj.hidden

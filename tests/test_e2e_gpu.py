@@ -399,3 +399,35 @@ def test_last_layer_tail_equals_the_full_last_layer(g4_model):
     if outs[True][2] is not None:
         for x, y in zip(outs[True][2], outs[False][2]):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("B", [24, 48])
+def test_decode_qkv_slab_fold_in_the_attention_launch_is_bit_identical(g4_model, B):
+    """Round 3: at decode batches of 17-64 rows the q|k|v projection's split-K slabs are no longer reduced by their own
+    launch - the attention launch folds them (slice order, RMS row factor, one bf16 rounding, exactly what rows_reduce_kernel stored).
+    The mc_llm option "fold_qkv" switches the fold off: ids, step logits and the KV cache must be BIT-identical either way, eagerly and
+    from the replayed graph."""
+    from modelcompose_amd import _lib
+    model, a, meta, sd = g4_model
+    g = torch.Generator().manual_seed(B)
+    V = model.config.vocab_size
+    ids = a["input_ids"][:1].repeat(B, 1)
+    ids[:, -4:] = torch.randint(3, V, (B, 4), generator=g)                  # different rows
+    px = a["pixels"][:1].repeat(B, 1, 1, 1) + 0.05 * torch.randn(B, *a["pixels"].shape[1:], generator=g).to(a["pixels"].dtype)
+    ids, px = ids.cuda(), px.cuda()
+    outs = {}
+    for fold in (1, 0):
+        _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"fold_qkv", fold), "set_option")
+        try:
+            res, lg = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=6, ignore_eos=True, return_step_logits=True)
+            res_g = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=6, ignore_eos=True)            # graph replay
+            torch.cuda.synchronize()
+            kv = [t.clone() for t in model._cache[next(k for k in model._cache if isinstance(k, tuple) and k and k[0] == "kv" and k[1] == 0)]]
+        finally:
+            _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"fold_qkv", 1), "set_option")
+        outs[fold] = (res.cpu(), lg.float().cpu(), res_g.cpu(), kv)
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][2], outs[0][2]) and torch.equal(outs[1][0], outs[1][2])
+    assert torch.equal(outs[1][1], outs[0][1])
+    for x, y in zip(outs[1][3], outs[0][3]):
+        assert torch.equal(x, y)
+    assert len(set(map(tuple, outs[1][0][:, ids.shape[1]:].tolist()))) > 1             # the rows really differ

@@ -35,7 +35,11 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # 2x the max |logit error| / max |oracle logit| measured on MI355X in round 3 (profiles/r03_parity.json)
-DEPTH_BOUND = {"depth8_iav": 3.6e-2, "fulldepth_iav": 6.0e-2}          # measured 1.76e-2 / 2.97e-2 (first GPU run of round 3)
+# 2x the max |logit error| / max |oracle logit| over the 17 teacher-forced steps measured on MI355X in round 3 (1.76e-2 / 4.01e-2)
+DEPTH_BOUND = {"depth8_iav": 3.6e-2, "fulldepth_iav": 8.0e-2}
+# a device argmax may differ from the oracle's only where the oracle's top-2 margin is below the measured size of the error itself
+# (observed departures: margins 1.7e-3 ... 1.04e-2)
+NEAR_TIE = {"depth8_iav": 1.8e-2, "fulldepth_iav": 4.0e-2}
 REPORT = {}
 
 
@@ -111,14 +115,15 @@ def _run(name, fname):
     json.dump(REPORT, open(os.path.join(out, "fulldepth_parity.json"), "w"), indent=1)
     print(name, json.dumps(REPORT[name]))
     assert tf["max_err"] <= bound, tf
+    tie = NEAR_TIE[name]
     for d in tf["disagreements"]:
-        assert d["oracle_margin"] < bound and d["chosen_gap"] < bound, d
+        assert d["oracle_margin"] < tie and d["chosen_gap"] < tie, d
     for row in rows:
         assert row["max_err_over_those_steps"] <= bound, row
         if row["steps_on_the_oracle_path"] < fc.N_NEW:
             # a departure is legitimate only at an oracle near-tie: margin and the chosen token's gap inside the error band of a logit
             # DIFFERENCE (two logits, each within `bound`/2 typical error)
-            assert row["departure_margin"] < bound and row["departure_chosen_gap"] < bound, row
+            assert row["departure_margin"] < tie and row["departure_chosen_gap"] < tie, row
     return rows
 
 
@@ -130,4 +135,4 @@ def test_full_depth_32_layers_against_the_committed_oracle_fixture():
     rows = _run("fulldepth_iav", "g15_fulldepth_iav")
     # the first generated token (the prefill's argmax over 32 layers x 2793 positions) is the oracle's unless its margin is a near-tie
     for row in rows:
-        assert row["steps_on_the_oracle_path"] >= 1 or row["departure_margin"] < DEPTH_BOUND["fulldepth_iav"]
+        assert row["steps_on_the_oracle_path"] >= 1 or row["departure_margin"] < NEAR_TIE["fulldepth_iav"]

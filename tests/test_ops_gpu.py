@@ -526,6 +526,48 @@ def test_skinny_gemm_in_kernel_rms_factor(M):
         ops.linear_ex(torch.zeros(100, K, dtype=torch.bfloat16, device="cuda"), pw, rms_eps=1e-5)      # M > 64
 
 
+@pytest.mark.parametrize("B,nsplit", [(48, 4), (17, 1), (64, 8), (33, 2)])
+def test_decode_qkv_slabs_folded_by_the_attention_launch(ops, B, nsplit):
+    """Round 3: the decode step's q|k|v projection at 17-64 rows is a split-K launch; with mc_gemm_args.defer_reduce the
+    slab-reduce launch is skipped and mc_attn_decode_rope_slabs_bf16 folds the slabs itself (slice order, RMS row factor, one bf16
+    rounding).  Vicuna-7B shapes: attention output AND the appended K / V rows are BITWISE those of projection -> reduce -> attention;
+    a launch the library does not split (S = 1) leaves the reference untouched (S == 0 reported, `out` written)."""
+    from modelcompose_amd import _lib
+    H, D, K = 32, 128, 4096
+    N = 3 * H * D
+    Smax = 192
+    g = torch.Generator().manual_seed(B)
+    w = ops.pack_weight(dev((torch.randn(N, K, generator=g) * K ** -0.5).to(BF)))
+    x = dev(torch.randn(B, K, generator=g).to(BF))
+    lens = dev(torch.randint(1, Smax - 1, (B,), generator=g, dtype=torch.int32))
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.outer(torch.arange(256).float(), inv)
+    cos, sin = dev(ang.cos().contiguous()), dev(ang.sin().contiguous())
+    kc0, vc0 = dev(rand_bf(B, H, Smax, D, seed=62)), dev(rand_bf(B, H, Smax, D, seed=63))
+    ws = torch.empty(B * H * nsplit * (D + 2), dtype=torch.float32, device="cuda")
+    # reference sequence: projection (its own reduce launch) -> attention
+    qkv = ops.linear_ex(x, w, rms_eps=1e-5)
+    kc1, vc1 = kc0.clone(), vc0.clone()
+    o1 = torch.empty(B, H * D, dtype=BF, device="cuda")
+    ops.attn_decode_rope(qkv, cos, sin, kc1, vc1, o1, lens, B, H, H, Smax, D, nsplit=nsplit, workspace=ws)
+    # folded: the projection leaves its slabs, the attention launch reduces them
+    ref = _lib.SlabRefC()
+    scratch = torch.full((B, N), 7.0, dtype=BF, device="cuda")
+    ops.linear_ex(x, w, rms_eps=1e-5, out=scratch, defer_reduce=ref)
+    assert ref.S >= 2 and ref.M == B and ref.N == N and ref.K == K, (ref.S, ref.M, ref.N, ref.K)
+    assert bool((scratch == 7.0).all())                                      # `out` is not written when the reduce is deferred
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    o2 = torch.empty(B, H * D, dtype=BF, device="cuda")
+    ops.attn_decode_rope(ref, cos, sin, kc2, vc2, o2, lens, B, H, H, Smax, D, nsplit=nsplit, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2) and torch.equal(o1, o2)
+    # a launch that is not split: nothing is deferred
+    ref2 = _lib.SlabRefC()
+    small = ops.pack_weight(dev((torch.randn(256, 256, generator=g) * 0.05).to(BF)))
+    y = ops.linear_ex(dev(torch.randn(B, 256, generator=g).to(BF)), small, rms_eps=1e-5, defer_reduce=ref2)
+    assert ref2.S == 0 and float(y.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("causal", [True, False])
 def test_prefill_attention_128_query_workgroups_match_64_query_ones(causal):
     """The 8-wave (128-query) instantiation used for long sequences computes exactly what the 4-wave one does (same per-wave arithmetic,
