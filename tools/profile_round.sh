@@ -10,7 +10,7 @@ tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o run -- python3 bench.py --no-cpu-baseline > gpurun_out/bench_prof_$tag.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o run -- python3 bench.py --no-cpu-baseline --no-secondary > gpurun_out/bench_prof_$tag.log 2>&1
 echo "stats rc=$?"
 grep '^{' gpurun_out/bench_prof_$tag.log | tail -1 | cut -c1-300
 rm -f gpurun_out/prof_$tag/*kernel_trace.csv
