@@ -245,6 +245,8 @@ typedef struct mc_attn_bwd_args {
     const void* o; const void* d_o; int64_t o_sb, o_st, o_sh; const float* lse; float* delta;
     void* dq; int64_t dq_sb, dq_st, dq_sh; void* dk; int64_t dk_sb, dk_st, dk_sh; void* dv; int64_t dv_sb, dv_st, dv_sh;
     const int32_t* kv_lens; int B, H, Lq, S, D, causal, q_offset; float scale;
+    float dropout_p; unsigned long long dropout_seed; unsigned int dropout_stream;   /* > 0: the forward was mc_attn_prefill_dropout_bf16 with
+                                                                                      * these values (masks are regenerated, S % 4 == 0) */
 } mc_attn_bwd_args;
 int mc_attn_bwd_bf16(const mc_attn_bwd_args* args, void* stream);
 
@@ -254,6 +256,13 @@ int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh
                          int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B, int H, int Hkv, int Lq,
                          int S, int D, int causal, int q_offset, float scale, const float* rel_table, int rel_stride, int rel_off,
                          const float* q_gate, void* stream);   /* rel_table/q_gate: gated relative-position bias of BEATs, may be null */
+/* training forward with dropout on the attention probabilities (BertSelfAttention.dropout of the Q-Former projector,
+ * multimodal_projector/Qformer.py:136, :259): O = (softmax(S) * keep / (1 - p)) V, lse of the un-dropped softmax; element
+ * e = ((b H + h) Lq + q) S + key is kept iff word (e & 3) of Philox4x32-10(counter = (e >> 2, stream_id, 0), key = seed) >= p 2^32 */
+int mc_attn_prefill_dropout_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
+                                 int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o, int64_t o_row_stride,
+                                 const int32_t* kv_lens, int B, int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
+                                 float* lse, float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream);
 /* as mc_attn_prefill_bf16, plus lse [B, H, Lq] fp32 = log2-sum-exp of the scaled scores (input of mc_attn_bwd_bf16) */
 int mc_attn_debug(int v);      /* diagnostics: bit 0 forces the 64-query prefill kernel, bit 1 allows the 128-query one at any length */
 int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,

@@ -83,7 +83,8 @@ class AttnBwdArgsC(C.Structure):
                  ("v", c_p), ("v_sb", c_l), ("v_st", c_l), ("v_sh", c_l), ("o", c_p), ("d_o", c_p), ("o_sb", c_l), ("o_st", c_l), ("o_sh", c_l),
                  ("lse", c_p), ("delta", c_p), ("dq", c_p), ("dq_sb", c_l), ("dq_st", c_l), ("dq_sh", c_l),
                  ("dk", c_p), ("dk_sb", c_l), ("dk_st", c_l), ("dk_sh", c_l), ("dv", c_p), ("dv_sb", c_l), ("dv_st", c_l), ("dv_sh", c_l),
-                 ("kv_lens", c_p)] + [(n, c_i) for n in ("B", "H", "Lq", "S", "D", "causal", "q_offset")] + [("scale", c_f)])
+                 ("kv_lens", c_p)] + [(n, c_i) for n in ("B", "H", "Lq", "S", "D", "causal", "q_offset")] + [("scale", c_f)] +
+                [("dropout_p", c_f), ("dropout_seed", C.c_uint64), ("dropout_stream", C.c_uint32)])
 
 
 class LlmConfigC(C.Structure):
@@ -106,6 +107,8 @@ _SIGS.update({
     "mc_attn_bwd_bf16": [C.POINTER(AttnBwdArgsC), c_p],
     "mc_attn_decode_rope_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
                                  c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "mc_attn_prefill_dropout_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p,
+                                     c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f, C.c_uint64, C.c_uint32, c_p],
     "mc_attn_decode_rope_slabs_bf16": [C.POINTER(SlabRefC), c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
                                  c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "mc_attn_prefill_lse_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,

@@ -28,6 +28,7 @@ struct AttnParams {
     //   score += q_gate[b,h,t] * rel_table[h*rel_stride + (key - t + rel_off)]
     const float* rel_table; const float* q_gate; int rel_stride, rel_off;
     float* lse;                                    // optional [B, H, Lq]: log2-sum-exp of the scaled scores (training: backward input)
+    AttnDropout drop;                              // DROP instantiations only: dropout on the probabilities (training, Q-Former projector)
 };
 
 #define NEG_BIG (-1.0e30f)
@@ -83,7 +84,9 @@ __device__ __forceinline__ void dma16s(const void* base_uniform, uint32_t off, c
 // one query block that is 32 KiB of LDS reads behind 32 MFMAs (512 cycles): four computing waves per CU ask for 256 B/clk, the LDS's peak
 // - the kernel is LDS-bandwidth bound at ~25 % MFMA utilisation.  With NQ = 2 every K / V fragment read feeds two MFMAs (one per query
 // block): half the LDS bytes per MFMA.
-template <int D, bool REL, int QW, int NQ>
+// DROP: dropout on the attention probabilities (BertSelfAttention.dropout, Qformer.py:259): P keeps its fp32 row sum (softmax is
+// normalised BEFORE the dropout in the reference) and enters P.V as bf16(P * keep / (1 - p)); masks from Philox (common.h)
+template <int D, bool REL, int QW, int NQ, bool DROP = false>
 __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) {
     constexpr int ROWB = D * 2;              // bytes per K/V row
     constexpr int CH = ROWB / 16;            // 16-byte chunks per row
@@ -137,6 +140,9 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
     int q_abs[NQ];                           // absolute position of this lane's queries
 #pragma unroll
     for (int nq = 0; nq < NQ; ++nq) q_abs[nq] = q0 + nq * 16 + c + p.q_offset;
+    int64_t drop_row[NQ];                    // DROP: row of this lane's queries in the [B H Lq, S] score matrix
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) drop_row[nq] = ((int64_t)b * p.H + h) * p.Lq + min(q0 + nq * 16 + c, p.Lq - 1);
     const float* relrow[NQ];
     float gate[NQ];
 #pragma unroll
@@ -295,23 +301,29 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
             if (masked) {
                 const float mm = m_run[nq];
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb) {
+                    float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (DROP) attn_dropout_quad(p.drop, drop_row[nq], p.S, kt * 64 + kb * 16 + g * 4, dm);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = valid[kb][r] ? fast_exp2(s[nq][kb][r] - mm) : 0.f;
                         lsum += pv;
-                        pf[nq][kb >> 1][(kb & 1) * 4 + r] = (bf16_t)pv;
+                        pf[nq][kb >> 1][(kb & 1) * 4 + r] = (bf16_t)(DROP ? pv * dm[r] : pv);
                     }
+                }
             } else {
                 const float nm = -m_run[nq];
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb) {
+                    float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (DROP) attn_dropout_quad(p.drop, drop_row[nq], p.S, kt * 64 + kb * 16 + g * 4, dm);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = fast_exp2(fmaf(s[nq][kb][r], p.scale_log2e, nm));
                         lsum += pv;
-                        pf[nq][kb >> 1][(kb & 1) * 4 + r] = (bf16_t)pv;
+                        pf[nq][kb >> 1][(kb & 1) * 4 + r] = (bf16_t)(DROP ? pv * dm[r] : pv);
                     }
+                }
             }
             l_run[nq] += lsum;
         }
@@ -721,6 +733,33 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
             else attn_prefill_kernel<64, false, 4, 1><<<grid, 256, 4 * 64 * 128, s>>>(p);
         }
     }
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// Training forward with dropout on the probabilities (the Q-Former projector of the audio stage-2 recipe: BertSelfAttention.dropout,
+// multimodal_projector/Qformer.py:136, :259, attention_probs_dropout_prob = 0.1 of the default BertConfig): the 64-query kernel, lse as in
+// mc_attn_prefill_lse_bf16 (of the UN-dropped softmax), masks keyed by (seed, stream_id, element of the [B H Lq, S] score matrix).
+extern "C" int mc_attn_prefill_dropout_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb,
+                                            int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                            void* o, int64_t o_row_stride, const int32_t* kv_lens, int B, int H, int Hkv, int Lq, int S, int D,
+                                            int causal, int q_offset, float scale, float* lse, float dropout_p, unsigned long long seed,
+                                            unsigned int stream_id, void* stream) {
+    MC_CHECK_ARG(q && k && v && o, "mc_attn_prefill_dropout_bf16: null pointer");
+    MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_prefill_dropout_bf16: head_dim %d not supported (64 or 128)", D);
+    MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Lq > 0 && S > 0 && S % 4 == 0, "mc_attn_prefill_dropout_bf16: bad shape (S must be a multiple of 4)");
+    MC_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "mc_attn_prefill_dropout_bf16: dropout probability has to be between 0 and 1, but got %g", (double)dropout_p);
+    MC_CHECK_ARG((q_st % 8 | q_sh % 8 | k_st % 8 | k_sh % 8 | v_st % 8 | v_sh % 8 | q_sb % 8 | k_sb % 8 | v_sb % 8) == 0,
+                 "mc_attn_prefill_dropout_bf16: strides must be multiples of 8 elements");
+    AttnParams p{(const bf16_t*)q, q_sb, q_st, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
+                 (bf16_t*)o, o_row_stride, nullptr, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
+                 scale * 1.4426950408889634f, nullptr, nullptr, 0, 0, lse};
+    const double t = (double)dropout_p * 4294967296.0;
+    p.drop = AttnDropout{t >= 4294967295.0 ? 4294967295u : (uint32_t)t, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, 1.0f / (1.0f - dropout_p)};
+    dim3 grid((Lq + 63) / 64, H, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 128) attn_prefill_kernel<128, false, 4, 1, true><<<grid, 256, 4 * 64 * 256, s>>>(p);
+    else attn_prefill_kernel<64, false, 4, 1, true><<<grid, 256, 4 * 64 * 128, s>>>(p);
     MC_CHECK_LAUNCH();
     return 0;
 }

@@ -34,6 +34,7 @@ struct AttnBwdParams {
     const int32_t* kv_lens;
     int B, H, Lq, S, causal, q_offset;
     float scale, scale_log2e;
+    AttnDropout drop;                               // DROP instantiations: the forward's dropout on the probabilities, regenerated
 };
 
 template <int D>
@@ -85,7 +86,9 @@ __device__ __forceinline__ void stage_tile(const bf16_t* src, int64_t row_stride
     }
 }
 
-template <int D>
+// DROP (forward ran mc_attn_prefill_dropout_bf16): O = (P ⊙ m) V with m = keep / (1 - p), so dP reaches the softmax through the same
+// mask: ds = p ⊙ (m ⊙ dp − delta) (delta = rowsum(dO ⊙ O) of the dropped output, unchanged), dV = (p ⊙ m)^T dO
+template <int D, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     constexpr int ROWB = D * 2, KS = D / 32, DB = D / 16;
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB];
@@ -160,14 +163,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
         }
         bf16x8 dsf[2];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < 4; ++kb) {
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (DROP) attn_dropout_quad(p.drop, stat, p.S, kt * 64 + kb * 16 + g * 4, dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 64 + kb * 16 + g * 4 + r;
                 const bool ok = key < kvlen && (!p.causal || key <= q_abs);
                 const float pv = ok ? fast_exp2(s[kb][r] * p.scale_log2e - lse) : 0.f;
-                dsf[kb >> 1][(kb & 1) * 4 + r] = (bf16_t)(pv * (dp[kb][r] - delta));
+                dsf[kb >> 1][(kb & 1) * 4 + r] = (bf16_t)(pv * ((DROP ? dp[kb][r] * dm[r] : dp[kb][r]) - delta));
             }
+        }
         // dQ^T[d][query] += K^T · dS^T   (K^T through the transposing LDS read of the linear tile)
         const int tq = (lane & 15) >> 2, tp = lane & 3;
 #pragma unroll
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     }
 }
 
-template <int D>
+template <int D, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     constexpr int ROWB = D * 2, KS = D / 32, DB = D / 16;
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ROWB + 2 * 64 * 4];
@@ -290,8 +296,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
                 const int tq_ = qt * 64 + ql;
                 const bool ok = tq_ < p.Lq && key < kvlen && (!p.causal || key <= tq_ + p.q_offset);
                 const float pv = ok ? fast_exp2(s[qb][r] * p.scale_log2e - lse_t[ql]) : 0.f;
-                pf[qb >> 1][(qb & 1) * 4 + r] = (bf16_t)pv;
-                dsf[qb >> 1][(qb & 1) * 4 + r] = (bf16_t)(pv * (dp[qb][r] - del_t[ql]));
+                // this lane owns one key and four consecutive QUERIES: one mask quad per element
+                const float dm = DROP ? attn_dropout_one(p.drop, stat0 + min(tq_, p.Lq - 1), p.S, keyc) : 1.f;
+                pf[qb >> 1][(qb & 1) * 4 + r] = (bf16_t)(DROP ? pv * dm : pv);
+                dsf[qb >> 1][(qb & 1) * 4 + r] = (bf16_t)(pv * ((DROP ? dp[qb][r] * dm : dp[qb][r]) - del_t[ql]));
             }
         const int tq = (lane & 15) >> 2, tp = lane & 3;
 #pragma unroll
@@ -336,17 +344,24 @@ extern "C" int mc_attn_bwd_bf16(const mc_attn_bwd_args* a, void* stream) {
                     a->lse, a->delta, (bf16_t*)a->dq, a->dq_sb, a->dq_st, a->dq_sh, (bf16_t*)a->dk, a->dk_sb, a->dk_st, a->dk_sh,
                     (bf16_t*)a->dv, a->dv_sb, a->dv_st, a->dv_sh, a->kv_lens, a->B, a->H, a->Lq, a->S, a->causal, a->q_offset,
                     a->scale, a->scale * 1.4426950408889634f};
+    const bool drop = a->dropout_p > 0.f;
+    if (drop) {
+        MC_CHECK_ARG(a->dropout_p < 1.f && a->S % 4 == 0, "mc_attn_bwd_bf16: dropout needs 0 <= p < 1 and S %% 4 == 0");
+        const double t = (double)a->dropout_p * 4294967296.0;
+        p.drop = AttnDropout{t >= 4294967295.0 ? 4294967295u : (uint32_t)t, (uint32_t)a->dropout_seed, (uint32_t)(a->dropout_seed >> 32),
+                             a->dropout_stream, 1.0f / (1.0f - a->dropout_p)};
+    }
     hipStream_t s = (hipStream_t)stream;
     const int rows = a->B * a->H * a->Lq;
     dim3 gq((a->Lq + 63) / 64, a->H, a->B), gk((a->S + 63) / 64, a->H, a->B);
     if (a->D == 128) {
         attn_delta_kernel<128><<<(rows + 15) / 16, 256, 0, s>>>(p);                 // 4 waves x 4 rows
-        attn_bwd_dq_kernel<128><<<gq, 256, 0, s>>>(p);
-        attn_bwd_dkv_kernel<128><<<gk, 256, 0, s>>>(p);
+        if (drop) { attn_bwd_dq_kernel<128, true><<<gq, 256, 0, s>>>(p); attn_bwd_dkv_kernel<128, true><<<gk, 256, 0, s>>>(p); }
+        else { attn_bwd_dq_kernel<128, false><<<gq, 256, 0, s>>>(p); attn_bwd_dkv_kernel<128, false><<<gk, 256, 0, s>>>(p); }
     } else {
         attn_delta_kernel<64><<<(rows + 31) / 32, 256, 0, s>>>(p);                  // 4 waves x 8 rows
-        attn_bwd_dq_kernel<64><<<gq, 256, 0, s>>>(p);
-        attn_bwd_dkv_kernel<64><<<gk, 256, 0, s>>>(p);
+        if (drop) { attn_bwd_dq_kernel<64, true><<<gq, 256, 0, s>>>(p); attn_bwd_dkv_kernel<64, true><<<gk, 256, 0, s>>>(p); }
+        else { attn_bwd_dq_kernel<64, false><<<gq, 256, 0, s>>>(p); attn_bwd_dkv_kernel<64, false><<<gk, 256, 0, s>>>(p); }
     }
     MC_CHECK_LAUNCH();
     return 0;

@@ -98,18 +98,6 @@ extern "C" int mc_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* g, 
 // Philox4x32-10(counter = (e >> 2 lo, e >> 2 hi, stream_id, 0), key = (seed_lo, seed_hi)) >= p * 2^32, so the backward pass (and the
 // CPU oracle, oracle/philox.py) regenerates the identical mask from (seed, stream_id) instead of storing it.
 //   out[m][k] = (accumulate ? out[m][k] : 0) + alpha * x[m][k] * keep / (1 - p)
-__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int M, int K,
                                                       uint32_t thr, float inv_keep, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
                                                       int accumulate, float alpha) {

@@ -479,8 +479,15 @@ def rope_inplace(x, row_pos, cos, sin, n_heads, D, sign):
     return x
 
 
-def attn_prefill_lse(q, k, v, out, lse, B, H, Lq, S, D, q_strides, k_strides, v_strides, o_row_stride, causal, scale=None, kv_lens=None):
+def attn_prefill_lse(q, k, v, out, lse, B, H, Lq, S, D, q_strides, k_strides, v_strides, o_row_stride, causal, scale=None, kv_lens=None,
+                     dropout=None):
+    """dropout = (p, seed, stream_id): dropout on the attention probabilities (mc_attn_prefill_dropout_bf16); pass the same triple to attn_bwd."""
     sc = (1.0 / math.sqrt(D)) if scale is None else scale
+    if dropout is not None and dropout[0] > 0:
+        _lib.check(_lib.lib().mc_attn_prefill_dropout_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_row_stride,
+                                                           _p(kv_lens), B, H, H, Lq, S, D, 1 if causal else 0, 0, sc, _p(lse), float(dropout[0]),
+                                                           int(dropout[1]) & (2 ** 64 - 1), int(dropout[2]), _stream()), "mc_attn_prefill_dropout_bf16")
+        return out
     _lib.check(_lib.lib().mc_attn_prefill_lse_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_row_stride, None,
                                                    _p(kv_lens), B, H, H, Lq, S, D, 1 if causal else 0, 0, sc, None, 0, 0, None, _p(lse),
                                                    _stream()), "mc_attn_prefill_lse_bf16")
@@ -488,12 +495,13 @@ def attn_prefill_lse(q, k, v, out, lse, B, H, Lq, S, D, q_strides, k_strides, v_
 
 
 def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, S, D, q_strides, k_strides, v_strides, o_strides, dq_strides, dk_strides, dv_strides,
-             causal, scale=None, kv_lens=None):
+             causal, scale=None, kv_lens=None, dropout=None):
     delta = torch.empty(B * H * Lq, dtype=torch.float32, device=q.device)
+    dp, dseed, dstream = (float(dropout[0]), int(dropout[1]) & (2 ** 64 - 1), int(dropout[2])) if dropout is not None else (0.0, 0, 0)
     a = _lib.AttnBwdArgsC(q.data_ptr(), *q_strides, k.data_ptr(), *k_strides, v.data_ptr(), *v_strides, o.data_ptr(), d_o.data_ptr(), *o_strides,
                           lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), *dq_strides, dk.data_ptr(), *dk_strides, dv.data_ptr(), *dv_strides,
                           0 if kv_lens is None else kv_lens.data_ptr(), B, H, Lq, S, D, 1 if causal else 0, 0,
-                          (1.0 / math.sqrt(D)) if scale is None else scale)
+                          (1.0 / math.sqrt(D)) if scale is None else scale, dp, dseed, dstream)
     _lib.check(_lib.lib().mc_attn_bwd_bf16(C.byref(a), _stream()), "mc_attn_bwd_bf16")
 
 

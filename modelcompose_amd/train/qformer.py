@@ -8,11 +8,12 @@ Every parameter of the projector is trainable (train_multimodal.py:436-465 unfre
 of libmc_hip.so: bf16 GEMMs (forward, input gradients through transposed packs, weight gradients by the TN kernel), flash attention
 forward with LSE + its backward, LayerNorm / GELU backward, column sums for biases.
 
-KNOWN DEVIATION: the reference builds this Q-Former from a default BertConfig, i.e. hidden_dropout_prob =
-attention_probs_dropout_prob = 0.1, active in model.train() on the embeddings (Qformer.py:108), the attention probabilities (:259) and
-both output dense layers (:288, :374).  This step applies NO dropout inside the projector (the LoRA-input dropout of the decoder layers is
-implemented, train/step.py).  The constructor says so with a RuntimeWarning every time; the step is the reference's with
-`hidden_dropout_prob = attention_probs_dropout_prob = 0` (what the autograd oracle of tests/test_train_step_gpu.py is configured with)."""
+Dropout: the reference builds this Q-Former from a default BertConfig - hidden_dropout_prob = attention_probs_dropout_prob
+= 0.1 - active in model.train() on the embeddings (Qformer.py:108), the attention probabilities (:259) and the three output dense
+layers of a layer (:288 self / cross attention output, :374 query FFN output).  All of them are applied here with counter-based Philox
+masks (the step's seed; stream ids below), regenerated in the backward pass: hidden dropouts by mc_dropout_bf16 (out = residual +
+dropout(dense(x))), probability dropout inside the flash attention forward / backward kernels (mc_attn_prefill_dropout_bf16)."""
+
 from __future__ import annotations
 
 from typing import Dict, List
@@ -29,10 +30,10 @@ class QformerTrainable:
     def __init__(self, step, modal: str, proj, raw: Dict[str, torch.Tensor]):
         """Registers every parameter of `proj` (a HipQformerProjector) in the step's flat master buffer under the reference's names."""
         self.step, self.modal, self.proj = step, modal, proj
-        import warnings
-        warnings.warn(f"Q-Former projector of modality '{modal}': the reference trains it with dropout 0.1 on the embeddings, the attention "
-                      f"probabilities and the two output dense layers (BertConfig defaults; Qformer.py:108, 259, 288, 374); this step "
-                      f"applies none of them - its regularisation differs from run_finetune_audio_damc.sh", RuntimeWarning, stacklevel=3)
+        # BertConfig defaults unless the projector's config says otherwise (multimodal_projector/builder.py:118-128 builds a default config)
+        self.p_hidden = float(getattr(proj, "hidden_dropout_prob", 0.1))
+        self.p_attn = float(getattr(proj, "attention_probs_dropout_prob", 0.1))
+        self.modal_idx = list(step.model.modal_names).index(modal) if modal in step.model.modal_names else 0
         self.pre = f"model.modal_projectors.{modal}."
         self.names: List[str] = []
         Dm = proj.hidden
@@ -90,6 +91,39 @@ class QformerTrainable:
         ops.colsum(dy, out=self.g32(name + ".bias"))
         return dx
 
+    # dropout sites: Philox stream ids 0x40000000 | modality << 16 | layer << 8 | site (LoRA-input dropout uses ids < 2^16)
+    SITE_EMB, SITE_SELF_OUT, SITE_CROSS_OUT, SITE_FFN_OUT, SITE_SELF_PROBS, SITE_CROSS_PROBS = range(6)
+
+    def stream_id(self, layer: int, site: int) -> int:
+        return 0x40000000 | (self.modal_idx << 16) | (layer << 8) | site
+
+    def _drop(self, x, layer, site, residual=None):
+        """residual + dropout(x) (residual None: dropout(x)); identity when the step runs without dropout (p = 0 / eval)."""
+        p = self.p_hidden if self.training else 0.0
+        if p <= 0.0:
+            return x if residual is None else ops.add(x, residual)
+        if residual is None:
+            return ops.dropout(x, p, self.step._seed, self.stream_id(layer, site))
+        out = residual.clone()
+        return ops.dropout(x, p, self.step._seed, self.stream_id(layer, site), out=out, accumulate=True)
+
+    def _lin_drop_res(self, x, name, layer, site, residual):
+        """residual + dropout(dense(x)): BertSelfOutput / BertOutput before their LayerNorm (Qformer.py:286-289, :372-375)."""
+        p = self.p_hidden if self.training else 0.0
+        if p <= 0.0:
+            return ops.linear(x, ops.pack_weight(self.w16(name + ".weight"), self.w16(name + ".bias")), residual=residual)
+        return self._drop(self._lin(x, name), layer, site, residual=residual)
+
+    def _drop_bwd(self, dy, layer, site):
+        p = self.p_hidden if self.training else 0.0
+        return dy if p <= 0.0 else ops.dropout(dy, p, self.step._seed, self.stream_id(layer, site))
+
+    def _attn_drop(self, layer, site):
+        p = self.p_attn if self.training else 0.0
+        return None if p <= 0.0 else (p, self.step._seed, self.stream_id(layer, site))
+
+    training = True            # the finetune step trains; set False to run the projector as in eval (no dropout)
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x (B, T, width) encoder tokens (frozen encoder: no gradient needed) -> (B, nq, llm hidden)."""
@@ -104,7 +138,8 @@ class QformerTrainable:
         sv["xe"] = xe
         q0 = self.w16("audio_query_tokens").reshape(N, Dm).repeat(B, 1).contiguous()
         sv["q0"] = q0
-        h = self._ln(q0, "audio_Qformer.bert.embeddings.LayerNorm")
+        h0 = self._ln(q0, "audio_Qformer.bert.embeddings.LayerNorm")
+        h = self._drop(h0, 0, self.SITE_EMB)                                                # Qformer.py:107-108
         M = B * N
         for i in range(pj.nl):
             p = f"audio_Qformer.bert.encoder.layer.{i}."
@@ -114,8 +149,8 @@ class QformerTrainable:
             a = torch.empty(M, Dm, dtype=BF16, device=dev)
             lse = torch.empty(B * H * N, dtype=F32, device=dev)
             st = (N * Dm, Dm, d)
-            ops.attn_prefill_lse(q, k, v, a, lse, B, H, N, N, d, st, st, st, Dm, False)
-            s1 = ops.linear(a, ops.pack_weight(self.w16(p + "attention.output.dense.weight"), self.w16(p + "attention.output.dense.bias")), residual=h)
+            ops.attn_prefill_lse(q, k, v, a, lse, B, H, N, N, d, st, st, st, Dm, False, dropout=self._attn_drop(i, self.SITE_SELF_PROBS))
+            s1 = self._lin_drop_res(a, p + "attention.output.dense", i, self.SITE_SELF_OUT, h)
             h1 = self._ln(s1, p + "attention.output.LayerNorm")
             L.update(q=q, k=k, v=v, a=a, lse=lse, s1=s1, h1=h1)
             # cross-attention to the encoder tokens
@@ -124,14 +159,14 @@ class QformerTrainable:
             ca = torch.empty(M, Dm, dtype=BF16, device=dev)
             clse = torch.empty(B * H * N, dtype=F32, device=dev)
             stk = (T * Dm, Dm, d)
-            ops.attn_prefill_lse(cq, ck, cv, ca, clse, B, H, N, T, d, st, stk, stk, Dm, False)
-            s2 = ops.linear(ca, ops.pack_weight(self.w16(p + "crossattention.output.dense.weight"), self.w16(p + "crossattention.output.dense.bias")), residual=h1)
+            ops.attn_prefill_lse(cq, ck, cv, ca, clse, B, H, N, T, d, st, stk, stk, Dm, False, dropout=self._attn_drop(i, self.SITE_CROSS_PROBS))
+            s2 = self._lin_drop_res(ca, p + "crossattention.output.dense", i, self.SITE_CROSS_OUT, h1)
             h2 = self._ln(s2, p + "crossattention.output.LayerNorm")
             L.update(cq=cq, ck=ck, cv=cv, ca=ca, clse=clse, s2=s2, h2=h2)
             # query FFN
             fpre = self._lin(h2, p + "intermediate_query.dense")
             f = ops.act(fpre, "gelu")
-            s3 = ops.linear(f, ops.pack_weight(self.w16(p + "output_query.dense.weight"), self.w16(p + "output_query.dense.bias")), residual=h2)
+            s3 = self._lin_drop_res(f, p + "output_query.dense", i, self.SITE_FFN_OUT, h2)
             h = self._ln(s3, p + "output_query.LayerNorm")
             L.update(fpre=fpre, f=f, s3=s3)
         sv["h_out"] = h
@@ -153,28 +188,30 @@ class QformerTrainable:
             L = sv[i]
             # h = LN(s3), s3 = fc2(gelu(fc1(h2))) + h2
             ds3 = self._ln_bwd(L["s3"], dh, p + "output_query.LayerNorm")
-            df = self._lin_bwd(L["f"], ds3, p + "output_query.dense")
+            df = self._lin_bwd(L["f"], self._drop_bwd(ds3, i, self.SITE_FFN_OUT), p + "output_query.dense")
             dfpre = ops.act(L["fpre"], "gelu", dy=df)
             dh2 = ops.add(self._lin_bwd(L["h2"], dfpre, p + "intermediate_query.dense"), ds3)
             # h2 = LN(s2), s2 = o(ca) + h1
             ds2 = self._ln_bwd(L["s2"], dh2, p + "crossattention.output.LayerNorm")
-            dca = self._lin_bwd(L["ca"], ds2, p + "crossattention.output.dense")
+            dca = self._lin_bwd(L["ca"], self._drop_bwd(ds2, i, self.SITE_CROSS_OUT), p + "crossattention.output.dense")
             dcq = torch.empty(M, Dm, dtype=BF16, device=dev)
             dck, dcv = (torch.empty(B * T, Dm, dtype=BF16, device=dev) for _ in range(2))
-            ops.attn_bwd(L["cq"], L["ck"], L["cv"], L["ca"], dca, L["clse"], dcq, dck, dcv, B, H, N, T, d, st, stk, stk, st, st, stk, stk, False)
+            ops.attn_bwd(L["cq"], L["ck"], L["cv"], L["ca"], dca, L["clse"], dcq, dck, dcv, B, H, N, T, d, st, stk, stk, st, st, stk, stk, False,
+                         dropout=self._attn_drop(i, self.SITE_CROSS_PROBS))
             dh1 = ops.add(self._lin_bwd(L["h1"], dcq, p + "crossattention.self.query"), ds2)
             for n_, g_ in (("key", dck), ("value", dcv)):
                 dx_ = self._lin_bwd(sv["xe"], g_, p + "crossattention.self." + n_)
                 dxe = dx_ if dxe is None else ops.add(dxe, dx_)
             # h1 = LN(s1), s1 = o(a) + h_in
             ds1 = self._ln_bwd(L["s1"], dh1, p + "attention.output.LayerNorm")
-            da = self._lin_bwd(L["a"], ds1, p + "attention.output.dense")
+            da = self._lin_bwd(L["a"], self._drop_bwd(ds1, i, self.SITE_SELF_OUT), p + "attention.output.dense")
             dq, dk, dv = (torch.empty(M, Dm, dtype=BF16, device=dev) for _ in range(3))
-            ops.attn_bwd(L["q"], L["k"], L["v"], L["a"], da, L["lse"], dq, dk, dv, B, H, N, N, d, st, st, st, st, st, st, st, False)
+            ops.attn_bwd(L["q"], L["k"], L["v"], L["a"], da, L["lse"], dq, dk, dv, B, H, N, N, d, st, st, st, st, st, st, st, False,
+                         dropout=self._attn_drop(i, self.SITE_SELF_PROBS))
             dh = ds1
             for n_, g_ in (("query", dq), ("key", dk), ("value", dv)):
                 dh = ops.add(dh, self._lin_bwd(L["h_in"], g_, p + "attention.self." + n_))
-        dq0 = self._ln_bwd(sv["q0"], dh, "audio_Qformer.bert.embeddings.LayerNorm")
+        dq0 = self._ln_bwd(sv["q0"], self._drop_bwd(dh, 0, self.SITE_EMB), "audio_Qformer.bert.embeddings.LayerNorm")
         # the learned queries are shared by the B samples (.expand): sum over the batch; likewise the position rows
         self.g32("audio_query_tokens").copy_(ops.colsum(dq0.view(B, N * Dm)).view(1, N, Dm))
         gpos = self.g32("audio_position_embedding.weight")

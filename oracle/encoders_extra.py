@@ -142,17 +142,32 @@ def beats_encode(fbank, padding_mask, sd, cfg):
 # =========================================================================================================
 # Q-Former projector
 # =========================================================================================================
-def _bert_attn(x, kv, sd, p, H, eps):
-    """BertAttention: BertSelfAttention (Qformer.py:176-277; scores / sqrt(d), no mask terms for all-ones masks) +
-    BertSelfOutput (dense, LayerNorm(h + input), :280-291)."""
+# training only: the nn.Dropout modules of the Q-Former (BertConfig defaults 0.1: Qformer.py:67/108 embeddings, :136/259 attention
+# probabilities, :284/288 BertSelfOutput, :370/374 BertOutput).  QFORMER_DROPOUT(tag, tensor) -> dropped tensor; None in eval mode.  Tags:
+# "emb", (layer, "self.probs" | "self.out" | "cross.probs" | "cross.out" | "ffn.out").  oracle tests pass the HIP step's Philox masks.
+QFORMER_DROPOUT = None
+
+
+def _qdrop(tag, x):
+    return x if QFORMER_DROPOUT is None else QFORMER_DROPOUT(tag, x)
+
+
+def _bert_attn(x, kv, sd, p, H, eps, tag=None):
+    """BertAttention: BertSelfAttention (Qformer.py:176-277; scores / sqrt(d), no mask terms for all-ones masks; dropout on the
+    probabilities :259) + BertSelfOutput (dense, dropout, LayerNorm(h + input), :280-291)."""
     B, L, Dm = x.shape
     d = Dm // H
     q = _lin(x, sd, f"{p}.self.query").view(B, L, H, d).transpose(1, 2)
     k = _lin(kv, sd, f"{p}.self.key").view(B, kv.shape[1], H, d).transpose(1, 2)
     v = _lin(kv, sd, f"{p}.self.value").view(B, kv.shape[1], H, d).transpose(1, 2)
     w = F.softmax((q @ k.transpose(-1, -2)) / math.sqrt(d), dim=-1)
+    if tag is not None:
+        w = _qdrop((tag[0], tag[1] + ".probs"), w)
     o = (w @ v).transpose(1, 2).reshape(B, L, Dm)
-    return _ln(_lin(o, sd, f"{p}.output.dense") + x, sd, f"{p}.output.LayerNorm", eps)
+    y = _lin(o, sd, f"{p}.output.dense")
+    if tag is not None:
+        y = _qdrop((tag[0], tag[1] + ".out"), y)
+    return _ln(y + x, sd, f"{p}.output.LayerNorm", eps)
 
 
 def qformer_project(x, sd, cfg, prefix=""):
@@ -165,12 +180,13 @@ def qformer_project(x, sd, cfg, prefix=""):
     x = x + sub["audio_position_embedding.weight"][:T][None]                  # :136-140
     q = sub["audio_query_tokens"].expand(B, -1, -1)
     h = _ln(q, sub, "audio_Qformer.bert.embeddings.LayerNorm", eps)            # BertEmbeddings with query_embeds only (:79-110)
+    h = _qdrop("emb", h)                                                       # :108
     for i in range(cfg["num_hidden_layers"]):
         p = f"audio_Qformer.bert.encoder.layer.{i}"
-        h = _bert_attn(h, h, sub, f"{p}.attention", H, eps)
-        h = _bert_attn(h, x, sub, f"{p}.crossattention", H, eps)              # cross_attention_freq = 1
+        h = _bert_attn(h, h, sub, f"{p}.attention", H, eps, tag=(i, "self"))
+        h = _bert_attn(h, x, sub, f"{p}.crossattention", H, eps, tag=(i, "cross"))   # cross_attention_freq = 1
         f = F.gelu(_lin(h, sub, f"{p}.intermediate_query.dense"))              # query FFN (:482-485)
-        h = _ln(_lin(f, sub, f"{p}.output_query.dense") + h, sub, f"{p}.output_query.LayerNorm", eps)
+        h = _ln(_qdrop((i, "ffn.out"), _lin(f, sub, f"{p}.output_query.dense")) + h, sub, f"{p}.output_query.LayerNorm", eps)
     return _lin(h, sub, "audio_llama_proj")
 
 

@@ -258,8 +258,9 @@ def test_audio_recipe_qformer_projector_backward_matches_the_oracle():
                 sd[f"{p}.lora_A.{ad}.weight"] = (torch.rand(32, k, generator=g) * 2 - 1) / math.sqrt(k)
                 sd[f"{p}.lora_B.{ad}.weight"] = torch.randn(n, 32, generator=g) * 0.02
     model = build_from_state_dict(meta, sd)
-    with pytest.warns(RuntimeWarning, match="dropout 0.1"):          # the projector-internal dropouts of the reference are not applied: said loudly
-        st = MultimodalTrainStep(model, lr=1e-3)
+    st = MultimodalTrainStep(model, lr=1e-3, dropout_seed=77)
+    qt = st.qformers["audio"]
+    assert qt.p_hidden == 0.1 and qt.p_attn == 0.1                # BertConfig defaults (the reference builds a default config)
     A = -203
     r = lambda n: torch.randint(3, meta["vocab_size"] - 1, (n,), generator=g).tolist()
     ids = torch.tensor([[1] + r(4) + [A, 13] + r(7), [1] + r(2) + [A, 13] + r(9)])
@@ -268,6 +269,11 @@ def test_audio_recipe_qformer_projector_backward_matches_the_oracle():
     labels[ids == A] = -100
     mi = {"audio": {"audio_inputs": a["fbank"], "audio_padding_mask": a["padding_mask"]}}
     mid = {"audio": {"audio_inputs": a["fbank"].cuda(), "audio_padding_mask": a["padding_mask"].cuda()}}
+    from oracle import encoders_extra as oex
+    from oracle import philox
+    import numpy as np
+    # (1) as model.eval() would run the projector: no dropout inside it
+    qt.training = False
     loss = st.forward_backward(ids.cuda(), labels.cuda(), mid)
     ref_loss, _, ref_grads = otrain.loss_and_grads(sd, meta, ids, labels, mi)
     assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
@@ -275,6 +281,45 @@ def test_audio_recipe_qformer_projector_backward_matches_the_oracle():
     qf = [k for k in ref_grads if k.startswith("model.modal_projectors.audio.")]
     assert len(qf) >= 40 and all(k in got for k in qf)
     worst = _check_grads({k: got[k] for k in ref_grads}, ref_grads, tol=8e-2, min_cos=0.99)
-    print("worst relative gradient error (audio recipe)", worst)
+    print("worst relative gradient error (audio recipe, no dropout)", worst)
+    loss_nodrop = loss.item()
+    # (2) as the reference trains it: dropout 0.1 on the embeddings, the attention probabilities and the three output dense
+    # layers of every layer (Qformer.py:108, :259, :288, :374).  The oracle applies the step's own Philox masks, regenerated in numpy.
+    qt.training = True
+    loss = st.forward_backward(ids.cuda(), labels.cuda(), mid)
+    seed = st._seed
+    pj = qt.proj
+    sites = {"self.out": qt.SITE_SELF_OUT, "cross.out": qt.SITE_CROSS_OUT, "ffn.out": qt.SITE_FFN_OUT, "self.probs": qt.SITE_SELF_PROBS,
+             "cross.probs": qt.SITE_CROSS_PROBS}
+    used = []
+
+    def qdrop(tag, x):
+        layer, site = (0, qt.SITE_EMB) if tag == "emb" else (tag[0], sites[tag[1]])
+        sid = qt.stream_id(layer, site)
+        if x.dim() == 4:                                           # probabilities (B, H, Lq, S): element ((b H + h) Lq + q) S + key
+            b_, h_, lq, s_ = x.shape
+            keep = philox.dropout_keep(b_ * h_ * lq, s_, qt.p_attn, seed, sid).reshape(x.shape)
+            p_ = qt.p_attn
+        else:                                                      # hidden states (B, N, Dm): element (b N + n) Dm + j
+            b_, n_, d_ = x.shape
+            keep = philox.dropout_keep(b_ * n_, d_, qt.p_hidden, seed, sid).reshape(x.shape)
+            p_ = qt.p_hidden
+        used.append((tag, float(keep.mean())))
+        return x * torch.from_numpy(keep.astype(np.float32) / (1.0 - p_))
+    oex.QFORMER_DROPOUT = qdrop
+    try:
+        ref_loss_d, _, ref_grads_d = otrain.loss_and_grads(sd, meta, ids, labels, mi)
+    finally:
+        oex.QFORMER_DROPOUT = None
+    assert len(used) == 1 + 5 * pj.nl and all(0.8 < m < 0.97 for _, m in used), used
+    assert abs(ref_loss_d.item() - ref_loss.item()) > 1e-4          # the masks change the function
+    assert abs(loss.item() - ref_loss_d.item()) < 2e-2 * abs(ref_loss_d.item())
+    assert abs(loss.item() - ref_loss_d.item()) < abs(loss_nodrop - ref_loss_d.item()) + 2e-3 * abs(ref_loss_d.item())
+    got = st.named_gradients()
+    worst = _check_grads({k: got[k] for k in ref_grads_d}, ref_grads_d, tol=8e-2, min_cos=0.99)
+    print("worst relative gradient error (audio recipe, dropout 0.1 inside the Q-Former)", worst)
+    # the masks are the step's: another step draws other masks, the same step the same ones
+    l1 = st.forward_backward(ids.cuda(), labels.cuda(), mid).item()
+    assert l1 == loss.item()
     st.step(ids.cuda(), labels.cuda(), mid)                       # the optimizer path over the Q-Former's parameter group
     assert st._aux_steps["audio"] == 1
