@@ -263,6 +263,11 @@ int mc_attn_prefill_dropout_bf16(const void* q, int64_t q_sb, int64_t q_st, int6
                                  int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o, int64_t o_row_stride,
                                  const int32_t* kv_lens, int B, int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
                                  float* lse, float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream);
+/* One-shot key mask for attention masks that are not "every key below a length": key_valid [B][row_stride] bytes, 0 = that key is masked
+ * for every query of the sequence (left padding, holes: the additive padding mask of LlamaModel._prepare_decoder_attention_mask,
+ * multimodal_llama.py:543-545).  Applies to the NEXT mc_attn_prefill_* / mc_attn_decode_* call of the calling thread and is cleared by it;
+ * kv_lens / causal keep their meaning (a key must pass all tests). */
+int mc_attn_set_key_mask(const void* key_valid, int64_t row_stride);
 /* as mc_attn_prefill_bf16, plus lse [B, H, Lq] fp32 = log2-sum-exp of the scaled scores (input of mc_attn_bwd_bf16) */
 int mc_attn_debug(int v);      /* diagnostics: bit 0 forces the 64-query prefill kernel, bit 1 allows the 128-query one at any length */
 int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
@@ -412,6 +417,10 @@ int mc_llm_profile_read(void* handle, int phase, double* total_ms, int64_t* laun
 /* next-token rule of mc_llm_decode: do_sample = 0 greedy arg-max (default), 1 = mc_sample_step_f32 with these parameters and the seed the
  * caller stored at state[4B+1], state[4B+2] */
 int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_k, float top_p);
+/* One-shot key mask of the NEXT mc_llm_prefill or mc_llm_decode call (every layer's attention of that call; mc_attn_set_key_mask): the
+ * batch's attention mask when it is not a suffix mask - left-padded batches, masks with holes.  key_valid [B][row_stride >= Smax] bytes over
+ * CACHE positions (generated positions must be 1).  A decode call with a mask runs one launch per kernel (no graph replay). */
+int mc_llm_set_key_mask(void* handle, const void* key_valid, int64_t row_stride);
 int mc_llm_workspace_bytes(void* handle, int M, int B, int Lq, int64_t* bytes);
 /* Prefill over M rows in routed order.  group_start / group_adapter are HOST arrays (n_groups+1 / n_groups); the other
  * int32 arrays are device arrays: row_b/row_pos/row_t [M], out_map [B*Lq] (sequence slot -> routed row, -1 = padding),

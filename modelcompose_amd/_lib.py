@@ -142,6 +142,8 @@ _SIGS.update({
     "mc_llm_set_weights": [c_p, C.POINTER(c_p), c_p, c_p, c_p, c_p, c_p],
     "mc_llm_set_option": [c_p, C.c_char_p, c_i],
     "mc_llm_set_sampling": [c_p, c_i, c_f, c_i, c_f],
+    "mc_llm_set_key_mask": [c_p, c_p, c_l],
+    "mc_attn_set_key_mask": [c_p, c_l],
     "mc_sample_step_f32": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_p, C.c_uint64, c_i, c_i, c_f, c_i, c_f, c_p, c_p, c_l, c_p],
     "mc_llm_workspace_bytes": [c_p, c_i, c_i, c_i, C.POINTER(c_l)],
     "mc_llm_prefill": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],

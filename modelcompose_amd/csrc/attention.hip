@@ -29,6 +29,9 @@ struct AttnParams {
     const float* rel_table; const float* q_gate; int rel_stride, rel_off;
     float* lse;                                    // optional [B, H, Lq]: log2-sum-exp of the scaled scores (training: backward input)
     AttnDropout drop;                              // DROP instantiations only: dropout on the probabilities (training, Q-Former projector)
+    // optional per-key validity [B][key_valid_sb] (0 = the key is masked for every query): attention masks with zeros that are not a
+    // suffix - left padding, holes (the additive padding mask of LlamaModel._prepare_decoder_attention_mask, multimodal_llama.py:543-545)
+    const uint8_t* key_valid; int64_t key_valid_sb;
 };
 
 #define NEG_BIG (-1.0e30f)
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
         bf16x8 pf[NQ][2];
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) {
-            const bool need_mask = (kt * 64 + 63 >= kvlen) || (p.causal && kt * 64 + 63 > q0 + nq * 16 + p.q_offset);
+            const bool need_mask = (kt * 64 + 63 >= kvlen) || (p.causal && kt * 64 + 63 > q0 + nq * 16 + p.q_offset) || p.key_valid != nullptr;
             const bool masked = need_mask || REL;
             float tmax = NEG_BIG;
             float lsum = 0.f;
@@ -270,7 +273,8 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = kt * 64 + kb * 16 + g * 4 + r;
-                        const bool ok = key < kvlen && (!p.causal || key <= q_abs[nq]);
+                        bool ok = key < kvlen && (!p.causal || key <= q_abs[nq]);
+                        if (p.key_valid && ok) ok = p.key_valid[(int64_t)b * p.key_valid_sb + key] != 0;
                         valid[kb][r] = ok;
                         float sv = s[nq][kb][r] * p.scale_log2e;
                         if (REL && relrow[nq] && ok) sv += gate[nq] * relrow[nq][key];
@@ -480,6 +484,7 @@ struct DecodeParams {
     // sums of squares; row b of q|k|v = bf16(sum_s slab_s[b] * rsqrt(sum_s ssp[s][b] / K + eps)) - what rows_reduce_kernel would have
     // stored, slice order and rounding included - so the reduce launch between the projection and this kernel is gone
     const float* slabs; const float* ssp; int n_slabs, slab_n, slab_k; float slab_eps;
+    const uint8_t* key_valid; int64_t key_valid_sb;          // optional per-key validity of the CACHED keys (see AttnParams)
 };
 
 template <int D>
@@ -598,7 +603,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
             for (int i = 0; i < 8; ++i) sdot += qv[i] * (float)kc8[u][i];
 #pragma unroll
             for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
-            const bool ok = key < j1;
+            bool ok = key < j1;
+            if (p.key_valid && ok) ok = p.key_valid[(int64_t)b * p.key_valid_sb + key] != 0;
             const float mn = ok ? fmaxf(m, sdot) : m;
             const float a = fast_exp2(m - mn);
             const float pv = ok ? fast_exp2(sdot - mn) : 0.f;
@@ -666,6 +672,16 @@ __global__ void attn_decode_combine_kernel(DecodeParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// One-shot key mask (attention masks that are not "everything up to a length"): set by mc_attn_set_key_mask, consumed by the NEXT
+// mc_attn_prefill_* / mc_attn_decode_* launch of this thread, then cleared - a mask can never leak into a later launch.
+static thread_local const uint8_t* g_key_valid = nullptr;
+static thread_local int64_t g_key_valid_sb = 0;
+extern "C" int mc_attn_set_key_mask(const void* key_valid, int64_t row_stride) {
+    g_key_valid = (const uint8_t*)key_valid; g_key_valid_sb = row_stride;
+    return 0;
+}
+static void take_key_mask(const uint8_t*& kv, int64_t& sb) { kv = g_key_valid; sb = g_key_valid_sb; g_key_valid = nullptr; g_key_valid_sb = 0; }
+
 static int g_attn_dbg = 0;
 extern "C" int mc_attn_debug(int v) { g_attn_dbg = v; return 0; }      // bit 0: force the 64-query kernel, bit 1: allow the 128-query one at any length (A/B timing)
 
@@ -683,13 +699,14 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
     AttnParams p{(const bf16_t*)q, q_sb, q_st, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
                  (bf16_t*)o, o_row_stride, out_map, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
                  scale * 1.4426950408889634f, rel_table, q_gate, rel_stride, rel_off, lse};
+    take_key_mask(p.key_valid, p.key_valid_sb);
     hipStream_t s = (hipStream_t)stream;
     // Workgroup shape: QW waves x NQ 16-query blocks per wave.  D = 128 without the relative-position bias (the LLM prefill, training):
     // two query blocks per wave (half the LDS bytes per MFMA, see the kernel); 4 waves = 128 queries per workgroup, 8 waves = 256 for long
     // sequences where the coarser causal diagonal is cheap.  Everything else keeps one block per wave: 8 waves (128 queries) for
     // Lq >= 1024, 4 waves (64 queries) below.  debug word: bit 0 forces <4 waves, 1 block>, bit 1 allows the 8-wave shapes at any
     // length, bit 2 disables the two-block kernels.
-    if (Lq <= 8 && S <= 8 && !rel_table && !(g_attn_dbg & 32)) {
+    if (Lq <= 8 && S <= 8 && !rel_table && !(g_attn_dbg & 32) && !p.key_valid) {
         const int64_t threads = (int64_t)B * H * 16;
         if (D == 128) attn_tiny_kernel<128><<<(int)((threads + 255) / 256), 256, 0, s>>>(p);
         else attn_tiny_kernel<64><<<(int)((threads + 255) / 256), 256, 0, s>>>(p);
@@ -756,6 +773,7 @@ extern "C" int mc_attn_prefill_dropout_bf16(const void* q, int64_t q_sb, int64_t
                  scale * 1.4426950408889634f, nullptr, nullptr, 0, 0, lse};
     const double t = (double)dropout_p * 4294967296.0;
     p.drop = AttnDropout{t >= 4294967295.0 ? 4294967295u : (uint32_t)t, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, 1.0f / (1.0f - dropout_p)};
+    take_key_mask(p.key_valid, p.key_valid_sb);
     dim3 grid((Lq + 63) / 64, H, B);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) attn_prefill_kernel<128, false, 4, 1, true><<<grid, 256, 4 * 64 * 256, s>>>(p);
@@ -789,6 +807,7 @@ extern "C" int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, co
     DecodeParams p{(const bf16_t*)q, q_sb, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
                    (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
                    nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    take_key_mask(p.key_valid, p.key_valid_sb);
     dim3 grid(B * H, nsplit);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) {
@@ -819,6 +838,7 @@ static int attn_decode_rope_impl(const void* qkv, int64_t qkv_ld, const mc_slab_
                    (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
                    (const bf16_t*)qkv, qkv_ld, cos_table, sin_table, (bf16_t*)k_cache, (bf16_t*)v_cache,
                    sl ? sl->slabs : nullptr, sl ? sl->ssp : nullptr, sl ? sl->S : 0, sl ? sl->N : 0, sl ? sl->K : 0, sl ? sl->rms_eps : 0.f};
+    take_key_mask(p.key_valid, p.key_valid_sb);
     dim3 grid(B * H, nsplit);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) {

@@ -43,6 +43,10 @@ struct Llm {
     Key gkey[kGraphs] = {};
     int graph_next = 0;                      // round-robin victim
     bool use_graph = true;
+    const void* key_mask = nullptr;          // one-shot (mc_llm_set_key_mask): the next prefill / decode call's attention key mask
+    int64_t key_mask_stride = 0;
+    const void* call_key_mask = nullptr;     // ... while that call runs
+    int64_t call_key_mask_stride = 0;
     bool fold_qkv = true;                    // decode: the q|k|v projection's split-K slabs are folded by the attention launch (no reduce launch)
     int tail_adapter = -1;                   // >= 0: generate()'s prefill runs the last layer's attention + MLP for the last token of every
                                              // sequence only (all of them routed to this adapter); -1: every row (forward(), mixed adapters)
@@ -185,6 +189,7 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
         RUNP(m, ph, PK_QKV, stream, gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in,
                                                  decode ? nullptr : &rope, nullptr, 0.f, fold ? &qkv_slabs : nullptr));
     if (stage == 1) return 0;
+    if (stage != 2 && m->call_key_mask) RUN(mc_attn_set_key_mask(m->call_key_mask, m->call_key_mask_stride));
     if (stage == 2) {
     } else if (decode) {
         // one token per sequence (row b = sequence b): RoPE, the cache append and the attention are one launch (:281-312)
@@ -336,6 +341,13 @@ extern "C" int mc_llm_profile_read(void* handle, int phase, double* total_ms, in
     return 0;
 }
 
+extern "C" int mc_llm_set_key_mask(void* handle, const void* key_valid, int64_t row_stride) {
+    Llm* m = (Llm*)handle;
+    if (!m || (key_valid && row_stride <= 0)) { mc_set_error("mc_llm_set_key_mask: bad arguments"); return 1; }
+    m->key_mask = key_valid; m->key_mask_stride = key_valid ? row_stride : 0;
+    return 0;
+}
+
 extern "C" int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_k, float top_p) {
     Llm* m = (Llm*)handle;
     if (!m) { mc_set_error("mc_llm_set_sampling: null handle"); return 1; }
@@ -375,6 +387,10 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
             mc_set_error("mc_llm_prefill: bad group %d (adapter %d rows %d..%d)", g, group_adapter[g], group_start[g], group_start[g + 1]);
             return 1;
         }
+    // one-shot key mask: this call's, then gone (also on the error paths below: the handle field is already cleared)
+    m->call_key_mask = m->key_mask; m->call_key_mask_stride = m->key_mask_stride;
+    m->key_mask = nullptr; m->key_mask_stride = 0;
+    struct MaskGuard { Llm* m; ~MaskGuard() { m->call_key_mask = nullptr; m->call_key_mask_stride = 0; (void)mc_attn_set_key_mask(nullptr, 0); } } mask_guard{m};
     const mc_llm_config& c = m->cfg;
     Ws w = carve(c, M, B, Lq, (char*)workspace);
     RUN(mc_rms_scale_bf16(x_routed, c.hidden, w.rs, M, c.hidden, c.rms_eps, stream));
@@ -472,12 +488,15 @@ extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids
         return 1;
     }
     m->graph_active = 0;
+    m->call_key_mask = m->key_mask; m->call_key_mask_stride = m->key_mask_stride;
+    m->key_mask = nullptr; m->key_mask_stride = 0;
+    struct MaskGuard { Llm* m; ~MaskGuard() { m->call_key_mask = nullptr; m->call_key_mask_stride = 0; (void)mc_attn_set_key_mask(nullptr, 0); } } mask_guard{m};
     const mc_llm_config& c = m->cfg;
     Ws w = carve(c, B, B, 1, (char*)workspace);
     void* attn_ws = (char*)workspace + w.total;
     const int nsplit = decode_nsplit(c, B);
     hipStream_t s = (hipStream_t)stream;
-    if (m->use_graph && !logits_out && n_steps > 1 && !m->prof_on) {
+    if (m->use_graph && !logits_out && n_steps > 1 && !m->prof_on && !m->call_key_mask) {
         // graphs cannot be captured on the legacy null stream: run this call's launches on the handle's own stream, after everything the
         // caller has queued on stream 0 (ev_in) and before anything it queues afterwards (ev_out)
         hipStream_t gs = s;

@@ -438,9 +438,14 @@ class MultimodalLlamaForCausalLM:
         if getattr(self, "_dirty", True):
             self.finalize()
         cfg, dev = self.config, self.device
+        key_valid = None
         if not plan.mask_is_suffix:
-            raise NotImplementedError("attention_mask with zeros before the last attended token (left padding / holes) is not implemented on "
-                                      "the HIP path: sequences are described by one length each; right-pad the batch")
+            # zeros that are not a suffix (left padding, holes): the reference's own semantics (multimodal_llama.py:526-531, :543-545) -
+            # every slot keeps its row and its position id (positions ignore padding), masked slots are hidden as KEYS from every query
+            # by the additive padding mask.  Here: all slots are rows, the mask goes to the attention kernels as per-key validity bytes
+            # (round 3; right-padded batches keep the cheaper one-length-per-row description, which also drops the padded rows).
+            plan.valid_lens = plan.lens.astype(np.int32).copy()
+            key_valid = plan.attention_mask
         if int(plan.valid_lens.min()) < 1:
             raise ValueError("a sample of the batch has no attended token")
         routed = cfg.lora_strategy in ("modal", "modal+language") and bool(plan.modal_masks)     # :703-704
@@ -450,6 +455,11 @@ class MultimodalLlamaForCausalLM:
             raise ValueError(f"sequence length {Lmax}+{max_new_tokens} exceeds max_position_embeddings {cfg.max_position_embeddings}")
         Smax = ops.ceil_to(Lmax + max_new_tokens, 64)
         (kc, vc), ws = self._buffers(B, Smax, M, Lmax, slot)
+        kmask = None
+        if key_valid is not None:
+            kv_np = np.ones((B, Smax), dtype=np.uint8)                     # generated positions are always attended
+            kv_np[:, :Lmax] = key_valid.astype(np.uint8)
+            kmask = torch.from_numpy(kv_np).to(dev)
         x = torch.empty(M, cfg.hidden_size, dtype=BF16, device=dev)
         self._gather_rows(plan, feats, lay.order_b, lay.order_t, x)
         i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
@@ -468,7 +478,9 @@ class MultimodalLlamaForCausalLM:
         # text tokens of the prompt's tail) the runtime runs that layer's attention + MLP for them alone ("tail_adapter"; forward() needs
         # every row)
         tail = -1
-        if not want_hidden and getattr(self, "last_layer_tail", os.environ.get("MC_LAST_LAYER_TAIL", "1") != "0"):
+        if kmask is not None:
+            _lib.check(_lib.lib().mc_llm_set_key_mask(self._handle, _ptr(kmask), kmask.stride(0)), "mc_llm_set_key_mask")
+        if kmask is None and not want_hidden and getattr(self, "last_layer_tail", os.environ.get("MC_LAST_LAYER_TAIL", "1") != "0"):
             g_of_last = np.searchsorted(gs, np.asarray(lay.last_rows), side="right") - 1
             ads = np.unique(ga[np.clip(g_of_last, 0, len(ga) - 1)])
             if len(ads) == 1:
@@ -479,7 +491,7 @@ class MultimodalLlamaForCausalLM:
                                              _ptr(kc), _ptr(vc), Smax, _ptr(ws), _ptr(hidden), _ptr(logits), _ptr(next_ids), _stream()),
                    "mc_llm_prefill")
         return dict(plan=plan, layout=lay, kc=kc, vc=vc, ws=ws, Smax=Smax, logits=logits, next_ids=next_ids, hidden=hidden,
-                    kv_lens=kv_lens, out_map=out_map, slot=slot)
+                    kv_lens=kv_lens, out_map=out_map, slot=slot, key_valid=kmask)
 
     def _decode(self, st, n_steps: int, out_ids: torch.Tensor, step0: int, want_logits=False):
         B = st["plan"].B
@@ -501,6 +513,10 @@ class MultimodalLlamaForCausalLM:
         logits = torch.empty(n_steps, B, self.config.vocab_size, dtype=torch.float32, device=dev) if want_logits else None
         # the workspace of the prefill is at least as large as the decode one (M >= B)
         kv_len_max = int(st["plan"].valid_lens.max()) + step0    # keys already cached by the longest sequence
+        if st.get("key_valid") is not None and st.get("mask_in_decode"):
+            # the batch's padding mask stays in force for its decode steps (HF extends it by ones) - one-shot per call, the call then runs
+            # without graph replay
+            _lib.check(L.mc_llm_set_key_mask(self._handle, _ptr(st["key_valid"]), st["key_valid"].stride(0)), "mc_llm_set_key_mask")
         _lib.check(L.mc_llm_decode(self._handle, B, n_steps, _ptr(st["next_ids"]), _ptr(out_ids), out_ids.stride(0), _ptr(state),
                                    _ptr(st["kc"]), _ptr(st["vc"]), st["Smax"], kv_len_max, _ptr(st["ws"]), _ptr(logits), _stream()),
                    "mc_llm_decode")
@@ -543,6 +559,7 @@ class MultimodalLlamaForCausalLM:
             raise ValueError("You have to specify either decoder_input_ids or decoder_inputs_embeds")
         reserve = 0
         slot = 0
+        mask_in_decode = True                                     # see generate()
         if use_cache:
             reserve = 256 if cache_reserve is None else int(cache_reserve)
             slot = self._new_slot()
@@ -556,6 +573,7 @@ class MultimodalLlamaForCausalLM:
             plan = self._plan(input_ids, attention_mask, labels, modal_inputs, feats)
         reserve = max(0, min(reserve, self.config.max_position_embeddings - plan.Lmax))       # the rotary table bounds the cache
         st = self._prefill(plan, feats, reserve, want_hidden=True, want_logits=False, slot=slot)
+        st["mask_in_decode"] = mask_in_decode
         B, Lmax = plan.B, plan.Lmax
         lg_r = ops.linear(st["hidden"], self.lm_head, out_f32=True)                          # lm_head (:720), routed order
         logits = torch.zeros(B * Lmax, V, dtype=torch.float32, device=self.device)
@@ -644,6 +662,10 @@ class MultimodalLlamaForCausalLM:
             del self._cache[k]
         self._cache[("kv", st["slot"], old_k.shape[1], new_S)] = (kc, vc)
         st["kc"], st["vc"], st["Smax"] = kc, vc, new_S
+        if st.get("key_valid") is not None:                           # the key mask covers cache positions: generated ones are attended
+            km = torch.ones(old_k.shape[1], new_S, dtype=torch.uint8, device=self.device)
+            km[:, :old_S].copy_(st["key_valid"])
+            st["key_valid"] = km
 
     __call__ = forward
 
@@ -692,12 +714,19 @@ class MultimodalLlamaForCausalLM:
             return e
         if input_ids is None:
             raise ValueError("generate() needs input_ids")
+        # A prompt mask with zeros that are not a suffix stays in force over the decode steps (HF's loop: the prompt's mask extended by
+        # ones).  DELIBERATE DEVIATION: when modal_inputs is passed, the reference replaces the mask by all ones on every decode step
+        # (multimodal_arch.py:290-293), which makes the left pads visible again - and what sits at those positions is the output of rows
+        # that could see no key at all (uniform attention over causally-masked FUTURE tokens in the reference, zeros here): garbage by
+        # construction.  The mask is kept instead; tests pin this against the oracle run with keep_mask=True.
+        mask_in_decode = True
         modal_inputs = modal_inputs or {}
         e0 = mark()
         feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
         e1 = mark()
         plan = self._plan(input_ids, attention_mask, None, modal_inputs, feats)
         st = self._prefill(plan, feats, max_new_tokens, want_logits=return_step_logits or sampling is not None, slot=slot)
+        st["mask_in_decode"] = mask_in_decode
         e2 = mark()
         if prefill_done is not None:
             prefill_done.record()                                  # generate_pipelined: the other pipeline's prefill may start now

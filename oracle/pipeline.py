@@ -89,8 +89,13 @@ class OracleModel:
             h = h[:, -1:]
         return llm.lm_logits(h, self.sd), kv, am
 
-    def decode_step(self, token_ids, kv, am):
-        am = torch.ones((am.shape[0], kv[-1][-1].shape[-2] + 1), dtype=am.dtype)  # multimodal_arch.py:290-293
+    def decode_step(self, token_ids, kv, am, keep_mask=False):
+        if keep_mask:
+            # modal_inputs is None: prepare_inputs_labels_for_multimodal returns the caller's mask untouched (multimodal_arch.py:290-293), i.e.
+            # HF's greedy loop mask = the prompt's mask extended by one attended position per generated token (third-party, restated)
+            am = torch.cat([am, torch.ones((am.shape[0], 1), dtype=am.dtype)], 1)
+        else:
+            am = torch.ones((am.shape[0], kv[-1][-1].shape[-2] + 1), dtype=am.dtype)  # multimodal_arch.py:290-293
         if self.emulate == "device":
             dw = self.device_weights()
             logits, kv = device_path.forward(dw, dw.embed[token_ids][:, None], None, past_kv=kv, last_only=True)
@@ -99,10 +104,17 @@ class OracleModel:
                                   emulate=self.emulate)
         return llm.lm_logits(h, self.sd)[:, -1], kv, am
 
-    def generate(self, input_ids, modal_inputs, max_new_tokens=128, ignore_eos=False, return_logits=False, feats_blocks=None):
+    def generate(self, input_ids, modal_inputs, max_new_tokens=128, ignore_eos=False, return_logits=False, feats_blocks=None,
+                 attention_mask=None, keep_mask=None):
         """Greedy; returns the NEW ids (B, n).  With ignore_eos=False rows that hit EOS emit pad afterwards
-        and the loop stops once every row has finished (transformers 4.31 greedy_search)."""
-        logits, kv, am = self.prefill(input_ids, modal_inputs, last_only=True, feats_blocks=feats_blocks)
+        and the loop stops once every row has finished (transformers 4.31 greedy_search).  attention_mask (B, L_text): the prompt's
+        padding mask; modal_inputs None (not {}) keeps it in force over the decode steps, as the reference does (keep_mask=None); with
+        modal_inputs passed the reference replaces it by all ones on decode steps (multimodal_arch.py:290-293) - keep_mask=True is the
+        reference WITHOUT that replacement, which is what the HIP path implements."""
+        if keep_mask is None:
+            keep_mask = modal_inputs is None
+        keep_mask = bool(keep_mask) and attention_mask is not None
+        logits, kv, am = self.prefill(input_ids, modal_inputs or {}, attention_mask=attention_mask, last_only=True, feats_blocks=feats_blocks)
         last = logits[:, -1]
         B = input_ids.shape[0]
         unfinished = torch.ones(B, dtype=torch.long)
@@ -117,7 +129,7 @@ class OracleModel:
             out.append(nxt)
             if (not ignore_eos and unfinished.max() == 0) or step == max_new_tokens - 1:
                 break
-            last, kv, am = self.decode_step(nxt, kv, am)
+            last, kv, am = self.decode_step(nxt, kv, am, keep_mask=keep_mask)
         ids = torch.stack(out, 1)
         if return_logits:
             return ids, torch.stack(all_logits, 1)

@@ -342,9 +342,9 @@ def test_decode_graph_is_really_replayed_on_the_default_stream(g4_model):
     assert torch.equal(out_s, out_g)
 
 
-def test_right_padded_batch_equals_per_sample_and_other_masks_raise(g4_model):
+def test_right_padded_batch_equals_per_sample(g4_model):
     """A batch right-padded by the collator with its attention mask: every row generates exactly what it generates alone (the device
-    path takes one length per sequence); masks with zeros elsewhere are refused, not silently attended."""
+    path takes one length per sequence)."""
     model, a, meta, sd = g4_model
     V = -200
     g = torch.Generator().manual_seed(5)
@@ -362,9 +362,78 @@ def test_right_padded_batch_equals_per_sample_and_other_masks_raise(g4_model):
         r1, l1 = model.generate(torch.tensor([row]).cuda(), modal_inputs=mi, max_new_tokens=n_new, ignore_eos=True, return_step_logits=True)
         assert torch.equal(l1[0, 0], lg[b, 0]), b                        # prefill logits: bitwise (batch-invariant kernels)
         assert torch.equal(r1[0, len(row):], res[b, L:]), b
-    left = am.flip(1)
-    with pytest.raises(NotImplementedError):
-        model.generate(ids.cuda(), modal_inputs={"vision": px.cuda()}, attention_mask=left.cuda(), max_new_tokens=2)
+
+
+def _oracle_of(meta, sd):
+    from oracle import pipeline
+    sdf = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+    return pipeline.OracleModel.from_state_dict(sdf, meta)
+
+
+def test_left_padded_and_holey_masks_follow_the_reference(g4_model):
+    """VERDICT r2 missing #4: attention masks whose zeros are not a suffix (multimodal_llama.py:526-531, :543-545: additive padding mask,
+    position ids ignore padding), against the oracle's restatement of the reference loop, teacher-forced so that every step compares:
+      (a) text-only left-padded batch, generate(modal_inputs=None): the mask hides the pad KEYS in the prefill and - extended by ones - in
+          every decode step, exactly the reference (multimodal_arch.py:290-293 returns the caller's mask untouched when modal_inputs is None);
+      (b) the same with modal_inputs={} and (c) a left-padded batch WITH an image and a hole in the mask: the reference left-extends the
+          mask by the inserted length (:445-449), so the zeros land on the first block tokens instead of the pads - reproduced through the
+          splice plan.  On decode steps the reference would replace the mask by all ones here (:292); the HIP path keeps it (DESIGN §7:
+          the unmasked pads hold the outputs of rows that saw no key - garbage by construction), so (b) / (c) are compared with the oracle
+          run with keep_mask=True, and (b) must equal (a)."""
+    model, a, meta, sd = g4_model
+    om = _oracle_of(meta, sd)
+    g = torch.Generator().manual_seed(9)
+    r = lambda n: torch.randint(3, 97, (n,), generator=g).tolist()
+    n_new = 5
+
+    def run(ids_, am_, mi_hip, mi_or, keep=None):
+        with torch.no_grad():
+            ids_o, lg_o = om.generate(ids_, mi_or, max_new_tokens=n_new, ignore_eos=True, return_logits=True, attention_mask=am_, keep_mask=keep)
+        res, lg = model.generate(ids_.cuda(), modal_inputs=mi_hip, attention_mask=am_.cuda(), max_new_tokens=n_new, ignore_eos=True,
+                                 return_step_logits=True, forced_ids=ids_o[:, :n_new - 1])
+        lg = lg.float().cpu()
+        sc = lg_o.abs().max()
+        err = ((lg - lg_o).abs().max() / sc).item()
+        got = res[:, ids_.shape[1]:].cpu()
+        top2 = lg_o.topk(2, -1).values
+        clear = ((top2[..., 0] - top2[..., 1]) / sc) > 2e-2                 # steps whose oracle margin is well above the logit error
+        assert err < 1.5e-2, ((lg - lg_o).abs().amax(-1) / sc)
+        assert torch.equal(got[clear], ids_o[clear]), (got, ids_o, clear)
+        return lg, lg_o, err, sc
+    rows = [[1] + r(9), [1] + r(4), [1] + r(6)]
+    L = max(len(x) for x in rows)
+    ids = torch.tensor([[0] * (L - len(x)) + x for x in rows])
+    am = torch.tensor([[0] * (L - len(x)) + [1] * len(x) for x in rows], dtype=torch.bool)
+    lg_a, lg_oa, err, scale = run(ids, am, None, None)
+    print(f"[err] left padding (a): {err:.3e}")
+    # the pads are really hidden: the first-token logits of every row equal those of the row alone, un-padded (RoPE is relative: shifting
+    # a whole sequence changes nothing but rounding)
+    for b, row in enumerate(rows):
+        r1, l1 = model.generate(torch.tensor([row]).cuda(), modal_inputs=None, max_new_tokens=1, ignore_eos=True, return_step_logits=True)
+        assert ((l1[0, 0].float().cpu() - lg_a[b, 0]).abs().max() / scale).item() < 1.5e-2, b
+    # and hiding them matters: without the mask rows 1 and 2 compute something else
+    _, lg_nomask = model.generate(ids.cuda(), modal_inputs=None, max_new_tokens=1, ignore_eos=True, return_step_logits=True)
+    assert ((lg_nomask.float().cpu()[1:, 0] - lg_a[1:, 0]).abs().max() / scale).item() > 5e-2
+    lg_b, _, err, _ = run(ids, am, {}, {}, keep=True)
+    print(f"[err] left padding (b): {err:.3e}")
+    assert torch.equal(lg_b, lg_a)                                              # same function as (a) on the HIP path
+    # (c) image + left padding, and a hole
+    V = -200
+    rows = [[1] + r(3) + [V, 13] + r(6), [1] + r(2) + [V, 13] + r(3)]
+    L = max(len(x) for x in rows)
+    ids = torch.tensor([[0] * (L - len(x)) + x for x in rows])
+    am = torch.tensor([[0] * (L - len(x)) + [1] * len(x) for x in rows], dtype=torch.bool)
+    am[0, 5] = False                                                            # a hole in the longest row
+    px = torch.cat([a["pixels"][:1], a["pixels"][:1] * 0.5])
+    _, _, err, _ = run(ids, am, {"vision": px.cuda()}, {"vision": px.float()}, keep=True)
+    print(f"[err] left padding + image + hole (c): {err:.3e}")
+    # forward() with such a mask: logits of the last positions against the oracle's prefill
+    out = model(input_ids=ids.cuda(), attention_mask=am.cuda(), modal_inputs={"vision": px.cuda()})
+    with torch.no_grad():
+        lo, _, _ = om.prefill(ids, {"vision": px.float()}, attention_mask=am)
+    assert out.logits.shape == lo.shape
+    e2 = ((out.logits.float().cpu() - lo).abs().amax(-1) / lo.abs().max())
+    assert float(e2[:, -8:].max()) < 1.5e-2
 
 
 def test_last_layer_tail_equals_the_full_last_layer(g4_model):
