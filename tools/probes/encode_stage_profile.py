@@ -1,0 +1,42 @@
+"""Per-modality time of the metric workload's encode stage (B = 48: 336 px image, 10 s audio, 8-frame video -> encoder + projector), HIP
+events on the launch stream, and - under `rocprofv3 --kernel-trace --stats -- python3 tools/probes/encode_stage_profile.py` - the kernel
+mix of the stage alone (the LLM is built with 1 layer and never run)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from modelcompose_amd import synthetic  # noqa: E402
+from modelcompose_amd.model.builder import build_from_state_dict  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    dev = torch.device("cuda", 0)
+    meta = bench.workload_meta("iav", 1)
+    sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
+    model = build_from_state_dict(meta, sd, device=dev)
+    del sd
+    mi = bench.synthetic_inputs(("vision", "audio", "video"), B, dev, 100)
+    out = {}
+    for modal in ("vision", "audio", "video", "all"):
+        inp = mi if modal == "all" else {modal: mi[modal]}
+        for _ in range(2):
+            model.encode_modal_inputs(inp)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            model.encode_modal_inputs(inp)
+        b.record()
+        torch.cuda.synchronize()
+        out[modal] = round(a.elapsed_time(b) / reps, 3)
+    print(json.dumps({"probe": "encode_stage", "batch": B, "ms": out}))
+
+
+if __name__ == "__main__":
+    main()
