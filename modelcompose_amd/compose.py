@@ -18,7 +18,7 @@ GPU by csrc/compose.hip.
                                  merge_unimodal_modelcompose.py:78-93): trim each flattened checkpoint to its top-K % magnitudes,
                                  elect a sign per parameter, aggregate the agreeing entries — on the GPU (csrc/merge.hip: exact
                                  radix select + two streaming passes); needs a HIP device, there is no CPU fallback.
-convert-* / drop-* strategies raise."""
+convert-* (checkpoints trained with lora_strategy 'same') and convert-drop-* are handled as the reference does (:42-73)."""
 from __future__ import annotations
 
 import argparse
@@ -54,29 +54,53 @@ def _read_checkpoint(path: str) -> Tuple[Dict[str, torch.Tensor], dict]:
     return load_tensors(tensors_file), cfg
 
 
-def _online_merge(per_ckpt: Sequence[Dict[str, torch.Tensor]], modals: Sequence[str]) -> Dict[str, torch.Tensor]:
-    owners: Dict[str, List[int]] = {}
+def _group_by_name(per_ckpt: Sequence[Dict[str, torch.Tensor]]) -> Dict[str, List[Tuple[int, torch.Tensor]]]:
+    """weights_to_merge of the reference (:30-40): name -> [(checkpoint index, tensor)] in order of first appearance."""
+    groups: Dict[str, List[Tuple[int, torch.Tensor]]] = {}
     for i, tensors in enumerate(per_ckpt):
-        for name in tensors:
-            owners.setdefault(name, []).append(i)
+        for name, t in tensors.items():
+            groups.setdefault(name, []).append((i, t))
+    return groups
+
+
+def _online_merge(groups: Dict[str, List[Tuple[int, torch.Tensor]]], modals: Sequence[str]) -> Dict[str, torch.Tensor]:
     out: Dict[str, torch.Tensor] = {}
-    for name, who in owners.items():
+    for name, who in groups.items():
         if len(who) == 1:
-            out[name] = per_ckpt[who[0]][name]
+            out[name] = who[0][1]
             continue
         if "default" not in name:
             raise AssertionError(f"tensor '{name}' is shared by several checkpoints but is not a 'default' adapter key")
-        for i in who:
-            out[name.replace("default", f"default-{modals[i]}")] = per_ckpt[i][name]
+        for i, t in who:
+            out[name.replace("default", f"default-{modals[i]}")] = t
     return out
 
 
-def _elementwise(per_ckpt: Sequence[Dict[str, torch.Tensor]], mean: bool) -> Dict[str, torch.Tensor]:
-    groups: Dict[str, List[torch.Tensor]] = {}
-    for tensors in per_ckpt:
-        for name, t in tensors.items():
-            groups.setdefault(name, []).append(t)
-    return {n: (sum(ts) / len(ts) if mean else sum(ts)) for n, ts in groups.items()}
+def _elementwise(groups: Dict[str, List[Tuple[int, torch.Tensor]]], mean: bool) -> Dict[str, torch.Tensor]:
+    out = {}
+    for n, who in groups.items():
+        ts = [t for _, t in who]
+        out[n] = sum(ts) / len(ts) if mean else sum(ts)
+    return out
+
+
+def _convert_same_to_modal_language(groups, configs) -> Dict[str, List[Tuple[int, torch.Tensor]]]:
+    """`convert-*` (merge_unimodal_modelcompose.py:42-59): checkpoints trained with lora_strategy 'same' hold only `.default` adapters;
+    each is re-labelled 'modal+language' and every `.default` tensor of checkpoint i gets a copy named after checkpoint i's modality."""
+    for cfg in configs:
+        if "lora_strategy" in cfg:
+            assert cfg["lora_strategy"] == "same"                                           # :47
+            cfg["lora_strategy"] = "modal+language"
+    modal_types = [get_modal_from_config(c) for c in configs]
+    converted: Dict[str, List[Tuple[int, torch.Tensor]]] = {}
+    for name, who in groups.items():
+        if ".default" in name:
+            for i, modal in enumerate(modal_types):
+                # the reference indexes the list by checkpoint number (:58): a `.default` tensor missing from a checkpoint is an error
+                if i >= len(who) or who[i][0] != i:
+                    raise IndexError(f"convert-: '{name}' is missing from checkpoint {i}")
+                converted.setdefault(name.replace("default", modal), []).append((i, who[i][1].clone()))
+    return converted
 
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -169,24 +193,21 @@ def ties_merge_state_dicts(checks: Sequence[Dict[str, torch.Tensor]], K=20, merg
     return out
 
 
-def _ties(per_ckpt: Sequence[Dict[str, torch.Tensor]], func: str, K) -> Dict[str, torch.Tensor]:
+def _ties(groups: Dict[str, List[Tuple[int, torch.Tensor]]], func: str, K) -> Dict[str, torch.Tensor]:
     """convert_delta_to_ft (ties_merging.py:224-250) + do_merging: tensors present in every checkpoint are merged, tensors present
-    in exactly one are kept."""
-    groups: Dict[str, List[torch.Tensor]] = {}
-    for tensors in per_ckpt:
-        for name, t in tensors.items():
-            groups.setdefault(name, []).append(t)
+    in exactly one are kept; merged tensors first (sorted names, as vector_to_state_dict rebuilds them), then the kept ones (:85-86)."""
     n = max(len(v) for v in groups.values())
-    out = {}
+    uniques = {}
     shared = [dict() for _ in range(n)]
-    for name, ts in groups.items():
-        if len(ts) == n:
+    for name, who in groups.items():
+        if len(who) == n:
             for i in range(n):
-                shared[i][name] = ts[i]
+                shared[i][name] = who[i][1]
         else:
-            assert len(ts) == 1, f"tensor '{name}' appears in {len(ts)} of {n} checkpoints"   # :246
-            out[name] = ts[0]
-    out.update(ties_merge_state_dicts(shared, K, func))
+            assert len(who) == 1, f"tensor '{name}' appears in {len(who)} of {n} checkpoints"   # :246
+            uniques[name] = who[0][1]
+    out = ties_merge_state_dicts(shared, K, func)
+    out.update(uniques)
     return out
 
 
@@ -288,14 +309,28 @@ def convert_llava_checkpoint(llava_checkpoint: str, output_path: str) -> None:
 
 def merge_checkpoints(filepaths: Sequence[str], output_path: str, strategy: str = "sum", K: int = 20):
     loaded = [_read_checkpoint(p) for p in filepaths]
-    tensors = [t for t, _ in loaded]
     configs = [c for _, c in loaded]
-    if strategy.startswith(("convert-", "drop-")):
-        raise NotImplementedError(f"Merge strategy [{strategy}] (convert / drop) is not implemented; use the reference script for it.")
+    groups = _group_by_name([t for t, _ in loaded])
+    merged = None
+    if strategy.startswith("convert-"):                                                     # :42-73
+        strategy = strategy[len("convert-"):]
+        converted = _convert_same_to_modal_language(groups, configs)
+        if strategy.startswith("drop-"):
+            # TIES over the tensors the checkpoints share, the single-owner tensors kept, the per-modality copies on top (:62-71); the
+            # strategy string then matches no later branch of the reference ("DO NOTHING") and labels merge_info as it stands
+            func = strategy[len("drop-"):]
+            merged = _ties(groups, func, K)
+            merged.update({name: who[0][1] for name, who in converted.items()})
+        else:
+            groups.update(converted)
+    elif strategy.startswith("drop-"):
+        raise NotImplementedError(f"Merge strategy [{strategy}]: drop-* is only defined behind convert- (the reference script fails on it)")
     label = strategy
     extra_cfg = {}
-    if strategy.startswith("online-merge-"):
-        merged = _online_merge(tensors, [get_modal_from_config(c) for c in configs])
+    if merged is not None:
+        pass
+    elif strategy.startswith("online-merge-"):
+        merged = _online_merge(groups, [get_modal_from_config(c) for c in configs])
         label = strategy[len("online-merge-"):]
         if label.startswith("reset-"):
             extra_cfg["reset_scaling_weights"] = label[len("reset-"):]
@@ -304,10 +339,10 @@ def merge_checkpoints(filepaths: Sequence[str], output_path: str, strategy: str 
     elif strategy.startswith("ties-"):
         func = strategy[len("ties-"):]
         assert func in ("sum", "mean", "max")                                               # merge_unimodal_modelcompose.py:80
-        merged = _ties(tensors, func, K)
+        merged = _ties(groups, func, K)
         label = f"dis-{func}-{K}"                                                           # :89
     elif strategy in ("sum", "mean"):
-        merged = _elementwise(tensors, mean=strategy == "mean")
+        merged = _elementwise(groups, mean=strategy == "mean")
     else:
         raise NotImplementedError(f"Merge strategy [{strategy}] not implemented")
     # union of the configs: first truthy value wins; the merge record is written while visiting the first config,

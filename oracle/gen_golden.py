@@ -1103,8 +1103,53 @@ def g15():
         del sd, om
 
 
+def g16():
+    """File-level goldens for the `convert-*` strategies of merge_checkpoints (merge_unimodal_modelcompose.py:42-73): checkpoints trained
+    with lora_strategy 'same' (only `.default` adapter keys) are re-labelled 'modal+language', every `.default` tensor of checkpoint i is
+    duplicated under its modality's name, and the rest of the strategy string runs on the result: online-merge-reset-*, sum, mean,
+    ties-mean, and `drop-mean` (TIES over the shared tensors, then the per-modality copies on top, :62-71)."""
+    refshim.install()
+    import importlib, io, contextlib
+    mm = importlib.import_module("merge_unimodal_modelcompose")
+    g = torch.Generator().manual_seed(161)
+    shapes = {"model.layers.0.self_attn.q_proj.lora_A.default.weight": (4, 24), "model.layers.0.self_attn.q_proj.lora_B.default.weight": (24, 4),
+              "model.layers.1.mlp.down_proj.lora_A.default.weight": (4, 40), "model.layers.1.mlp.down_proj.lora_B.default.weight": (24, 4)}
+    order = (("vision", "mm_vision_encoder"), ("audio", "mm_audio_encoder"), ("point", "mm_point_encoder"))
+    arrays, meta = {}, {"order": [m for m, _ in order], "cases": {}}
+    with tempfile.TemporaryDirectory() as tmp:
+        paths, in_cfg = [], {}
+        for modal, enc_key in order:
+            d = os.path.join(tmp, f"ckpt-{modal}")
+            os.makedirs(d)
+            w = {k: torch.randn(shp, generator=g) for k, shp in shapes.items()}
+            w[f"model.modal_projectors.{modal}.0.weight"] = torch.randn(8, 6, generator=g)
+            w[f"prefix_tokens.{modal}"] = torch.randn(1, 2, 8, generator=g)
+            torch.save(w, os.path.join(d, "adapter_model.bin"))
+            c = {"model_type": "multimodal", enc_key: f"/ckpts/{modal}", "lora_r": 4, "lora_alpha": 8, "lora_strategy": "same",
+                 "local_prefix_tokens": 2, "hidden_size": 8}
+            json.dump(c, open(os.path.join(d, "config.json"), "w"))
+            paths.append(d)
+            in_cfg[modal] = c
+            for k, v in w.items():
+                arrays[f"in::{modal}::{k}"] = v
+        meta["in_configs"] = in_cfg
+        for tag, strat in (("online", "convert-online-merge-reset-default-vision=0.5,default-audio=0.25,default-point=0.25"),
+                           ("online_plain", "convert-online-merge-0.3"), ("sum", "convert-sum"), ("mean", "convert-mean"),
+                           ("ties", "convert-ties-mean"), ("drop", "convert-drop-mean"), ("dropsum", "convert-drop-sum")):
+            outp = os.path.join(tmp, f"merged-{tag}")
+            with contextlib.redirect_stdout(io.StringIO()):
+                mm.merge_checkpoints(list(paths), outp, strat, K=20)
+            merged = torch.load(os.path.join(outp, "adapter_model.bin"))
+            for k, v in merged.items():
+                arrays[f"out::{tag}::{k}"] = v
+            meta["cases"][tag] = {"strategy": strat, "out_config": json.load(open(os.path.join(outp, "config.json"))),
+                                  "merge_info": open(os.path.join(outp, "merge_info.txt")).read().replace(tmp, "<TMP>"),
+                                  "keys": list(merged)}
+    _save("g16_merge_convert", meta=np.array(json.dumps(meta)), **arrays)
+
+
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
-          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14}
+          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g16": g16}
 SLOW_GROUPS = {"g15": g15}          # by name only
 
 

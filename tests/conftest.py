@@ -35,3 +35,29 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def run_g16_cases(tmp_path, tags):
+    """merge_checkpoints(convert-*) on the inputs of tests/golden/g16_merge_convert.npz: tensors, key ORDER, config.json and merge_info.txt
+    must equal what the reference's own script wrote for the same inputs."""
+    import json
+    import torch
+    from modelcompose_amd import compose
+    a, meta, _ = load_golden("g16_merge_convert")
+    paths = []
+    for modal in meta["order"]:
+        d = tmp_path / f"ckpt-{modal}"
+        d.mkdir(exist_ok=True)
+        torch.save({k.split("::", 2)[2]: v for k, v in a.items() if k.startswith(f"in::{modal}::")}, d / "adapter_model.bin")
+        json.dump(meta["in_configs"][modal], open(d / "config.json", "w"))
+        paths.append(str(d))
+    for tag in tags:
+        case = meta["cases"][tag]
+        out = tmp_path / f"merged-{tag}"
+        compose.merge_checkpoints(paths, str(out), case["strategy"], K=20)
+        got = torch.load(out / "adapter_model.bin")
+        assert list(got) == case["keys"], tag
+        for k in case["keys"]:
+            assert torch.equal(got[k], a[f"out::{tag}::{k}"]), (tag, k)
+        assert json.load(open(out / "config.json")) == case["out_config"], tag
+        assert open(out / "merge_info.txt").read().replace(str(tmp_path), "<TMP>") == case["merge_info"], tag

@@ -112,8 +112,10 @@ def test_merge_cli_matches_reference_golden(tmp_path):
     assert sorted(got) == sorted(exp) and all(torch.equal(got[k], exp[k]) for k in exp)
     assert json.load(open(out / "config.json")) == meta["out_config"]
     assert open(out / "merge_info.txt").read().replace(str(tmp_path), "<TMP>") == meta["merge_info"]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):           # convert-* is for checkpoints trained with lora_strategy 'same' (:47)
         compose.merge_checkpoints(paths, str(out), "convert-ties-sum")
+    with pytest.raises(NotImplementedError):
+        compose.merge_checkpoints(paths, str(out), "slerp")
     if not torch.cuda.is_available():             # TIES runs on the HIP device and fails loudly without one (no CPU fallback)
         with pytest.raises(RuntimeError):
             compose.merge_checkpoints(paths, str(out), "ties-sum")
@@ -250,3 +252,21 @@ def test_preprocess_and_collator_match_reference_data_utils():
     n0 = sum(len(c["value"].split()) for c in convs["text_only"])
     n1 = sum(len(c["value"].split()) for c in convs["one_round_image"])
     assert ds2.modality_lengths == [-n0, n1 + 256, n0 + 257 * 8]
+
+
+def test_convert_merge_strategies_match_the_reference_script(tmp_path):
+    """merge_unimodal_modelcompose.py:42-73 `convert-*`: 'same'-strategy checkpoints -> 'modal+language' + per-modality copies, then
+    online-merge(-reset) / sum / mean on the result (the ties / drop forms run on the GPU: tests/test_merge_gpu.py)."""
+    from conftest import run_g16_cases
+    from modelcompose_amd import compose
+    run_g16_cases(tmp_path, ["online", "online_plain", "sum", "mean"])
+    with pytest.raises(NotImplementedError):
+        compose.merge_checkpoints([str(tmp_path / "ckpt-vision"), str(tmp_path / "ckpt-audio")], str(tmp_path / "x"), "drop-mean")
+    # a checkpoint that is not 'same'-strategy is refused, as the reference's assert does
+    import json
+    cfgp = tmp_path / "ckpt-audio" / "config.json"
+    cfg = json.load(open(cfgp))
+    cfg["lora_strategy"] = "modal+language"
+    json.dump(cfg, open(cfgp, "w"))
+    with pytest.raises(AssertionError):
+        compose.merge_checkpoints([str(tmp_path / "ckpt-vision"), str(tmp_path / "ckpt-audio")], str(tmp_path / "y"), "convert-sum")

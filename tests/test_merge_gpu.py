@@ -103,3 +103,9 @@ def test_interference_metrics_large_vs_oracle(dtype):
     got = compose.interference_metrics(flat.cuda(), 50)
     for k, v in ref.items():
         assert abs(got[k] - v) <= 2e-6 * max(1.0, abs(v)), (k, got[k], v)
+
+
+def test_convert_ties_and_drop_strategies_match_the_reference_script(tmp_path):
+    """merge_unimodal_modelcompose.py:42-73 with the TIES arithmetic on the GPU: convert-ties-mean, convert-drop-mean, convert-drop-sum."""
+    from conftest import run_g16_cases
+    run_g16_cases(tmp_path, ["ties", "drop", "dropsum"])
