@@ -679,6 +679,8 @@ class MultimodalLlamaForCausalLM:
         top_k=0 to disable - then top_p) and draws with a Philox stream keyed by `seed` (kwarg; default: drawn from torch's global
         generator, so torch.manual_seed makes runs repeatable).  Beam search is not implemented."""
         if num_beams not in (None, 1):
+            # (the reference cannot run it either on multimodal samples: transformers 4.31 expands input_ids num_beams times but not the
+            # modal_inputs dict, and the splice loop runs out of feature items - multimodal_arch.py:343-346 - IndexError)
             raise NotImplementedError("beam search (num_beams > 1) is not implemented on the HIP path")
         sampling = None
         if do_sample:
