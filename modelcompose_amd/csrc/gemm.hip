@@ -405,7 +405,7 @@ struct G2Src {
 // half (-5 %); reading X0 of the next K-tile during P4 to balance the fragment reads 8/4/8/4 (+-0).
 // NI: 16-column weight blocks per (wave_n, nh) quadrant: 4 = 256-column tiles, 3 = 192-column tiles (the fourth block slot of every LDS
 // piece is then staged with a duplicate and never read, which keeps the DMA count per wave - and so the counted waits - unchanged)
-template <int MODE, int ABL, int NI>
+template <int MODE, int ABL, int NI, int DIST = 2222>
 __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, int xoff, const G2Src& src,
                                         f32x4 (&acc)[2][4][2][2], bf16x8 (&wf)[4][2], bf16x8 (&xf)[2][2][2]) {
     char* cur = smem + (t & 1) * G2_STAGE;
@@ -453,6 +453,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
             case 0: g2_waitvm<0>(); break;
             case 2: g2_waitvm<2>(); break;
             case 4: g2_waitvm<4>(); break;
+            case 7: g2_waitvm<7>(); break;
             case 8: g2_waitvm<8>(); break;
             default: break;        // -1: no wait
         }
@@ -474,6 +475,42 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
     };
     // wait counts {steady, t == nt-2, t == nt-1}: pieces are issued and retired in one fixed order, so "all but the N youngest
     // DMA instructions of this wave have landed" identifies the piece.
+    if constexpr (DIST != 2222) {
+        // Round 3: the tile's 8 DMA instructions a..h = X1(t+1) | W1(t+1) | W0(t+2) | X0(t+2) (issue order unchanged) dealt n1 / n2 / n3 / n4
+        // over the four load halves (DIST = decimal n1 n2 n3 n4) instead of 2 / 2 / 2 / 2 - the halves carry 12 / 4 / 8 / 0 fragment reads, and
+        // every distribution that keeps the DMA out of P1 measured +0.3 ... +1.6 % on the LLM shapes (0 / 2 / 3 / 3 ships for the 256-column
+        // kernel; profiles/r03_probes/gemm_dma_distribution_ab.json; debug word (7 << 3) launches 2 / 2 / 2 / 2).  e..h overwrite operands of THIS tile's P1: they stay in P3 / P4 (n1 + n2 <= 4).  The
+        // counted waits follow from the issue order: "X1(t) landed" = all but the 6 + n1 youngest, "W1(t)" = 4 + n1 + n2, "W0, X0(t+1)" = 8.
+        constexpr int n1 = DIST / 1000, n2 = (DIST / 100) % 10, n3 = (DIST / 10) % 10, n4 = DIST % 10;
+        static_assert(n1 + n2 + n3 + n4 == 8 && n1 + n2 <= 4, "bad DMA distribution");
+        constexpr int m1 = n1 < 4 ? n1 : 4, m2 = (n1 + n2 < 4 ? n1 + n2 : 4) - m1;       // of a..d (the only ones tile nt-2 issues)
+        auto issue = [&](int from, int to) {
+#pragma unroll
+            for (int i = from; i < to; ++i) stage1(i >> 1, i & 1);
+        };
+        auto tail_wait = [&](auto ws, auto w1, auto w2) {
+            if (ABL & 1) return;
+            if constexpr (MODE == 0) g2_waitvm<decltype(ws)::value>();
+            else if constexpr (MODE == 1) g2_waitvm<decltype(w1)::value>();
+            else if constexpr (decltype(w2)::value >= 0) g2_waitvm<decltype(w2)::value>();
+        };
+        read_x(0);
+        read_w(0);
+        issue(0, n1);
+        tail_wait(std::integral_constant<int, 6 + n1>{}, std::integral_constant<int, 6 + m1>{}, std::integral_constant<int, 2>{});
+        mma(0, 0);
+        read_x(1);
+        issue(n1, n1 + n2);
+        tail_wait(std::integral_constant<int, 4 + n1 + n2>{}, std::integral_constant<int, 4 + m1 + m2>{}, std::integral_constant<int, 0>{});
+        mma(0, 1);
+        read_w(1);
+        issue(n1 + n2, n1 + n2 + n3);
+        mma(1, 1);
+        issue(n1 + n2 + n3, 8);
+        tail_wait(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, -1>{});
+        mma(1, 0);
+        return;
+    }
     // P1 (0,0): reads W0,X0; stages X1(t+1); waits for X1(t)
     read_x(0);
     read_w(0);
@@ -550,7 +587,7 @@ struct G2Groups {
 // in-kernel clock diagnostic (ABL bit 3): shader-clock and 100 MHz real-time ticks across one workgroup's main loop
 __device__ unsigned long long g2_stamps[2 * 4096];
 
-template <int ABL, int NI = 4>
+template <int ABL, int NI = 4, int DIST = 2222>
 __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx, G2Groups grp, int N, int K,
                                                               Epilogue ep, int tiles_m, int tiles_n, int raster) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -665,9 +702,9 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     int t = 0;
     unsigned long long st0 = 0, sr0 = 0;
     if (ABL & 8) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
-    for (; t < nt - 2; ++t) g2_tile<0, ABL, NI>(smem, t, wave, woff, xoff, src, acc, wf, xf);
-    g2_tile<1, ABL, NI>(smem, t, wave, woff, xoff, src, acc, wf, xf);
-    g2_tile<2, ABL, NI>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf);
+    for (; t < nt - 2; ++t) g2_tile<0, ABL, NI, DIST>(smem, t, wave, woff, xoff, src, acc, wf, xf);
+    g2_tile<1, ABL, NI, DIST>(smem, t, wave, woff, xoff, src, acc, wf, xf);
+    g2_tile<2, ABL, NI, DIST>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf);
     if (ABL & 8) {
         const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0 && blockIdx.x < 4096) { g2_stamps[2 * blockIdx.x] = st1 - st0; g2_stamps[2 * blockIdx.x + 1] = sr1 - sr0; }
@@ -1528,6 +1565,7 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     const int lds = 2 * G2_STAGE;
     if (!attr256_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1562,8 +1600,9 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         case 3: G2_LAUNCH(3); break;
         case 4: G2_LAUNCH(4); break;
         case 5: G2_LAUNCH(8); break;
+        case 7: G2_LAUNCH(0); break;         // A/B: the round-1 distribution of the DMA instructions (2 / 2 / 2 / 2; results identical)
         case 6: G2_LAUNCH(16); break;        // same kernel compiled with the whole 512-entry register file (launch_bounds(512,1)): measured +-0
-        default: G2_LAUNCH(0); break;
+        default: gemm_tile256_kernel<0, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster); break;
     }
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
 }
