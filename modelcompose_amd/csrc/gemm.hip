@@ -458,10 +458,12 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
             default: break;        // -1: no wait
         }
     };
+    // (s_setprio(1) around the MFMA cluster, as rounds 1-2 had it, costs 1.0-1.8 % on every LLM shape: ABL bit 6 builds it back for A/B;
+    // raising the LOAD half's priority instead: +-0; DMA instructions moved behind the 12th / 16th MFMA of the preceding MFMA half: -1.5 ... -6 %)
     auto mma = [&](int nh, int mh) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr ((ABL & 64) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -469,12 +471,10 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
                     acc[nh][i][mh][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][kk], xf[mh][jj][kk], acc[nh][i][mh][jj], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr ((ABL & 64) != 0) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
-    // wait counts {steady, t == nt-2, t == nt-1}: pieces are issued and retired in one fixed order, so "all but the N youngest
-    // DMA instructions of this wave have landed" identifies the piece.
     if constexpr (DIST != 2222) {
         // Round 3: the tile's 8 DMA instructions a..h = X1(t+1) | W1(t+1) | W0(t+2) | X0(t+2) (issue order unchanged) dealt n1 / n2 / n3 / n4
         // over the four load halves (DIST = decimal n1 n2 n3 n4) instead of 2 / 2 / 2 / 2 - the halves carry 12 / 4 / 8 / 0 fragment reads, and
@@ -1565,7 +1565,9 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     const int lds = 2 * G2_STAGE;
     if (!attr256_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1600,7 +1602,10 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         case 3: G2_LAUNCH(3); break;
         case 4: G2_LAUNCH(4); break;
         case 5: G2_LAUNCH(8); break;
-        case 7: G2_LAUNCH(0); break;         // A/B: the round-1 distribution of the DMA instructions (2 / 2 / 2 / 2; results identical)
+        case 7:                              // A/B builds (results identical): bits 12-14 = 0: the round-1 DMA distribution 2 / 2 / 2 / 2 (with s_setprio)
+            if (((g_gemm_dbg >> 12) & 7) == 1) gemm_tile256_kernel<64, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // + s_setprio
+            else G2_LAUNCH(64);
+            break;
         case 6: G2_LAUNCH(16); break;        // same kernel compiled with the whole 512-entry register file (launch_bounds(512,1)): measured +-0
         default: gemm_tile256_kernel<0, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster); break;
     }
