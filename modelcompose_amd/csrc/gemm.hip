@@ -392,6 +392,13 @@ __device__ __forceinline__ void g2_waitvm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
+
+// LDS-DMA of 16 bytes per lane, scalar-base form: wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset (one address VGPR
+// instead of two, no v_lshl_add_u64 per piece); M0 = the wave-uniform LDS destination
+__device__ __forceinline__ void g2_dma16s(const char* base_uniform, uint32_t off, uint32_t lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
+}
+
 struct G2Src {
     const char* wbase;       // wave-uniform bases (SGPRs); the K-tile offset is added to them on the scalar unit
     const char* xbase;
@@ -420,6 +427,13 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
         char* buf = (piece < 2) ? nxt : cur;
         const bool is_w = (piece == 1 || piece == 2);
         const int h = (piece < 2) ? 1 : 0;
+        if constexpr ((ABL & 256) != 0) {          // A/B: scalar-base addressing, LDS destination as an integer on the scalar unit
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+            const uint32_t dst = lds0 + (uint32_t)(((piece < 2) ? ((t + 1) & 1) : (t & 1)) * G2_STAGE + (is_w ? 0 : G2_XOFF) + h * 16384 + (wave * 2 + e) * 1024);
+            if (is_w) g2_dma16s(src.wbase + (int64_t)tt * 2048, src.w[h][e], dst);
+            else g2_dma16s(src.xbase + (int64_t)tt * 128, src.x[h][e], dst);
+            return;
+        }
         if (is_w)
             __builtin_amdgcn_global_load_lds((gbl_void*)(src.wbase + (int64_t)tt * 2048 + src.w[h][e]),
                                              (lds_void*)(buf + h * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
@@ -1582,6 +1596,7 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<32, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<256, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1619,6 +1634,7 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         case 7:                              // A/B builds (results identical): bits 12-14 = 0: the round-1 DMA distribution 2 / 2 / 2 / 2 (with s_setprio)
             if (((g_gemm_dbg >> 12) & 7) == 1) gemm_tile256_kernel<64, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // + s_setprio
             else if (((g_gemm_dbg >> 12) & 7) == 2) gemm_tile256_kernel<32, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // timing-only: no epilogue
+            else if (((g_gemm_dbg >> 12) & 7) == 3) gemm_tile256_kernel<256, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // scalar-base DMA
             else G2_LAUNCH(64);
             break;
         case 6: G2_LAUNCH(16); break;        // same kernel compiled with the whole 512-entry register file (launch_bounds(512,1)): measured +-0
