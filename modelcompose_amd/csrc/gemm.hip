@@ -427,19 +427,11 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
         char* buf = (piece < 2) ? nxt : cur;
         const bool is_w = (piece == 1 || piece == 2);
         const int h = (piece < 2) ? 1 : 0;
-        if constexpr ((ABL & 256) != 0) {          // A/B: scalar-base addressing, LDS destination as an integer on the scalar unit
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-            const uint32_t dst = lds0 + (uint32_t)(((piece < 2) ? ((t + 1) & 1) : (t & 1)) * G2_STAGE + (is_w ? 0 : G2_XOFF) + h * 16384 + (wave * 2 + e) * 1024);
-            if (is_w) g2_dma16s(src.wbase + (int64_t)tt * 2048, src.w[h][e], dst);
-            else g2_dma16s(src.xbase + (int64_t)tt * 128, src.x[h][e], dst);
-            return;
-        }
-        if (is_w)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(src.wbase + (int64_t)tt * 2048 + src.w[h][e]),
-                                             (lds_void*)(buf + h * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((gbl_void*)(src.xbase + (int64_t)tt * 128 + src.x[h][e]),
-                                             (lds_void*)(buf + G2_XOFF + h * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
+        // scalar-base form (round 3: +0.5 ... +2.5 % over per-lane 64-bit addresses): no vector instruction in the load halves but the DMA itself
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+        const uint32_t dst = lds0 + (uint32_t)(((piece < 2) ? ((t + 1) & 1) : (t & 1)) * G2_STAGE + (is_w ? 0 : G2_XOFF) + h * 16384 + (wave * 2 + e) * 1024);
+        if (is_w) g2_dma16s(src.wbase + (int64_t)tt * 2048, src.w[h][e], dst);
+        else g2_dma16s(src.xbase + (int64_t)tt * 128, src.x[h][e], dst);
     };
     auto read_w = [&](int nh) {
         if ((ABL & 2) && t > 0) return;
@@ -695,17 +687,16 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
 
     // prologue: all of K-tile 0, then W0 / X0 of K-tile 1 (the order the steady state would have produced)
     {
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
         auto pw = [&](int buf, int nh, int tt) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(src.wbase + (int64_t)tt * 2048 + src.w[nh][e]),
-                                                 (lds_void*)(smem + buf * G2_STAGE + nh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
+                g2_dma16s(src.wbase + (int64_t)tt * 2048, src.w[nh][e], lds0 + (uint32_t)(buf * G2_STAGE + nh * 16384 + (wave * 2 + e) * 1024));
         };
         auto px = [&](int buf, int mh, int tt) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(src.xbase + (int64_t)tt * 128 + src.x[mh][e]),
-                                                 (lds_void*)(smem + buf * G2_STAGE + G2_XOFF + mh * 16384 + (wave * 2 + e) * 1024), 16, 0, 0);
+                g2_dma16s(src.xbase + (int64_t)tt * 128, src.x[mh][e], lds0 + (uint32_t)(buf * G2_STAGE + G2_XOFF + mh * 16384 + (wave * 2 + e) * 1024));
         };
         pw(0, 0, 0); px(0, 0, 0); px(0, 1, 0); pw(0, 1, 0); pw(1, 0, 1); px(1, 0, 1);
         g2_waitvm<8>();
@@ -1596,7 +1587,6 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<32, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<256, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1634,7 +1624,6 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         case 7:                              // A/B builds (results identical): bits 12-14 = 0: the round-1 DMA distribution 2 / 2 / 2 / 2 (with s_setprio)
             if (((g_gemm_dbg >> 12) & 7) == 1) gemm_tile256_kernel<64, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // + s_setprio
             else if (((g_gemm_dbg >> 12) & 7) == 2) gemm_tile256_kernel<32, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // timing-only: no epilogue
-            else if (((g_gemm_dbg >> 12) & 7) == 3) gemm_tile256_kernel<256, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // scalar-base DMA
             else G2_LAUNCH(64);
             break;
         case 6: G2_LAUNCH(16); break;        // same kernel compiled with the whole 512-entry register file (launch_bounds(512,1)): measured +-0

@@ -20,7 +20,7 @@ from modelcompose_amd import _lib, ops
 BF = torch.bfloat16
 L = _lib.lib()
 VAR = {"base": 4, "hyb": 4 + (7 << 3), "noX": 4 + (3 << 3), "noDMA": 4 + (1 << 3)}
-DISTS = {"r2_2222_prio": 0, "sbase": 3}       # the round-2 main loop (2 / 2 / 2 / 2 + s_setprio); the shipped 0 / 2 / 3 / 3 with s_setprio back           # the shipped kernel deals 0 / 2 / 3 / 3; other distributions need their instantiation back in gemm.hip
+DISTS = {"r2_2222_prio": 0, "prio": 1}       # the round-2 main loop (2 / 2 / 2 / 2 + s_setprio); the shipped 0 / 2 / 3 / 3 with s_setprio back           # the shipped kernel deals 0 / 2 / 3 / 3; other distributions need their instantiation back in gemm.hip
 for _k, _v in DISTS.items():
     VAR[_k] = 4 + (7 << 3) + (_v << 12)
 
@@ -42,7 +42,7 @@ def check():
         torch.cuda.synchronize()
         same = all(torch.equal(a, b) for nm in DISTS for a, b in zip(outs["base"], outs[nm]))
         ref = x.float() @ w.float().t()
-        err = ((outs["sbase"][2].float() - ref).abs().max() / ref.abs().max()).item()
+        err = ((outs["prio"][2].float() - ref).abs().max() / ref.abs().max()).item()
         print(f"check M={M} N={N} K={K}: hybrid bit-identical to base: {same}; rel err vs fp32 {err:.2e}", flush=True)
         ok &= same and err < 1e-2
     # race screen: the same launch many times must give the same bits
