@@ -89,7 +89,7 @@ __device__ __forceinline__ void dma16s(const void* base_uniform, uint32_t off, c
 // block): half the LDS bytes per MFMA.
 // DROP: dropout on the attention probabilities (BertSelfAttention.dropout, Qformer.py:259): P keeps its fp32 row sum (softmax is
 // normalised BEFORE the dropout in the reference) and enters P.V as bf16(P * keep / (1 - p)); masks from Philox (common.h)
-template <int D, bool REL, int QW, int NQ, bool DROP = false>
+template <int D, bool REL, int QW, int NQ, bool DROP = false, int LATE = 0>
 __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) {
     constexpr int ROWB = D * 2;              // bytes per K/V row
     constexpr int CH = ROWB / 16;            // 16-byte chunks per row
@@ -228,10 +228,11 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
         const char* vl = kl + TILE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
         __builtin_amdgcn_s_barrier();                          // ... and everyone's; all reads of the other buffer (tile kt-1) are done
-        if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1);
         // causal: a tile that starts after this wave's last query contributes nothing (only the upper waves of a block reach
-        // the block's last key tile); the wave still took part in the staging and the barrier above
-        if (p.causal && kt * 64 > q0 + WQ - 1 + p.q_offset) continue;
+        // the block's last key tile); the wave still takes part in the staging and the barrier above
+        const bool idle_tile = p.causal && kt * 64 > q0 + WQ - 1 + p.q_offset;
+        if ((LATE == 0 || idle_tile) && kt + 1 < ntiles) stage(kt + 1, buf ^ 1);
+        if (idle_tile) continue;
 
         // ---- S^T[key][query] = K · Q^T : every K fragment feeds the MFMAs of all NQ query blocks
         f32x4 s[NQ][4];
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                 for (int nq = 0; nq < NQ; ++nq) s[nq][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[nq][ks], s[nq][kb], 0, 0, 0);
             }
         }
+        if (LATE == 1 && kt + 1 < ntiles) stage(kt + 1, buf ^ 1);        // the next tile's DMA issued behind K.Q^T instead of beside its fragment reads
         // ---- mask, online softmax (lane owns query column c of each block; keys 16kb + 4g + r).  Only the diagonal tile (causal) and a
         // partial last tile need the per-score index tests; every other tile takes the mask-free path (wave-uniform branch per block).
         // (s_setprio(1) around the two MFMA clusters was measured: -3 %)
@@ -726,7 +728,10 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
         // bit-identical results) measured 794 - it is not in the tree
         const bool w8 = (g_attn_dbg & 2) && (int64_t)((Lq + 255) / 256) * H * B >= 512 && !(g_attn_dbg & 8);
         if (w8) attn_prefill_kernel<128, false, 8, 2><<<dim3((Lq + 255) / 256, H, B), 512, 4 * 64 * 256, s>>>(p);
-        else attn_prefill_kernel<128, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+        // LATE = 1 (round 3): the next tile's LDS-DMA is issued behind K.Q^T, in front of the softmax's VALU-only stretch, instead of beside the
+        // K fragment reads at the top of the tile: +1 % (debug bit 6: at the top, as every other shape does)
+        else if (g_attn_dbg & 64) attn_prefill_kernel<128, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+        else attn_prefill_kernel<128, false, 4, 2, false, 1><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
         MC_CHECK_LAUNCH();
         return 0;
     }
