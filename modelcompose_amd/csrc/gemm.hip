@@ -412,9 +412,9 @@ struct G2Src {
 // half (-5 %); reading X0 of the next K-tile during P4 to balance the fragment reads 8/4/8/4 (+-0).
 // NI: 16-column weight blocks per (wave_n, nh) quadrant: 4 = 256-column tiles, 3 = 192-column tiles (the fourth block slot of every LDS
 // piece is then staged with a duplicate and never read, which keeps the DMA count per wave - and so the counted waits - unchanged)
-template <int MODE, int ABL, int NI, int DIST = 2222>
+template <int MODE, int ABL, int NI, int DIST = 2222, class LastHalf>
 __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, int xoff, const G2Src& src,
-                                        f32x4 (&acc)[2][4][2][2], bf16x8 (&wf)[4][2], bf16x8 (&xf)[2][2][2]) {
+                                        f32x4 (&acc)[2][4][2][2], bf16x8 (&wf)[4][2], bf16x8 (&xf)[2][2][2], LastHalf&& last_half) {
     char* cur = smem + (t & 1) * G2_STAGE;
     char* nxt = smem + ((t + 1) & 1) * G2_STAGE;
     // piece ids: 0 = X1(t+1) -> nxt, 1 = W1(t+1) -> nxt, 2 = W0(t+2) -> cur, 3 = X0(t+2) -> cur
@@ -514,6 +514,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
         mma(1, 1);
         issue(n1 + n2 + n3, 8);
         tail_wait(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, -1>{});
+        if constexpr (MODE == 2) last_half();          // the launch's last load half: nothing is staged, nothing waited for
         mma(1, 0);
         return;
     }
@@ -532,6 +533,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
     mma(1, 1);
     // P4 (1,0): stages X0(t+2); waits for W0(t+1), X0(t+1)
     load_tail(3, 8, 4, -1);
+    if constexpr (MODE == 2) last_half();
     mma(1, 0);
 }
 
@@ -590,27 +592,8 @@ struct G2Groups {
     const bf16_t* wp[8];
 };
 
-// in-kernel clock diagnostic (ABL bit 3): shader-clock and 100 MHz real-time ticks across one workgroup's main loop
-__device__ unsigned long long g2_stamps[2 * 4096];
-
-template <int ABL, int NI = 4, int DIST = 2222>
-__global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx, G2Groups grp, int N, int K,
-                                                              Epilogue ep, int tiles_m, int tiles_n, int raster) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA destinations stay on the scalar unit
-    const int wave_n = wave >> 2, wave_m = wave & 3;
-    const int c16 = lane & 15, q4 = lane >> 4;
-
-    // XCD-aware tile order.  Logical order: groups of 8 m-tiles, inside a group n-tile columns, m fastest, so that 32 consecutive
-    // tiles are an 8 x 4 block (12 tile-rows of operands for 32 tiles through one XCD's L2).  Blocks b and b+8 of the grid share an XCD
-    // (round-robin dispatch; speed only).  raster 0: every XCD owns a contiguous eighth of the logical order - the XCDs work on
-    // different m-groups, 8 groups' activations (8 x 256 x K each) plus the weight sweep are live in the 256-MiB Infinity Cache.
-    // raster 1 (large M): the 32-tile blocks are dealt round-robin over the XCDs, so all eight work on the SAME m-group at the same
-    // time: its activations are fetched from HBM once and hit the Infinity Cache for the other seven, and the weight matrix, re-swept
-    // once per m-group, stays resident - L2 misses become Infinity-Cache hits instead of HBM round trips.
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
+// blockIdx -> (tm, tn) of gemm_tile256_kernel
+__device__ __forceinline__ void g2_map_tile(int bid, int nwg, int tiles_m, int tiles_n, int raster, int& tm, int& tn) {
     if ((raster & 255) == 1) {
         const int full = nwg & ~255;
         if (bid < full) {
@@ -639,8 +622,32 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     const int g = bid / per_group;
     const int first_m = g * GROUP;
     const int gsz = min(tiles_m - first_m, GROUP);
-    const int tm = first_m + (bid % per_group) % gsz;
-    const int tn = tn_base + (bid % per_group) / gsz;
+    tm = first_m + (bid % per_group) % gsz;
+    tn = tn_base + (bid % per_group) / gsz;
+}
+
+// in-kernel clock diagnostic (ABL bit 3): shader-clock and 100 MHz real-time ticks across one workgroup's main loop
+__device__ unsigned long long g2_stamps[2 * 4096];
+
+template <int ABL, int NI = 4, int DIST = 2222>
+__global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(const bf16_t* __restrict__ x, int64_t ldx, G2Groups grp, int N, int K,
+                                                              Epilogue ep, int tiles_m, int tiles_n, int raster) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA destinations stay on the scalar unit
+    const int wave_n = wave >> 2, wave_m = wave & 3;
+    const int c16 = lane & 15, q4 = lane >> 4;
+
+    // XCD-aware tile order.  Logical order: groups of 8 m-tiles, inside a group n-tile columns, m fastest, so that 32 consecutive
+    // tiles are an 8 x 4 block (12 tile-rows of operands for 32 tiles through one XCD's L2).  Blocks b and b+8 of the grid share an XCD
+    // (round-robin dispatch; speed only).  raster 0: every XCD owns a contiguous eighth of the logical order - the XCDs work on
+    // different m-groups, 8 groups' activations (8 x 256 x K each) plus the weight sweep are live in the 256-MiB Infinity Cache.
+    // raster 1 (large M): the 32-tile blocks are dealt round-robin over the XCDs, so all eight work on the SAME m-group at the same
+    // time: its activations are fetched from HBM once and hit the Infinity Cache for the other seven, and the weight matrix, re-swept
+    // once per m-group, stays resident - L2 misses become Infinity-Cache hits instead of HBM round trips.
+    const int nwg = tiles_m * tiles_n;
+    int tm, tn;
+    g2_map_tile(blockIdx.x, nwg, tiles_m, tiles_n, raster, tm, tn);
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i)
@@ -653,6 +660,39 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     const int kblocks = K >> 5;
     const int nblocks = (N + 15) >> 4;
     const int nt = K >> 6;
+
+    // L2 warm-up for the workgroup that follows this one on the CU (round 3; ABL bit 8 builds it out for A/B).  One workgroup per CU and equal
+    // tile times: block b + 256 starts where block b ends, on the same XCD (b mod 8).  Its prologue waits for K-tiles 0 and 1 of its
+    // operands (128 KiB = 1024 lines, 2 - 3 us from the Infinity Cache / HBM with nothing else to do); this workgroup touches those lines
+    // from its LAST load half - no DMA is issued there and nothing waits on the vector-memory counter any more - as LDS-DMA into a
+    // scratch KiB nobody reads: one line per lane, two instructions per wave.  +0.8 ... +2.2 % at K >= 4096 (q|k|v +1.0, o +1.7,
+    // gate|up +1.2, down +1.6); at K = 1024 the extra fills cost more than the shorter prologue gives (-0.4 ... -1.5 %): from 32 K-tiles up.
+    // (K-tiles 0 .. 3 instead of 0, 1: no better)
+    const char* pf_w = nullptr;
+    const char* pf_x = nullptr;
+    if constexpr ((ABL & 256) == 0) {
+        const int nb_ = (int)blockIdx.x + 256;
+        if (nb_ < nwg && nt >= 32) {
+            int tm2, tn2;
+            g2_map_tile(nb_, nwg, tiles_m, tiles_n, raster, tm2, tn2);
+            int gi2 = 0;
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+                if (i < grp.n && tm2 >= grp.tile_start[i]) gi2 = i;
+            const int m02 = grp.row_start[gi2] + (tm2 - grp.tile_start[gi2]) * 256, M2 = grp.row_start[gi2 + 1];
+            const int nb2 = min(((tn2 * NT) >> 4) + (tid >> 5), nblocks - 1);          // 16 weight block-rows x 32 lines (K-tiles 0, 1 = 4 KiB each)
+            pf_w = (const char*)grp.wp[gi2] + (int64_t)nb2 * kblocks * 1024 + (tid & 31) * 128;
+            pf_x = (const char*)x + (int64_t)min(m02 + (tid >> 1), M2 - 1) * ldx * 2 + (tid & 1) * 128;      // 256 rows x 2 lines
+        }
+    }
+    auto last_half = [&] {
+        if constexpr ((ABL & 256) == 0) {
+            if (pf_w) {
+                const uint32_t scratch = (uint32_t)(uintptr_t)(lds_void*)smem + 2 * G2_STAGE;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\tglobal_load_lds_dword %1, off" ::"v"(pf_w), "v"(pf_x), "s"(scratch) : "memory");
+            }
+        }
+    };
 
     G2Src src;
     src.wbase = (const char*)wp;
@@ -707,9 +747,9 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     int t = 0;
     unsigned long long st0 = 0, sr0 = 0;
     if (ABL & 8) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
-    for (; t < nt - 2; ++t) g2_tile<0, ABL, NI, DIST>(smem, t, wave, woff, xoff, src, acc, wf, xf);
-    g2_tile<1, ABL, NI, DIST>(smem, t, wave, woff, xoff, src, acc, wf, xf);
-    g2_tile<2, ABL, NI, DIST>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf);
+    for (; t < nt - 2; ++t) g2_tile<0, ABL, NI, DIST>(smem, t, wave, woff, xoff, src, acc, wf, xf, last_half);
+    g2_tile<1, ABL, NI, DIST>(smem, t, wave, woff, xoff, src, acc, wf, xf, last_half);
+    g2_tile<2, ABL, NI, DIST>(smem, t + 1, wave, woff, xoff, src, acc, wf, xf, last_half);
     if (ABL & 8) {
         const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0 && blockIdx.x < 4096) { g2_stamps[2 * blockIdx.x] = st1 - st0; g2_stamps[2 * blockIdx.x + 1] = sr1 - sr0; }
@@ -1580,13 +1620,14 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     const int ni = tile_ni(grp.tile_start[grp.n], N, a->swiglu != 0 || a->rope != nullptr || ep.ss_parts != nullptr);
     const int tiles_m = grp.tile_start[grp.n], tiles_n = ni == 3 ? (N + 191) / 192 : (N + 255) / 256;
     static bool attr256_set = false;
-    const int lds = 2 * G2_STAGE;
+    const int lds = 2 * G2_STAGE + 1024;            // + 1 KiB nobody reads (destination of the next-tile L2 warm-up)
     if (!attr256_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<32, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<256, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1624,6 +1665,7 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         case 7:                              // A/B builds (results identical): bits 12-14 = 0: the round-1 DMA distribution 2 / 2 / 2 / 2 (with s_setprio)
             if (((g_gemm_dbg >> 12) & 7) == 1) gemm_tile256_kernel<64, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // + s_setprio
             else if (((g_gemm_dbg >> 12) & 7) == 2) gemm_tile256_kernel<32, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // timing-only: no epilogue
+            else if (((g_gemm_dbg >> 12) & 7) == 3) gemm_tile256_kernel<256, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // without the next-tile L2 warm-up
             else G2_LAUNCH(64);
             break;
         case 6: G2_LAUNCH(16); break;        // same kernel compiled with the whole 512-entry register file (launch_bounds(512,1)): measured +-0
