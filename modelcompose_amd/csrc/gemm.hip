@@ -836,7 +836,31 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     const int actc = ep.act == MC_ACT_NONE ? 0 : ((ep.act == MC_ACT_QUICK_GELU || ep.act == MC_ACT_SILU) ? 1 : (ep.act == MC_ACT_GELU ? 3 : 2));
     const float act_k = ep.act == MC_ACT_QUICK_GELU ? 1.702f : 1.0f;
     bf16x4 res[2][2][2][NI];
-    if (has_res) {
+    // residual rows in 16-byte loads (round 3): the lane reads the 8 columns it will STORE (the layout behind the epilogue's
+    // v_permlane16_swap) and swaps them back into the accumulator layout - the exchange is its own inverse; half the load instructions
+    const bool res16 = has_res && NI % 2 == 0 && ep.ldr % 8 == 0 && ((uintptr_t)ep.residual % 16 == 0) && !(ABL & 1024);
+    if (res16) {
+        if constexpr (NI % 2 == 0) {
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int mc = min(m0 + wave_m * 64 + mh * 32 + jj * 16 + c16, M - 1);
+                    const bf16_t* rrow = ep.residual + (int64_t)mc * ep.ldr + n0 + wave_n * (2 * NI * 16) + (q4 & 1) * 16 + (q4 >> 1) * 8;
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int i = 0; i < NI; i += 2) {
+                            const u32x4 v = *(const u32x4*)(rrow + nh * (NI * 16) + i * 16);
+                            auto r0 = __builtin_amdgcn_permlane16_swap(v[0], v[2], false, false);
+                            auto r1 = __builtin_amdgcn_permlane16_swap(v[1], v[3], false, false);
+                            const u32x2 lo = {r0[0], r1[0]}, hi = {r0[1], r1[1]};
+                            res[mh][jj][nh][i] = __builtin_bit_cast(bf16x4, lo);
+                            res[mh][jj][nh][i + 1] = __builtin_bit_cast(bf16x4, hi);
+                        }
+                }
+        }
+    } else if (has_res) {
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -1628,12 +1652,14 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<32, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<256, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1024, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr256_set = true;
     }
@@ -1655,7 +1681,8 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     // debug word bits 3-5: timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1;
     // 40 = correct results + clock stamps around the main loop (mc_gemm_clock_read)
     if (ni == 3) {
-        gemm_tile256_kernel<0, 3><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);
+        if (((g_gemm_dbg >> 3) & 7) == 7) gemm_tile256_kernel<0, 3><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // A/B: 2 / 2 / 2 / 2
+        else gemm_tile256_kernel<0, 3, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);
     } else switch ((g_gemm_dbg >> 3) & 7) {
         case 1: G2_LAUNCH(1); break;
         case 2: G2_LAUNCH(2); break;
@@ -1666,6 +1693,7 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
             if (((g_gemm_dbg >> 12) & 7) == 1) gemm_tile256_kernel<64, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // + s_setprio
             else if (((g_gemm_dbg >> 12) & 7) == 2) gemm_tile256_kernel<32, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // timing-only: no epilogue
             else if (((g_gemm_dbg >> 12) & 7) == 3) gemm_tile256_kernel<256, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // without the next-tile L2 warm-up
+            else if (((g_gemm_dbg >> 12) & 7) == 4) gemm_tile256_kernel<1024, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // residual in 8-byte loads
             else G2_LAUNCH(64);
             break;
         case 6: G2_LAUNCH(16); break;        // same kernel compiled with the whole 512-entry register file (launch_bounds(512,1)): measured +-0

@@ -5,7 +5,8 @@ import json, os, statistics, sys
 sys.path.insert(0, os.getcwd())
 import torch
 import bench
-from modelcompose_amd import ops
+from modelcompose_amd import _lib, ops
+L_ = _lib.lib()
 BF = torch.bfloat16
 B = bench.WORKLOADS["iav"][2]
 Hd, I = 4096, 11008
@@ -51,12 +52,14 @@ def t_of(f, iters=4):
 res = {}
 for rnd_ in range(4):
     for name, (N, K, real, plain, grouped) in cases.items():
-        for nm, f in (("model", real), ("plain", plain), ("groups_only", grouped)):
+        for nm, f in (("model", real), ("plain", plain), ("groups_only", grouped), ("model_res8", real)):
+            L_.mc_gemm_debug((7 << 3) + (4 << 12) if nm == "model_res8" else 0)      # A/B build: residual rows in 8-byte loads (round 2)
             res.setdefault((name, nm), []).append(t_of(f))
+            L_.mc_gemm_debug(0)
 out = []
 for name, (N, K, *_r) in cases.items():
     row = {"gemm": name, "M": M, "N": N, "K": K}
-    for nm in ("model", "plain", "groups_only"):
+    for nm in ("model", "plain", "groups_only", "model_res8"):
         row[nm + "_tflops"] = round(2.0 * M * N * K / statistics.median(res[(name, nm)]) / 1e12, 1)
     out.append(row); print(json.dumps(row), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
