@@ -433,20 +433,37 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
         if (is_w) g2_dma16s(src.wbase + (int64_t)tt * 2048, src.w[h][e], dst);
         else g2_dma16s(src.xbase + (int64_t)tt * 128, src.x[h][e], dst);
     };
-    auto read_w = [&](int nh) {
+    // fragment reads in the order the MFMA cluster consumes them - k-step 0 of every block, then k-step 1 - pinned by sched_barriers (hipcc
+    // otherwise issues them block-major and the cluster's first half waits for 11 of P1's 12 reads instead of 6)
+    auto read_w1 = [&](int nh, int kk) {
         if ((ABL & 2) && t > 0) return;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i) wf[i][kk] = *(const bf16x8*)(cur + nh * 16384 + woff + i * 2048 + kk * 1024);
+    };
+    auto read_x1 = [&](int mh, int kk) {
+        if ((ABL & 2) && t > 0) return;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) wf[i][kk] = *(const bf16x8*)(cur + nh * 16384 + woff + i * 2048 + kk * 1024);
+        for (int jj = 0; jj < 2; ++jj) xf[mh][jj][kk] = *(const bf16x8*)(cur + G2_XOFF + mh * 16384 + ((xoff + jj * 2048) ^ (kk * 64)));
+    };
+    auto read_w = [&](int nh) {
+        read_w1(nh, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_w1(nh, 1);
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto read_x = [&](int mh) {
-        if ((ABL & 2) && t > 0) return;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                xf[mh][jj][kk] = *(const bf16x8*)(cur + G2_XOFF + mh * 16384 + ((xoff + jj * 2048) ^ (kk * 64)));
+        read_x1(mh, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x1(mh, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_xw = [&](int mh, int nh) {          // P1: both operands
+        read_x1(mh, 0);
+        read_w1(nh, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x1(mh, 1);
+        read_w1(nh, 1);
+        __builtin_amdgcn_sched_barrier(0);
     };
     // load half: the phase's two DMA instructions, then the counted wait for the pieces the NEXT phase reads.
     // count = 2 x (pieces issued after the awaited one, before this point) = 8 in the steady state
@@ -500,8 +517,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
             else if constexpr (MODE == 1) g2_waitvm<decltype(w1)::value>();
             else if constexpr (decltype(w2)::value >= 0) g2_waitvm<decltype(w2)::value>();
         };
-        read_x(0);
-        read_w(0);
+        read_xw(0, 0);
         issue(0, n1);
         tail_wait(std::integral_constant<int, 6 + n1>{}, std::integral_constant<int, 6 + m1>{}, std::integral_constant<int, 2>{});
         mma(0, 0);
@@ -519,8 +535,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
         return;
     }
     // P1 (0,0): reads W0,X0; stages X1(t+1); waits for X1(t)
-    read_x(0);
-    read_w(0);
+    read_xw(0, 0);
     load_tail(0, 8, 8, 2);
     mma(0, 0);
     // P2 (0,1): reads X1; stages W1(t+1); waits for W1(t)
@@ -592,6 +607,18 @@ struct G2Groups {
     const bf16_t* wp[8];
 };
 
+// adapter group of m-tile tm: first row, end row, weight - running selects over statically indexed kernel arguments (a dynamic index
+// into the by-value struct costs a dependent s_load per field between the block id and the first DMA)
+__device__ __forceinline__ void g2_group_of(const G2Groups& grp, int tm, int& m0, int& M, const bf16_t*& wp) {
+    int rs = grp.row_start[0], ts = grp.tile_start[0], re = grp.row_start[1];
+    wp = grp.wp[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < grp.n && tm >= grp.tile_start[i]) { rs = grp.row_start[i]; ts = grp.tile_start[i]; re = grp.row_start[i + 1]; wp = grp.wp[i]; }
+    m0 = rs + (tm - ts) * 256;
+    M = re;
+}
+
 // blockIdx -> (tm, tn) of gemm_tile256_kernel
 __device__ __forceinline__ void g2_map_tile(int bid, int nwg, int tiles_m, int tiles_n, int raster, int& tm, int& tn) {
     if ((raster & 255) == 1) {
@@ -618,12 +645,20 @@ __device__ __forceinline__ void g2_map_tile(int bid, int nwg, int tiles_m, int t
         tiles_n_eff = min(SW, tiles_n - tn_base);
         bid -= sidx * per_slab;
     }
-    const int per_group = GROUP * tiles_n_eff;
-    const int g = bid / per_group;
-    const int first_m = g * GROUP;
-    const int gsz = min(tiles_m - first_m, GROUP);
-    tm = first_m + (bid % per_group) % gsz;
-    tn = tn_base + (bid % per_group) / gsz;
+    // full m-groups (all but possibly the last) need one division, by tiles_n_eff; m fastest inside a group
+    const int full_groups = tiles_m >> 3;
+    const int g8 = (bid >> 3) / tiles_n_eff;      // group index if every group before this tile is full
+    if (g8 < full_groups) {
+        const int in_group = bid - g8 * (GROUP * tiles_n_eff);
+        tm = g8 * GROUP + (in_group & 7);
+        tn = tn_base + (in_group >> 3);
+        return;
+    }
+    const int first_m = full_groups * GROUP;
+    const int gsz = tiles_m - first_m;            // 1 .. 7 m-tiles in the last group
+    const int rest = bid - full_groups * (GROUP * tiles_n_eff);
+    tm = first_m + rest % gsz;
+    tn = tn_base + rest / gsz;
 }
 
 // in-kernel clock diagnostic (ABL bit 3): shader-clock and 100 MHz real-time ticks across one workgroup's main loop
@@ -648,19 +683,18 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     const int nwg = tiles_m * tiles_n;
     int tm, tn;
     g2_map_tile(blockIdx.x, nwg, tiles_m, tiles_n, raster, tm, tn);
-    int gi = 0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i)
-        if (i < grp.n && tm >= grp.tile_start[i]) gi = i;
     constexpr int NT = NI * 64;                   // tile width in weight rows: 2 wave_n x 2 nh x NI blocks of 16
-    const int m0 = grp.row_start[gi] + (tm - grp.tile_start[gi]) * 256, n0 = tn * NT;
-    const int M = grp.row_start[gi + 1];          // rows of this tile beyond the group's end are clamped on load and not stored
-    const bf16_t* wp = grp.wp[gi];
+    int m0, M;                                    // rows of this tile beyond the group's end (M) are clamped on load and not stored
+    const bf16_t* wp;
+    g2_group_of(grp, tm, m0, M, wp);
+    const int n0 = tn * NT;
 
     const int kblocks = K >> 5;
     const int nblocks = (N + 15) >> 4;
     const int nt = K >> 6;
 
+    const char* pf_w = nullptr;
+    const char* pf_x = nullptr;
     // L2 warm-up for the workgroup that follows this one on the CU (round 3; ABL bit 8 builds it out for A/B).  One workgroup per CU and equal
     // tile times: block b + 256 starts where block b ends, on the same XCD (b mod 8).  Its prologue waits for K-tiles 0 and 1 of its
     // operands (128 KiB = 1024 lines, 2 - 3 us from the Infinity Cache / HBM with nothing else to do); this workgroup touches those lines
@@ -668,20 +702,16 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     // scratch KiB nobody reads: one line per lane, two instructions per wave.  +0.8 ... +2.2 % at K >= 4096 (q|k|v +1.0, o +1.7,
     // gate|up +1.2, down +1.6); at K = 1024 the extra fills cost more than the shorter prologue gives (-0.4 ... -1.5 %): from 32 K-tiles up.
     // (K-tiles 0 .. 3 instead of 0, 1: no better)
-    const char* pf_w = nullptr;
-    const char* pf_x = nullptr;
     if constexpr ((ABL & 256) == 0) {
         const int nb_ = (int)blockIdx.x + 256;
         if (nb_ < nwg && nt >= 32) {
             int tm2, tn2;
             g2_map_tile(nb_, nwg, tiles_m, tiles_n, raster, tm2, tn2);
-            int gi2 = 0;
-#pragma unroll
-            for (int i = 1; i < 8; ++i)
-                if (i < grp.n && tm2 >= grp.tile_start[i]) gi2 = i;
-            const int m02 = grp.row_start[gi2] + (tm2 - grp.tile_start[gi2]) * 256, M2 = grp.row_start[gi2 + 1];
+            int m02, M2;
+            const bf16_t* wp2;
+            g2_group_of(grp, tm2, m02, M2, wp2);
             const int nb2 = min(((tn2 * NT) >> 4) + (tid >> 5), nblocks - 1);          // 16 weight block-rows x 32 lines (K-tiles 0, 1 = 4 KiB each)
-            pf_w = (const char*)grp.wp[gi2] + (int64_t)nb2 * kblocks * 1024 + (tid & 31) * 128;
+            pf_w = (const char*)wp2 + (int64_t)nb2 * kblocks * 1024 + (tid & 31) * 128;
             pf_x = (const char*)x + (int64_t)min(m02 + (tid >> 1), M2 - 1) * ldx * 2 + (tid & 1) * 128;      // 256 rows x 2 lines
         }
     }
@@ -743,6 +773,12 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
         __builtin_amdgcn_s_barrier();
     }
     bf16x8 wf[4][2], xf[2][2][2];
+    // Every scalar load of the prologue (kernel arguments) is retired HERE, explicitly.  hipcc's wait-count pass otherwise carries "a
+    // scalar load may still be pending" into the loop header, and because scalar loads return out of order it then guards the first MFMA
+    // cluster of every K-tile with one lgkmcnt(0) instead of the counted lgkmcnt(7) / (5) / (3) / (1) that let the MFMAs start behind the
+    // first five of P1's twelve fragment reads - measured -1.5 ... -2.3 % on the K >= 4096 shapes, and which of the two it emits flips with
+    // unrelated changes to the prologue (profiles/r03_probes/README.md)
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0), vmcnt / expcnt untouched
     if (wave_n == 1) __builtin_amdgcn_s_barrier();      // second group runs one barrier behind
     int t = 0;
     unsigned long long st0 = 0, sr0 = 0;
