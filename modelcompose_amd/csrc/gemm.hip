@@ -1682,7 +1682,6 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     static bool attr256_set = false;
     const int lds = 2 * G2_STAGE + 1024;            // + 1 KiB nobody reads (destination of the next-tile L2 warm-up)
     if (!attr256_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1690,13 +1689,8 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<256, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1024, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr256_set = true;
     }
     ProfRec rec{};
@@ -1714,16 +1708,13 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     // n-slabs ("raster_slab" option, default 0 = off; see the kernel): only with the shared-m-group raster and when there is more than one slab
     if (raster == 1 && g_raster_slab > 0 && tiles_n > g_raster_slab && tiles_n > g_raster_slab_min) raster |= g_raster_slab << 8;
 #define G2_LAUNCH(A) gemm_tile256_kernel<A><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster)
-    // debug word bits 3-5: timing-only ablations (wrong results): 8 = no LDS-DMA, 16 = no fragment reads, 32 = DMA re-reads K-tiles 0/1;
-    // 40 = correct results + clock stamps around the main loop (mc_gemm_clock_read)
+    // debug word bits 3-5: 8 = timing-only ablation without the LDS-DMA (wrong results); 40 = correct results + clock stamps around the main
+    // loop (mc_gemm_clock_read); 56 = A/B builds, picked by bits 12-14.  (The round-1 ablations "no fragment reads" / "DMA re-reads K-tiles
+    // 0/1" and the launch_bounds(512,1) build are no longer instantiated: ABL bits 1, 2, 4 - their results are in DESIGN.md.)
     if (ni == 3) {
-        if (((g_gemm_dbg >> 3) & 7) == 7) gemm_tile256_kernel<0, 3><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // A/B: 2 / 2 / 2 / 2
-        else gemm_tile256_kernel<0, 3, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);
+        gemm_tile256_kernel<0, 3, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);
     } else switch ((g_gemm_dbg >> 3) & 7) {
         case 1: G2_LAUNCH(1); break;
-        case 2: G2_LAUNCH(2); break;
-        case 3: G2_LAUNCH(3); break;
-        case 4: G2_LAUNCH(4); break;
         case 5: G2_LAUNCH(8); break;
         case 7:                              // A/B builds (results identical): bits 12-14 = 0: the round-1 DMA distribution 2 / 2 / 2 / 2 (with s_setprio)
             if (((g_gemm_dbg >> 12) & 7) == 1) gemm_tile256_kernel<64, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // + s_setprio
@@ -1732,7 +1723,6 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
             else if (((g_gemm_dbg >> 12) & 7) == 4) gemm_tile256_kernel<1024, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // residual in 8-byte loads
             else G2_LAUNCH(64);
             break;
-        case 6: G2_LAUNCH(16); break;        // same kernel compiled with the whole 512-entry register file (launch_bounds(512,1)): measured +-0
         default: gemm_tile256_kernel<0, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster); break;
     }
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
