@@ -60,7 +60,8 @@ def test_gemm_matches_fp32_matmul(ops, M, N, K):
     close_bf16(got, ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 192), (257, 4096, 1024), (2000, 1028, 4096), (3000, 4096, 11008), (2728, 4096, 4096)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 192), (257, 4096, 1024), (2000, 1028, 4096), (3000, 4096, 11008), (2728, 4096, 4096),
+                                   (16500, 4096, 2048)])      # the last: 1040 tiles = XCD round-robin raster + next-tile L2 warm-up (32 K-tiles)
 def test_gemm_tile256_kernel_bit_identical_to_tile128(ops, M, N, K):
     """The 256x256 ping-pong kernel (forced through the debug word) accumulates every output in the same k order as the 128x128
     kernel: outputs must be bit-identical, and both within bf16 rounding of the fp32 matmul (edge tiles in M and N, K tails)."""
@@ -86,6 +87,27 @@ def test_gemm_tile256_kernel_bit_identical_to_tile128(ops, M, N, K):
     close_bf16(big, F.gelu(x.float() @ w.float().t() + b.float()) + r.float())
     ref = x.float() @ w.float().t() + b.float()
     assert (big32.cpu() - ref.cpu()).abs().max().item() <= 1e-3 * ref.abs().max().item()
+
+
+def test_gemm_tile256_ab_builds_are_bit_identical(ops):
+    """The A/B builds the probes select through the debug word - the round-2 main loop (DMA 2 / 2 / 2 / 2 + s_setprio), s_setprio back on the shipped
+    loop, no next-tile L2 warm-up, residual rows in 8-byte loads - differ in issue order only: same bits as the shipped kernel."""
+    from modelcompose_amd import _lib
+    L = _lib.lib()
+    M, N, K = 16500, 4096, 4096
+    x = dev(rand_bf(M, K, seed=15))
+    pw = ops.pack_weight(dev(rand_bf(N, K, scale=K ** -0.5, seed=16)))
+    r = dev(rand_bf(M, N, seed=17))
+    outs = {}
+    try:
+        for name, dbg in (("shipped", 4), ("r2_loop", 4 + (7 << 3)), ("prio", 4 + (7 << 3) + (1 << 12)), ("nowarm", 4 + (7 << 3) + (3 << 12)), ("res8", 4 + (7 << 3) + (4 << 12))):
+            L.mc_gemm_debug(dbg)
+            outs[name] = ops.linear(x, pw, residual=r)
+    finally:
+        L.mc_gemm_debug(0)
+    for name, o in outs.items():
+        assert torch.equal(o, outs["shipped"]), name
+    close_bf16(outs["shipped"], x.float() @ ops.unpack_weight(pw).float().t() + r.float())
 
 
 @pytest.mark.parametrize("M", [8, 300])
