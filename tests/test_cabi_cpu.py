@@ -99,3 +99,31 @@ def test_product_does_not_import_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dp, f)).read(), flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_hot_kernels_do_not_spill():
+    """The dominant kernels sit AT the register limit of two waves per SIMD (gemm_tile256_kernel: 256 VGPRs): a source change that pushes
+    hipcc over it does not fail the build, it spills into scratch inside the main loop.  Read the code objects' metadata out of the built
+    library (tools/kernel_resources.py) and refuse spills in the shipped instantiations."""
+    import importlib.util
+    import os
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang-offload-bundler") and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf")
+            and shutil.which("true")):
+        pytest.skip("ROCm LLVM tools not available")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ks = {k["name"]: k for k in mod.kernel_resources()}
+    assert len(ks) > 50, "no kernels found in libmc_hip.so"
+    hot = ["_Z19gemm_tile256_kernelILi0ELi4ELi233EEvPKDF16bl8G2Groupsii8Epilogueiii", "_Z19gemm_tile256_kernelILi0ELi3ELi233EEvPKDF16bl8G2Groupsii8Epilogueiii",
+           "_Z19attn_prefill_kernelILi128ELb0ELi4ELi2ELb0ELi1EEv10AttnParams", "_Z18attn_decode_kernelILi128EEv12DecodeParams"]
+    for name in hot:
+        assert name in ks, f"{name} is not in the library (renamed instantiation? update this list)"
+        k = ks[name]
+        assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+        assert k["vgpr_count"] + k["agpr_count"] <= 256, k          # two waves per SIMD
+    for name, k in ks.items():                                     # the decode GEMMs: every instantiation
+        if name.startswith("_Z16gemm_rows_kernel"):
+            assert k["vgpr_spill_count"] == 0, k
