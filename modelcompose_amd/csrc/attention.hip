@@ -94,7 +94,7 @@ __device__ __forceinline__ void dma16si(const void* base_uniform, uint32_t off, 
 // block): half the LDS bytes per MFMA.
 // DROP: dropout on the attention probabilities (BertSelfAttention.dropout, Qformer.py:259): P keeps its fp32 row sum (softmax is
 // normalised BEFORE the dropout in the reference) and enters P.V as bf16(P * keep / (1 - p)); masks from Philox (common.h)
-template <int D, bool REL, int QW, int NQ, bool DROP = false, int LATE = 0>
+template <int D, bool REL, int QW, int NQ, bool DROP = false, int LATE = 0, bool KM = true, bool CL = true>
 __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) {
     constexpr int ROWB = D * 2;              // bytes per K/V row
     constexpr int CH = ROWB / 16;            // 16-byte chunks per row
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
     auto stage = [&](int kt, int buf) {
         char* kb_ = lds + buf * (2 * TILE);
         char* vb_ = kb_ + TILE;
-        if (off32_ok && kt * 64 + 63 < p.S) {
+        if (!CL || (off32_ok && kt * 64 + 63 < p.S)) {          // CL = false: the launcher guarantees S % 64 == 0 and 32-bit tile offsets: the clamped path is compiled out
             const bf16_t* kt_k = kbase + (int64_t)kt * 64 * p.k_st;
             const bf16_t* kt_v = vbase + (int64_t)kt * 64 * p.v_st;
             const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + (uint32_t)(buf * (2 * TILE));
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
         bf16x8 pf[NQ][2];
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) {
-            const bool need_mask = (kt * 64 + 63 >= kvlen) || (p.causal && kt * 64 + 63 > q0 + nq * 16 + p.q_offset) || p.key_valid != nullptr;
+            const bool need_mask = (kt * 64 + 63 >= kvlen) || (p.causal && kt * 64 + 63 > q0 + nq * 16 + p.q_offset) || (KM && p.key_valid != nullptr);
             const bool masked = need_mask || REL;
             float tmax = NEG_BIG;
             float lsum = 0.f;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                     for (int r = 0; r < 4; ++r) {
                         const int key = kt * 64 + kb * 16 + g * 4 + r;
                         bool ok = key < kvlen && (!p.causal || key <= q_abs[nq]);
-                        if (p.key_valid && ok) ok = p.key_valid[(int64_t)b * p.key_valid_sb + key] != 0;
+                        if (KM && p.key_valid && ok) ok = p.key_valid[(int64_t)b * p.key_valid_sb + key] != 0;      // KM = false: compiled out (the LLM's unmasked launches)
                         valid[kb][r] = ok;
                         float sv = s[nq][kb][r] * p.scale_log2e;
                         if (REL && relrow[nq] && ok) sv += gate[nq] * relrow[nq][key];
@@ -737,7 +737,10 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
         // LATE = 1 (round 3): the next tile's LDS-DMA is issued behind K.Q^T, in front of the softmax's VALU-only stretch, instead of beside the
         // K fragment reads at the top of the tile: +1 % (debug bit 6: at the top, as every other shape does)
         else if (g_attn_dbg & 64) attn_prefill_kernel<128, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
-        else attn_prefill_kernel<128, false, 4, 2, false, 1><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+        else if (p.key_valid) attn_prefill_kernel<128, false, 4, 2, false, 1><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+        else if (S % 64 == 0 && 64LL * k_st * 2 + 256 < (1LL << 31) && 64LL * v_st * 2 + 256 < (1LL << 31))     // the LLM's launches: no per-key mask, whole key tiles
+            attn_prefill_kernel<128, false, 4, 2, false, 1, false, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+        else attn_prefill_kernel<128, false, 4, 2, false, 1, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);      // no per-key mask: its loads and branches compiled out
         MC_CHECK_LAUNCH();
         return 0;
     }
