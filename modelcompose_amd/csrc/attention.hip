@@ -241,21 +241,32 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
         if (idle_tile) continue;
 
         // ---- S^T[key][query] = K · Q^T : every K fragment feeds the MFMAs of all NQ query blocks
+        // K fragments are fetched one key block (KS reads) AHEAD of the MFMAs that use them, into their own registers
         f32x4 s[NQ][4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-            for (int nq = 0; nq < NQ; ++nq) s[nq][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 kfr[2][KS];
+        auto ldk = [&](int kb, bf16x8 (&dst)[KS]) {
             const int row = kb * 16 + c;     // A operand row = key
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int ch = ks * 4 + g;
                 int sw;
                 if (CH == 16) sw = ch ^ (row & 15); else sw = ch ^ ((row >> 1) & 7);
-                const bf16x8 kf = *(const bf16x8*)(kl + row * ROWB + sw * 16);
-#pragma unroll
-                for (int nq = 0; nq < NQ; ++nq) s[nq][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[nq][ks], s[nq][kb], 0, 0, 0);
+                dst[ks] = *(const bf16x8*)(kl + row * ROWB + sw * 16);
             }
+        };
+        ldk(0, kfr[0]);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb < 3) ldk(kb + 1, kfr[(kb + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nq = 0; nq < NQ; ++nq) s[nq][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int nq = 0; nq < NQ; ++nq) s[nq][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kb & 1][ks], qf[nq][ks], s[nq][kb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (LATE == 1 && kt + 1 < ntiles) stage(kt + 1, buf ^ 1);        // the next tile's DMA issued behind K.Q^T instead of beside its fragment reads
         // ---- mask, online softmax (lane owns query column c of each block; keys 16kb + 4g + r).  Only the diagonal tile (causal) and a
@@ -342,12 +353,17 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
 
         // ---- O^T[d][query] += V^T · P^T ; V fragments through the transposing LDS read, each feeding all NQ query blocks
         const int tq = (lane & 15) >> 2, tp = lane & 3;
+        // fragment f = pr * DB + db (key pair pr, d block db), fetched in groups of GV one group ahead of their MFMAs (left to hipcc a
+        // fragment's two transposing reads are issued one fragment - 32 MFMA cycles - ahead of its use, under the LDS latency); the MFMA
+        // order per accumulator is unchanged (pr = 0 then pr = 1)
+        constexpr int GV = 4, NG = 2 * DB / GV;
+        bf16x8 vfr[2][GV];
+        auto ldv = [&](int grp, bf16x8 (&dst)[GV]) {
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const int key_lo = (2 * pr) * 16 + g * 4 + tq;
-            const int key_hi = (2 * pr + 1) * 16 + g * 4 + tq;
-#pragma unroll
-            for (int db = 0; db < DB; ++db) {
+            for (int i = 0; i < GV; ++i) {
+                const int f = grp * GV + i, pr = f / DB, db = f % DB;
+                const int key_lo = (2 * pr) * 16 + g * 4 + tq;
+                const int key_hi = (2 * pr + 1) * 16 + g * 4 + tq;
                 // 8 bytes at logical column (db*16 + tp*4) of row key: 16-byte chunk db*2 + (tp>>1), XOR-swizzled per row (256-byte rows = one
                 // full bank line each).  A transposing read is served in two groups of 32 lanes = 8 rows x 2 chunks x 2 halves: with
                 // chunk ^ (2 * (row & 7)) the 16 (row, chunk) pairs of a group land on 16 different chunk slots = all 64 banks once
@@ -363,9 +379,21 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                 bf16x8 vf;
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                 vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-#pragma unroll
-                for (int nq = 0; nq < NQ; ++nq) oacc[nq][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nq][pr], oacc[nq][db], 0, 0, 0);
+                dst[i] = vf;
             }
+        };
+        ldv(0, vfr[0]);
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            if (grp + 1 < NG) ldv(grp + 1, vfr[(grp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GV; ++i) {
+                const int f = grp * GV + i, pr = f / DB, db = f % DB;
+#pragma unroll
+                for (int nq = 0; nq < NQ; ++nq) oacc[nq][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[grp & 1][i], pf[nq][pr], oacc[nq][db], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- finalize: total row sum over the 4 lane groups that share query c
