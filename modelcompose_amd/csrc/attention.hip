@@ -353,10 +353,10 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
 
         // ---- O^T[d][query] += V^T · P^T ; V fragments through the transposing LDS read, each feeding all NQ query blocks
         const int tq = (lane & 15) >> 2, tp = lane & 3;
-        // fragment f = pr * DB + db (key pair pr, d block db), fetched in groups of GV one group ahead of their MFMAs (left to hipcc a
+        // fragment f = pr * DB + db (key pair pr, d block db), fetched in groups of GV = 2 one group ahead of their MFMAs (groups of 4: -0.2 ... -1.1 % against 2; of 8: -1 ... -2 %; a three-deep ring of groups of 2: -0.3 %) (left to hipcc a
         // fragment's two transposing reads are issued one fragment - 32 MFMA cycles - ahead of its use, under the LDS latency); the MFMA
         // order per accumulator is unchanged (pr = 0 then pr = 1)
-        constexpr int GV = 4, NG = 2 * DB / GV;
+        constexpr int GV = 2, NG = 2 * DB / GV;
         bf16x8 vfr[2][GV];
         auto ldv = [&](int grp, bf16x8 (&dst)[GV]) {
 #pragma unroll
