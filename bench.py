@@ -11,7 +11,12 @@ Default workload `iav` = the metric's config: BASELINE configs[2]'s model (onlin
 resident in HBM before the timed region.  Other workloads (parity-test configs, not the headline): `vision` = configs[1],
 `mcub4` = configs[3], `train` = configs[4].
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Under `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) the process IS a rank and
+WORLD_SIZE must equal --gpus.  Run bare (`python bench.py --gpus N`, as the reference starts its N workers from one command,
+scripts/model_composition/test/MCUB-4.sh:21,42-70) the process is only a launcher: before anything touches the GPU it starts N child
+processes of this file with the rank environment set, relays rank 0's JSON line and exits with the children's worst status.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt) with these extra objects, all measured OUTSIDE the timed region
 in a separate profiled pass of the same step:
@@ -444,11 +449,72 @@ def generate_main(args, world, rank, local):
         torch.distributed.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------------------------------------------- N-rank launcher
+def rank_commands(n: int, argv: list[str], port: int, base_env=None):
+    """The N child processes of `python bench.py --gpus N`: [(command, environment)] - one per GPU, the same arguments, the rank
+    environment torch.distributed.run would have set (MCUB-4.sh:42-58 starts one worker per GPU chunk the same way)."""
+    base = dict(os.environ if base_env is None else base_env)
+    out = []
+    for r in range(n):
+        env = dict(base)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out.append(([sys.executable, os.path.abspath(__file__)] + list(argv), env))
+    return out
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """Parent of an N-rank run.  Never touches the GPU (no HIP call, no torch.cuda.is_available()): it only starts the children, passes
+    rank 0's stdout through, keeps the other ranks' output for the error case, and returns the worst exit status.  A rank that fails
+    takes the others down (they would hang in the next collective)."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    procs = []
+    for r, (cmd, env) in enumerate(rank_commands(n, argv, port)):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.PIPE, stderr=None if r == 0 else subprocess.STDOUT,
+                                      text=True))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0:
+                rc = rc or code
+                if r != 0:
+                    sys.stderr.write(f"[bench.py launcher] rank {r} exited with {code}:\n{(procs[r].stdout.read() or '')[-2000:]}\n")
+                for o in alive:                      # exact PIDs we started, nothing by pattern
+                    procs[o].terminate()
+        time.sleep(0.2)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or bare, which "
+                         f"starts the ranks itself)")
+    if os.environ.get("MC_BENCH_LAUNCH_PROBE") == "1":
+        # launcher self-test (tests/test_bench_launcher_cpu.py): a rank reports the environment it was started with and leaves, GPU untouched
+        print(json.dumps({"probe": True, "rank": rank, "local_rank": local, "world": world, "gpus": args.gpus,
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "steps": args.steps}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     if DIST or world > 1:

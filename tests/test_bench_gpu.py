@@ -1,0 +1,30 @@
+"""bench.py's N > 1 code path on the one-GPU box: MC_BENCH_FORCE_DIST=1 runs RCCL init, the barriers, the id all-gather and the MAX
+all-reduce of the timing in a world of one; `--gpus` must equal the world."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(argv, env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=900, env=env)
+
+
+def test_bench_world_of_one_over_rccl():
+    r = _bench(["--gpus", "1", "--layers", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--new-tokens", "4", "--no-profile",
+                "--no-cpu-baseline", "--no-secondary"], {"MC_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "dp1"
+
+
+def test_bench_rejects_a_world_that_is_not_gpus():
+    r = _bench(["--gpus", "2", "--layers", "2", "--steps", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)

@@ -1,0 +1,54 @@
+"""`python bench.py --gpus N` starts N ranks itself (the reference starts its N workers from one command,
+scripts/model_composition/test/MCUB-4.sh:21,42-70).  CPU tier: the launcher's command / environment construction and a real N-process
+launch in probe mode (every rank reports the environment it was given and leaves before touching a GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_rank_commands_build_one_child_per_gpu():
+    import bench
+    cmds = bench.rank_commands(4, ["--gpus", "4", "--steps", "3"], 29517, base_env={"PATH": "/usr/bin", "WORLD_SIZE_IGNORED": "x"})
+    assert len(cmds) == 4
+    for r, (cmd, env) in enumerate(cmds):
+        assert cmd[0] == sys.executable and cmd[1] == os.path.join(ROOT, "bench.py")
+        assert cmd[2:] == ["--gpus", "4", "--steps", "3"]
+        assert env["RANK"] == str(r) and env["LOCAL_RANK"] == str(r) and env["WORLD_SIZE"] == "4"
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29517"
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"          # dmabuf IPC only on this pool: RCCL needs it in every rank
+
+
+def _run(argv, extra_env):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_bare_launch_starts_n_ranks_and_relays_rank0():
+    r = _run(["--gpus", "3", "--steps", "7"], {"MC_BENCH_LAUNCH_PROBE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # only rank 0's line reaches stdout
+    j = lines[0]
+    assert j["rank"] == 0 and j["world"] == 3 and j["gpus"] == 3 and j["steps"] == 7
+    assert j["master"].startswith("127.0.0.1:")
+
+
+def test_world_size_mismatch_fails_loudly():
+    r = _run(["--gpus", "8"], {"MC_BENCH_LAUNCH_PROBE": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_failing_rank_fails_the_launch():
+    # no GPU in this container: every rank stops at "bench.py needs an MI355X" -> the launcher must return non-zero, not hang
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    r = _run(["--gpus", "2", "--steps", "1", "--no-cpu-baseline"], {})
+    assert r.returncode != 0
