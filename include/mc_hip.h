@@ -375,6 +375,9 @@ int mc_ckpt_copy_to_device(void* handle, int index, void* dst_device, void* stre
 #define MC_CKPT_INT 2
 #define MC_CKPT_FLOAT 3
 #define MC_CKPT_STR 4
+#define MC_CKPT_EMPTY_LIST 5   /* an empty list / tuple / dict keeps its place in the tree (BEATs cfg entries such as [] or ()) */
+#define MC_CKPT_EMPTY_TUPLE 6
+#define MC_CKPT_EMPTY_DICT 7
 int mc_ckpt_entry_path(void* handle, int index, const char** path);
 int mc_ckpt_scalar_count(void* handle, int* n_scalars);
 int mc_ckpt_scalar(void* handle, int index, const char** name, const char** path, int* kind, int64_t* ivalue, double* fvalue,

@@ -85,6 +85,8 @@ class MappedCheckpoint:
                 v = int(iv.value)
             elif k == 3:
                 v = float(fv.value)
+            elif k in (5, 6, 7):                                   # MC_CKPT_EMPTY_LIST / _TUPLE / _DICT: the container keeps its place
+                v = [] if k == 5 else () if k == 6 else {}
             else:
                 v = C.string_at(sv.value, sl.value).decode("utf-8", "surrogateescape") if sl.value else ""
             out[(path if by_path else name).value.decode("utf-8", "surrogateescape")] = v
@@ -92,7 +94,7 @@ class MappedCheckpoint:
 
     def nested(self):
         """The file's object tree rebuilt from the reader's paths: dicts (string / integer keys come back as strings), lists (tuples
-        come back as lists), tensors and scalar leaves.  Empty containers and opaque objects are not represented."""
+        come back as lists; EMPTY lists / tuples / dicts keep their own type), tensors and scalar leaves.  Opaque objects are not represented."""
         SEP, IDX = "\x1f", "\x1e"
         leaves = list(self.tensors(by_path=True).items()) + list(self.scalars(by_path=True).items())
         if len(leaves) == 1 and leaves[0][0] == "":
@@ -122,10 +124,12 @@ def _is_legacy_torch_file(path: str) -> bool:
     """torch.save before 1.6 (or _use_new_zipfile_serialization=False): a pickled magic number, not a zip archive."""
     try:
         with open(path, "rb") as f:
-            head = f.read(4)
+            head = f.read(14)
     except OSError:
         return False
-    return head[:2] != b"PK" and not str(path).endswith(".safetensors")
+    # detected POSITIVELY (ADVICE r3): protocol-2 pickle of torch's legacy magic number 0x1950a86a20f9469cfc6c (serialization.py MAGIC_NUMBER);
+    # everything else - zip archives, safetensors with or without the suffix - goes to the native reader, which sniffs by content
+    return head == b"\x80\x02\x8a\x0a\x6c\xfc\x9c\x46\xf9\x20\x6a\xa8\x50\x19"
 
 
 def _legacy_load(path: str):

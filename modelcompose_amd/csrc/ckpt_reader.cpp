@@ -56,6 +56,7 @@ struct Ckpt {
     size_t size = 0;
     std::vector<Entry> entries;
     std::vector<Scalar> scalars;
+    int64_t visited_nodes = 0;      // flatten()'s global budget
     ~Ckpt() {
         if (map) munmap(map, size);
         if (fd >= 0) close(fd);
@@ -334,12 +335,22 @@ struct Unpickler {
 };
 
 constexpr int MAX_DEPTH = 64;       // of the object tree (a pickle can build a self-referential container through its memo)
+// of visited nodes: memo references make the tree a DAG, so `l = [l, l]` nested n times expands to 2^n leaves from a 300-byte file
+// (ADVICE r3).  The largest real checkpoint on this path holds a few thousand leaves; 4 M is far above any of them.
+constexpr int64_t MAX_NODES = 4 * 1000 * 1000;
 
 bool flatten(const VP& v, const std::string& prefix, const std::string& path, int depth, Ckpt& c, const std::map<std::string, ZipRec>& recs,
              const std::string& root, std::string& err) {
     if (depth > MAX_DEPTH) { err = "object tree deeper than 64 levels (or self-referential) at '" + prefix + "'"; return false; }
+    if (++c.visited_nodes > MAX_NODES) { err = "object tree expands to more than 4000000 nodes (shared containers referenced repeatedly?)"; return false; }
     auto join = [](const std::string& a, const std::string& b, char sep) { return a.empty() ? b : a + sep + b; };
+    auto empty_marker = [&](int kind) {
+        Scalar sc;
+        sc.name = prefix; sc.path = path; sc.i = 0; sc.f = 0; sc.kind = kind;
+        c.scalars.push_back(std::move(sc));
+    };
     if (v->kind == Val::DICT) {
+        if (v->dict.empty() && depth > 0) { empty_marker(MC_CKPT_EMPTY_DICT); return true; }
         for (auto& kv : v->dict) {
             std::string key;
             if (kv.first->kind == Val::STR) key = kv.first->s;
@@ -350,6 +361,7 @@ bool flatten(const VP& v, const std::string& prefix, const std::string& path, in
         return true;
     }
     if (v->kind == Val::LIST || v->kind == Val::TUPLE) {
+        if (v->items.empty() && depth > 0) { empty_marker(v->kind == Val::LIST ? MC_CKPT_EMPTY_LIST : MC_CKPT_EMPTY_TUPLE); return true; }
         for (size_t k = 0; k < v->items.size(); ++k) {
             const std::string key = std::to_string(k);
             if (!flatten(v->items[k], join(prefix, key, '.'), join(path, std::string(1, PATH_IDX) + key, PATH_SEP), depth + 1, c, recs, root, err)) return false;
@@ -589,9 +601,11 @@ extern "C" int mc_ckpt_open(const char* path, void** handle) {
     const size_t len = strlen(path);
     const bool st_ext = len > 12 && strcmp(path + len - 12, ".safetensors") == 0;
     const bool is_zip = c->size >= 4 && rd32(c->map) == 0x04034b50u;
+    // safetensors by CONTENT too (a file saved without the suffix): u64 header length inside the file, header opens a JSON object
+    const bool st_sniff = !is_zip && c->size > 9 && rd64(c->map) <= (uint64_t)c->size - 8 && rd64(c->map) >= 2 && c->map[8] == '{';
     bool ok;
     if (is_zip) ok = load_torch_zip(*c, err);
-    else if (st_ext) ok = load_safetensors(*c, err);
+    else if (st_ext || st_sniff) ok = load_safetensors(*c, err);
     else { ok = false; err = "neither a zip (torch.save) archive nor a .safetensors file"; }
     if (!ok) { mc_set_error("mc_ckpt_open: %s: %s", path, err.c_str()); return 1; }
     *handle = c.release();

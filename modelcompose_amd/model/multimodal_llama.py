@@ -8,7 +8,9 @@ Composition: at load every LocalLoRA linear is expanded into one dense weight pe
 (W + Σ scale·B·A, csrc/compose.hip), so a forward is plain GEMMs over adapter-grouped rows."""
 from __future__ import annotations
 
+import functools
 import os
+import threading
 
 import ctypes as C
 import math
@@ -23,6 +25,19 @@ from .config import MultimodalConfig, adapter_plan, composition_terms, infer_mod
 from .splice import SplicePlan, plan_splice, routed_layout
 
 BF16 = torch.bfloat16
+
+
+def _serialised(fn):
+    """generate() / forward() drive the C handle through per-handle one-shot state (tail_adapter, key mask, sampling): calls on one model
+    are serialised by the model's re-entrant lock, which a ContinuousBatcher that owns the model takes around its admissions and decode
+    steps too - another thread's generate() then waits for a step instead of consuming the engine's settings."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        with self._lock:
+            return fn(self, *a, **kw)
+    return wrapper
+
+
 LINEARS = (("self_attn", ("q_proj", "k_proj", "v_proj", "o_proj")), ("mlp", ("gate_proj", "up_proj", "down_proj")))
 
 
@@ -133,6 +148,7 @@ class MultimodalLlamaForCausalLM:
         self._handle = C.c_void_p(0)
         self._keep = []                                                # device tensors referenced by the C handle
         self._cache = {}
+        self._lock = threading.RLock()                                 # see _serialised
         self.use_graph = True
 
     # ------------------------------------------------------------------ reference accessors
@@ -459,6 +475,10 @@ class MultimodalLlamaForCausalLM:
         if key_valid is not None:
             kv_np = np.ones((B, Smax), dtype=np.uint8)                     # generated positions are always attended
             kv_np[:, :Lmax] = key_valid.astype(np.uint8)
+            for b in range(B):
+                # a row shorter than Lmax appends its generated tokens at lens[b] + s (valid_lens): the splice's right-pad zeros of the
+                # mask over [lens[b], Lmax) must not hide them (mixed spliced lengths in a left-padded batch)
+                kv_np[b, int(plan.lens[b]):] = 1
             kmask = torch.from_numpy(kv_np).to(dev)
         x = torch.empty(M, cfg.hidden_size, dtype=BF16, device=dev)
         self._gather_rows(plan, feats, lay.order_b, lay.order_t, x)
@@ -529,6 +549,7 @@ class MultimodalLlamaForCausalLM:
         return v.value
 
     # ------------------------------------------------------------------ public API
+    @_serialised
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, modal_inputs=None, return_dict=None, *, modal_attention_mask=None,
                 cache_reserve=None):
@@ -599,7 +620,8 @@ class MultimodalLlamaForCausalLM:
 
     def _release_slot(self, slot):
         if isinstance(slot, tuple) and slot and slot[0] == "ext":
-            for k in [k for k in self._cache if isinstance(k, tuple) and len(k) > 1 and k[1] == slot]:
+            # the slot's own buffers and those of its admission prefills (serve.ContinuousBatcher: slot ("adm", slot))
+            for k in [k for k in self._cache if isinstance(k, tuple) and len(k) > 1 and k[1] in (slot, ("adm", slot))]:
                 del self._cache[k]
 
     def _plan_from_embeds(self, inputs_embeds, attention_mask, modal_attention_mask):
@@ -669,6 +691,7 @@ class MultimodalLlamaForCausalLM:
 
     __call__ = forward
 
+    @_serialised
     @torch.no_grad()
     def generate(self, input_ids=None, modal_inputs=None, do_sample=False, temperature=None, top_p=None, num_beams=1,
                  max_new_tokens=128, use_cache=True, attention_mask=None, ignore_eos=False, return_step_logits=False, slot=0,

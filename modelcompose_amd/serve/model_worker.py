@@ -106,7 +106,10 @@ class ContinuousBatcher:
         if req.do_sample:
             seed = req.seed if req.seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
             sampling = (float(req.temperature), int(req.top_k or 0), float(req.top_p), int(seed))
-        st = m._prefill(plan, feats, 0, want_logits=True, slot=("adm", self.slot))
+        # the admission cache is sized ONCE, at the worker's context (reserve = Smax - L): a prompt whose ceil64(L) differs from the last one's
+        # does not reallocate and zero a full-depth KV cache
+        reserve = max(0, min(self.Smax, m.config.max_position_embeddings) - int(plan.Lmax))
+        st = m._prefill(plan, feats, reserve, want_logits=True, slot=("adm", self.slot))
         if sampling is not None:
             from .. import ops
             first = ops.sample_step(st["logits"], sampling[0], sampling[1], sampling[2], seed=sampling[3], step=-1)
@@ -160,8 +163,9 @@ class ContinuousBatcher:
                 except queue.Empty:
                     break
                 try:
-                    self._admit(row, req)
-                except BaseException as e:                        # a bad request must not take the engine down
+                    with m._lock:                                 # the model's one-shot handle state is ours for the whole admission
+                        self._admit(row, req)
+                except Exception as e:                            # a bad request must not take the engine down (KeyboardInterrupt / SystemExit do)
                     self.rows[row] = req
                     self._retire(row, e)
         active = [r for r in range(self.B) if self.rows[r] is not None]
@@ -170,7 +174,8 @@ class ContinuousBatcher:
         # (2) one decode step for every row: the token in next_ids[row] is appended at position lens[row]
         st = self._state()
         sampled = [r for r in active if getattr(self.rows[r], "_sampling", None) is not None]
-        lg = m._decode(st, 1, self.out, 0, want_logits=bool(sampled))
+        with m._lock:
+            lg = m._decode(st, 1, self.out, 0, want_logits=bool(sampled))
         self.kv_lens += 1                                           # every row advanced (idle rows are reset below)
         self.lens += 1
         toks = self.out[:, 0].clone()
@@ -188,7 +193,11 @@ class ContinuousBatcher:
                 self.lens[r] = 1
         # (3) deliver
         for r in active:
-            self._emit(r, int(toks[r]))
+            try:
+                self._emit(r, int(toks[r]))
+            except Exception as e:                                # a request's own callback / stopping criterion failed: retire that row only
+                if self.rows[r] is not None:
+                    self._retire(r, e)
         return sum(r is not None for r in self.rows)
 
     def _state(self):
@@ -221,7 +230,14 @@ class ContinuousBatcher:
         self._stop.set()
         if self._thread is not None:
             self._thread.join(30)
-            self._thread = None
+            if not self._thread.is_alive():                       # a loop still inside a long step keeps its handle: start() must not spawn a second one
+                self._thread = None
+
+    def close(self):
+        """shutdown() + give the model back the engine's buffer slots (decode state, admission KV cache)."""
+        self.shutdown()
+        if self._thread is None:
+            self.model._release_slot(self.slot)
 
     def _loop(self):
         try:

@@ -77,6 +77,33 @@ def test_nested_containers_are_flattened_and_scalars_skipped(tmp_path):
     same(tree["model"]["b"]["c"], torch.zeros(3, dtype=torch.int64))
 
 
+def test_empty_containers_keep_their_place_and_type(tmp_path):
+    """a BEATs `cfg` entry holding [] or () must not fall back to the config default without notice."""
+    obj = {"cfg": {"conv_bias": [], "layers": (), "extra": {}, "n": 3, "nested": [[], [1]]}, "model": {"w": torch.ones(2)}}
+    p = tmp_path / "e.bin"
+    torch.save(obj, p)
+    tree = load_nested(str(p))
+    assert tree["cfg"]["conv_bias"] == [] and isinstance(tree["cfg"]["conv_bias"], list)
+    assert tree["cfg"]["layers"] == () and isinstance(tree["cfg"]["layers"], tuple)
+    assert tree["cfg"]["extra"] == {} and tree["cfg"]["n"] == 3
+    assert tree["cfg"]["nested"] == [[], [1]]
+    assert set(load_tensors(str(p))) == {"model.w"}
+
+
+def test_safetensors_without_the_suffix_goes_to_the_native_reader(tmp_path):
+    """only files that carry torch's legacy magic number are legacy files."""
+    from safetensors.torch import save_file
+    from modelcompose_amd.checkpoint_io import _is_legacy_torch_file
+    q = tmp_path / "weights.bin"
+    save_file({"w": torch.arange(6, dtype=torch.float32).reshape(2, 3)}, str(q))
+    assert not _is_legacy_torch_file(str(q))
+    same(load_tensors(str(q))["w"], torch.arange(6, dtype=torch.float32).reshape(2, 3))
+    old = tmp_path / "old.bin"
+    torch.save({"w": torch.ones(3)}, old, _use_new_zipfile_serialization=False)
+    assert _is_legacy_torch_file(str(old))
+    same(load_tensors(str(old))["w"], torch.ones(3))
+
+
 def test_keys_with_dots_and_numeric_keys_survive_the_tree_form(tmp_path):
     obj = {"cfg": {"a.b": 1, "neg": -5, "big": 2 ** 40, "f": -0.25, "s": "caf\u00e9", "empty": ""}, "model": {"enc.0.weight": torch.ones(2), "0": torch.zeros(1)},
            3: {"x": 2.5}}
@@ -388,6 +415,17 @@ def test_self_referential_and_deep_object_trees_are_refused_not_overflowed(tmp_p
     q = tmp_path / "deep.bin"
     open(q, "wb").write(archive(b"\x80\x02" + b"]" * 10000 + b"a" * 9999 + b"."))
     _refused(q, "deeper than 64")
+    # a DAG bomb: l0 = [0]; l(i) = [l(i-1), l(i-1)] through the memo - 40 levels = 2^40 leaves from 300 bytes, inside the depth limit
+    body = b"\x80\x02]q\x00K\x00a"                                # (earlier levels stay on the stack below the result: legal)
+    for i in range(1, 41):
+        body += b"]q" + bytes([i]) + b"h" + bytes([i - 1]) + b"ah" + bytes([i - 1]) + b"a"
+    body += b"."
+    q = tmp_path / "dag.bin"
+    open(q, "wb").write(archive(body))
+    import time as _t
+    t0 = _t.perf_counter()
+    _refused(q, "more than 4000000 nodes")
+    assert _t.perf_counter() - t0 < 30
     # safetensors metadata with 100 000 nested arrays
     s = tmp_path / "deep.safetensors"
     hdr = (b'{"__metadata__":' + b"[" * 100000 + b"]" * 100000 + b',"w":{"dtype":"F32","shape":[1],"data_offsets":[0,4]}}')

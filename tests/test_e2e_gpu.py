@@ -436,6 +436,40 @@ def test_left_padded_and_holey_masks_follow_the_reference(g4_model):
     assert float(e2[:, -8:].max()) < 1.5e-2
 
 
+def test_left_padded_batch_of_mixed_spliced_lengths_equals_each_row_alone(g4_model):
+    """a left-padded batch whose rows carry different numbers of modal tokens (an image row + a text-only row).  The
+    shorter row's spliced length is below Lmax, the splice right-pads its mask with zeros over [lens[b], Lmax), and decode appends that
+    row's generated tokens exactly there: those slots must be open as keys.  Every row must generate what it generates alone (same
+    tokens teacher-forced; logits to rounding - RoPE is relative, the shift only changes rounding)."""
+    model, a, meta, sd = g4_model
+    g = torch.Generator().manual_seed(21)
+    r = lambda n: torch.randint(3, 97, (n,), generator=g).tolist()
+    V = -200
+    rows = [[1] + r(3) + [V, 13] + r(6), [1] + r(5)]                      # image row, text-only row
+    L = max(len(x) for x in rows)
+    ids = torch.tensor([[0] * (L - len(x)) + x for x in rows])
+    am = torch.tensor([[0] * (L - len(x)) + [1] * len(x) for x in rows], dtype=torch.bool)
+    px = a["pixels"][:1]
+    n_new = 6
+    alone = []
+    for row in rows:
+        mi = {"vision": px.cuda()} if V in row else {}
+        r1, l1 = model.generate(torch.tensor([row]).cuda(), modal_inputs=mi, max_new_tokens=n_new, ignore_eos=True, return_step_logits=True)
+        alone.append((r1[0, len(row):].cpu(), l1[0].float().cpu()))
+    forced = torch.stack([x[0][:n_new - 1] for x in alone])
+    res, lg = model.generate(ids.cuda(), modal_inputs={"vision": px.cuda()}, attention_mask=am.cuda(), max_new_tokens=n_new, ignore_eos=True,
+                             return_step_logits=True, forced_ids=forced)
+    lg = lg.float().cpu()
+    for b in range(len(rows)):
+        sc = alone[b][1].abs().max()
+        err = ((lg[b] - alone[b][1]).abs().amax(-1) / sc)
+        print(f"[err] mixed-length left padding, row {b}: {err.tolist()}")
+        assert float(err.max()) < 1.5e-2, (b, err)                        # before the fix: the text row lost sight of its own new tokens
+        top2 = alone[b][1].topk(2, -1).values
+        clear = ((top2[:, 0] - top2[:, 1]) / sc) > 2e-2
+        assert torch.equal(res[b, L:].cpu()[clear], alone[b][0][clear]), b
+
+
 def test_last_layer_tail_equals_the_full_last_layer(g4_model):
     """generate()'s prefill runs the last decoder layer's attention + MLP for the last token of every sequence only (mc_llm option
     "tail_adapter"): the first-step logits agree with the all-rows path to fp32 summation order of one attention row and three small GEMMs
