@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 7
+#define MC_ABI_VERSION 8
 
 /* activation codes for mc_gemm_bf16 */
 #define MC_ACT_NONE 0
@@ -235,6 +235,16 @@ int mc_rope_inplace_bf16(void* x, int64_t ld, const int32_t* row_pos, const floa
                          int n_heads, int D, float sign, void* stream);
 int mc_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* AdamW with two learning-rate groups chosen per element (llava_trainer.py:210-290: --mm_projector_lr / --mm_language_lr put the
+ * lora_A.default / lora_B.default tensors into the projector group; run_finetune_vision_damc.sh:28).  The flat buffer is described by
+ * chunks; element e of a chunk's tensor takes lr_alt when (idx0 + e) mod period < width (period 0: always lr).  off / n / idx0 / period /
+ * width are multiples of 4 elements. */
+typedef struct mc_adamw_seg { long long off; int n; int idx0; int period; int width; } mc_adamw_seg;
+int mc_adamw_segments_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, const mc_adamw_seg* segs_dev,
+                          int n_segs, float lr, float lr_alt, float beta1, float beta2, float eps, float weight_decay, int step,
+                          float grad_scale, void* stream);
+/* y += alpha * x (fp32, flat): gradient accumulation over micro-batches (run_finetune_vision_damc.sh:45 --gradient_accumulation_steps) */
+int mc_axpy_f32(float* y, const float* x, int64_t n, float alpha, void* stream);
 int mc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
 
 /* ---- attention backward (training step; replaces autograd through multimodal_llama.py:295-312 and the flash-attn backward of

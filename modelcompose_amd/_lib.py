@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -122,6 +122,8 @@ _SIGS.update({
     "mc_colsum_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_rope_inplace_bf16": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "mc_adamw_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p],
+    "mc_adamw_segments_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p],
+    "mc_axpy_f32": [c_p, c_p, c_l, c_f, c_p],
     "mc_cast_f32_bf16": [c_p, c_p, c_l, c_p],
     "mc_layernorm_bwd_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_dropout_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_f, C.c_uint64, C.c_uint32, c_i, c_f, c_p],

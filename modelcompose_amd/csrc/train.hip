@@ -423,6 +423,74 @@ extern "C" int mc_adamw_f32(float* param, const float* grad, float* exp_avg, flo
     return 0;
 }
 
+// AdamW over a flat buffer whose tensors belong to TWO learning-rate groups chosen per element (llava_trainer.py:210-290: with
+// --mm_projector_lr / --mm_language_lr the `lora_A.default` / `lora_B.default` tensors take the projector group's rate, the modal adapters
+// the base rate; here an adapter's A rows / B columns are slices of stacked tensors).  The buffer is described by chunks
+// {offset, length, index of the chunk's first element inside its tensor, period, width}: element e of a tensor is in the ALTERNATE group
+// when e mod period < width (A_in [n_lin * nA * r, K]: period nA*r*K, width r*K; B_cat [N, nA*r]: period nA*r, width r).  Offsets,
+// lengths, periods and widths are multiples of 4, so a 16-byte vector never straddles two groups.
+struct AdamwSeg { long long off; int n; int idx0; int period; int width; };
+static_assert(sizeof(AdamwSeg) == sizeof(mc_adamw_seg), "mc_adamw_seg layout");
+
+__global__ __launch_bounds__(256) void adamw_seg_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                        bf16_t* __restrict__ p16, const AdamwSeg* __restrict__ segs, int n_segs, float lr, float lr_alt,
+                                                        float b1, float b2, float eps, float wd, float bc1, float bc2, float grad_scale) {
+    for (int sidx = blockIdx.x; sidx < n_segs; sidx += gridDim.x) {
+        const AdamwSeg sg = segs[sidx];
+        const int n4 = sg.n >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const int64_t e = (sg.off >> 2) + i;
+            const bool alt = sg.period > 0 && (uint32_t)(sg.idx0 + 4 * i) % (uint32_t)sg.period < (uint32_t)sg.width;
+            const float l = alt ? lr_alt : lr;
+            f32x4 pv = ((f32x4*)p)[e], mv = ((f32x4*)m)[e], vv = ((f32x4*)v)[e];
+            const f32x4 gv = ((const f32x4*)g)[e];
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = pv[j], mj = mv[j], vj = vv[j];
+                o[j] = (bf16_t)adamw_one(pj, gv[j], mj, vj, l, b1, b2, eps, wd, bc1, bc2, grad_scale);
+                pv[j] = pj; mv[j] = mj; vv[j] = vj;
+            }
+            ((f32x4*)p)[e] = pv; ((f32x4*)m)[e] = mv; ((f32x4*)v)[e] = vv;
+            if (p16) ((bf16x4*)p16)[e] = o;
+        }
+    }
+}
+
+extern "C" int mc_adamw_segments_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, const mc_adamw_seg* segs_dev,
+                                     int n_segs, float lr, float lr_alt, float beta1, float beta2, float eps, float weight_decay, int step,
+                                     float grad_scale, void* stream) {
+    MC_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && segs_dev && n_segs > 0 && step >= 1, "mc_adamw_segments_f32: bad arguments");
+    MC_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0 && (uintptr_t)param_bf16 % 8 == 0,
+                 "mc_adamw_segments_f32: buffers must be 16-byte aligned (bf16 copy: 8)");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    adamw_seg_kernel<<<min(n_segs, 16384), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, (bf16_t*)param_bf16, (const AdamwSeg*)segs_dev,
+                                                                         n_segs, lr, lr_alt, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
+// y += alpha * x over flat fp32 buffers (gradient accumulation over micro-batches: run_finetune_vision_damc.sh:45 --gradient_accumulation_steps 4)
+__global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n, float alpha) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 a = ((f32x4*)y)[i];
+        const f32x4 b = ((const f32x4*)x)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = fmaf(alpha, b[j], a[j]);
+        ((f32x4*)y)[i] = a;
+    }
+    const int64_t t = (n4 << 2) + blockIdx.x * 256LL + threadIdx.x;
+    if (t < n) y[t] = fmaf(alpha, x[t], y[t]);
+}
+
+extern "C" int mc_axpy_f32(float* y, const float* x, int64_t n, float alpha, void* stream) {
+    MC_CHECK_ARG(y && x && n > 0 && ((uintptr_t)y | (uintptr_t)x) % 16 == 0, "mc_axpy_f32: bad arguments");
+    axpy_f32_kernel<<<(int)min((int64_t)8192, (n / 4 + 256) / 256), 256, 0, (hipStream_t)stream>>>(y, x, n, alpha);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // fp32 -> bf16 cast of a flat buffer (working copies of the trainable parameters)
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {

@@ -510,6 +510,18 @@ def adamw(p32, g32, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
                "mc_adamw_f32")
 
 
+def adamw_segments(p32, g32, m, v, p16, segs_dev, n_segs, lr, lr_alt, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    """AdamW with two learning-rate groups chosen per element (mc_adamw_segments_f32; segs_dev: uint8 tensor of mc_adamw_seg records)."""
+    _lib.check(_lib.lib().mc_adamw_segments_f32(_p(p32), _p(g32), _p(m), _p(v), _p(p16), _p(segs_dev), n_segs, lr, lr_alt, beta1, beta2, eps, wd,
+                                                step, grad_scale, _stream()), "mc_adamw_segments_f32")
+
+
+def axpy_f32(y, x, alpha=1.0):
+    """y += alpha * x (flat fp32)."""
+    assert y.dtype == torch.float32 and x.dtype == torch.float32 and y.numel() == x.numel()
+    _lib.check(_lib.lib().mc_axpy_f32(_p(y), _p(x), y.numel(), float(alpha), _stream()), "mc_axpy_f32")
+
+
 def layernorm_bwd(x, g, dy, eps, want_t=True):
     """-> (dx, t = dy * xhat or None): LayerNorm backward w.r.t. the input; dgamma = colsum(t), dbeta = colsum(dy)."""
     M, D = x.shape

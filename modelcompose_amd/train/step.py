@@ -58,7 +58,13 @@ class _Param:
 
 class MultimodalTrainStep:
     def __init__(self, model: MultimodalLlamaForCausalLM, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 bucket_layers: int = 4, process_group=None, overlap_wgrad: bool = True, force_exchange: bool = False, dropout_seed: int = 0):
+                 bucket_layers: int = 4, process_group=None, overlap_wgrad: bool = True, force_exchange: bool = False, dropout_seed: int = 0,
+                 mm_projector_lr: Optional[float] = None, mm_language_lr: Optional[float] = None):
+        """lr / mm_projector_lr / mm_language_lr: the reference's optimizer groups (llava_trainer.py:210-290; run_finetune_vision_damc.sh:28
+        `--mm_projector_lr 2e-5 --mm_language_lr 1e-5`).  With mm_projector_lr set, every `modal_projectors.*` tensor takes that rate; with
+        mm_language_lr ALSO set, the `lora_A.default` / `lora_B.default` tensors join the projector group - at mm_projector_lr: the reference
+        uses mm_language_lr only as the switch (:212-213), its value never reaches the optimizer; reproduced as is.  Everything else (modal
+        adapters, prefix / suffix tokens) takes `lr`.  mm_language_lr without mm_projector_lr changes nothing (:210)."""
         cfg = model.config
         self.p = float(getattr(cfg, "lora_dropout", 0.0) or 0.0)
         if not 0.0 <= self.p < 1.0:
@@ -78,6 +84,11 @@ class MultimodalTrainStep:
         if self.R % 64:
             raise ValueError(f"n_adapters * lora_r = {self.R} must be a multiple of 64 for the MFMA GEMMs")
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.mm_projector_lr = None if mm_projector_lr is None else float(mm_projector_lr)
+        self.mm_language_lr = None if mm_language_lr is None else float(mm_language_lr)
+        self._accum_n = 0                                          # micro-batches whose gradients wait in self.Gacc (gradient accumulation)
+        self.Gacc = None
+        self._present_acc: List[str] = []
         self.bucket_layers, self.pg = bucket_layers, process_group
         self.world = 1
         try:
@@ -99,6 +110,52 @@ class MultimodalTrainStep:
         self._build_frozen()
         self._build_trainable()
         self._buckets = bucket_ranges(self.layer_end, cfg.num_hidden_layers, bucket_layers, self.n_params)
+        self._segs = None                                          # chunk table of the two-rate AdamW (built on first use)
+
+    def lr_of(self, name: str) -> float:
+        """Learning rate of a parameter under the REFERENCE's name (lora_A.{adapter}.weight, modal_projectors.*, prefix_tokens.*): the
+        group llava_trainer.py:210-290 puts it in."""
+        if self.mm_projector_lr is None:
+            return self.lr
+        if "modal_projectors" in name or "mm_projector" in name:
+            return self.mm_projector_lr
+        if self.mm_language_lr is not None and ("lora_A.default" in name or "lora_B.default" in name):
+            return self.mm_projector_lr                            # :212-213 extends the projector group; its rate is mm_projector_lr
+        return self.lr
+
+    def _lora_segments(self):
+        """mc_adamw_seg records over [0, aux_lo): chunks of <= 64 Ki elements, the `default` adapter's rows of every A_in and columns of
+        every B_cat flagged as the alternate-rate group."""
+        if self._segs is None:
+            CH = 1 << 16
+            recs = []
+            covered = 0
+            for name, p_ in self.params.items():
+                if p_.off >= self.aux_lo:
+                    continue
+                if p_.off > covered:                               # alignment padding between tensors: plain elements (zero gradient)
+                    recs.append((covered, p_.off - covered, 0, 0, 0))
+                if name.endswith(".A_in"):
+                    K = p_.shape[1]
+                    period, width = self.R * K, self.r * K
+                elif name.endswith(".B_cat"):
+                    period, width = self.R, self.r
+                else:
+                    raise AssertionError(name)
+                assert period % 4 == 0 and width % 4 == 0 and p_.off % 4 == 0
+                for c0 in range(0, p_.n, CH):
+                    n = min(CH, p_.n - c0)
+                    recs.append((p_.off + c0, n, c0 % period, period, width))
+                covered = p_.off + p_.n
+            if covered < self.aux_lo:
+                recs.append((covered, self.aux_lo - covered, 0, 0, 0))
+            for off, n, *_ in recs:
+                assert off % 4 == 0 and (n % 4 == 0 or off + n == self.aux_lo), (off, n)
+            arr = np.zeros(len(recs), dtype=np.dtype([("off", "<i8"), ("n", "<i4"), ("idx0", "<i4"), ("period", "<i4"), ("width", "<i4")]))
+            for i, rcd in enumerate(recs):
+                arr[i] = rcd
+            self._segs = (torch.from_numpy(arr.view(np.uint8).copy()).to(self.dev), len(recs))
+        return self._segs
 
     # ------------------------------------------------------------------ weights
     def _build_frozen(self):
@@ -237,9 +294,16 @@ class MultimodalTrainStep:
 
     def named_gradients(self) -> Dict[str, torch.Tensor]:
         """Gradients under the reference's parameter names (lora_A.{adapter}.weight ...)."""
+        return self._named(self.G)
+
+    def named_parameters(self) -> Dict[str, torch.Tensor]:
+        """fp32 master weights under the reference's parameter names (views of the flat buffer)."""
+        return self._named(self.P)
+
+    def _named(self, buf) -> Dict[str, torch.Tensor]:
         out = {}
         for name, p in self.params.items():
-            g = self.view(self.G, name)
+            g = self.view(buf, name)
             if name.endswith(".A_in"):
                 l, gname = name.split(".")[2], name.split(".")[3]
                 lins = dict(GROUPS)[gname]
@@ -365,17 +429,55 @@ class MultimodalTrainStep:
                     alpha=self.scale)
 
     # ------------------------------------------------------------------ one step
-    def forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
-        """Returns the loss (fp32 scalar tensor); gradients of this rank's batch are left in self.G."""
+    def forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None, accumulate: bool = False) -> torch.Tensor:
+        """Returns the loss (fp32 scalar tensor) of this micro-batch.
+
+        accumulate=False: the LAST (or only) micro-batch of an optimizer step - afterwards self.G holds the gradient SUM over this call and
+        every accumulate=True call since the last optimizer_step(), all-reduced over the ranks; optimizer_step() divides by
+        world x micro-batches (HF Trainer: each micro-batch's loss / gradient_accumulation_steps, gradients summed;
+        run_finetune_vision_damc.sh:45 `--gradient_accumulation_steps 4`).
+        accumulate=True: an earlier micro-batch - its gradient is added to the pending sum, nothing is exchanged (DDP no_sync)."""
         from .. import _lib
-        if self._wstream is None:
-            return self._forward_backward(input_ids, labels, modal_inputs, attention_mask)
-        # the side stream fills the CUs an under-filled base GEMM leaves idle; narrower tiles would compete with it for them
-        _lib.check(_lib.lib().mc_gemm_set_option(b"tile192", 0), "mc_gemm_set_option")
+        pending = self._accum_n > 0
+        exch = self._exchange
+        if accumulate or pending:
+            self._exchange = False                                 # exchange once, on the sum
         try:
-            return self._forward_backward(input_ids, labels, modal_inputs, attention_mask)
+            if self._wstream is None:
+                loss = self._forward_backward(input_ids, labels, modal_inputs, attention_mask)
+            else:
+                # the side stream fills the CUs an under-filled base GEMM leaves idle; narrower tiles would compete with it for them
+                _lib.check(_lib.lib().mc_gemm_set_option(b"tile192", 0), "mc_gemm_set_option")
+                try:
+                    loss = self._forward_backward(input_ids, labels, modal_inputs, attention_mask)
+                finally:
+                    _lib.lib().mc_gemm_set_option(b"tile192", 1)
         finally:
-            _lib.lib().mc_gemm_set_option(b"tile192", 1)
+            self._exchange = exch
+        if accumulate:
+            if self.Gacc is None:
+                self.Gacc = torch.zeros_like(self.G)
+            if self._accum_n == 0:
+                self.Gacc.copy_(self.G)
+                self._present_acc = list(self._present)
+            else:
+                ops.axpy_f32(self.Gacc, self.G)
+                self._present_acc += [m for m in self._present if m not in self._present_acc]
+            self._accum_n += 1
+            self._micro = self._accum_n
+            return loss
+        if pending:
+            ops.axpy_f32(self.G, self.Gacc)                        # G = sum over the micro-batches of this optimizer step
+            self._present = self._present_acc + [m for m in self._present if m not in self._present_acc]
+            self._micro = self._accum_n + 1
+            self._accum_n = 0
+            if self._exchange:
+                hs = [self._allreduce_async(lo, hi) for (_, lo, hi) in self._buckets]
+                for h in hs:
+                    h.wait()
+        else:
+            self._micro = 1
+        return loss
 
     def _forward_backward(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
         model, cfg, dev = self.model, self.cfg, self.dev
@@ -599,11 +701,20 @@ class MultimodalTrainStep:
 
     def optimizer_step(self):
         """AdamW on the mean gradient over ranks (DDP semantics: all-reduce SUM, then 1 / world_size)."""
+        if self._accum_n:
+            raise RuntimeError("optimizer_step() with accumulated micro-batches pending: the last forward_backward of a step takes accumulate=False")
         self.step_count += 1
         b1, b2 = self.betas
         lo = self.aux_lo
-        ops.adamw(self.P[:lo], self.G[:lo], self.m1[:lo], self.m2[:lo], self.P16[:lo], self.lr, b1, b2, self.eps, self.wd, self.step_count,
-                  grad_scale=1.0 / self.world)
+        gs = 1.0 / (self.world * max(getattr(self, "_micro", 1), 1))
+        lr_default_adapter = self.lr_of("lora_A.default")
+        if lr_default_adapter != self.lr:
+            segs, n_segs = self._lora_segments()
+            ops.adamw_segments(self.P, self.G, self.m1, self.m2, self.P16, segs, n_segs, self.lr, lr_default_adapter, b1, b2, self.eps, self.wd,
+                               self.step_count, grad_scale=gs)
+        else:
+            ops.adamw(self.P[:lo], self.G[:lo], self.m1[:lo], self.m2[:lo], self.P16[:lo], self.lr, b1, b2, self.eps, self.wd, self.step_count,
+                      grad_scale=gs)
         # projector / prefix / suffix tensors: only those of modalities that were in the batch (torch.optim.AdamW skips grad-None tensors and
         # keeps a step count per tensor).  Under data parallelism a modality must be present on every rank or on none (as with DDP, where a
         # parameter unused on one rank is an error without find_unused_parameters).
@@ -611,14 +722,26 @@ class MultimodalTrainStep:
             self._aux_steps[m] += 1
             for p_ in self.aux_params[m]:
                 sl = slice(p_.off, p_.off + p_.n)
-                ops.adamw(self.P[sl], self.G[sl], self.m1[sl], self.m2[sl], self.P16[sl], self.lr, b1, b2, self.eps, self.wd, self._aux_steps[m],
-                          grad_scale=1.0 / self.world)
+                # weight decay: not on biases, not on LayerNorm parameters (llava_trainer.py:208-209 `decay_parameters`)
+                wd = 0.0 if (p_.name.endswith("bias") or "layernorm" in p_.name.lower()) else self.wd
+                ops.adamw(self.P[sl], self.G[sl], self.m1[sl], self.m2[sl], self.P16[sl], self.lr_of(p_.name), b1, b2, self.eps, wd,
+                          self._aux_steps[m], grad_scale=gs)
         self._repack()
 
-    def step(self, input_ids, labels, modal_inputs) -> torch.Tensor:
-        loss = self.forward_backward(input_ids, labels, modal_inputs)
+    def step(self, input_ids, labels, modal_inputs, attention_mask=None) -> torch.Tensor:
+        loss = self.forward_backward(input_ids, labels, modal_inputs, attention_mask)
         self.optimizer_step()
         return loss
+
+    def step_accumulated(self, micro_batches) -> torch.Tensor:
+        """One optimizer step over several micro-batches [(input_ids, labels, modal_inputs[, attention_mask]), ...] (HF Trainer with
+        gradient_accumulation_steps = len(micro_batches)); returns the mean of the micro-batch losses."""
+        micro_batches = list(micro_batches)
+        losses = []
+        for i, mb in enumerate(micro_batches):
+            losses.append(self.forward_backward(*mb, accumulate=i < len(micro_batches) - 1))
+        self.optimizer_step()
+        return torch.stack([l.reshape(()) for l in losses]).mean()
 
 
 def raw_or_fail(raw, key):

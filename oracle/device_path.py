@@ -16,6 +16,9 @@ BASELINE.json names (1e-3 of the logit scale, greedy ids bit-exact) instead of t
   * prefill attention: P = bf16(exp(s - rowmax)) multiplies V, the row sum that normalises is taken over the fp32 P (csrc/attention.hip);
     decode attention: fp32 softmax, no rounding of P (attn_decode_kernel);
   * decode steps use the 'default' adapter only (multimodal_llama.py:435-438).
+Every rounding point can be switched off one at a time (`rounding={...}`, names in ROUNDING_POINTS): the error budget of
+profiles/r04_parity.json and the fp32-residual-stream A/B come from that.  `lazy=True` composes a layer's weights when the layer
+runs (a 32-layer model with 4 routed adapters is 104 GB as fp32 tensors; lazily it is the bf16 state dict + one layer).
 What is NOT reproduced: fp32 summation order inside the kernels (MFMA tiling, split reductions) and the online-softmax's
 running maximum (P is rounded relative to the final row maximum here).  Both perturb results far below one bf16 step.
 """
@@ -36,39 +39,71 @@ def bf(x: torch.Tensor) -> torch.Tensor:
     return x.to(BF).to(torch.float32)
 
 
+# where the HIP path stores bf16 (True = rounded there, the shipped path).  "operand": the x operand of a GEMM is bf16 even when the
+# residual stream it comes from is kept in fp32 ("resid_attn" / "resid_mlp" False = an fp32 residual stream).
+ROUNDING_POINTS = ("weights", "embed", "qkv", "rope", "p", "attn_out", "resid_attn", "resid_mlp", "operand", "gate_up", "inter", "final")
+
+
+def _rounding(r: Optional[dict]) -> dict:
+    out = {k: True for k in ROUNDING_POINTS}
+    if r:
+        unknown = set(r) - set(ROUNDING_POINTS)
+        assert not unknown, unknown
+        out.update(r)
+    return out
+
+
 class DeviceWeights:
     """Per layer and routed adapter: q|k|v (norm folded), o, gate / up (norm folded), down as fp32 tensors holding bf16 values.
     Adapters without any LoRA term share the base tensors (as the device path shares their storage)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], cfg: llm.LLMConfig):
-        self.cfg = cfg
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: llm.LLMConfig, lazy: bool = False, round_weights: bool = True):
+        self.cfg, self.sd, self.lazy = cfg, sd, lazy
+        self._rw = bf if round_weights else (lambda t: t)
+        self._default_cache: Dict[int, Dict[str, torch.Tensor]] = {}      # lazy mode: the decode adapter's layers, kept as bf16 tensors
         self.layers: List[Dict[str, Dict[str, torch.Tensor]]] = []
-        names = list(cfg.modal_names)
-        for i in range(cfg.num_hidden_layers):
-            p = f"model.layers.{i}"
-            g_in = sd[f"{p}.input_layernorm.weight"].float()
-            g_post = sd[f"{p}.post_attention_layernorm.weight"].float()
-            per = {}
-            cache = {}
-            for ad in names:
-                w = {}
-                for blk, lins in (("self_attn", llm.LINEARS_ATTN), ("mlp", llm.LINEARS_MLP)):
-                    for lin in lins:
-                        pre = f"{p}.{blk}.{lin}"
-                        key = (lin, self._terms_key(sd, pre, cfg, ad))
-                        if key not in cache:
-                            m = llm.merged_weight(sd, pre, cfg, ad)
-                            if lin in ("q_proj", "k_proj", "v_proj"):
-                                m = m * g_in[None, :]
-                            elif lin in ("gate_proj", "up_proj"):
-                                m = m * g_post[None, :]
-                            cache[key] = bf(m)
-                        w[lin] = cache[key]
-                per[ad] = w
-            self.layers.append(per)
+        if not lazy:
+            for i in range(cfg.num_hidden_layers):
+                self.layers.append(self._build_layer(i, list(cfg.modal_names)))
         self.final_norm = sd["model.norm.weight"].float()
-        self.lm_head = bf(sd["lm_head.weight"].float())
-        self.embed = bf(sd["model.embed_tokens.weight"].float())
+        self.lm_head = self._rw(sd["lm_head.weight"].float())
+        self.embed = self._rw(sd["model.embed_tokens.weight"].float())
+
+    def _build_layer(self, i: int, adapters) -> Dict[str, Dict[str, torch.Tensor]]:
+        sd, cfg = self.sd, self.cfg
+        p = f"model.layers.{i}"
+        g_in = sd[f"{p}.input_layernorm.weight"].float()
+        g_post = sd[f"{p}.post_attention_layernorm.weight"].float()
+        per, cache = {}, {}
+        for ad in adapters:
+            w = {}
+            for blk, lins in (("self_attn", llm.LINEARS_ATTN), ("mlp", llm.LINEARS_MLP)):
+                for lin in lins:
+                    pre = f"{p}.{blk}.{lin}"
+                    key = (lin, self._terms_key(sd, pre, cfg, ad))
+                    if key not in cache:
+                        m = llm.merged_weight(sd, pre, cfg, ad)
+                        if lin in ("q_proj", "k_proj", "v_proj"):
+                            m = m * g_in[None, :]
+                        elif lin in ("gate_proj", "up_proj"):
+                            m = m * g_post[None, :]
+                        cache[key] = self._rw(m)
+                    w[lin] = cache[key]
+            per[ad] = w
+        return per
+
+    def layer(self, i: int, adapters) -> Dict[str, Dict[str, torch.Tensor]]:
+        """The dense weights of layer i for the named routed adapters."""
+        if not self.lazy:
+            return self.layers[i]
+        adapters = list(adapters)
+        if adapters == ["default"]:
+            if i not in self._default_cache:
+                w = self._build_layer(i, adapters)["default"]
+                # bf16-valued when rounded; an unrounded budget run keeps fp32 (small models only)
+                self._default_cache[i] = {k: (v.to(BF) if self._rw is bf else v) for k, v in w.items()}
+            return {"default": {k: v.float() for k, v in self._default_cache[i].items()}}
+        return self._build_layer(i, adapters)
 
     @staticmethod
     def _terms_key(sd, pre, cfg, ad):
@@ -95,20 +130,24 @@ def _rs(x2d: torch.Tensor, eps: float) -> torch.Tensor:
     return torch.rsqrt(x2d.pow(2).mean(-1, keepdim=True) + eps)
 
 
-def _rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+def _rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, rnd: bool = True) -> torch.Tensor:
     """x (B, L, H, D) fp32; cos / sin (B, L, D/2): rope_kv_kernel's pairing (i, i + D/2), rounded to bf16."""
     half = x.shape[-1] // 2
     a, b = x[..., :half], x[..., half:]
     c, s = cos[:, :, None, :], sin[:, :, None, :]
-    return bf(torch.cat([a * c - b * s, b * c + a * s], dim=-1))
+    y = torch.cat([a * c - b * s, b * c + a * s], dim=-1)
+    return bf(y) if rnd else y
 
 
 def forward(dw: DeviceWeights, x: torch.Tensor, adapter_masks: Optional[Dict[str, torch.Tensor]], past_kv=None, last_only=False,
-            trace: Optional[dict] = None):
+            trace: Optional[dict] = None, rounding: Optional[dict] = None):
     """x (B, L, hidden) fp32 holding bf16 values (spliced embeddings, or the embedding rows of one decode token).
     adapter_masks: {adapter: bool (B, L)} one-hot over the routed adapters, or None (= every token 'default').
     Returns (logits fp32 (B, L or 1, vocab), present_kv)."""
     cfg = dw.cfg
+    R = _rounding(rounding)
+    r = lambda name, t: bf(t) if R[name] else t
+    opx = (lambda t: t) if (R["resid_attn"] and R["resid_mlp"]) or not R["operand"] else bf      # GEMM operand of an fp32 stream
     B, L, Hd = x.shape
     H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     eps = cfg.rms_norm_eps
@@ -134,15 +173,16 @@ def forward(dw: DeviceWeights, x: torch.Tensor, adapter_masks: Optional[Dict[str
     presents = []
     scale = 1.0 / math.sqrt(D)
     for i in range(cfg.num_hidden_layers):
-        W = dw.layers[i]
+        W = dw.layer(i, [g_[0] for g_ in groups])
         rs = _rs(h, eps)
-        q = bf(_routed(h, W, "q_proj", groups) * rs).view(B, L, H, D)
-        k = bf(_routed(h, W, "k_proj", groups) * rs).view(B, L, Hkv, D)
-        v = bf(_routed(h, W, "v_proj", groups) * rs).view(B, L, Hkv, D)
+        hx = opx(h)
+        q = r("qkv", _routed(hx, W, "q_proj", groups) * rs).view(B, L, H, D)
+        k = r("qkv", _routed(hx, W, "k_proj", groups) * rs).view(B, L, Hkv, D)
+        v = r("qkv", _routed(hx, W, "v_proj", groups) * rs).view(B, L, Hkv, D)
         if trace is not None:
             trace[f"{i}.rs"] = rs.clone()
             trace[f"{i}.qkv"] = torch.cat([q.reshape(B * L, -1), k.reshape(B * L, -1), v.reshape(B * L, -1)], 1)
-        q, k = _rope(q, cos, sin), _rope(k, cos, sin)
+        q, k = _rope(q, cos, sin, R["rope"]), _rope(k, cos, sin, R["rope"])
         if trace is not None:
             trace[f"{i}.q_rot"] = q.reshape(B * L, -1).clone()
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)            # (B, H, L, D)
@@ -162,22 +202,24 @@ def forward(dw: DeviceWeights, x: torch.Tensor, adapter_masks: Optional[Dict[str
             s = s.masked_fill(~causal, float("-inf"))
             m = s.max(dim=-1, keepdim=True).values
             p = torch.exp(s - m)
-            o = torch.matmul(bf(p), vv) / p.sum(-1, keepdim=True)
-        o = bf(o).transpose(1, 2).reshape(B * L, H * D)
-        h = bf(h + _routed(o, W, "o_proj", groups))
+            o = torch.matmul(r("p", p), vv) / p.sum(-1, keepdim=True)
+        o = r("attn_out", o).transpose(1, 2).reshape(B * L, H * D)
+        h = r("resid_attn", h + _routed(o, W, "o_proj", groups))
         if trace is not None:
             trace[f"{i}.attn"] = o.clone()
             trace[f"{i}.x1"] = h.clone()
         rs = _rs(h, eps)
-        g = bf(_routed(h, W, "gate_proj", groups) * rs)
-        u = bf(_routed(h, W, "up_proj", groups) * rs)
-        inter = bf(g / (1.0 + torch.exp(-g)) * u)
-        h = bf(h + _routed(inter, W, "down_proj", groups))
+        hx = opx(h)
+        g = r("gate_up", _routed(hx, W, "gate_proj", groups) * rs)
+        u = r("gate_up", _routed(hx, W, "up_proj", groups) * rs)
+        inter = r("inter", g / (1.0 + torch.exp(-g)) * u)
+        h = r("resid_mlp", h + _routed(inter, W, "down_proj", groups))
+        del W
         if trace is not None:
             trace[f"{i}.inter"] = inter.clone()
             trace[f"{i}.x2"] = h.clone()
     hid = h.view(B, L, Hd)
     if last_only:
         hid = hid[:, -1:]
-    nl = bf(hid * _rs(hid, eps) * dw.final_norm)
+    nl = r("final", hid * _rs(hid, eps) * dw.final_norm)
     return F.linear(nl, dw.lm_head), tuple(presents)

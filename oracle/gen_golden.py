@@ -1103,6 +1103,73 @@ def g15():
         del sd, om
 
 
+def g17(phase=None):
+    """Full depth, EIGHT rows, BOTH oracles (VERDICT r3 #2a).  Case: tests/fullwidth_cases.py DEPTH_CASES["fulldepth_iav8"].
+      phase A: the fp32 branch-form oracle (oracle/llm.py; multimodal_llama.py:488-619) free-running greedy, two rows at a time (35 GB of
+               fp32 weights + the fp32 KV cache of two 2793-token rows); chunk results are kept under /tmp so an interrupted run resumes;
+      phase B: the device-rounding restatement (oracle/device_path.py, lazy per-layer composition over the bf16 state dict) TEACHER-FORCED
+               on phase A's ids, fed phase A's encoders (fp32 oracle encoders: the backbone is what is compared).
+    The two phases run in separate processes (`python -m oracle.gen_golden g17a`, then `g17b`): their weights do not fit together.
+    Stored: ids, fp32-oracle logits, device-oracle logits (full fp32 rows), margins, and per-row norms of the oracle's feature blocks."""
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    import fullwidth_cases as fc
+    from . import pipeline
+    torch.set_num_threads(os.cpu_count() or 1)
+    name = "fulldepth_iav8"
+    seeds = fc.DEPTH_CASES[name]["row_seeds"]
+    chunks = [seeds[i:i + 2] for i in range(0, len(seeds), 2)]
+    tmp = os.environ.get("MC_G17_TMP", "/tmp/mc_g17")
+    os.makedirs(tmp, exist_ok=True)
+    if phase == "a":
+        meta, sd = fc.build_weights(name)
+        fc.sd_to_f32_inplace(sd)
+        om = pipeline.OracleModel.from_state_dict(sd, meta)
+        for ci, rs in enumerate(chunks):
+            f = os.path.join(tmp, f"a{ci}.pt")
+            if os.path.exists(f):
+                continue
+            t0 = time.time()
+            ids, mi = fc.build_rows(name, rs)
+            with torch.no_grad():
+                new_ids, logits = om.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True)
+            torch.save({"ids": new_ids, "logits": logits.float(), "input_ids": ids, "seconds": time.time() - t0}, f)
+            print(f"g17a chunk {ci} rows {rs}: {time.time() - t0:.0f}s ids {new_ids.tolist()}", flush=True)
+        return
+    if phase == "b":
+        meta, sd = fc.build_weights(name)                               # bf16; only what the fp32 encoders touch is widened
+        for k in list(sd):
+            if sd[k].is_floating_point() and not k.startswith("model.layers.") and k not in ("lm_head.weight",):
+                sd[k] = sd[k].float()
+        om = pipeline.OracleModel.from_state_dict(sd, meta, emulate="device", device_opts={"lazy": True})
+        for ci, rs in enumerate(chunks):
+            f = os.path.join(tmp, f"b{ci}.pt")
+            if os.path.exists(f):
+                continue
+            a = torch.load(os.path.join(tmp, f"a{ci}.pt"))
+            t0 = time.time()
+            ids, mi = fc.build_rows(name, rs)
+            assert torch.equal(ids, a["input_ids"])
+            with torch.no_grad():
+                new_ids, logits = om.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True,
+                                              forced_ids=a["ids"])
+            torch.save({"ids": new_ids, "logits": logits.float(), "seconds": time.time() - t0}, f)
+            print(f"g17b chunk {ci} rows {rs}: {time.time() - t0:.0f}s argmax agreement with fp32 "
+                  f"{int((new_ids == a['ids']).sum())}/{new_ids.numel()}", flush=True)
+        return
+    # assemble
+    A = [torch.load(os.path.join(tmp, f"a{ci}.pt")) for ci in range(len(chunks))]
+    Bd = [torch.load(os.path.join(tmp, f"b{ci}.pt")) for ci in range(len(chunks))]
+    ids = torch.cat([a["ids"] for a in A])
+    lg = torch.cat([a["logits"] for a in A])
+    lgd = torch.cat([b["logits"] for b in Bd])
+    _save("g17_fulldepth_iav8", ids=ids, logits=lg, logits_device=lgd, ids_device=torch.cat([b["ids"] for b in Bd]),
+          input_ids=torch.cat([a["input_ids"] for a in A]), margins=fc.margins(lg),
+          meta=np.frombuffer(json.dumps({"case": name, "layers": 32, "seed": fc.DEPTH_CASES[name]["seed"], "row_seeds": seeds,
+                                         "oracle_seconds": [round(a["seconds"], 1) for a in A],
+                                         "device_oracle_seconds": [round(b["seconds"], 1) for b in Bd]}).encode(), dtype=np.uint8))
+
+
 def g16():
     """File-level goldens for the `convert-*` strategies of merge_checkpoints (merge_unimodal_modelcompose.py:42-73): checkpoints trained
     with lora_strategy 'same' (only `.default` adapter keys) are re-labelled 'modal+language', every `.default` tensor of checkpoint i is
@@ -1150,7 +1217,7 @@ def g16():
 
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
           "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g16": g16}
-SLOW_GROUPS = {"g15": g15}          # by name only
+SLOW_GROUPS = {"g15": g15, "g17a": lambda: g17("a"), "g17b": lambda: g17("b"), "g17": g17}          # by name only
 
 
 def main(argv):

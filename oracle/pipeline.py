@@ -19,8 +19,11 @@ from . import llm, splice
 
 
 class OracleModel:
-    def __init__(self, sd: Dict[str, torch.Tensor], cfg: llm.LLMConfig, meta: dict, emulate: Optional[str] = None):
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: llm.LLMConfig, meta: dict, emulate: Optional[str] = None,
+                 device_opts: Optional[dict] = None):
         self.sd, self.cfg, self.meta, self.emulate = sd, cfg, meta, emulate
+        # emulate == "device" only: {"lazy": compose a layer's weights when it runs, "rounding": {point: bool}} (oracle/device_path.py)
+        self.device_opts = dict(device_opts or {})
         self.modals = [m for m in cfg.modal_names if m != "default"]
         self.prefix = {k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("prefix_tokens.")} or None
         self.suffix = {k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("suffix_tokens.")} or None
@@ -29,7 +32,7 @@ class OracleModel:
         self._dw = None
 
     @classmethod
-    def from_state_dict(cls, sd, meta, emulate=None):
+    def from_state_dict(cls, sd, meta, emulate=None, device_opts=None):
         cfg = llm.LLMConfig(
             vocab_size=meta["vocab_size"], hidden_size=meta["hidden_size"], intermediate_size=meta["intermediate_size"],
             num_hidden_layers=meta["num_hidden_layers"], num_attention_heads=meta["num_attention_heads"],
@@ -38,7 +41,7 @@ class OracleModel:
             lora_strategy=meta.get("lora_strategy"), modal_names=tuple(meta["modal_names"]),
             reset_scaling_weights=meta.get("reset_scaling_weights"), pad_token_id=meta.get("pad_token_id", 0),
             eos_token_id=meta.get("eos_token_id", 2))
-        return cls(sd, cfg, meta, emulate)
+        return cls(sd, cfg, meta, emulate, device_opts)
 
     # -- encoders -----------------------------------------------------------
     def _sub(self, prefix):
@@ -72,7 +75,9 @@ class OracleModel:
 
     def device_weights(self):
         if self._dw is None:
-            self._dw = device_path.DeviceWeights(self.sd, self.cfg)
+            rnd = self.device_opts.get("rounding") or {}
+            self._dw = device_path.DeviceWeights(self.sd, self.cfg, lazy=bool(self.device_opts.get("lazy")),
+                                                 round_weights=rnd.get("weights", True))
         return self._dw
 
     def prefill(self, input_ids, modal_inputs, attention_mask=None, last_only=False, feats_blocks=None):
@@ -81,7 +86,9 @@ class OracleModel:
             mam = None
         if self.emulate == "device":
             assert bool(am.all()), "the device-path restatement takes unpadded batches"
-            logits, kv = device_path.forward(self.device_weights(), device_path.bf(emb.float()), mam, last_only=last_only)
+            rnd = self.device_opts.get("rounding")
+            e0 = emb.float() if rnd and not rnd.get("embed", True) else device_path.bf(emb.float())
+            logits, kv = device_path.forward(self.device_weights(), e0, mam, last_only=last_only, rounding=rnd)
             return logits, kv, am
         h, kv = llm.model_forward(self.sd, self.cfg, inputs_embeds=emb, attention_mask=am, modal_attention_mask=mam,
                                   emulate=self.emulate)
@@ -98,19 +105,22 @@ class OracleModel:
             am = torch.ones((am.shape[0], kv[-1][-1].shape[-2] + 1), dtype=am.dtype)  # multimodal_arch.py:290-293
         if self.emulate == "device":
             dw = self.device_weights()
-            logits, kv = device_path.forward(dw, dw.embed[token_ids][:, None], None, past_kv=kv, last_only=True)
+            logits, kv = device_path.forward(dw, dw.embed[token_ids][:, None], None, past_kv=kv, last_only=True,
+                                             rounding=self.device_opts.get("rounding"))
             return logits[:, -1], kv, am
         h, kv = llm.model_forward(self.sd, self.cfg, input_ids=token_ids[:, None], attention_mask=am, past_key_values=kv,
                                   emulate=self.emulate)
         return llm.lm_logits(h, self.sd)[:, -1], kv, am
 
     def generate(self, input_ids, modal_inputs, max_new_tokens=128, ignore_eos=False, return_logits=False, feats_blocks=None,
-                 attention_mask=None, keep_mask=None):
+                 attention_mask=None, keep_mask=None, forced_ids=None):
         """Greedy; returns the NEW ids (B, n).  With ignore_eos=False rows that hit EOS emit pad afterwards
         and the loop stops once every row has finished (transformers 4.31 greedy_search).  attention_mask (B, L_text): the prompt's
         padding mask; modal_inputs None (not {}) keeps it in force over the decode steps, as the reference does (keep_mask=None); with
         modal_inputs passed the reference replaces it by all ones on decode steps (multimodal_arch.py:290-293) - keep_mask=True is the
-        reference WITHOUT that replacement, which is what the HIP path implements."""
+        reference WITHOUT that replacement, which is what the HIP path implements.  forced_ids (B, >= n - 1): TEACHER
+        FORCING - decode step s is fed forced_ids[:, s] instead of this model's own argmax (the returned ids stay the argmaxes), so that two
+        implementations can be compared step by step on one history."""
         if keep_mask is None:
             keep_mask = modal_inputs is None
         keep_mask = bool(keep_mask) and attention_mask is not None
@@ -129,7 +139,8 @@ class OracleModel:
             out.append(nxt)
             if (not ignore_eos and unfinished.max() == 0) or step == max_new_tokens - 1:
                 break
-            last, kv, am = self.decode_step(nxt, kv, am, keep_mask=keep_mask)
+            feed = nxt if forced_ids is None else forced_ids[:, step]
+            last, kv, am = self.decode_step(feed, kv, am, keep_mask=keep_mask)
         ids = torch.stack(out, 1)
         if return_logits:
             return ids, torch.stack(all_logits, 1)

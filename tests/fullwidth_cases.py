@@ -50,6 +50,10 @@ CASES = {
 DEPTH_CASES = {
     "fulldepth_iav": dict(modals=("vision", "audio", "video"), reset="default-vision=0.333,default-audio=0.333,default-video=0.333",
                           inputs=("vision", "audio", "video"), seed=41, row_seeds=[700, 701], layers=32),
+    # EIGHT unscreened rows of the same model (rows 700 / 701 are the two above), with the logits of BOTH oracles - the fp32
+    # branch form and the device-rounding restatement teacher-forced on the fp32 oracle's ids - tests/golden/g17_fulldepth_iav8.npz
+    "fulldepth_iav8": dict(modals=("vision", "audio", "video"), reset="default-vision=0.333,default-audio=0.333,default-video=0.333",
+                           inputs=("vision", "audio", "video"), seed=41, row_seeds=[700, 701, 702, 703, 704, 705, 706, 707], layers=32),
     "depth8_iav": dict(modals=("vision", "audio", "video"), reset="default-vision=0.333,default-audio=0.333,default-video=0.333",
                        inputs=("vision", "audio", "video"), seed=41, row_seeds=[700], layers=8),
 }

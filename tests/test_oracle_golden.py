@@ -150,6 +150,45 @@ def test_g4_end_to_end_vision_greedy_ids():
     torch.testing.assert_close(step_logits, a["step_logits"], rtol=2e-4, atol=5e-5)
 
 
+def test_device_rounding_oracle_lazy_weights_toggles_and_teacher_forcing():
+    """oracle/device_path.py (round 4): lazily composed layers give the same numbers as the eager ones; with every rounding point switched off
+    and fp32 weights it IS the fp32 branch-form oracle (to summation order); every single toggle moves the result by less than all
+    together; teacher forcing feeds the given history while reporting this model's own argmaxes."""
+    from oracle import device_path, pipeline
+    a, meta, sd = load_golden("g4_e2e_vision")
+    mi = {"vision": a["pixels"]}
+    ref = pipeline.OracleModel.from_state_dict(sd, meta)
+    ids_r, lg_r = ref.generate(a["input_ids"], mi, max_new_tokens=5, ignore_eos=True, return_logits=True)
+    eager = pipeline.OracleModel.from_state_dict(sd, meta, emulate="device")
+    lazy = pipeline.OracleModel.from_state_dict(sd, meta, emulate="device", device_opts={"lazy": True})
+    ids_e, lg_e = eager.generate(a["input_ids"], mi, max_new_tokens=5, ignore_eos=True, return_logits=True, forced_ids=ids_r)
+    ids_l, lg_l = lazy.generate(a["input_ids"], mi, max_new_tokens=5, ignore_eos=True, return_logits=True, forced_ids=ids_r)
+    assert torch.equal(lg_e, lg_l) and torch.equal(ids_e, ids_l)
+    scale = lg_r.abs().max()
+    all_on = ((lg_e - lg_r).abs().max() / scale).item()
+    off = {k: False for k in device_path.ROUNDING_POINTS}
+    exact = pipeline.OracleModel.from_state_dict(sd, meta, emulate="device", device_opts={"lazy": True, "rounding": off})
+    _, lg_x = exact.generate(a["input_ids"], mi, max_new_tokens=5, ignore_eos=True, return_logits=True, forced_ids=ids_r)
+    assert ((lg_x - lg_r).abs().max() / scale).item() < 2e-5          # pre-merged one-adapter-per-token form == branch form in fp32
+    assert 1e-4 < all_on < 3e-2
+    for point in ("resid_attn", "qkv", "weights"):
+        only = dict(off)
+        only[point] = True
+        if point.startswith("resid"):
+            only["resid_mlp"] = True
+        om = pipeline.OracleModel.from_state_dict(sd, meta, emulate="device", device_opts={"lazy": True, "rounding": only})
+        _, lg_p = om.generate(a["input_ids"], mi, max_new_tokens=5, ignore_eos=True, return_logits=True, forced_ids=ids_r)
+        e = ((lg_p - lg_r).abs().max() / scale).item()
+        assert 0 < e < 2 * all_on, (point, e, all_on)
+    # teacher forcing: the history is the given one - feeding the model's own ids is free running
+    ids_f, lg_f = eager.generate(a["input_ids"], mi, max_new_tokens=5, ignore_eos=True, return_logits=True)
+    ids_t, lg_t = eager.generate(a["input_ids"], mi, max_new_tokens=5, ignore_eos=True, return_logits=True, forced_ids=ids_f)
+    assert torch.equal(lg_f, lg_t) and torch.equal(ids_f, ids_t)
+    wrong = (ids_f + 1) % meta["vocab_size"]
+    _, lg_w = eager.generate(a["input_ids"], mi, max_new_tokens=5, ignore_eos=True, return_logits=True, forced_ids=wrong)
+    assert torch.equal(lg_w[:, 0], lg_f[:, 0]) and not torch.equal(lg_w[:, 1:], lg_f[:, 1:])
+
+
 def test_g5_imagebind_audio_branch():
     from oracle import encoders_extra as ex
     a, meta, sd = load_golden("g5_imagebind")
