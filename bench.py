@@ -85,6 +85,10 @@ def parse():
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one generate() call per step, nothing overlapped")
     ap.add_argument("--no-overlap", action="store_true", help="debug only (train): weight-gradient / rank-projection GEMMs on the main stream")
     ap.add_argument("--gemm-debug", type=int, default=0, help="debug only: mc_gemm_debug word (A/B of kernel variants)")
+    ap.add_argument("--ab-tile192", action="store_true",
+                    help="informational, after the timed region: the same K batches through the pipelined loop with every large GEMM on the "
+                         "186-register 192-column tiles (mc_gemm_set_option force_tile192), which leave room for the decode attention's waves "
+                         "beside a resident GEMM workgroup")
     ap.add_argument("--workload", default="iav", choices=["iav", "vision", "generate", "mcub4", "train"],
                     help="iav (default) = the metric's config; vision (alias generate) = configs[1]; mcub4 = configs[3]; train = configs[4], the "
                          "stage-2 finetune step (forward + backward + gradient all-reduce + AdamW)")
@@ -176,8 +180,8 @@ def secondary_runs(new_tokens: int):
     import subprocess
     out = {}
     for name, steps, warm in (("vision", 6, 2), ("mcub4", 4, 2), ("train", 10, 3)):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--steps", str(steps), "--warmup", str(warm), "--no-profile",
-               "--no-cpu-baseline", "--no-secondary", "--new-tokens", str(new_tokens)]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--steps", str(steps), "--warmup", str(warm),
+               "--no-cpu-baseline", "--no-secondary", "--new-tokens", str(new_tokens)] + ([] if name == "train" else ["--no-profile"])
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MC_BENCH_FORCE_DIST")}
         try:
             t0 = time.perf_counter()
@@ -192,12 +196,35 @@ def secondary_runs(new_tokens: int):
                          "config": {k: v for k, v in j["config"].items() if k in ("workload", "per_gpu_batch", "new_tokens", "layers", "spliced_length",
                                                                                  "pipelined", "parallelism", "trainable_params")},
                          "wall_s_incl_model_build": round(time.perf_counter() - t0, 1)}
+            if j.get("roofline"):
+                out[name]["roofline"] = j["roofline"]
         except Exception as e:                                           # evidence only: never lose the headline line to it
             out[name] = {"error": repr(e)[:300]}
     return out
 
 
 # ------------------------------------------------------------------------------------------------------------------- train (configs[4])
+def train_step_flops(meta, B, L, n_targets, n_img_tokens):
+    """Algorithmic FLOPs of one configs[4] step (what the function needs, not what a particular implementation spends):
+    frozen-base forward + input-gradient pass of the 224 decoder linears (no base weight gradients), causal attention forward + backward
+    (2.5x), LoRA rank-r branch of the token's OWN adapter forward + input gradient + weight gradient, lm_head forward + input gradient on
+    the target rows only, CLIP-L forward (frozen), projector forward + backward."""
+    Hd, I, V, Ln, r = meta["hidden_size"], meta["intermediate_size"], meta["vocab_size"], meta["num_hidden_layers"], meta["lora_r"]
+    T = B * L
+    p_lin = Ln * (4 * Hd * Hd + 3 * Hd * I)
+    base = 2 * (2.0 * T * p_lin)
+    attn = 3.5 * B * (4.0 * L * L * Hd / 2) * Ln
+    lora = 3 * 2.0 * T * r * Ln * (4 * (Hd + Hd) + 3 * (Hd + I))
+    head = 2 * 2.0 * B * n_targets * V * Hd
+    c = meta.get("clip") or {}
+    D, Di, Lc = c.get("hidden_size", 1024), c.get("intermediate_size", 4096), c.get("num_hidden_layers", 24) - 1
+    Tc = n_img_tokens + 1
+    clip = B * (2.0 * Tc * Lc * (4 * D * D + 2 * D * Di) + 4.0 * Tc * Tc * D * Lc + 2.0 * n_img_tokens * 588 * D)
+    proj = B * n_img_tokens * 2.0 * (D * Hd + Hd * Hd) * 3 - B * n_img_tokens * 2.0 * D * Hd      # fwd + wgrad + dgrad, no dgrad into the frozen tower
+    return {"base_linears": base, "attention": attn, "lora": lora, "lm_head": head, "clip": clip, "projector": proj,
+            "total": base + attn + lora + head + clip + proj}
+
+
 def train_main(args, world, rank, local):
     """BASELINE configs[4]: stage-2 finetune step of the vision LocalLoRA model (adapters default + vision, r=128), per-GPU batch 4
     synthetic image-text pairs (683-token spliced sequence, the last 60 tokens are targets), bf16 compute, fp32 master weights;
@@ -240,14 +267,41 @@ def train_main(args, world, rank, local):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        fl = train_step_flops(meta, B, 683, 60, 576)
+        roof = {"bound": "mfma", "kernel": "whole step (forward + backward + AdamW; dominant kernel gemm_tile256_kernel)",
+                "achieved": round(fl["total"] / (ms_step * 1e-3) / 1e12, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl["total"] / (ms_step * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "algorithmic_flops_per_step": {k: float(v) for k, v in fl.items()}}
+        if not args.no_profile:
+            # the dominant kernel alone: two more steps with every GEMM on the main stream (side-stream launches would overlap the bracketed
+            # ones) and one HIP-event bracket per gemm_tile256_kernel launch
+            from modelcompose_amd import _lib
+            L_ = _lib.lib()
+            ws, st._wstream = st._wstream, None
+            torch.cuda.synchronize()
+            L_.mc_gemm_profile_enable(1)
+            for _ in range(2):
+                st.step(ids, labels, {"vision": pixels})
+            torch.cuda.synchronize()
+            L_.mc_gemm_profile_enable(0)
+            st._wstream = ws
+            ms_, fl_, n_ = C.c_double(0), C.c_double(0), C.c_int64(0)
+            L_.mc_gemm_profile_read(C.byref(ms_), C.byref(fl_), C.byref(n_))
+            ach = (fl_.value / max(ms_.value, 1e-9)) / 1e9
+            roof["dominant_kernel"] = {"kernel": "gemm_tile256_kernel", "achieved": round(ach, 2), "unit": "TFLOP/s",
+                                       "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "launches_per_step": int(n_.value // 2),
+                                       "ms_per_step": round(ms_.value / 2, 3), "flops_per_step_launched": fl_.value / 2,
+                                       "note": "HIP events per launch, non-overlapped pass (the timed steps overlap weight-gradient GEMMs on a side stream)"}
         print(json.dumps({
             "metric": "samples/sec (whole node) stage-2 finetune step, composed Vicuna-7B", "value": round(world * B * args.steps / dt, 4),
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[4]: stage-2 finetune step, vision LocalLoRA Vicuna-7B (r128, default+vision adapters), "
                                    f"batch {B} per GPU, 683-token sequences, fwd+bwd+all-reduce+AdamW", "per_gpu_batch": B,
                        "layers": args.layers, "parallelism": f"ddp{world}", "trainable_params": int(st.n_params),
-                       "final_loss": float(loss.item())}}), flush=True)
+                       "final_loss": float(loss.item())},
+            "roofline": roof}), flush=True)
     if DIST or world > 1:
         torch.distributed.destroy_process_group()
 
@@ -438,6 +492,23 @@ def generate_main(args, world, rank, local):
             "value": round(B * args.steps / dtp, 4), "unit": "samples/s", "ms_per_step": round(dtp / args.steps * 1e3, 3),
             "note": ("bench.py --no-pipeline: one generate() call per batch, nothing overlapped; same tokens" if was else
                      "bench.py --pipeline: decode of batch i overlapped with encoders + prefill of batch i+1; same tokens")}
+    if world == 1 and args.ab_tile192:
+        L_ = _lib.lib()
+        was = args.pipeline
+        args.pipeline = True
+        res = {}
+        for tag, on in (("tile256", 0), ("tile192", 1), ("tile256_again", 0)):
+            _lib.check(L_.mc_gemm_set_option(b"force_tile192", on), "force_tile192")
+            run_steps(2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t0
+            res[tag] = {"value": round(B * args.steps / dtp, 4), "ms_per_step": round(dtp / args.steps * 1e3, 3)}
+        _lib.check(L_.mc_gemm_set_option(b"force_tile192", 0), "force_tile192")
+        args.pipeline = was
+        line["ab_tile192_pipelined"] = res
     del model
     torch.cuda.empty_cache()
     if world == 1 and not DIST and not args.no_secondary and name == "iav" and args.layers == 32:

@@ -1417,6 +1417,11 @@ static float* splitk_workspace(size_t floats) {
 // (12 instead of 16 MFMAs per phase behind the same X reads and DMA issues).  M = 2728 (the finetune step), N = 4096: 176 tiles of 256
 // fill 69 % of the CUs, 242 tiles of 192 fill 95 %.  debug word bit 10 forces 192, bit 11 forces 256.
 static bool g_tile192 = true;
+// "force_tile192" (round 4, co-residency experiment / mode): EVERY launch of the 256-row kernel takes the 192-column instantiation - 186
+// VGPRs instead of 256, i.e. 2 x 192 of a SIMD's 512 registers, which leaves room for one wave of a <= 104-register kernel (the decode
+// attention: 102) per SIMD BESIDE a resident GEMM workgroup.  The fused epilogues that need a wave to own a whole head or 128 columns
+// (RoPE + cache scatter, the next norm's factor) take their separate-launch routes; SwiGLU takes the 8-byte store path.
+static bool g_force192 = false;
 static bool g_raster_auto = true;          // "raster_shared" option
 static bool g_rows_on = true;              // "rows_kernel" option: M <= 64 launches with ceil(M / 16) >= "rows_min_mb" take gemm_rows_kernel
 static int g_rows_min_mb = 2;
@@ -1429,6 +1434,7 @@ static int g_raster_min_tiles = 1024;      // launches with at least this many t
 // device, samples/s  overlap + 256: 33.4, overlap + 192: 31.8, no overlap + 192: 32.8, no overlap + 256: 31.1)
 extern "C" int mc_gemm_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tile192")) { g_tile192 = value != 0; return 0; }
+    if (name && !strcmp(name, "force_tile192")) { g_force192 = value != 0; return 0; }
     if (name && !strcmp(name, "raster_shared")) { g_raster_auto = value != 0; return 0; }
     if (name && !strcmp(name, "raster_slab")) { g_raster_slab = value < 0 ? 0 : (value > 255 ? 255 : value); g_raster_slab_min = 0; return 0; }
     if (name && !strcmp(name, "raster_min_tiles")) { g_raster_min_tiles = value; return 0; }
@@ -1439,6 +1445,7 @@ extern "C" int mc_gemm_set_option(const char* name, int value) {
 }
 
 static int tile_ni(int64_t m_tiles, int N, bool swiglu) {
+    if (g_force192) return 3;
     if (g_gemm_dbg & 2048) return 4;
     if (!g_tile192 && !(g_gemm_dbg & 1024)) return 4;
     if (swiglu) return 4;
@@ -1772,7 +1779,7 @@ static float* rms_parts_buffer(const mc_gemm_args* a, int64_t M_total, hipStream
     return ws ? (float*)(ws + kRowsSsBytes) : nullptr;
 }
 static float* rms_out_parts(const mc_gemm_args* a, int64_t M_total, hipStream_t s) {
-    if (!a->rms_out || a->N % 256 || a->act != MC_ACT_NONE || a->ldo % 8 || ((uintptr_t)a->out % 16) || (g_gemm_dbg & (1 << 29))) return nullptr;
+    if (!a->rms_out || a->N % 256 || a->act != MC_ACT_NONE || a->ldo % 8 || ((uintptr_t)a->out % 16) || (g_gemm_dbg & (1 << 29)) || g_force192) return nullptr;
     return rms_parts_buffer(a, M_total, s);
 }
 // parts: what the epilogue left (null: another route ran).  Without a workspace (first launch inside a capture) or for N that is not a
@@ -1802,7 +1809,7 @@ static bool rope_args_ok(const mc_gemm_args* a) {
 // the register route: a wave's 128 columns of a 256-column tile must be one head.  debug word bit 31 keeps the separate launch (A/B)
 static bool rope_in_epilogue(const mc_gemm_args* a) {
     const mc_rope_scatter* r = a->rope;
-    return r && r->D == 128 && a->N % 256 == 0 && !(g_gemm_dbg & (1u << 31));
+    return r && r->D == 128 && a->N % 256 == 0 && !(g_gemm_dbg & (1u << 31)) && !g_force192;
 }
 static void rope_fill(Epilogue& ep, const mc_rope_scatter* r, int64_t row0) {
     ep.rope = Epilogue::Rope{r->row_b + row0, r->row_pos + row0, r->row_t + row0, r->cos_table, r->sin_table, (bf16_t*)r->q_out,

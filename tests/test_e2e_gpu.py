@@ -470,6 +470,30 @@ def test_left_padded_batch_of_mixed_spliced_lengths_equals_each_row_alone(g4_mod
         assert torch.equal(res[b, L:].cpu()[clear], alone[b][0][clear]), b
 
 
+def test_forced_192_column_tiles_give_the_same_tokens_and_logits():
+    """mc_gemm_set_option("force_tile192"): every large GEMM on the 186-register 192-column instantiation, RoPE + cache scatter and the
+    next norm's factor on their separate-launch routes, SwiGLU on the 8-byte store path - the co-residency mode of the pipelined eval
+    loop.  Same function at the real widths (2-layer Vicuna-7B-wide vision model, 683-token prompts): ids and step logits BITWISE equal
+    to the default path - the tile shapes and the fused / separate routes are bit-identical by construction."""
+    import fullwidth_cases as fc
+    from modelcompose_amd import _lib
+    from modelcompose_amd.model.builder import build_from_state_dict
+    meta, sd, ids, mi = fc.build_case("configs1_vision", [449, 470])
+    model = build_from_state_dict(meta, sd)
+    ids, mid = ids.cuda(), fc.to_dev(mi)
+    r0, l0 = model.generate(ids, modal_inputs=mid, max_new_tokens=6, ignore_eos=True, return_step_logits=True)
+    f0 = model.forward(input_ids=ids, modal_inputs=mid).logits.clone()
+    _lib.check(_lib.lib().mc_gemm_set_option(b"force_tile192", 1), "force_tile192")
+    try:
+        r1, l1 = model.generate(ids, modal_inputs=mid, max_new_tokens=6, ignore_eos=True, return_step_logits=True)
+        f1 = model.forward(input_ids=ids, modal_inputs=mid).logits.clone()
+    finally:
+        _lib.check(_lib.lib().mc_gemm_set_option(b"force_tile192", 0), "force_tile192")
+    assert torch.equal(r0, r1)
+    assert torch.equal(l0, l1), ((l0.float() - l1.float()).abs().max().item() / l0.float().abs().max().item())
+    assert torch.equal(f0, f1), ((f0.float() - f1.float()).abs().max().item() / f0.float().abs().max().item())
+
+
 def test_last_layer_tail_equals_the_full_last_layer(g4_model):
     """generate()'s prefill runs the last decoder layer's attention + MLP for the last token of every sequence only (mc_llm option
     "tail_adapter"): the first-step logits agree with the all-rows path to fp32 summation order of one attention row and three small GEMMs
