@@ -61,6 +61,16 @@ int mc_compose_weight_ex_bf16(const void* w_rowmajor, int64_t ldw, const void* c
                               const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
                               int N, int K, const float* col_scale, int nb_stride, int nb_offset, float* retention_parts, void* stream);
 
+/* As mc_compose_weight_ex_bf16 with dither_seed != 0: the single bf16 rounding is UNBIASED - the magnitude is rounded up with probability
+ * equal to the discarded fraction, the uniform bits from a counter hash of (dither_seed, n, k), reproducible - so that E[W'] is the fp32
+ * composition.  For adapters whose delta lies below half a bf16 step of W (retention < 0.9 under round-to-nearest: W + dW rounds back
+ * to W, a SYSTEMATIC loss the reference's branch form, multimodal_llama.py:130-149, does not have) the delta is kept in expectation, at
+ * the price of rounding noise of the size an off-grid weight always has (<= 1 bf16 step, zero mean).  dither_seed 0 = the ex form.  */
+int mc_compose_weight_dither_bf16(const void* w_rowmajor, int64_t ldw, const void* const* at_list, const void* const* b_list,
+                                  const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
+                                  int N, int K, const float* col_scale, int nb_stride, int nb_offset, float* retention_parts,
+                                  uint32_t dither_seed, void* stream);
+
 /* ---- audio front-end: Kaldi log-mel filterbank + BEATs normalisation + zero padding (beats/audio_processor.py:143-170; replaces
  * torchaudio.compliance.kaldi.fbank, a third-party CPU dependency of the reference).  wav [B, wav_stride] fp32 at 16 kHz,
  * n_samples [B] (device), out [B, frames_out, 128] bf16 and / or fp32; window [400], mel [128, 257], mel_lo / mel_hi [128].    */

@@ -25,6 +25,8 @@ _SIGS = {
     "mc_compose_weight_bf16": [c_p, c_l, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_f), c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p],
     "mc_gemm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
     "mc_compose_weight_ex_bf16": [c_p, c_l, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_f), c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
+    "mc_compose_weight_dither_bf16": [c_p, c_l, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_f), c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_i, c_p,
+                                      C.c_uint32, c_p],
     "mc_rms_scale_bf16": [c_p, c_l, c_p, c_i, c_i, c_f, c_p],
     "mc_residual_rms_bf16": [c_p, c_l, c_p, c_l, c_i, c_p, c_i, c_i, c_f, c_p],
     "mc_gemm_profile_enable": [c_i],

@@ -27,7 +27,26 @@ struct ComposeParams {
     int nb_stride, nb_offset;                // packed 16-row block nb is written at block index nb*nb_stride + nb_offset
     float* retention_parts;                  // optional [gridDim.y][gridDim.x][2]: per-workgroup partial sums of (W' - bf16(W c)) * (dW c) and
                                              // (dW c)^2: how much of the delta survives the single bf16 rounding (see mc_hip.h)
+    uint32_t dither_seed;                    // 0: round to nearest even.  != 0: UNBIASED rounding (round up with probability = the discarded
+                                             // fraction, from a counter hash of (seed, n, k)): E[W'] = the fp32 value, so a delta below half a
+                                             // bf16 step of W is kept in expectation instead of rounding back to W (round 4; mc_hip.h)
 };
+
+// 32-bit mix (lowbias32): the dither's uniform bits for element (n, k)
+__device__ __forceinline__ uint32_t compose_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ bf16_t compose_round(float v, uint32_t seed, int n, int k) {
+    if (seed == 0) return (bf16_t)v;
+    uint32_t bits = __builtin_bit_cast(uint32_t, v);
+    if ((bits & 0x7f800000U) == 0x7f800000U) return (bf16_t)v;               // inf / nan: as the plain cast
+    const uint32_t r = compose_hash(seed ^ compose_hash((uint32_t)n * 0x9E3779B1U + (uint32_t)k)) & 0xFFFFU;
+    bits += r;                                                                // sign-magnitude: the magnitude goes up with probability frac / 2^16
+    const uint16_t hi = (uint16_t)(bits >> 16);
+    return __builtin_bit_cast(bf16_t, hi);
+}
 
 // workgroup = 4 waves; tile = 32 rows (n) x 256 cols (k); wave w owns cols [64w, 64w+64)
 __global__ __launch_bounds__(256) void compose_kernel(ComposeParams p) {
@@ -107,7 +126,7 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeParams p) {
             }
             bf16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (inb && k + j < p.K) ? (bf16_t)r4[j] : (bf16_t)0.0f;
+            for (int j = 0; j < 4; ++j) o[j] = (inb && k + j < p.K) ? compose_round(r4[j], p.dither_seed, n, k + j) : (bf16_t)0.0f;
             if (p.retention_parts && p.w && inb) {
                 // the composed weight against the base weight rounded the same way: the part of (W' - bf16(W c)) that lies along dW c
 #pragma unroll
@@ -150,10 +169,10 @@ __global__ __launch_bounds__(256) void compose_kernel(ComposeParams p) {
     }
 }
 
-extern "C" int mc_compose_weight_ex_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,
-                                         const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor,
-                                         int64_t ldo, int N, int K, const float* col_scale, int nb_stride, int nb_offset,
-                                         float* retention_parts, void* stream) {
+extern "C" int mc_compose_weight_dither_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,
+                                             const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor,
+                                             int64_t ldo, int N, int K, const float* col_scale, int nb_stride, int nb_offset,
+                                             float* retention_parts, uint32_t dither_seed, void* stream) {
     MC_CHECK_ARG(out_packed && N > 0 && K > 0, "mc_compose_weight_bf16: bad arguments");
     MC_CHECK_ARG(n_terms >= 0 && n_terms <= MC_MAX_TERMS, "mc_compose_weight_bf16: at most %d terms (got %d)", MC_MAX_TERMS, n_terms);
     MC_CHECK_ARG(n_terms == 0 || (r > 0 && r % 32 == 0), "mc_compose_weight_bf16: rank %d must be a multiple of 32 (pad A^T / B)", r);
@@ -170,10 +189,19 @@ extern "C" int mc_compose_weight_ex_bf16(const void* w, int64_t ldw, const void*
     p.N = N; p.K = K; p.Kp = (K + 63) / 64 * 64;
     p.col_scale = col_scale; p.nb_stride = nb_stride; p.nb_offset = nb_offset;
     p.retention_parts = retention_parts;
+    p.dither_seed = dither_seed;
     dim3 grid((p.Kp + 255) / 256, (N + 31) / 32);
     compose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
     MC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mc_compose_weight_ex_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,
+                                         const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor,
+                                         int64_t ldo, int N, int K, const float* col_scale, int nb_stride, int nb_offset,
+                                         float* retention_parts, void* stream) {
+    return mc_compose_weight_dither_bf16(w, ldw, at_list, b_list, scales, n_terms, r, out_packed, out_rowmajor, ldo, N, K, col_scale, nb_stride,
+                                         nb_offset, retention_parts, 0u, stream);
 }
 
 extern "C" int mc_compose_weight_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,

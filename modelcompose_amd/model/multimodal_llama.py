@@ -222,10 +222,13 @@ class MultimodalLlamaForCausalLM:
     def _has_lora(self, prefix, key):
         return f"{prefix}.lora_A.{key}.weight" in self._raw and f"{prefix}.lora_B.{key}.weight" in self._raw
 
-    def _compose_linear(self, prefix: str, adapter: str, out: torch.Tensor, N: int, K: int, col_scale=None, nb_stride=1, nb_offset=0):
+    def _compose_linear(self, prefix: str, adapter: str, out: torch.Tensor, N: int, K: int, col_scale=None, nb_stride=1, nb_offset=0, dither=False):
         """dense weight of `adapter` for one LocalLoRA linear -> packed buffer `out` (block nb at nb*nb_stride + nb_offset),
-        columns multiplied by col_scale (the preceding RMSNorm's weight) before the single bf16 rounding."""
+        columns multiplied by col_scale (the preceding RMSNorm's weight) before the single bf16 rounding.  dither: the unbiased rounding of
+        mc_compose_weight_dither_bf16 (finalize() re-composes the adapters whose delta round-to-nearest would lose)."""
         dev = self.device
+        if not dither:
+            self._composed.setdefault(adapter, []).append((prefix, out, N, K, col_scale, nb_stride, nb_offset))
         w = self._raw[f"{prefix}.weight"].to(dev, BF16)
         terms = composition_terms(self.config, adapter, lambda key: self._has_lora(prefix, key))
         tl = []
@@ -235,7 +238,10 @@ class MultimodalLlamaForCausalLM:
             a = self._raw[f"{prefix}.lora_A.{key}.weight"].to(dev)
             b = self._raw[f"{prefix}.lora_B.{key}.weight"].to(dev)
             tl.append((a, b, scale))
-        _compose_into(w, tl, N, K, out, col_scale, nb_stride, nb_offset, retention=self._retention_parts.setdefault(adapter, []))
+        import zlib
+        seed = (zlib.crc32(f"{prefix}|{adapter}".encode()) | 1) if dither else 0          # one reproducible stream of bits per (linear, adapter)
+        _compose_into(w, tl, N, K, out, col_scale, nb_stride, nb_offset, retention=self._retention_parts.setdefault(adapter, []),
+                      dither_seed=seed)
 
     def finalize(self):
         """Compose + pack every weight, create the C runtime handle."""
@@ -246,6 +252,7 @@ class MultimodalLlamaForCausalLM:
         nA = len(names)
         raw = self._raw
         self._retention_parts = {}
+        self._composed = {}                                          # adapter -> [(prefix, out, N, K, col_scale, nb_stride, nb_offset)] of this pass
         if "model.embed_tokens.weight" not in raw:
             raise ValueError("state dict lacks model.embed_tokens.weight")
         self.model.embed_tokens = raw["model.embed_tokens.weight"].to(dev, BF16).contiguous()
@@ -311,6 +318,9 @@ class MultimodalLlamaForCausalLM:
         self._summarise_delta_retention()
         return self
 
+    # below this share of the delta surviving round-to-nearest, an adapter's weights are re-composed with the unbiased rounding
+    DITHER_BELOW = 0.9
+
     def _summarise_delta_retention(self):
         """delta_retention[adapter] = Σ (W' - bf16(W c))·(ΔW c) / Σ (ΔW c)² over every composed linear of the adapter: the share of the
         LoRA delta that survives the single bf16 rounding of the pre-merged weight, projected on the delta itself.  1.0 for trained
@@ -331,7 +341,29 @@ class MultimodalLlamaForCausalLM:
             if den > 0:
                 self.delta_retention[ad] = num / den
         self._retention_parts = {}
-        low = {a: round(v, 3) for a, v in self.delta_retention.items() if v < 0.9}
+        low = {a: round(v, 3) for a, v in self.delta_retention.items() if v < self.DITHER_BELOW}
+        self.delta_retention_rne = dict(self.delta_retention)       # what round-to-nearest would have kept
+        self.delta_dithered = sorted(low)
+        if low and os.environ.get("MC_COMPOSE_DITHER", "1") != "0":
+            # Round 4: keep the delta instead of warning.  W + dW rounds back to W when |dW| is below half a bf16 step of W - a
+            # systematic loss.  Those adapters are composed again, in place, with UNBIASED rounding (E[W'] = the fp32 composition): the delta
+            # survives in expectation (retention 1.00 +- 1e-3 over the 16 M elements of a linear), the price is zero-mean rounding noise of at
+            # most one bf16 step per weight - what any off-grid weight carries.
+            for ad in low:
+                for (prefix, out, N, K, col_scale, nb_stride, nb_offset) in self._composed.get(ad, []):
+                    self._compose_linear(prefix, ad, out, N, K, col_scale, nb_stride, nb_offset, dither=True)
+            torch.cuda.synchronize()
+            for ad in low:
+                num = den = 0.0
+                for parts in self._retention_parts.get(ad, []):
+                    h = parts.double().cpu().numpy()
+                    num += float(h[:, 0].sum())
+                    den += float(h[:, 1].sum())
+                if den > 0:
+                    self.delta_retention[ad] = num / den
+            self._retention_parts = {}
+            low = {a: round(v, 3) for a, v in self.delta_retention.items() if v < self.DITHER_BELOW}
+        self._composed = {}
         if low:
             warnings.warn(f"LoRA deltas of adapters {low} are below the bf16 resolution of the base weights: only that share of them "
                           f"survives the pre-merge rounding (the reference's branch form keeps small deltas)", RuntimeWarning)
@@ -927,7 +959,8 @@ def _cat_rows(parts: List[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col_scale=None, nb_stride=1, nb_offset=0, retention=None):
+def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col_scale=None, nb_stride=1, nb_offset=0, retention=None,
+                  dither_seed: int = 0):
     """W' = (W + Σ scale·B·A)·diag(col_scale) packed into the preallocated buffer `out` (16-row block nb at nb*nb_stride + nb_offset).
     retention: a list that receives this call's [workgroups, 2] fp32 partial sums (Σ (W' - bf16(W c))·(ΔW c), Σ (ΔW c)²), see
     delta_retention()."""
@@ -957,7 +990,8 @@ def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col
     if retention is not None and n > 0:
         parts = torch.empty(((ops.ceil_to(K, 64) + 255) // 256) * ((N + 31) // 32), 2, dtype=torch.float32, device=out.device)
         retention.append(parts)
-    _lib.check(_lib.lib().mc_compose_weight_ex_bf16(_ptr(w), w.stride(0), at_arr, b_arr, sc, n, r, _ptr(out), None, 0, N, K,
-                                                    _ptr(col_scale), nb_stride, nb_offset, _ptr(parts), _stream()), "mc_compose_weight_ex_bf16")
+    _lib.check(_lib.lib().mc_compose_weight_dither_bf16(_ptr(w), w.stride(0), at_arr, b_arr, sc, n, r, _ptr(out), None, 0, N, K,
+                                                        _ptr(col_scale), nb_stride, nb_offset, _ptr(parts), int(dither_seed) & 0xFFFFFFFF,
+                                                        _stream()), "mc_compose_weight_dither_bf16")
     # keep operands alive until the kernel has been enqueued on the stream (stream-ordered allocator semantics)
     return out

@@ -457,6 +457,65 @@ def test_compose_small_delta_retention_is_the_rne_value(ops, log2_ratio):
     assert abs(cy - c_got) <= 0.03, (cy, c_got)
 
 
+@pytest.mark.parametrize("log2_ratio", [-7, -10, -12])
+def test_compose_dithered_rounding_keeps_a_small_delta_unbiased(ops, log2_ratio):
+    """Round 4 (multimodal_llama.py:130-149 keeps s B A x whatever its size).  mc_compose_weight_dither_bf16 with a non-zero seed
+    rounds the fp32 composition to bf16 WITHOUT bias: every element is one of the two bf16 neighbours of the fp32 value, the upper one
+    with probability = the discarded fraction.  So: (1) each W' element is within one bf16 step of fp32(W + s B A) and on the correct side
+    pair; (2) the delta's projection that survives is 1 +- 1e-2 even at |dW| / |W| = 2^-12, where round-to-nearest keeps < 0.3; (3) the
+    result is reproducible for a seed and differs between seeds; (4) the GEMM sees it: (x W'^T - x W^T) projected on x dW^T is ~1."""
+    import ctypes as C
+    from modelcompose_amd import _lib
+    N, K, r = 512, 2048, 128
+    g_ = torch.Generator().manual_seed(79)
+    w = (torch.randn(N, K, generator=g_) * 0.02).to(BF)
+    a = ((torch.rand(r, K, generator=g_) * 2 - 1) / K ** 0.5).to(BF)
+    b0 = torch.randn(N, r, generator=g_)
+    dw0 = 2.0 * (b0.to(BF).float() @ a.float())
+    b = (b0 * ((2.0 ** log2_ratio) * w.float().abs().mean() / dw0.abs().mean())).to(BF)
+    dw = 2.0 * (b.float() @ a.float())
+    full = w.float() + dw
+    wd, ad, bd = dev(w), dev(a), dev(b)
+    at = ad.t().contiguous()
+    arr_a, arr_b, sc = (C.c_void_p * 1)(at.data_ptr()), (C.c_void_p * 1)(bd.data_ptr()), (C.c_float * 1)(2.0)
+
+    def compose(seed):
+        out = torch.zeros(ops.packed_elems(N, K), dtype=BF, device="cuda")
+        parts = torch.zeros(((K + 255) // 256) * ((N + 31) // 32), 2, dtype=torch.float32, device="cuda")
+        _lib.check(_lib.lib().mc_compose_weight_dither_bf16(wd.data_ptr(), wd.stride(0), arr_a, arr_b, sc, 1, r, out.data_ptr(), None, 0, N, K,
+                                                            None, 1, 0, parts.data_ptr(), seed, None), "compose_dither")
+        torch.cuda.synchronize()
+        p_ = parts.double().cpu()
+        return out, ops.unpack_weight(ops.PackedWeight(out, N, K)).cpu().float(), (p_[:, 0].sum() / p_[:, 1].sum()).item()
+    _, rne, c_rne = compose(0)
+    out1, d1, c1 = compose(12345)
+    _, d1b, _ = compose(12345)
+    _, d2, c2 = compose(999)
+    assert torch.equal(d1, d1b) and not torch.equal(d1, d2)
+    # neighbours: the bf16 values just below / above the fp32 value (magnitude-wise): truncation and truncation + one step
+    bits = full.view(torch.int32)
+    lo = (bits & ~0xFFFF).view(torch.float32)
+    hi = ((bits & ~0xFFFF) + 0x10000).view(torch.float32)
+    ok = (d1 == lo) | (d1 == hi)
+    # fp32 summation order of the rank-128 product can move the fp32 value across a bf16 boundary on a handful of elements
+    assert ok.float().mean().item() > 0.998
+    coef = lambda wp: (((wp - w.float()) * dw).sum() / (dw * dw).sum()).item()
+    print(f"|dW|/|W| = 2^{log2_ratio}: retained projection RNE {coef(rne):.3f} (kernel {c_rne:.3f}); dithered {coef(d1):.4f} / {coef(d2):.4f} (kernel {c1:.4f} / {c2:.4f})")
+    assert abs(coef(d1) - 1.0) <= 2e-2 and abs(coef(d2) - 1.0) <= 2e-2 and abs(c1 - coef(d1)) <= 1e-2
+    if log2_ratio <= -10:
+        assert coef(rne) < 0.9                                      # what the dither repairs
+    # unbiased: the mean rounding error is zero to sampling accuracy (RNE of on-grid W + tiny delta is biased by -dW instead)
+    err = (d1 - full)
+    step = (hi - lo).abs()
+    assert abs((err / step).mean().item()) < 2e-3
+    x = rand_bf(256, K, seed=80)
+    y1 = ops.linear(dev(x), ops.PackedWeight(out1, N, K), out_f32=True).cpu()
+    y0 = ops.linear(dev(x), ops.pack_weight(wd), out_f32=True).cpu()
+    d = x.float() @ dw.t()
+    cy = (((y1 - y0) * d).sum() / (d * d).sum()).item()
+    assert abs(cy - 1.0) <= 0.05, cy
+
+
 @pytest.mark.parametrize("sizes", [(700, 1500, 300), (0, 2000, 513), (40, 3000)])
 def test_gemm_grouped_one_launch_equals_per_group(ops, sizes):
     """Routed LocalLoRA linear: one grouped launch of the 256x256 kernel over adapter-grouped rows (group boundaries inside the

@@ -25,6 +25,10 @@ def timed(fa, fb):
     if fa: fa()
     if fb: fb()
     torch.cuda.synchronize(); return time.perf_counter() - t0
+from modelcompose_amd import _lib
+force = int(sys.argv[1]) if len(sys.argv) > 1 else 0          # 1: every large GEMM on the 186-register 192-column tiles (round 4)
+_lib.check(_lib.lib().mc_gemm_set_option(b"force_tile192", force), "force_tile192")
+print(f"force_tile192 = {force}")
 gemms(); copies("copy"); copies("sum"); torch.cuda.synchronize()
 tg = timed(gemms, None)
 print(f"GEMMs alone: {tg*1e3:.1f} ms ({2*M*N*K*NG/tg/1e12:.0f} TFLOP/s)")
