@@ -333,6 +333,11 @@ int mc_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream
 int mc_add_rows_bf16(const void* x, int64_t ldx, const void* table, int64_t ldt, const int32_t* idx, void* out, int64_t ldo,
                      int n_rows, int D, void* stream);       /* out[r] = x[r] + table[idx[r]]  (languagebind/video/modeling_video.py:110-113) */
 int mc_zero_rows_bf16(void* x, int64_t ldx, const int32_t* rows, int n_rows, int D, void* stream);   /* beats/backbone.py:150-151 */
+/* BEATs forward_padding_mask + x[padding_mask] = 0 on the device (beats/BEATs.py:120-132, beats/backbone.py:150-151): frame mask uint8
+ * [B, mask_stride] (non-zero = padded frame; the first T * span frames count), token t of a clip is padded when all its `span` frames
+ * are; kv_lens[b] = un-padded tokens, padded rows of x [B * T, ldx] are zeroed, bad_flag[0] |= 1 when a clip's padding is not a suffix. */
+int mc_beats_padding_bf16(const void* frame_mask_u8, int64_t mask_stride, int B, int T, int span, void* x, int64_t ldx, int D,
+                          int32_t* kv_lens, int32_t* bad_flag, void* stream);
 int mc_im2col_ex_bf16(const void* in, int64_t s_b, int64_t s_c, int64_t s_h, int64_t s_w, void* out, int B, int C, int Hin, int Win,
                       int c0, int Cg, int kh, int kw, int sh, int sw, int ph, int pw, int oh, int ow, int Kp, void* stream);
 int mc_beats_gate_f32(const float* g8, const float* grep_a, float* gate, int B, int L, int H, void* stream);   /* beats/backbone.py:689-697 */

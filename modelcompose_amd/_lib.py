@@ -131,6 +131,7 @@ _SIGS.update({
     "mc_dropout_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_f, C.c_uint64, C.c_uint32, c_i, c_f, c_p],
     "mc_add_rows_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_p],
     "mc_zero_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
+    "mc_beats_padding_bf16": [c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_p, c_p],
     "mc_im2col_ex_bf16": [c_p, c_l, c_l, c_l, c_l, c_p] + [c_i] * 15 + [c_p],
     "mc_beats_gate_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "mc_group_max_bf16": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],

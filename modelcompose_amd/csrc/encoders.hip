@@ -54,6 +54,53 @@ extern "C" int mc_zero_rows_bf16(void* x, int64_t ldx, const int32_t* rows, int 
     return 0;
 }
 
+// BEATs forward_padding_mask + `x[padding_mask] = 0` (beats/BEATs.py:120-132, beats/backbone.py:150-151) WITHOUT a host round trip (round 4:
+// the host-side analysis of the frame mask cost a device -> host sync at the top of every audio encode).  One workgroup per clip:
+// token t is padded when ALL of its `span` frames are (mask: uint8 [B, mask_stride], the first T * span frames are used); kv_lens[b] =
+// number of un-padded tokens; the rows of padded tokens are zeroed; bad[0] is set when a clip's padding is not a suffix (the attention
+// kernels take one length per clip - the host raises on it at its next natural sync point).
+__global__ __launch_bounds__(256) void beats_padding_kernel(const unsigned char* __restrict__ mask, int64_t mask_stride, int T, int span,
+                                                            bf16_t* __restrict__ x, int64_t ldx, int D, int32_t* __restrict__ kv_lens,
+                                                            int32_t* __restrict__ bad) {
+    __shared__ int s_valid, s_last_valid, s_first_pad;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) { s_valid = 0; s_last_valid = -1; s_first_pad = T; }
+    __syncthreads();
+    const unsigned char* m = mask + (int64_t)b * mask_stride;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        bool padded = true;
+        for (int j = 0; j < span; ++j) padded = padded && (m[(int64_t)t * span + j] != 0);
+        if (padded) atomicMin(&s_first_pad, t);
+        else { atomicAdd(&s_valid, 1); atomicMax(&s_last_valid, t); }
+    }
+    __syncthreads();
+    const int valid = s_valid;
+    if (threadIdx.x == 0) {
+        kv_lens[b] = valid;
+        if (s_last_valid >= s_first_pad) atomicOr(bad, 1);       // a padded token in front of a valid one
+    }
+    // zero the padded rows (with trailing padding: rows valid .. T-1; in general every padded token)
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int chunks = D >> 3;
+    for (int t = 0; t < T; ++t) {
+        bool padded = true;
+        for (int j = 0; j < span && padded; ++j) padded = m[(int64_t)t * span + j] != 0;
+        if (!padded) continue;
+        bf16_t* xr = x + ((int64_t)b * T + t) * ldx;
+        for (int c = threadIdx.x; c < chunks; c += 256) *(bf16x8*)(xr + c * 8) = z;
+    }
+}
+
+extern "C" int mc_beats_padding_bf16(const void* frame_mask_u8, int64_t mask_stride, int B, int T, int span, void* x, int64_t ldx, int D,
+                                     int32_t* kv_lens, int32_t* bad_flag, void* stream) {
+    MC_CHECK_ARG(frame_mask_u8 && x && kv_lens && bad_flag && B > 0 && T > 0 && span > 0 && D % 8 == 0 && mask_stride >= (int64_t)T * span,
+                 "mc_beats_padding_bf16: bad arguments");
+    beats_padding_kernel<<<B, 256, 0, (hipStream_t)stream>>>((const unsigned char*)frame_mask_u8, mask_stride, T, span, (bf16_t*)x, ldx, D, kv_lens,
+                                                            bad_flag);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
 // in [B, C, Hin, Win]; channels [c0, c0+Cg) ; zero padding (ph, pw); only the first oh x ow outputs are produced.
 // out [B*oh*ow, Kp], column = (c*kh + i)*kw + j.
 __global__ __launch_bounds__(256) void im2col_ex_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int C, int Hin,

@@ -65,6 +65,7 @@ class HipBeatsAudioEncoder:
     def __init__(self, audio_encoder: Optional[str], args=None, delay_load=False, config: Optional[BeatsConfig] = None, device="cuda"):
         self.audio_encoder_name, self.device, self.dtype = audio_encoder, torch.device(device), BF16
         self.is_loaded, self.cfg, self.audio_processor = False, config, None
+        self._bad_mask, self._pending_mask_check = None, False               # device flag of the padding analysis (forward / check_pending)
         try:
             from .audio_processor import HipBeatsAudioProcessor
             self.audio_processor = HipBeatsAudioProcessor(device=device)          # audio_encoder.py:33 (BeatsAudioProcessor())
@@ -161,22 +162,41 @@ class HipBeatsAudioEncoder:
         T = oh * ow
         h = ops.linear(cols, self.patch_w)                                     # conv patch embedding, tokens time-major
         h = ops.layernorm(h, self.ln0[0], self.ln0[1], 1e-5)
-        kv_lens, pooled = None, None
+        kv_lens, pooled, pm_dev = None, None, None
         if audio_padding_mask is not None:                                     # forward_padding_mask (BEATs.py:120-132)
-            pm = audio_padding_mask.to("cpu").bool()
-            extra = pm.shape[1] % T
-            pm = pm[:, :-extra] if extra > 0 else pm
-            pooled = pm.view(B, T, -1).all(-1)
-            valid = (~pooled).long().sum(1)
-            if not bool((pooled == (torch.arange(T)[None] >= valid[:, None])).all()):
-                raise NotImplementedError("only trailing audio padding is supported (what BeatsAudioProcessor produces)")
-            kv_lens = valid.to(torch.int32).to(dev)
+            if audio_padding_mask.device.type == "cpu":
+                # a host mask: analysed on the host for free, the unsupported case refused at once
+                pm = audio_padding_mask.bool()
+                extra = pm.shape[1] % T
+                pm = pm[:, :-extra] if extra > 0 else pm
+                pooled = pm.view(B, T, -1).all(-1)
+                valid = (~pooled).long().sum(1)
+                if not bool((pooled == (torch.arange(T)[None] >= valid[:, None])).all()):
+                    raise NotImplementedError("only trailing audio padding is supported (what BeatsAudioProcessor produces)")
+                kv_lens = valid.to(torch.int32).to(dev)
+            else:
+                # a device mask (the eval loop moves the collator's batch to the GPU): NO host round trip (round 4 - the .to("cpu") here cost a
+                # device sync per audio encode, after which the host issued the encoder's ~200 launches with the GPU waiting on it).  One launch
+                # pools the frame mask, writes the clip lengths, zeroes the padded rows and flags non-suffix padding; the flag is read at
+                # the caller's next natural sync (check_pending: MultimodalLlamaForCausalLM._plan copies the ids to the host anyway).
+                pm_dev = audio_padding_mask.to(torch.uint8)
+                if not pm_dev.is_contiguous():
+                    pm_dev = pm_dev.contiguous()
+                kv_lens = torch.empty(B, dtype=torch.int32, device=dev)
+                if self._bad_mask is None:
+                    self._bad_mask = torch.zeros(1, dtype=torch.int32, device=dev)
         if self.proj is not None:
             h = ops.linear(h, self.proj)
         C = c.encoder_embed_dim
         if pooled is not None and bool(pooled.any()):                          # x[padding_mask] = 0 (backbone.py:150-151)
             rows = torch.nonzero(pooled.reshape(-1)).to(torch.int32).reshape(-1).to(dev)
             ops.zero_rows(h, rows)
+        if pm_dev is not None:
+            span = pm_dev.shape[1] // T
+            if span < 1:
+                raise ValueError(f"audio_padding_mask has {pm_dev.shape[1]} frames for {T} tokens")
+            ops.beats_padding(pm_dev, B, T, span, h, kv_lens, self._bad_mask)
+            self._pending_mask_check = True
         # convolutional position embedding: grouped conv1d(k, pad k//2) -> drop last -> GELU, added to x (backbone.py:71-85,153-155)
         # No im2col: the tokens of every clip are laid out with k/2 zero rows before and k/2 after (Tp = T + k rows per clip); with the
         # weights' reduction index ordered (tap, channel) the operand row of output token (b, t) is the contiguous run of k x Cg values
@@ -233,8 +253,21 @@ class HipBeatsAudioEncoder:
             f = ops.linear(h, L["fc1"], act="gelu")
             h = ops.layernorm(ops.linear(f, L["fc2"], residual=h, beta=alpha), L["ln2"][0], L["ln2"][1], 1e-5)
         feats = h.view(B, T, C)
-        mask = None if pooled is None else (~pooled).to(dev)
+        if pooled is not None:
+            mask = (~pooled).to(dev)
+        elif kv_lens is not None:
+            mask = torch.arange(T, device=dev)[None] < kv_lens[:, None]        # valid-token mask (the caller ignores it, multimodal_arch.py:233-235)
+        else:
+            mask = None
         return feats, mask
+
+    def check_pending(self):
+        """Deferred refusal of a device padding mask that was not a suffix (read at a point where the caller synchronises anyway)."""
+        if getattr(self, "_pending_mask_check", False):
+            self._pending_mask_check = False
+            if int(self._bad_mask.item()) != 0:
+                self._bad_mask.zero_()
+                raise NotImplementedError("only trailing audio padding is supported (what BeatsAudioProcessor produces)")
 
 
 # =========================================================================================================
@@ -397,13 +430,20 @@ class HipLanguageBindVideoTower:
         if c.add_time_attn and t != 1 and t != T:
             raise ValueError(f"video has {T} frames but the tower was built for num_frames={t}")
         if c.add_time_attn and t != 1:
-            r = np.arange(B * T * n)
-            tt = (r // n) % T
-            t_idx = torch.from_numpy(tt.astype(np.int32)).to(dev)                # temporal embedding row per (b t n) row
-            # (b n t) order for the temporal attention; out_map scatters its output back to (b t n)
-            bb, nn_, t2 = np.meshgrid(np.arange(B), np.arange(n), np.arange(T), indexing="ij")
-            perm = ((bb * T + t2) * n + nn_).reshape(-1).astype(np.int32)
-            perm_d = torch.from_numpy(perm).to(dev)
+            # index tensors of the temporal branch, built once per shape: a host -> device copy from pageable memory is ordered behind
+            # everything already queued on the stream and blocks the host until then (round 4: the per-call copies here made the host wait
+            # for the previous encoder to finish before it could issue this tower's launches)
+            key = ("tidx", B, T, n)
+            cache = self.__dict__.setdefault("_idx_cache", {})
+            if key not in cache:
+                r = np.arange(B * T * n)
+                tt = (r // n) % T
+                t_idx = torch.from_numpy(tt.astype(np.int32)).to(dev)            # temporal embedding row per (b t n) row
+                # (b n t) order for the temporal attention; out_map scatters its output back to (b t n)
+                bb, nn_, t2 = np.meshgrid(np.arange(B), np.arange(n), np.arange(T), indexing="ij")
+                perm = ((bb * T + t2) * n + nn_).reshape(-1).astype(np.int32)
+                cache[key] = (t_idx, torch.from_numpy(perm).to(dev))
+            t_idx, perm_d = cache[key]
         st_s = (n * 3 * D, 3 * D, d)
         st_t = (T * 3 * D, 3 * D, d)
         for i in range(index):

@@ -410,6 +410,11 @@ class MultimodalLlamaForCausalLM:
 
     def _plan(self, input_ids, attention_mask, labels, modal_inputs, feats) -> SplicePlan:
         ids = input_ids.detach().cpu().numpy()
+        # the copy above synchronised with the encoders: deferred input checks of theirs are read here at no extra cost
+        for enc in self.model.modal_encoders.values():
+            chk = getattr(enc, "check_pending", None)
+            if chk is not None:
+                chk()
         am = None if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool)
         lb = None if labels is None else labels.detach().cpu().numpy()
         keys = list(modal_inputs.keys())

@@ -323,6 +323,13 @@ def zero_rows(x, rows):
     return x
 
 
+def beats_padding(frame_mask_u8, B, T, span, x, kv_lens, bad_flag):
+    """Device-side forward_padding_mask + x[padding_mask] = 0 of BEATs (mc_beats_padding_bf16): fills kv_lens [B] int32, zeroes the padded
+    token rows of x [B * T, D], ORs 1 into bad_flag[0] when some clip's padding is not a suffix."""
+    _lib.check(_lib.lib().mc_beats_padding_bf16(_p(frame_mask_u8), frame_mask_u8.stride(0), B, T, span, _p(x), x.stride(0), x.shape[1], _p(kv_lens),
+                                                _p(bad_flag), _stream()), "mc_beats_padding_bf16")
+
+
 def im2col_ex(x, strides, B, Cc, Hin, Win, c0, Cg, kh, kw, sh, sw, ph, pw, oh, ow, Kp=None):
     """x: bf16 device tensor addressed as x[b*s_b + c*s_c + y*s_h + x*s_w]."""
     K = Cg * kh * kw

@@ -23,7 +23,8 @@ def main():
     del sd
     mi = bench.synthetic_inputs(("vision", "audio", "video"), B, dev, 100)
     out = {}
-    for modal in ("vision", "audio", "video", "all"):
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else ("vision", "audio", "video", "all")      # e.g. "audio": that modality's kernel mix alone
+    for modal in only:
         inp = mi if modal == "all" else {modal: mi[modal]}
         for _ in range(2):
             model.encode_modal_inputs(inp)
