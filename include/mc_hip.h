@@ -201,6 +201,10 @@ int mc_gemm_clock_read(int n_wg, double* ghz);
 int mc_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* out, int64_t ldo, int M, int D, float eps, void* stream);
 int mc_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, void* out, int64_t ldo, int M, int D,
                       float eps, void* stream);
+/* sum_out[r] = bf16(x[r] + table[idx ? idx[r] : r]); out[r] = LayerNorm(sum_out[r]) - one pass for `hidden_states + temporal_embedding`
+ * followed by temporal_layer_norm1 (languagebind/video/modeling_video.py:105-115); bit-identical to mc_add_rows_bf16 + mc_layernorm_bf16. */
+int mc_add_layernorm_bf16(const void* x, int64_t ldx, const void* table, int64_t ldt, const int32_t* idx, void* sum_out, int64_t lds,
+                          const void* w, const void* b, void* out, int64_t ldo, int M, int D, float eps, void* stream);
 /* RMSNorm's per-row factor only (its weight is folded into the next linear): row_scale[m] = rsqrt(mean(x[m]^2) + eps)        */
 int mc_rms_scale_bf16(const void* x, int64_t ldx, float* row_scale, int M, int D, float eps, void* stream);
 /* h[m] = bf16(h[m] + sum_s part[s][m]); row_scale[m] = rsqrt(mean(h[m]^2) + eps) (may be NULL): residual add of the decoder
@@ -288,6 +292,11 @@ int mc_attn_prefill_dropout_bf16(const void* q, int64_t q_sb, int64_t q_st, int6
  * multimodal_llama.py:543-545).  Applies to the NEXT mc_attn_prefill_* / mc_attn_decode_* call of the calling thread and is cleared by it;
  * kv_lens / causal keep their meaning (a key must pass all tests). */
 int mc_attn_set_key_mask(const void* key_valid, int64_t row_stride);
+/* One-shot two-level batch index for the NEXT mc_attn_prefill_* launch of the calling thread: batch entry b = (b / b_inner, b % b_inner)
+ * is addressed at (b / b_inner) * *_sb + (b % b_inner) * inner_stride.  Only for launches with Lq, S <= 8 and no relative-position table
+ * (the temporal attention of LanguageBind-Video, modeling_video.py:105-130, over the (b t) n d layout: sequence (b, n), its t tokens a
+ * frame apart - attended in place instead of through a permuted copy); any other launch is refused. */
+int mc_attn_set_batch_split(int b_inner, int64_t inner_stride);
 /* as mc_attn_prefill_bf16, plus lse [B, H, Lq] fp32 = log2-sum-exp of the scaled scores (input of mc_attn_bwd_bf16) */
 int mc_attn_debug(int v);      /* diagnostics: bit 0 forces the 64-query prefill kernel, bit 1 allows the 128-query one at any length */
 int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,

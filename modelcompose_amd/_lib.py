@@ -43,6 +43,8 @@ _SIGS = {
     "mc_pack_weight_batch_bf16": [c_p, c_i, c_i, c_p],
     "mc_rmsnorm_bf16": [c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_layernorm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
+    "mc_add_layernorm_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
+    "mc_attn_set_batch_split": [c_i, c_l],
     "mc_rope_kv_bf16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "mc_attn_prefill_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
                              c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p, c_p],

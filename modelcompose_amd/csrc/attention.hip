@@ -32,6 +32,10 @@ struct AttnParams {
     // optional per-key validity [B][key_valid_sb] (0 = the key is masked for every query): attention masks with zeros that are not a
     // suffix - left padding, holes (the additive padding mask of LlamaModel._prepare_decoder_attention_mask, multimodal_llama.py:543-545)
     const uint8_t* key_valid; int64_t key_valid_sb;
+    // optional two-level batch index (attn_tiny_kernel only; mc_attn_set_batch_split): batch entry b = (b / b_inner, b % b_inner) sits at
+    // (b / b_inner) * *_sb + (b % b_inner) * sbi - sequences that interleave in memory (the temporal attention of LanguageBind-Video over
+    // the (b t) n d layout: sequence (b, n), tokens a frame apart) are attended in place, without a permuted copy
+    int b_inner; int64_t sbi;
 };
 
 #define NEG_BIG (-1.0e30f)
@@ -436,7 +440,11 @@ __global__ __launch_bounds__(256) void attn_tiny_kernel(AttnParams p) {
     const int hk = h / (p.H / p.Hkv);
     const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
     const int tq = min(t, p.Lq - 1);
-    const bf16_t* qp = p.q + b * p.q_sb + (int64_t)tq * p.q_st + h * p.q_sh + half * HALF;
+    // batch offsets: one stride, or the two-level form
+    const int64_t bq = p.b_inner ? (int64_t)(b / p.b_inner) * p.q_sb + (int64_t)(b % p.b_inner) * p.sbi : (int64_t)b * p.q_sb;
+    const int64_t bk = p.b_inner ? (int64_t)(b / p.b_inner) * p.k_sb + (int64_t)(b % p.b_inner) * p.sbi : (int64_t)b * p.k_sb;
+    const int64_t bv = p.b_inner ? (int64_t)(b / p.b_inner) * p.v_sb + (int64_t)(b % p.b_inner) * p.sbi : (int64_t)b * p.v_sb;
+    const bf16_t* qp = p.q + bq + (int64_t)tq * p.q_st + h * p.q_sh + half * HALF;
     float qv[HALF];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_tiny_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int key = min(j, p.S - 1);
-        const bf16_t* kp = p.k + b * p.k_sb + (int64_t)key * p.k_st + hk * p.k_sh + half * HALF;
+        const bf16_t* kp = p.k + bk + (int64_t)key * p.k_st + hk * p.k_sh + half * HALF;
         float d = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(256) void attn_tiny_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int key = min(j, p.S - 1);
-        const bf16_t* vp = p.v + b * p.v_sb + (int64_t)key * p.v_st + hk * p.v_sh + half * HALF;
+        const bf16_t* vp = p.v + bv + (int64_t)key * p.v_st + hk * p.v_sh + half * HALF;
         // P is rounded to bf16 before it multiplies V, as in the flash kernel (and normalised by the fp32 sum)
         const float pj = (float)(bf16_t)sc[j];
 #pragma unroll
@@ -717,6 +725,15 @@ extern "C" int mc_attn_set_key_mask(const void* key_valid, int64_t row_stride) {
     return 0;
 }
 static void take_key_mask(const uint8_t*& kv, int64_t& sb) { kv = g_key_valid; sb = g_key_valid_sb; g_key_valid = nullptr; g_key_valid_sb = 0; }
+// One-shot two-level batch index for the NEXT mc_attn_prefill_* launch of this thread (see AttnParams::b_inner); the launch must be one
+// the tiny kernel takes (Lq, S <= 8, no relative-position table, no key mask) - anything else is refused, never silently mis-addressed.
+static thread_local int g_b_inner = 0;
+static thread_local int64_t g_sbi = 0;
+extern "C" int mc_attn_set_batch_split(int b_inner, int64_t inner_stride) {
+    if (b_inner < 0 || inner_stride % 8) { mc_set_error("mc_attn_set_batch_split: bad arguments"); return 1; }
+    g_b_inner = b_inner; g_sbi = inner_stride;
+    return 0;
+}
 
 static int g_attn_dbg = 0;
 extern "C" int mc_attn_debug(int v) { g_attn_dbg = v; return 0; }      // bit 0: force the 64-query kernel, bit 1: allow the 128-query one at any length (A/B timing)
@@ -736,13 +753,17 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
                  (bf16_t*)o, o_row_stride, out_map, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
                  scale * 1.4426950408889634f, rel_table, q_gate, rel_stride, rel_off, lse};
     take_key_mask(p.key_valid, p.key_valid_sb);
+    p.b_inner = g_b_inner; p.sbi = g_sbi;
+    g_b_inner = 0; g_sbi = 0;
+    MC_CHECK_ARG(p.b_inner == 0 || (Lq <= 8 && S <= 8 && !rel_table && !p.key_valid && B % p.b_inner == 0),
+                 "mc_attn_prefill_bf16: a two-level batch index (mc_attn_set_batch_split) is only defined for the Lq, S <= 8 kernel");
     hipStream_t s = (hipStream_t)stream;
     // Workgroup shape: QW waves x NQ 16-query blocks per wave.  D = 128 without the relative-position bias (the LLM prefill, training):
     // two query blocks per wave (half the LDS bytes per MFMA, see the kernel); 4 waves = 128 queries per workgroup, 8 waves = 256 for long
     // sequences where the coarser causal diagonal is cheap.  Everything else keeps one block per wave: 8 waves (128 queries) for
     // Lq >= 1024, 4 waves (64 queries) below.  debug word: bit 0 forces <4 waves, 1 block>, bit 1 allows the 8-wave shapes at any
     // length, bit 2 disables the two-block kernels.
-    if (Lq <= 8 && S <= 8 && !rel_table && !(g_attn_dbg & 32) && !p.key_valid) {
+    if (Lq <= 8 && S <= 8 && !rel_table && (!(g_attn_dbg & 32) || p.b_inner) && !p.key_valid) {
         const int64_t threads = (int64_t)B * H * 16;
         if (D == 128) attn_tiny_kernel<128><<<(int)((threads + 255) / 256), 256, 0, s>>>(p);
         else attn_tiny_kernel<64><<<(int)((threads + 255) / 256), 256, 0, s>>>(p);

@@ -181,6 +181,73 @@ extern "C" int mc_layernorm_bf16(const void* x, int64_t ldx, const void* w, cons
     return 0;
 }
 
+// h[r] += table[idx[r]] and LayerNorm of the new row in ONE pass (round 4; LanguageBind-Video's temporal branch, video/modeling_video.py:105-115:
+// `hidden_states + temporal_embedding[:, :t]` then temporal_layer_norm1).  One wave per row like norm_rows_kernel; the sum is rounded to
+// bf16 and stored (it is the residual the branch's output is added to), and the statistics are taken over those bf16 values - exactly
+// what add_rows_kernel followed by norm_rows_kernel computes, in one read and two writes instead of two reads and ... three passes.
+__global__ __launch_bounds__(256) void add_norm_rows_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ table, int64_t ldt,
+                                                            const int32_t* __restrict__ idx, bf16_t* __restrict__ sum_out, int64_t lds,
+                                                            const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                                            int64_t ldo, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16_t* xr = x + (int64_t)row * ldx;
+    const bf16_t* tr = table + (int64_t)(idx ? idx[row] : row) * ldt;
+    bf16_t* sr = sum_out + (int64_t)row * lds;
+    bf16_t* orow = out + (int64_t)row * ldo;
+    const int nv = D >> 3;
+    float v[4][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = it * 64 + lane;
+        if (i < nv) {
+            const bf16x8 a = *(const bf16x8*)(xr + i * 8), b = *(const bf16x8*)(tr + i * 8);
+            bf16x8 sm;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sm[j] = (bf16_t)((float)a[j] + (float)b[j]);
+                const float f = (float)sm[j];
+                v[it][j] = f;
+                s1 += f;
+            }
+            *(bf16x8*)(sr + i * 8) = sm;
+        }
+    }
+    const float mean = wave_sum(s1) / D;
+    float sv = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (it * 64 + lane < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[it][j] - mean; sv += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sv) / D + eps);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = it * 64 + lane;
+        if (i < nv) {
+            const bf16x8 wv = *(const bf16x8*)(w + i * 8), bv = *(const bf16x8*)(bias + i * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((v[it][j] - mean) * rstd * (float)wv[j] + (float)bv[j]);
+            *(bf16x8*)(orow + i * 8) = o;
+        }
+    }
+}
+
+extern "C" int mc_add_layernorm_bf16(const void* x, int64_t ldx, const void* table, int64_t ldt, const int32_t* idx, void* sum_out, int64_t lds,
+                                     const void* w, const void* b, void* out, int64_t ldo, int M, int D, float eps, void* stream) {
+    MC_CHECK_ARG(x && table && sum_out && w && b && out && M > 0 && D > 0 && D % 8 == 0 && D <= 2048 && ldx % 8 == 0 && ldt % 8 == 0 && lds % 8 == 0 &&
+                 ldo % 8 == 0, "mc_add_layernorm_bf16: bad arguments (D=%d)", D);
+    add_norm_rows_kernel<<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, (const bf16_t*)table, ldt, idx, (bf16_t*)sum_out, lds,
+                                                                       (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out, ldo, M, D, eps);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // RMSNorm split in two: the norm weight is folded into the next linear's columns at compose time, so what is left at run
 // time is the per-row factor 1/rms (LlamaRMSNorm: variance in fp32 of the bf16 hidden state, multimodal_llama.py:405-406),

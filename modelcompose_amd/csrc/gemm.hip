@@ -1422,6 +1422,8 @@ static bool g_tile192 = true;
 // attention: 102) per SIMD BESIDE a resident GEMM workgroup.  The fused epilogues that need a wave to own a whole head or 128 columns
 // (RoPE + cache scatter, the next norm's factor) take their separate-launch routes; SwiGLU takes the 8-byte store path.
 static bool g_force192 = false;
+static thread_local bool g_in_tail = false, g_force128 = false;      // mc_gemm_ex_bf16's tail split (below)
+static bool g_tail_split = false;     // measured +-0 on the encode stage (in-process A/B 127.0-127.7 vs 127.2-127.5 ms): off by default
 static bool g_raster_auto = true;          // "raster_shared" option
 static bool g_rows_on = true;              // "rows_kernel" option: M <= 64 launches with ceil(M / 16) >= "rows_min_mb" take gemm_rows_kernel
 static int g_rows_min_mb = 2;
@@ -1435,6 +1437,7 @@ static int g_raster_min_tiles = 1024;      // launches with at least this many t
 extern "C" int mc_gemm_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tile192")) { g_tile192 = value != 0; return 0; }
     if (name && !strcmp(name, "force_tile192")) { g_force192 = value != 0; return 0; }
+    if (name && !strcmp(name, "tail_split")) { g_tail_split = value != 0; return 0; }
     if (name && !strcmp(name, "raster_shared")) { g_raster_auto = value != 0; return 0; }
     if (name && !strcmp(name, "raster_slab")) { g_raster_slab = value < 0 ? 0 : (value > 255 ? 255 : value); g_raster_slab_min = 0; return 0; }
     if (name && !strcmp(name, "raster_min_tiles")) { g_raster_min_tiles = value; return 0; }
@@ -1459,6 +1462,7 @@ static int tile_ni(int64_t m_tiles, int N, bool swiglu) {
 // 256-row tiles need enough tiles to fill most of the 256 CUs; bit 1 of the debug word forces the 128x128 kernel, bit 2 the 256-row one
 static bool use_tile256(int M, int N, int K) {
     if (K < 128) return false;
+    if (g_force128) return false;
     if (g_gemm_dbg & 2) return false;
     if (g_gemm_dbg & 4) return true;
     // measured crossover on MI355X (tools/bench_ops.py mid): 176 tiles (M=2732, N=4096) 1.15-1.4x faster than the 128x128 kernel,
@@ -1894,6 +1898,37 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
             default: launch_skinny2<4>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
         }
     } else if (use_tile256(M, N, K)) {
+        // Round 4 - tail split ("tail_split" option; DEFAULT OFF after measurement: the replacement launch - a kernel boundary plus one 128 x 128
+        // tile time - costs what the almost-empty round of 256 x 256 tiles cost): one workgroup per CU means a launch runs in rounds of 256 tiles; a launch of
+        // 6.03 rounds (the video tower's out_proj / fc2: 386 m-tiles x 4 tile columns = 1544 tiles) spends a whole round on its last 8
+        // tiles.  When the last round is less than a quarter full and only a few m-tiles deep, the launch covers the rows of the whole rounds
+        // and the remaining rows (a few hundred) go to the 128 x 128 kernel, whose two small workgroups per CU finish in a fraction of a
+        // tile time.  Same values (the two kernels are bit-identical); plain epilogues only.
+        if (g_tail_split && !g_in_tail && !a->rope && !a->rms_out && !a->swiglu && !a->defer_reduce && split_k == 1) {
+            const int64_t tm = (M + 255) / 256;
+            const int ni0 = tile_ni(tm, N, false);
+            const int64_t tn = ni0 == 3 ? (N + 191) / 192 : (N + 255) / 256;
+            const int64_t total = tm * tn, rounds = total / 256, rem = total % 256;
+            if (rounds >= 2 && rounds <= 40 && rem > 0 && rem <= 64) {
+                const int64_t m_keep = (rounds * 256) / tn;                        // m-tiles that fit the whole rounds
+                const int64_t rows_main = m_keep * 256;
+                if (m_keep > 0 && rows_main < M && tm - m_keep <= 3 && tile_ni(m_keep, N, false) == ni0 && use_tile256((int)rows_main, N, K)) {
+                    mc_gemm_args a1 = *a, a2 = *a;
+                    a1.M = (int)rows_main;
+                    const int64_t r0 = rows_main;
+                    a2.M = M - (int)rows_main;
+                    a2.x = (const char*)a->x + r0 * a->ldx * 2;
+                    a2.out = (char*)a->out + r0 * a->ldo * (a->out_f32 ? 4 : 2);
+                    if (a->residual) a2.residual = (const char*)a->residual + r0 * a->ldr * 2;
+                    if (a->row_scale) a2.row_scale = a->row_scale + r0;
+                    g_in_tail = true;
+                    int rc = mc_gemm_ex_bf16(&a1, stream);
+                    if (rc == 0) { g_force128 = true; rc = mc_gemm_ex_bf16(&a2, stream); g_force128 = false; }
+                    g_in_tail = false;
+                    return rc;
+                }
+            }
+        }
         G2Groups grp{};
         grp.n = 1; grp.tile_start[0] = 0; grp.tile_start[1] = (M + 255) / 256; grp.row_start[0] = 0; grp.row_start[1] = M;
         grp.wp[0] = (const bf16_t*)w_packed;

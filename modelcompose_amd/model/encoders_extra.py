@@ -446,16 +446,19 @@ class HipLanguageBindVideoTower:
             t_idx, perm_d = cache[key]
         st_s = (n * 3 * D, 3 * D, d)
         st_t = (T * 3 * D, 3 * D, d)
+        st_tn = (T * n * 3 * D, n * 3 * D, d)                                    # clip stride, frame stride (tokens of one (b, n) sequence), head
         for i in range(index):
             L = self.layers[i]
             if c.add_time_attn:                                                  # modeling_video.py:105-130
                 if t != 1:
-                    h = ops.add_rows(h, L["t_emb"], t_idx)
-                    hp = torch.empty_like(h)
-                    ops.copy_rows(h, hp, B * T * n, perm_d, None)
-                    qkv = ops.linear(ops.layernorm(hp, L["t_ln"][0], L["t_ln"][1], c.layer_norm_eps), L["t_qkv"])
+                    # round 4: `h + temporal_embedding` and temporal_layer_norm1 in one pass, and the temporal attention IN PLACE over the
+                    # (b t) n d layout - sequence (b, n) starts at row b T n + n', its tokens lie n rows apart - instead of through a
+                    # permuted copy of the hidden state (rows are independent in the LayerNorm and the GEMM: same values, no permutation)
+                    h, nrm = ops.add_layernorm(h, L["t_emb"], t_idx, L["t_ln"][0], L["t_ln"][1], c.layer_norm_eps)
+                    qkv = ops.linear(nrm, L["t_qkv"])
                     a = torch.empty(B * T * n, D, dtype=BF16, device=dev)
-                    ops.attn_prefill(qkv, qkv[:, D:], qkv[:, 2 * D:], a, B * n, H, H, T, T, d, st_t, st_t, st_t, D, False, 0,
+                    ops.attn_set_batch_split(n, 3 * D)
+                    ops.attn_prefill(qkv, qkv[:, D:], qkv[:, 2 * D:], a, B * n, H, H, T, T, d, st_tn, st_tn, st_tn, D, False, 0,
                                      scale=d ** -0.5, out_map=perm_d)
                 else:                                                            # bt < t: every token attends to itself only
                     qkv = ops.linear(ops.layernorm(h, L["t_ln"][0], L["t_ln"][1], c.layer_norm_eps), L["t_qkv"])

@@ -217,6 +217,22 @@ def layernorm(x, w, b, eps, out=None):
     return out
 
 
+def add_layernorm(x, table, idx, w, b, eps, sum_out=None, out=None):
+    """(sum, LayerNorm(sum)) with sum[r] = bf16(x[r] + table[idx[r]]) in one pass (mc_add_layernorm_bf16); sum_out may alias x."""
+    _req(x, BF16, "x")
+    M, D = x.shape
+    sum_out = torch.empty_like(x) if sum_out is None else sum_out
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().mc_add_layernorm_bf16(_p(x), x.stride(0), _p(table), table.stride(0), _p(idx), _p(sum_out), sum_out.stride(0), _p(w), _p(b),
+                                                _p(out), out.stride(0), M, D, eps, _stream()), "mc_add_layernorm_bf16")
+    return sum_out, out
+
+
+def attn_set_batch_split(b_inner: int, inner_stride: int):
+    """One-shot two-level batch index of the next attn_prefill launch (mc_attn_set_batch_split)."""
+    _lib.check(_lib.lib().mc_attn_set_batch_split(int(b_inner), int(inner_stride)), "mc_attn_set_batch_split")
+
+
 def rope_kv(qkv, row_b, row_pos, row_t, cos, sin, q_out, k_cache, v_cache, H, Hkv, D, Lq, Smax):
     M = qkv.shape[0]
     _lib.check(_lib.lib().mc_rope_kv_bf16(_p(qkv), qkv.stride(0), _p(row_b), _p(row_pos), _p(row_t), _p(cos), _p(sin), _p(q_out),

@@ -175,3 +175,48 @@ def test_languagebind_video_processor_matches_torch_transform():
             assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item(), (T, H, W, flip)
     out = HipLanguageBindVideoProcessor()(images=[torch.randint(0, 256, (8, 120, 160, 3), generator=g, dtype=torch.uint8)] * 2)
     assert out["pixel_values"].shape == (2, 3, 8, 224, 224) and out["pixel_values"].dtype == torch.bfloat16
+
+
+def test_fused_add_layernorm_and_in_place_temporal_attention_are_bit_identical():
+    """Round 4 (LanguageBind-Video temporal branch, video/modeling_video.py:105-130): `h + temporal_embedding` + temporal_layer_norm1 in one
+    pass equals add_rows followed by layernorm bit for bit; the temporal attention addressed in place over the (b t) n d layout
+    (mc_attn_set_batch_split) equals the attention over a permuted (b n) t d copy bit for bit; a launch the tiny kernel does not take
+    refuses the split instead of mis-addressing."""
+    from modelcompose_amd import _lib, ops
+    g = torch.Generator().manual_seed(5)
+    B, T, n, D, H = 3, 8, 37, 1024, 16
+    d = D // H
+    M = B * T * n
+    h = torch.randn(M, D, generator=g).to(torch.bfloat16).cuda()
+    temb = (torch.randn(T, D, generator=g) * 0.3).to(torch.bfloat16).cuda()
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(torch.bfloat16).cuda()
+    b = (0.1 * torch.randn(D, generator=g)).to(torch.bfloat16).cuda()
+    t_idx = ((torch.arange(M) // n) % T).to(torch.int32).cuda()
+    s0 = ops.add_rows(h, temb, t_idx)
+    n0 = ops.layernorm(s0, w, b, 1e-5)
+    s1, n1 = ops.add_layernorm(h, temb, t_idx, w, b, 1e-5)
+    assert torch.equal(s0, s1) and torch.equal(n0, n1)
+    # attention: (b n) sequences of T tokens
+    qkv = torch.randn(M, 3 * D, generator=g).to(torch.bfloat16).cuda()
+    import numpy as np
+    bb, nn_, t2 = np.meshgrid(np.arange(B), np.arange(n), np.arange(T), indexing="ij")
+    perm = torch.from_numpy(((bb * T + t2) * n + nn_).reshape(-1).astype(np.int32)).cuda()
+    qp = torch.empty_like(qkv)
+    ops.copy_rows(qkv, qp, M, perm, None)                                   # the permuted copy the old path attended over
+    a0 = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
+    st_t = (T * 3 * D, 3 * D, d)
+    ops.attn_prefill(qp, qp[:, D:], qp[:, 2 * D:], a0, B * n, H, H, T, T, d, st_t, st_t, st_t, D, False, 0, scale=d ** -0.5, out_map=perm)
+    a1 = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
+    st_tn = (T * n * 3 * D, n * 3 * D, d)
+    ops.attn_set_batch_split(n, 3 * D)
+    ops.attn_prefill(qkv, qkv[:, D:], qkv[:, 2 * D:], a1, B * n, H, H, T, T, d, st_tn, st_tn, st_tn, D, False, 0, scale=d ** -0.5, out_map=perm)
+    assert torch.equal(a0, a1) and a1.float().abs().max().item() > 0
+    # the split is one-shot: the next launch is an ordinary one
+    a2 = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
+    ops.attn_prefill(qp, qp[:, D:], qp[:, 2 * D:], a2, B * n, H, H, T, T, d, st_t, st_t, st_t, D, False, 0, scale=d ** -0.5, out_map=perm)
+    assert torch.equal(a2, a0)
+    # and it is refused where the tiny kernel does not run (64 tokens per sequence)
+    ops.attn_set_batch_split(n, 3 * D)
+    with pytest.raises(ValueError):
+        ops.attn_prefill(qkv, qkv[:, D:], qkv[:, 2 * D:], a2, B, H, H, 64, 64, d, (64 * 3 * D, 3 * D, d), (64 * 3 * D, 3 * D, d), (64 * 3 * D, 3 * D, d), D,
+                         False, 0, scale=d ** -0.5)

@@ -89,6 +89,31 @@ def test_gemm_tile256_kernel_bit_identical_to_tile128(ops, M, N, K):
     assert (big32.cpu() - ref.cpu()).abs().max().item() <= 1e-3 * ref.abs().max().item()
 
 
+def test_gemm_tail_split_is_bit_identical(ops):
+    """Round 4: a launch of a whole number of rounds of 256 tiles plus a few tiles (the video tower's out_proj / fc2: 6.03 rounds) gives the
+    rows of the last, almost empty round to the 128 x 128 kernel (mc_gemm_set_option "tail_split"; off by default - it measured +-0).  Same values bit for bit,
+    with bias + activation + residual and with a row factor; shapes without such a tail take one launch as before."""
+    from modelcompose_amd import _lib
+    L = _lib.lib()
+    K, N = 256, 1024                                         # 4 tile columns: 128 m-tiles = 2 whole rounds
+    M = 128 * 256 + 300                                      # + 2 m-tiles: 520 tiles = 2.03 rounds
+    x, w, bias, r = rand_bf(M, K, seed=1), rand_bf(N, K, scale=0.05, seed=2), rand_bf(N, seed=3), rand_bf(M, N, seed=4)
+    rs = (torch.rand(M, generator=torch.Generator().manual_seed(5)) + 0.5).cuda()
+    xd, rd = dev(x), dev(r)
+    pw = ops.pack_weight(dev(w), dev(bias))
+    outs = {}
+    for on in (1, 0):
+        _lib.check(L.mc_gemm_set_option(b"tail_split", on), "tail_split")
+        try:
+            outs[on] = (ops.linear(xd, pw, act="gelu", residual=rd), ops.linear_ex(xd, pw, row_scale=rs))
+        finally:
+            _lib.check(L.mc_gemm_set_option(b"tail_split", 0), "tail_split")
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    ref = torch.nn.functional.gelu(x.float() @ w.float().t() + bias.float()) + r.float()
+    assert (outs[1][0].float().cpu() - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+    assert outs[1][0][-300:].float().abs().max().item() > 0   # the tail rows were written
+
+
 def test_gemm_tile256_ab_builds_are_bit_identical(ops):
     """The A/B builds the probes select through the debug word - the round-2 main loop (DMA 2 / 2 / 2 / 2 + s_setprio), s_setprio back on the shipped
     loop, no next-tile L2 warm-up, residual rows in 8-byte loads - differ in issue order only: same bits as the shipped kernel."""

@@ -36,7 +36,28 @@ def main():
         b.record()
         torch.cuda.synchronize()
         out[modal] = round(a.elapsed_time(b) / reps, 3)
-    print(json.dumps({"probe": "encode_stage", "batch": B, "ms": out}))
+    res = {"probe": "encode_stage", "batch": B, "ms": out}
+    if os.environ.get("MC_ENC_AB"):
+        # in-process A/B of a library option (device-to-device spread on this pool is +-3 %: only same-process numbers compare), e.g.
+        # MC_ENC_AB=tail_split: the whole stage with the option off / on, interleaved rounds
+        from modelcompose_amd import _lib
+        opt = os.environ["MC_ENC_AB"].encode()
+        ab = {0: [], 1: []}
+        for _ in range(4):
+            for on in (0, 1):
+                _lib.check(_lib.lib().mc_gemm_set_option(opt, on), "set_option")
+                model.encode_modal_inputs(mi)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    model.encode_modal_inputs(mi)
+                b.record()
+                torch.cuda.synchronize()
+                ab[on].append(round(a.elapsed_time(b) / reps, 3))
+        _lib.check(_lib.lib().mc_gemm_set_option(opt, 0), "set_option")
+        res["ab"] = {"option": os.environ["MC_ENC_AB"], "off_ms": ab[0], "on_ms": ab[1]}
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":
