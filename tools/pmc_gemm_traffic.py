@@ -31,7 +31,7 @@ def main():
                            "ratio": round(t / l["algorithmic_bytes"], 2)}
         tot_t += t
         tot_a += l["algorithmic_bytes"]
-    out = {"round": 3, "tag": tag, "date": datetime.date.today().isoformat(), "workload": "iav", "per_gpu_batch": info.get("per_gpu_batch"),
+    out = {"round": int("".join(ch for ch in tag[1:3] if ch.isdigit()) or 0), "tag": tag, "date": datetime.date.today().isoformat(), "workload": "iav", "per_gpu_batch": info.get("per_gpu_batch"),
            "kernel": "gemm_tile256_kernel",
            "gemm_tile256_kernel_bytes_per_launch": tot_t / len(L), "algorithmic_bytes_per_launch": tot_a / len(L), "ratio": round(tot_t / tot_a, 2),
            "per_gemm": rows,

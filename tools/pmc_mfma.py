@@ -43,8 +43,16 @@ def main():
             e["mfma_busy_frac"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
         if ns and c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"):
             e["tflops_from_mops"] = round(c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512 / ns / 1e3, 1)
-        if c.get("SQ_WAVE_CYCLES"):
+        if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c:
             e["wait_any_frac_of_wave_cycles"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
+        if ns and c.get("GRBM_GUI_ACTIVE") and "SQ_LDS_IDX_ACTIVE" in c:
+            # LDS-array cycles per CU-cycle (256 CUs; GRBM_GUI_ACTIVE is summed over the 8 XCDs).  Units as the counters report them: if SQ
+            # counts quad-cycles on this part the fraction reads 1/4 - compare with the analytic LDS cycles of the tile
+            cu_cycles = c["GRBM_GUI_ACTIVE"] / 8 * 256
+            e["lds_idx_active_per_cu_cycle"] = round(c["SQ_LDS_IDX_ACTIVE"] / cu_cycles, 4)
+            e["lds_bank_conflict_frac_of_lds_cycles"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), 4)
+            if c.get("SQ_WAVE_CYCLES"):
+                e["wait_inst_lds_frac_of_wave_cycles"] = round(c.get("SQ_WAIT_INST_LDS", 0.0) / c["SQ_WAVE_CYCLES"], 4)
         res[k] = e
     json.dump({"round": tag, "note": __doc__.split("\n\n")[-1].replace("\n", " "), "kernels": res}, open(out, "w"), indent=1)
     for k, e in sorted(res.items(), key=lambda kv: -kv[1]["duration_ms"])[:8]:
