@@ -142,7 +142,11 @@ def test_full_depth_32_layers_against_the_committed_oracle_fixture():
 # tests/golden/g17_fulldepth_iav8.npz (`python -m oracle.gen_golden g17a / g17b / g17`): the fp32 branch-form oracle's free-running ids +
 # logits for EIGHT unscreened rows, and the logits of the device-rounding restatement (oracle/device_path.py) teacher-forced on those ids.
 # Bounds = 2x what MI355X measured in round 4 (profiles/r04_parity.json).
-DEV_BOUND = 3.0e-2          # HIP backbone vs the device-rounding oracle, both fed the fp32 oracle's encoder blocks, 32 layers (measured 1.5e-2)
+# HIP backbone vs the device-rounding oracle, both fed the fp32 oracle's encoder blocks, 32 layers: measured 2.87e-2 (rms 3.0e-2) - NOT a
+# fraction of the fp32 distance (3.4e-2): the restatement itself sits 3.15e-2 from fp32, and two implementations with the same storage
+# points but different fp32 summation order decorrelate to the full bf16 noise level within a layer, so at depth the three
+# pairwise distances are all of one size.  What the pair of oracles does pin: the HIP path is no noisier than the CPU restatement (below).
+DEV_BOUND = 5.8e-2
 FP32_BOUND8 = 8.0e-2        # HIP (own bf16 encoders) vs the fp32 oracle, as for the two-row fixture
 
 
@@ -165,7 +169,8 @@ def test_full_depth_eight_rows_against_both_oracles():
           FP32_BOUND8, argmax disagreements only at oracle near-ties; free-running: tokens matched per row are REPORTED;
       (2) the check that can see a depth-dependent defect of the BACKBONE: HIP fed the fp32 oracle's encoder blocks vs the device-rounding
           restatement (same storage points, same pre-merged weights, CPU fp32 arithmetic) fed the same blocks, same teacher-forced history:
-          within DEV_BOUND - a fraction of the fp32 distance, because what remains is fp32 summation order amplified by bf16 re-rounding."""
+          within DEV_BOUND, and no further from the fp32 oracle than 1.5x the restatement's own distance from it (+5e-3) - a backbone that
+          accumulated a depth-dependent error would be noisier than the CPU implementation with the same storage points."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import time

@@ -20,6 +20,10 @@ BF = torch.bfloat16
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    import os
+    if os.environ.get("MC_GEMM_DEBUG"):                      # A/B builds of the kernel under the counters (e.g. 12344 = without the next-tile L2 warm-up)
+        from modelcompose_amd import _lib
+        _lib.lib().mc_gemm_debug(int(os.environ["MC_GEMM_DEBUG"]))
     import bench
     B = int(sys.argv[2]) if len(sys.argv) > 2 else bench.WORKLOADS["iav"][2]
     Hd, I = 4096, 11008
