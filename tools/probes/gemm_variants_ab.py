@@ -21,7 +21,8 @@ from modelcompose_amd import _lib, ops
 BF = torch.bfloat16
 L = _lib.lib()
 VAR = {"base": 4, "hyb": 4 + (7 << 3), "noX": 4 + (3 << 3), "noDMA": 4 + (1 << 3)}
-DISTS = {"r2_2222_prio": 0, "nowarm": 3}       # the round-2 main loop (2 / 2 / 2 / 2 + s_setprio); the shipped 0 / 2 / 3 / 3 with s_setprio back           # the shipped kernel deals 0 / 2 / 3 / 3; other distributions need their instantiation back in gemm.hip
+DISTS = {"nowarm": 3, "st_sc1": 5, "st_sc0sc1": 6}     # round 4: the epilogue's output stores with sc1 (write through, line dropped from L2) / sc0 sc1
+_OLD_DISTS = {"r2_2222_prio": 0, "nowarm": 3}       # the round-2 main loop (2 / 2 / 2 / 2 + s_setprio); the shipped 0 / 2 / 3 / 3 with s_setprio back           # the shipped kernel deals 0 / 2 / 3 / 3; other distributions need their instantiation back in gemm.hip
 for _k, _v in DISTS.items():
     VAR[_k] = 4 + (7 << 3) + (_v << 12)
 
