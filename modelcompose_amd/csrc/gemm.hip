@@ -552,19 +552,13 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
     mma(1, 0);
 }
 
-// 16-byte output store of the 256x256 kernel's epilogues.  STM 0: plain (the line stays in the XCD's L2); STM 1 (A/B build, ABL bit 9): `sc1` -
-// the store writes through and DROPS the line from L2 (MI355X_MICROARCH.md, "stores of each flavour"): a round of 256 tiles writes 4 MiB of
-// output per XCD, the whole capacity of its L2, through the cache that holds the operand slices of the tiles computing beside it.
-template <int STM>
-__device__ __forceinline__ void g2_store16(bf16_t* p, const u32x4& v) {
-    if constexpr (STM == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-    else if constexpr (STM == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-    else *(u32x4*)p = v;
-}
-
+// (Round 4, measured and NOT in the tree - profiles/r04_probes/gemm_store_sc1_ab.json: the epilogue's 16-byte output stores as `sc1` / `sc0 sc1`
+// (write through, line dropped from the XCD's L2, so that a round's 4 MiB of output per XCD does not pass through the cache that holds the
+// operand slices): -17 ... -43 % on every shape - the write-back L2 is what absorbs the 128 KiB per tile; residual rows by nontemporal
+// loads: -0.1 ... -0.9 % at K >= 4096, -9 % at K = 1024.)
 // wide epilogue of the 256x256 kernel for plain bf16 outputs (bias / activation / residual), one instantiation per activation class so
 // that no element walks a branch tree: every lane stores 16 bytes per block pair (v_permlane16_swap, see above)
-template <int ACTC, int BIASC, int RESC, int NI, bool SS = false, int STM = 0>
+template <int ACTC, int BIASC, int RESC, int NI, bool SS = false>
 __device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc)[2][4][2][2], bf16x4 (&res)[2][2][2][NI], bool has_res, int m0,
                                                  int n0, int M, int wave_m, int wave_n, int c16, int q4, float act_k) {
     const int nw = n0 + wave_n * (2 * NI * 16);
@@ -597,7 +591,7 @@ __device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc
                     auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
                     auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
                     const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                    if (live) g2_store16<STM>(orow + nb + (q4 & 1) * 16 + (q4 >> 1) * 8, o);
+                    if (live) *(u32x4*)(orow + nb + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
                 }
             if constexpr (SS) {
                 // this wave's 128 columns of row m: the four column quarters (q4) of the row, then one store per row
@@ -819,7 +813,6 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     // row, ALL residual values of the lane requested before the first store: one exposed memory latency per tile instead of one per row -
     // a workgroup owns its CU, so nothing else runs while its epilogue waits); everything else the 8-byte path.
     const bool wide = !ep.out_f32 && (n0 + NT <= N) && (ep.ldo % 8 == 0) && ((uintptr_t)ep.out % 16 == 0) && (NI % 2 == 0);
-    constexpr int STM_ = (ABL & 512) ? 1 : ((ABL & 2048) ? 2 : 0);         // A/B builds: output stores with sc1 / sc0 sc1
     if constexpr (NI == 4) {
         if (wide && ep.rope.q_out) {
             // RoPE + scatter (what rope_kv_kernel does to the stored q|k|v row): the values are rounded to bf16 first, exactly as the unfused
@@ -868,12 +861,12 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
                         auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
                         auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
                         const u32x4 o1 = {r0[0], r1[0], r0[1], r1[1]};
-                        if (put) g2_store16<STM_>(drow + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8, o1);
+                        if (put) *(u32x4*)(drow + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o1;
                         pa = __builtin_bit_cast(u32x2, v2[i]); pb = __builtin_bit_cast(u32x2, v2[i + 1]);
                         r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
                         r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
                         const u32x4 o2 = {r0[0], r1[0], r0[1], r1[1]};
-                        if (put) g2_store16<STM_>(drow + 64 + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8, o2);
+                        if (put) *(u32x4*)(drow + 64 + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o2;
                     }
                 }
             return;
@@ -923,10 +916,10 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
     if constexpr (NI % 2 == 0) {
         if (wide && !ep.swiglu) {
             // the common combinations get their own straight-line instantiation; the rest decide bias / residual per call
-#define G2_EPI(A, B, R) g2_epilogue_wide<A, B, R, NI, false, STM_>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k)
+#define G2_EPI(A, B, R) g2_epilogue_wide<A, B, R, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k)
             const bool hb = ep.bias != nullptr;
-            if (ep.ss_parts && NI == 4 && actc == 0 && !hb && has_res) g2_epilogue_wide<0, 0, 1, NI, true, STM_>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);   // LLM o / down + next norm's factor
-            else if (ep.ss_parts && NI == 4 && actc == 0) g2_epilogue_wide<0, -1, -1, NI, true, STM_>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
+            if (ep.ss_parts && NI == 4 && actc == 0 && !hb && has_res) g2_epilogue_wide<0, 0, 1, NI, true>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);   // LLM o / down + next norm's factor
+            else if (ep.ss_parts && NI == 4 && actc == 0) g2_epilogue_wide<0, -1, -1, NI, true>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
             else if (actc == 0 && !hb && !has_res) G2_EPI(0, 0, 0);            // LLM q|k|v (without the RoPE route), plain projections
             else if (actc == 0 && !hb && has_res) G2_EPI(0, 0, 1);        // LLM o / down
             else if (actc == 0 && hb && !has_res) G2_EPI(0, 1, 0);        // encoder q|k|v
@@ -959,7 +952,7 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
                         auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
                         auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
                         const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                        if (live) g2_store16<STM_>(orow + (f >> 1) * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8, o);
+                        if (live) *(u32x4*)(orow + (f >> 1) * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
                     }
                     continue;
                 }
@@ -1710,8 +1703,6 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<32, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<256, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1024, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<512, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<2048, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1745,8 +1736,6 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
             else if (((g_gemm_dbg >> 12) & 7) == 2) gemm_tile256_kernel<32, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // timing-only: no epilogue
             else if (((g_gemm_dbg >> 12) & 7) == 3) gemm_tile256_kernel<256, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // without the next-tile L2 warm-up
             else if (((g_gemm_dbg >> 12) & 7) == 4) gemm_tile256_kernel<1024, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // residual in 8-byte loads
-            else if (((g_gemm_dbg >> 12) & 7) == 5) gemm_tile256_kernel<512, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);    // output stores sc1 (round 4)
-            else if (((g_gemm_dbg >> 12) & 7) == 6) gemm_tile256_kernel<2048, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // output stores sc0 sc1
             else G2_LAUNCH(64);
             break;
         default: gemm_tile256_kernel<0, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster); break;

@@ -21,7 +21,7 @@ from modelcompose_amd import _lib, ops
 BF = torch.bfloat16
 L = _lib.lib()
 VAR = {"base": 4, "hyb": 4 + (7 << 3), "noX": 4 + (3 << 3), "noDMA": 4 + (1 << 3)}
-DISTS = {"nowarm": 3, "st_sc1": 5, "st_sc0sc1": 6}     # round 4: the epilogue's output stores with sc1 (write through, line dropped from L2) / sc0 sc1
+DISTS = {"nowarm": 3}          # round 4: st_sc1 (5), st_sc0sc1 (6), res_nt (7) measured and removed from gemm.hip: profiles/r04_probes/gemm_store_sc1_ab.json     # round 4: the epilogue's output stores with sc1 (write through, line dropped from L2) / sc0 sc1
 _OLD_DISTS = {"r2_2222_prio": 0, "nowarm": 3}       # the round-2 main loop (2 / 2 / 2 / 2 + s_setprio); the shipped 0 / 2 / 3 / 3 with s_setprio back           # the shipped kernel deals 0 / 2 / 3 / 3; other distributions need their instantiation back in gemm.hip
 for _k, _v in DISTS.items():
     VAR[_k] = 4 + (7 << 3) + (_v << 12)
@@ -69,25 +69,26 @@ def bench(shapes, variants, rounds=7, iters=6):
         w = ops.pack_weight((torch.randn(N, K, device="cuda") * K ** -0.5).to(BF))
         x = torch.randn(M, K, device="cuda").to(BF)
         out = torch.empty(M, N, dtype=BF, device="cuda")
-        bufs[(M, N, K)] = (w, x, out)
+        res_ = torch.randn(M, N, device="cuda").to(BF) if os.environ.get("MC_AB_RESIDUAL") and N == 4096 else None      # o / down carry a residual
+        bufs[(M, N, K)] = (w, x, out, res_)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # settle the clock
-    w, x, out = bufs[shapes[0]]
+    w, x, out, res_ = bufs[shapes[0]]
     for _ in range(30):
         ops.linear(x, w, out=out)
     torch.cuda.synchronize()
     for r in range(rounds):
         for shp in shapes:
-            w, x, out = bufs[shp]
+            w, x, out, res_ = bufs[shp]
             order = list(variants)
             random.Random(1000 * r + len(res)).shuffle(order)          # no variant always runs first after a shape switch
             for nm in order:
                 L.mc_gemm_debug(VAR[nm])
                 for _ in range(3):
-                    ops.linear(x, w, out=out)
+                    ops.linear(x, w, out=out, residual=res_)
                 e0.record()
                 for _ in range(iters):
-                    ops.linear(x, w, out=out)
+                    ops.linear(x, w, out=out, residual=res_)
                 e1.record()
                 torch.cuda.synchronize()
                 res.setdefault((shp, nm), []).append(e0.elapsed_time(e1) / iters * 1e-3)
