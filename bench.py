@@ -546,11 +546,14 @@ def launch_ranks(n: int, argv: list[str]) -> int:
     rank 0's stdout through, keeps the other ranks' output for the error case, and returns the worst exit status.  A rank that fails
     takes the others down (they would hang in the next collective)."""
     import subprocess
+    import tempfile
     port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
-    procs = []
+    procs, logs = [], []
     for r, (cmd, env) in enumerate(rank_commands(n, argv, port)):
-        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.PIPE, stderr=None if r == 0 else subprocess.STDOUT,
-                                      text=True))
+        # ranks > 0 write to a file, not a pipe nobody drains (a rank that fills a 64-KiB pipe with warnings would block inside a collective)
+        log = None if r == 0 else tempfile.TemporaryFile(mode="w+")
+        logs.append(log)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=log, stderr=None if r == 0 else subprocess.STDOUT, text=True))
     rc = 0
     alive = set(range(n))
     while alive:
@@ -562,10 +565,14 @@ def launch_ranks(n: int, argv: list[str]) -> int:
             if code != 0:
                 rc = rc or code
                 if r != 0:
-                    sys.stderr.write(f"[bench.py launcher] rank {r} exited with {code}:\n{(procs[r].stdout.read() or '')[-2000:]}\n")
+                    logs[r].seek(0)
+                    sys.stderr.write(f"[bench.py launcher] rank {r} exited with {code}:\n{logs[r].read()[-2000:]}\n")
                 for o in alive:                      # exact PIDs we started, nothing by pattern
                     procs[o].terminate()
         time.sleep(0.2)
+    for log in logs:
+        if log is not None:
+            log.close()
     return rc
 
 
