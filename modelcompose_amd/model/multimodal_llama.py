@@ -374,39 +374,63 @@ class MultimodalLlamaForCausalLM:
         modalities are skipped: the reference runs their encoder on zeros only as a ZeRO-3 workaround (:203-206)
         and never uses the result."""
         feats, masks = {}, {}
-        for modal in [m for m in self.modal_names if m != "default"]:
-            if modal not in inputs:
-                continue
-            encoder, projector = self.model.get_modal_encoder(modal), self.model.get_modal_projector(modal)
-            x = inputs[modal]
-            if type(x) is list:
-                if modal == "audio":
-                    x = torch.stack(x, dim=0)                          # :215
-                else:
-                    raise ValueError("list-of-tensors inputs are only defined for audio in the reference (:224-230 raises)")
-            if modal == "audio" and isinstance(x, dict):
-                f = encoder(**x)
-                f = f[0] if isinstance(f, tuple) else f                # :233-235
-                f = projector(f)
-            elif modal == "video":
-                f = encoder(x)                                         # b t n d
-                b, t, n, d = f.shape
-                f = projector(f.reshape(b, t * n, d))                  # :236-240
+        present = [m for m in self.modal_names if m != "default" and m in inputs]
+        # Round 4 (`encode_streams`, default on; MC_ENC_STREAMS=0 / model.encode_streams = False: one stream): the towers are independent, and the
+        # short ones run many launches of one or two rounds of tiles (BEATs: 288-384 tiles per GEMM) - on side streams their launches fill each
+        # other's partial rounds: 128.2 -> 123.5 ms for image + audio + video at B = 48 (in-process A/B, profiles/r04_probes/encode_streams_ab.json).
+        # Results are the same bits: every launch computes what it computes alone.
+        side = None
+        if len(present) > 1 and getattr(self, "encode_streams", os.environ.get("MC_ENC_STREAMS", "1") != "0") and torch.cuda.is_current_stream_capturing() is False:
+            cur = torch.cuda.current_stream()
+            pool = self._cache.get(("enc_streams",))
+            if pool is None or len(pool) < len(present):
+                pool = [torch.cuda.Stream(device=self.device) for _ in present]
+                self._cache[("enc_streams",)] = pool
+            side = dict(zip(present, pool))
+        for modal in present:
+            if side is not None:
+                side[modal].wait_stream(cur)
+                with torch.cuda.stream(side[modal]):
+                    f = self._encode_one(modal, inputs[modal], prefix_tokens, suffix_tokens)
+                f.record_stream(cur)
             else:
-                f = projector(encoder(x))
-            f = f.to(BF16)
-            b = f.shape[0]
-            parts = []
-            if prefix_tokens is not None and modal in prefix_tokens:
-                parts.append(prefix_tokens[modal].view(1, -1, f.shape[-1]).expand(b, -1, -1))
-            parts.append(f)
-            if suffix_tokens is not None and modal in suffix_tokens:
-                parts.append(suffix_tokens[modal].view(1, -1, f.shape[-1]).expand(b, -1, -1))
-            if len(parts) > 1:
-                f = _cat_rows(parts)
-            feats[modal] = f.contiguous()
-            masks[modal] = torch.ones(b, f.shape[1], device=f.device)
+                f = self._encode_one(modal, inputs[modal], prefix_tokens, suffix_tokens)
+            feats[modal] = f
+            masks[modal] = torch.ones(f.shape[0], f.shape[1], device=f.device)
+        if side is not None:
+            for modal in present:
+                cur.wait_stream(side[modal])
         return feats, masks
+
+    def _encode_one(self, modal, x, prefix_tokens, suffix_tokens):
+        """One modality: encoder -> projector -> cat(prefix, feat, suffix) on the current stream."""
+        encoder, projector = self.model.get_modal_encoder(modal), self.model.get_modal_projector(modal)
+        if type(x) is list:
+            if modal == "audio":
+                x = torch.stack(x, dim=0)                          # :215
+            else:
+                raise ValueError("list-of-tensors inputs are only defined for audio in the reference (:224-230 raises)")
+        if modal == "audio" and isinstance(x, dict):
+            f = encoder(**x)
+            f = f[0] if isinstance(f, tuple) else f                # :233-235
+            f = projector(f)
+        elif modal == "video":
+            f = encoder(x)                                         # b t n d
+            b, t, n, d = f.shape
+            f = projector(f.reshape(b, t * n, d))                  # :236-240
+        else:
+            f = projector(encoder(x))
+        f = f.to(BF16)
+        b = f.shape[0]
+        parts = []
+        if prefix_tokens is not None and modal in prefix_tokens:
+            parts.append(prefix_tokens[modal].view(1, -1, f.shape[-1]).expand(b, -1, -1))
+        parts.append(f)
+        if suffix_tokens is not None and modal in suffix_tokens:
+            parts.append(suffix_tokens[modal].view(1, -1, f.shape[-1]).expand(b, -1, -1))
+        if len(parts) > 1:
+            f = _cat_rows(parts)
+        return f.contiguous()
 
     def _plan(self, input_ids, attention_mask, labels, modal_inputs, feats) -> SplicePlan:
         ids = input_ids.detach().cpu().numpy()
