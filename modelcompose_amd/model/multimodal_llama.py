@@ -379,27 +379,46 @@ class MultimodalLlamaForCausalLM:
         # short ones run many launches of one or two rounds of tiles (BEATs: 288-384 tiles per GEMM) - on side streams their launches fill each
         # other's partial rounds: 128.2 -> 123.5 ms for image + audio + video at B = 48 (in-process A/B, profiles/r04_probes/encode_streams_ab.json).
         # Results are the same bits: every launch computes what it computes alone.
-        side = None
-        if len(present) > 1 and getattr(self, "encode_streams", os.environ.get("MC_ENC_STREAMS", "1") != "0") and torch.cuda.is_current_stream_capturing() is False:
+        use_streams = bool(present) and getattr(self, "encode_streams", os.environ.get("MC_ENC_STREAMS", "1") != "0") and \
+            torch.cuda.is_current_stream_capturing() is False
+        # (`encode_split` / MC_ENC_SPLIT = n > 1: every tower's batch in n parts on streams of their own, so that two half-batch chains fill each
+        # other's partly filled last rounds of tiles - measured and OFF: 127.9 ms one stream, 124-126 towers on side streams, **141.6** with halves,
+        # 132.2 with quarters (same bits): two launches of one GEMM interleaved on an XCD lose the raster's operand sharing in L2.)
+        nsplit = max(1, int(getattr(self, "encode_split", os.environ.get("MC_ENC_SPLIT", "1")))) if use_streams else 1
+        work = []                                                  # (modal, chunk of the modality's input)
+        for modal in present:
+            x = inputs[modal]
+            xb = x if torch.is_tensor(x) else (next(iter(x.values())) if isinstance(x, dict) and x else None)
+            nb = int(xb.shape[0]) if torch.is_tensor(xb) else 0
+            # (PointBERT keeps a per-sample FPS start index on the encoder: its batch stays whole)
+            if nsplit > 1 and modal != "point" and nb >= 8 * nsplit and (torch.is_tensor(x) or (isinstance(x, dict) and all(torch.is_tensor(v) and v.shape[0] == nb for v in x.values()))):
+                cuts = [nb * i // nsplit for i in range(nsplit + 1)]
+                for i0, i1 in zip(cuts[:-1], cuts[1:]):
+                    work.append((modal, x[i0:i1] if torch.is_tensor(x) else {k: v[i0:i1] for k, v in x.items()}))
+            else:
+                work.append((modal, x))
+        if not use_streams or len(work) < 2:
+            for modal, x in work:
+                feats[modal] = self._encode_one(modal, x, prefix_tokens, suffix_tokens)
+        else:
             cur = torch.cuda.current_stream()
             pool = self._cache.get(("enc_streams",))
-            if pool is None or len(pool) < len(present):
-                pool = [torch.cuda.Stream(device=self.device) for _ in present]
+            if pool is None or len(pool) < len(work):
+                pool = [torch.cuda.Stream(device=self.device) for _ in work]
                 self._cache[("enc_streams",)] = pool
-            side = dict(zip(present, pool))
-        for modal in present:
-            if side is not None:
-                side[modal].wait_stream(cur)
-                with torch.cuda.stream(side[modal]):
-                    f = self._encode_one(modal, inputs[modal], prefix_tokens, suffix_tokens)
+            parts = {}
+            for (modal, x), st in zip(work, pool):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    f = self._encode_one(modal, x, prefix_tokens, suffix_tokens)
                 f.record_stream(cur)
-            else:
-                f = self._encode_one(modal, inputs[modal], prefix_tokens, suffix_tokens)
-            feats[modal] = f
+                parts.setdefault(modal, []).append(f)
+            for st in pool[:len(work)]:
+                cur.wait_stream(st)
+            for modal, fl in parts.items():
+                feats[modal] = fl[0] if len(fl) == 1 else torch.cat(fl, dim=0)
+        for modal, f in feats.items():
             masks[modal] = torch.ones(f.shape[0], f.shape[1], device=f.device)
-        if side is not None:
-            for modal in present:
-                cur.wait_stream(side[modal])
         return feats, masks
 
     def _encode_one(self, modal, x, prefix_tokens, suffix_tokens):

@@ -58,26 +58,29 @@ def main():
         _lib.check(_lib.lib().mc_gemm_set_option(opt, 0), "set_option")
         res["ab"] = {"option": os.environ["MC_ENC_AB"], "off_ms": ab[0], "on_ms": ab[1]}
     if os.environ.get("MC_ENC_STREAMS_AB"):
-        # the towers on side streams (model.encode_streams) against one stream, interleaved rounds in this process; outputs compared bitwise
-        ab = {0: [], 1: []}
+        # the towers on side streams (model.encode_streams) / their batches in halves or quarters (model.encode_split) against one stream,
+        # interleaved rounds in this process; outputs compared bitwise
+        modes = {"one_stream": (False, 1), "streams": (True, 1), "streams_split2": (True, 2), "streams_split4": (True, 4)}
+        ab = {k: [] for k in modes}
         ref = None
         for _ in range(4):
-            for on in (0, 1):
-                model.encode_streams = bool(on)
+            for name, (on, sp) in modes.items():
+                model.encode_streams, model.encode_split = on, sp
                 f, _m = model.encode_modal_inputs(mi)
                 torch.cuda.synchronize()
                 if ref is None:
                     ref = {k: v.clone() for k, v in f.items()}
                 else:
-                    assert all(torch.equal(ref[k], f[k]) for k in ref), "side streams changed the features"
+                    assert all(torch.equal(ref[k], f[k]) for k in ref), f"{name} changed the features"
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(reps):
                     model.encode_modal_inputs(mi)
                 b.record()
                 torch.cuda.synchronize()
-                ab[on].append(round(a.elapsed_time(b) / reps, 3))
-        res["encode_streams_ab"] = {"one_stream_ms": ab[0], "side_streams_ms": ab[1], "bitwise_equal": True}
+                ab[name].append(round(a.elapsed_time(b) / reps, 3))
+        del model.encode_streams, model.encode_split
+        res["encode_streams_ab"] = {"ms": ab, "bitwise_equal": True}
     print(json.dumps(res))
 
 
