@@ -21,8 +21,9 @@ from modelcompose_amd import _lib, ops
 BF = torch.bfloat16
 L = _lib.lib()
 VAR = {"base": 4, "hyb": 4 + (7 << 3), "noX": 4 + (3 << 3), "noDMA": 4 + (1 << 3)}
-DISTS = {"nowarm": 3}
-TIMING_ONLY = {"no_epilogue": 2}       # wrong results: only timed.  (no_prologue: 5 and no_prologue_no_epilogue: 6 were ABL bit 14 builds, measured in round 4 and removed from gemm.hip: profiles/r04_probes/gemm_prologue_epilogue_ceiling.json)
+DISTS = {"nowarm": 3}       # round 4 probe builds (bits 12-14 = 5 .. 7), measured and removed from gemm.hip: sc1 / nt stores, prologue / epilogue ceilings, quarter of the
+# workgroups storing, first-round stagger within and across XCDs - profiles/r04_probes/gemm_*.json      # round 4: first-round workgroups delayed by group x delta (results identical)
+TIMING_ONLY = {"no_epilogue": 2}           # (quarter_of_wgs_store was bits 12-14 = 5 of a probe build: profiles/r04_probes/gemm_quarter_of_wgs_store.json)       # wrong results: only timed.  (no_prologue: 5 and no_prologue_no_epilogue: 6 were ABL bit 14 builds, measured in round 4 and removed from gemm.hip: profiles/r04_probes/gemm_prologue_epilogue_ceiling.json)
 for _k, _v in TIMING_ONLY.items():
     VAR[_k] = 4 + (7 << 3) + (_v << 12)          # round 4: st_sc1 (5), st_sc0sc1 (6), res_nt (7) measured and removed from gemm.hip: profiles/r04_probes/gemm_store_sc1_ab.json     # round 4: the epilogue's output stores with sc1 (write through, line dropped from L2) / sc0 sc1
 _OLD_DISTS = {"r2_2222_prio": 0, "nowarm": 3}       # the round-2 main loop (2 / 2 / 2 / 2 + s_setprio); the shipped 0 / 2 / 3 / 3 with s_setprio back           # the shipped kernel deals 0 / 2 / 3 / 3; other distributions need their instantiation back in gemm.hip
