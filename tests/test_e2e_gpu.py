@@ -153,6 +153,17 @@ def test_g8_four_modality_composed_model_matches_reference():
         assert feats[m].shape == a[f"feat_{m}"].shape
         # bf16 encoders (2-3 layers) + projector vs the fp32 reference; point: bf16 rounding of the coordinates on top
         within(f"6 feats[{m}]", feats[m], a[f"feat_{m}"], 2e-2)       # measured: audio 1.0e-2, video 8.9e-3, point 9.2e-3
+    # round 4: the towers run on side streams by default (each tower's launches fill the others' partly filled rounds of tiles); one stream,
+    # and a tower's batch split over streams, compute the same bits - every launch computes what it computes alone
+    assert getattr(model, "encode_streams", True)
+    for streams, split in ((False, 1), (True, 2)):
+        model.encode_streams, model.encode_split = streams, split
+        try:
+            f2, _ = model.encode_modal_inputs(mi, model.prefix_tokens, model.suffix_tokens)
+        finally:
+            del model.encode_streams, model.encode_split
+        for m in feats:
+            assert torch.equal(f2[m], feats[m]), (m, streams, split)
     ids = a["input_ids"].cuda()
     out = model.forward(input_ids=ids, modal_inputs=mi)
     assert out.logits.shape == a["logits_prefill"].shape
