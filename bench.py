@@ -594,11 +594,20 @@ def main():
                           "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "steps": args.steps}), flush=True)
         return
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # MC_BENCH_SHARE_GPU=1 + MC_BENCH_BACKEND=gloo (functional test only, never a measurement): N ranks on a box with fewer GPUs - rank r
+    # uses device r mod #devices and the collectives run over gloo (RCCL refuses two ranks on one device) - so that the N > 1 path of this
+    # file (launcher, barriers, MAX all-reduce of the timing, rank-major gather of the ids) runs with N real processes on the 1-GPU test box
+    if os.environ.get("MC_BENCH_SHARE_GPU") == "1":
+        local = local % torch.cuda.device_count()
+    backend = os.environ.get("MC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     if DIST or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gemm_debug:
         from modelcompose_amd import _lib as _l
         _l.lib().mc_gemm_debug(args.gemm_debug)

@@ -36,6 +36,11 @@ def gather_ids(ids: torch.Tensor, world_size: int, force: bool = False, pad_valu
     import torch.distributed as dist
     assert ids.dim() == 2, "gather_ids takes [rows, tokens]"
     ids = ids.contiguous()
+    if ids.is_cuda and dist.get_backend() == "gloo":
+        # gloo moves device tensors for broadcast / all-reduce only: gather on the host (functional multi-process tests on a box with fewer GPUs
+        # than ranks; the measured path is RCCL)
+        res = gather_ids(ids.cpu(), world_size, force=force, pad_value=pad_value, equal_shapes=equal_shapes, return_rows=return_rows)
+        return (res[0].to(ids.device), res[1]) if return_rows else res.to(ids.device)
     if equal_shapes:
         out = torch.empty((world_size * ids.shape[0], ids.shape[1]), dtype=ids.dtype, device=ids.device)
         dist.all_gather_into_tensor(out, ids)

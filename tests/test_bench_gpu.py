@@ -28,3 +28,17 @@ def test_bench_world_of_one_over_rccl():
 def test_bench_rejects_a_world_that_is_not_gpus():
     r = _bench(["--gpus", "2", "--layers", "2", "--steps", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def test_bare_launch_of_two_ranks_runs_the_n_rank_path_with_two_processes():
+    """`python bench.py --gpus 2` bare: the launcher starts two rank processes.  On this one-GPU box both share the device and
+    the collectives run over gloo (MC_BENCH_SHARE_GPU / MC_BENCH_BACKEND: functional only) - barriers, the MAX all-reduce of the timing and the
+    rank-major gather of the ids execute across two real processes, and rank 0's line reports the whole job: n_gpus 2, value = 2 x B x K / t."""
+    r = _bench(["--gpus", "2", "--layers", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--new-tokens", "4", "--no-profile",
+                "--no-cpu-baseline", "--no-secondary"], {"MC_BENCH_SHARE_GPU": "1", "MC_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                          # rank 0's line only
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["steps"] == 2
+    assert abs(j["value"] - 2 * 4 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-2 * j["value"]
