@@ -42,3 +42,14 @@ def test_bare_launch_of_two_ranks_runs_the_n_rank_path_with_two_processes():
     j = lines[0]
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["steps"] == 2
     assert abs(j["value"] - 2 * 4 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-2 * j["value"]
+
+
+def test_two_rank_finetune_step_all_reduces_the_gradients_across_two_processes():
+    """configs[4] with two real ranks (same functional set-up): the bucketed gradient all-reduce of the train step runs between two
+    processes, the line reports ddp2 and a finite loss."""
+    r = _bench(["--gpus", "2", "--workload", "train", "--layers", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-profile",
+                "--no-cpu-baseline", "--no-secondary"], {"MC_BENCH_SHARE_GPU": "1", "MC_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "ddp2" and j["value"] > 0
+    assert j["config"]["final_loss"] == j["config"]["final_loss"] and 0 < j["config"]["final_loss"] < 20       # finite
