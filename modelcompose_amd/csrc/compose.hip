@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t compose_hash(uint32_t x) {
 __device__ __forceinline__ bf16_t compose_round(float v, uint32_t seed, int n, int k) {
     if (seed == 0) return (bf16_t)v;
     uint32_t bits = __builtin_bit_cast(uint32_t, v);
-    if ((bits & 0x7f800000U) == 0x7f800000U) return (bf16_t)v;               // inf / nan: as the plain cast
+    if ((bits & 0x7f800000U) == 0x7f800000U || (bits & 0x7fff0000U) == 0x7f7f0000U) return (bf16_t)v;   // inf / nan, and the largest finite bf16 (the carry would make it inf): as the plain cast
     const uint32_t r = compose_hash(seed ^ compose_hash((uint32_t)n * 0x9E3779B1U + (uint32_t)k)) & 0xFFFFU;
     bits += r;                                                                // sign-magnitude: the magnitude goes up with probability frac / 2^16
     const uint16_t hi = (uint16_t)(bits >> 16);
