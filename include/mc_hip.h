@@ -183,7 +183,7 @@ int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgro
  * Infinity Cache across the sweep over M.  None of these changes results. */
 int mc_gemm_set_option(const char* name, int value);
 /* M <= 64 launches with more than 16 rows run gemm_rows_kernel (activations through LDS, K split over workgroups, fp32 slabs folded by the
- * last-arriving workgroup).  Its workspaces (8 x 50 MiB, one per launching stream so that concurrent streams share nothing) are allocated
+ * last-arriving workgroup).  Its workspaces (16 x 50 MiB, one per launching stream so that concurrent streams share nothing) are allocated
  * at the first such launch made outside stream capture; a launch that finds no workspace (first launch ever is inside a capture, or a
  * ninth live stream) keeps the older skinny kernel, whose fp32 summation order differs.  Call this once before capturing when the process may
  * capture before it has launched eagerly (mc_llm_create does).  Options "rows_kernel" (default 1) and "rows_min_mb" (default 2 = more

@@ -1608,7 +1608,7 @@ constexpr size_t kRowsSlabFloats = (size_t)12 << 20;          // 48 MiB of fp32 
 constexpr int kRowsMaxSplit = 8;
 constexpr size_t kRowsSsBytes = (size_t)kRowsMaxSplit * 64 * sizeof(float);
 std::vector<RowsWs> g_rows_ws;
-constexpr int kRowsPool = 8;
+constexpr int kRowsPool = 16;          // (round 4: 8 -> 16; default, capture, two pipeline and up to four tower streams already make 8)
 char* g_rows_pool = nullptr;
 }  // namespace
 

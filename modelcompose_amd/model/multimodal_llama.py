@@ -27,6 +27,20 @@ from .splice import SplicePlan, plan_splice, routed_layout
 BF16 = torch.bfloat16
 
 
+# Side streams are shared by every model instance of the process (one set per device): the library keeps per-stream state - the split-K
+# workspace of the 17-64-row GEMM kernel is handed out per launching stream from a pool of 16 (mc_gemm_reserve_rows) - so streams created per
+# model would exhaust it after a few instances and later launches would silently take the older kernel (other fp32 summation order).
+_STREAM_POOLS: Dict = {}
+
+
+def _shared_streams(device, kind: str, n: int):
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), kind)
+    pool = _STREAM_POOLS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 def _serialised(fn):
     """generate() / forward() drive the C handle through per-handle one-shot state (tail_adapter, key mask, sampling): calls on one model
     are serialised by the model's re-entrant lock, which a ContinuousBatcher that owns the model takes around its admissions and decode
@@ -402,10 +416,7 @@ class MultimodalLlamaForCausalLM:
                 feats[modal] = self._encode_one(modal, x, prefix_tokens, suffix_tokens)
         else:
             cur = torch.cuda.current_stream()
-            pool = self._cache.get(("enc_streams",))
-            if pool is None or len(pool) < len(work):
-                pool = [torch.cuda.Stream(device=self.device) for _ in work]
-                self._cache[("enc_streams",)] = pool
+            pool = _shared_streams(self.device, "encode", len(work))
             parts = {}
             for (modal, x), st in zip(work, pool):
                 st.wait_stream(cur)
@@ -926,10 +937,7 @@ class MultimodalLlamaForCausalLM:
         units.  Same tokens as sequential generate() calls; host syncs inside generate() (EOS checks without ignore_eos) shorten the
         overlap but do not break it."""
         cur = torch.cuda.current_stream()
-        streams = self._cache.get(("pipe_streams",))
-        if streams is None:
-            streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
-            self._cache[("pipe_streams",)] = streams
+        streams = _shared_streams(self.device, "pipeline", 2)
         pending = None
         last_prefill = None
         for i, item in enumerate(batches):

@@ -106,7 +106,11 @@ class MultimodalTrainStep:
         self.step_count = 0
         # weight-gradient (TN) GEMMs run on a second HIP stream: they only feed the gradient buffer, so they overlap the main stream's
         # input-gradient GEMMs, which at B*L = 2728 rows fill only 176 of the 256 CUs
-        self._wstream = torch.cuda.Stream(device=self.dev) if overlap_wgrad else None
+        if overlap_wgrad:
+            from ..model.multimodal_llama import _shared_streams       # one side stream per device, shared by every instance (library per-stream state)
+            self._wstream = _shared_streams(self.dev, "train_side", 1)[0]
+        else:
+            self._wstream = None
         self._build_frozen()
         self._build_trainable()
         self._buckets = bucket_ranges(self.layer_end, cfg.num_hidden_layers, bucket_layers, self.n_params)
