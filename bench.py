@@ -42,6 +42,31 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def pin_rank_cpus(environ=None, apply=True):
+    """Per-rank CPU affinity, set in the rank process BEFORE torch is imported (its thread pools size themselves from the affinity mask):
+    rank r of the node's W ranks takes the r-th contiguous block of the cores this process may run on.  Every rank issues several hundred
+    encoder launches per batch from Python; eight unpinned ranks on one host migrate across sockets and contend for the same cores
+    (the reference pins nothing: scripts/model_composition/test/MCUB-4.sh:42-58 just backgrounds one worker per GPU).  MC_BENCH_PIN=0 turns
+    it off.  Returns the core list (None = not pinned)."""
+    env = os.environ if environ is None else environ
+    r, w = env.get("LOCAL_RANK"), env.get("LOCAL_WORLD_SIZE") or env.get("WORLD_SIZE")
+    if r is None or w is None or env.get("MC_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_getaffinity"):
+        return None
+    r, w = int(r), int(w)
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // max(w, 1)
+    if w < 2 or per < 1 or not 0 <= r < w:
+        return None
+    mine = cpus[r * per:(r + 1) * per]
+    if apply:
+        os.sched_setaffinity(0, mine)
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(per, 32)))
+    return mine
+
+
+PINNED_CPUS = pin_rank_cpus() if __name__ == "__main__" else None
+
 import torch  # noqa: E402
 
 # MC_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL init, barriers, gathers, the MAX all-reduce of the timing) in a world of one
@@ -278,21 +303,32 @@ def train_main(args, world, rank, local):
             # ones) and one HIP-event bracket per gemm_tile256_kernel launch
             from modelcompose_amd import _lib
             L_ = _lib.lib()
+            # (with no side stream forward_backward would leave the tile choice at its default - 192-column tiles for these under-filled
+            # launches - while the timed steps, which fill the idle CUs from the side stream, run 256-column tiles: the bracketed launches are
+            # kept on the timed steps' tile choice.  The two extra optimizer steps come after final_loss has been taken.)
+            final_loss = float(loss.item())
             ws, st._wstream = st._wstream, None
+            tile_opt = 0 if ws is not None else 1
             torch.cuda.synchronize()
+            L_.mc_gemm_set_option(b"tile192", tile_opt)
             L_.mc_gemm_profile_enable(1)
-            for _ in range(2):
-                st.step(ids, labels, {"vision": pixels})
-            torch.cuda.synchronize()
-            L_.mc_gemm_profile_enable(0)
-            st._wstream = ws
+            try:
+                for _ in range(2):
+                    st.step(ids, labels, {"vision": pixels})
+                torch.cuda.synchronize()
+            finally:
+                L_.mc_gemm_profile_enable(0)
+                L_.mc_gemm_set_option(b"tile192", 1)
+                st._wstream = ws
             ms_, fl_, n_ = C.c_double(0), C.c_double(0), C.c_int64(0)
             L_.mc_gemm_profile_read(C.byref(ms_), C.byref(fl_), C.byref(n_))
             ach = (fl_.value / max(ms_.value, 1e-9)) / 1e9
             roof["dominant_kernel"] = {"kernel": "gemm_tile256_kernel", "achieved": round(ach, 2), "unit": "TFLOP/s",
                                        "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "launches_per_step": int(n_.value // 2),
                                        "ms_per_step": round(ms_.value / 2, 3), "flops_per_step_launched": fl_.value / 2,
-                                       "note": "HIP events per launch, non-overlapped pass (the timed steps overlap weight-gradient GEMMs on a side stream)"}
+                                       "tile192_option": tile_opt,
+                                       "note": "HIP events per launch, non-overlapped pass (the timed steps overlap weight-gradient GEMMs on a side stream); "
+                                               "same tile selection as the timed steps"}
         print(json.dumps({
             "metric": "samples/sec (whole node) stage-2 finetune step, composed Vicuna-7B", "value": round(world * B * args.steps / dt, 4),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -300,7 +336,7 @@ def train_main(args, world, rank, local):
             "config": {"workload": "configs[4]: stage-2 finetune step, vision LocalLoRA Vicuna-7B (r128, default+vision adapters), "
                                    f"batch {B} per GPU, 683-token sequences, fwd+bwd+all-reduce+AdamW", "per_gpu_batch": B,
                        "layers": args.layers, "parallelism": f"ddp{world}", "trainable_params": int(st.n_params),
-                       "final_loss": float(loss.item())},
+                       "final_loss": final_loss if not args.no_profile else float(loss.item())},
             "roofline": roof}), flush=True)
     if DIST or world > 1:
         torch.distributed.destroy_process_group()
@@ -541,38 +577,92 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(n: int, argv: list[str]) -> int:
+def launch_ranks(n: int, argv: list[str], deadline_s: float | None = None) -> int:
     """Parent of an N-rank run.  Never touches the GPU (no HIP call, no torch.cuda.is_available()): it only starts the children, passes
     rank 0's stdout through, keeps the other ranks' output for the error case, and returns the worst exit status.  A rank that fails
-    takes the others down (they would hang in the next collective)."""
+    takes the others down (they would hang in the next collective).  Clean-up is unconditional: every child runs in its own
+    session (a signal aimed at the parent's group does not reach it half-way through a collective), and whatever ends the parent - the
+    poll loop's own verdict, SIGTERM / SIGINT / SIGHUP from a caller's timeout, an exception, the wall-clock deadline
+    (MC_BENCH_LAUNCH_TIMEOUT seconds, default 7200) - terminates the exact PIDs it started, then kills what is left after a grace period."""
+    import signal
     import subprocess
     import tempfile
     port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("MC_BENCH_LAUNCH_TIMEOUT", "7200"))
     procs, logs = [], []
-    for r, (cmd, env) in enumerate(rank_commands(n, argv, port)):
-        # ranks > 0 write to a file, not a pipe nobody drains (a rank that fills a 64-KiB pipe with warnings would block inside a collective)
-        log = None if r == 0 else tempfile.TemporaryFile(mode="w+")
-        logs.append(log)
-        procs.append(subprocess.Popen(cmd, env=env, stdout=log, stderr=None if r == 0 else subprocess.STDOUT, text=True))
+
+    def reap(grace=5.0):
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            try:
+                p.terminate()
+            except OSError:
+                pass
+        t_end = time.time() + grace
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    p.kill()
+                    p.wait(timeout=5)
+                except (OSError, subprocess.TimeoutExpired):
+                    pass
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Stop(signum)
+
+    old_handlers = {}
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            old_handlers[sg] = signal.signal(sg, on_signal)
+        except (ValueError, OSError):            # not the main thread: the finally clause below still cleans up
+            pass
     rc = 0
-    alive = set(range(n))
-    while alive:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            alive.discard(r)
-            if code != 0:
-                rc = rc or code
-                if r != 0:
-                    logs[r].seek(0)
-                    sys.stderr.write(f"[bench.py launcher] rank {r} exited with {code}:\n{logs[r].read()[-2000:]}\n")
-                for o in alive:                      # exact PIDs we started, nothing by pattern
-                    procs[o].terminate()
-        time.sleep(0.2)
-    for log in logs:
-        if log is not None:
-            log.close()
+    t_start = time.time()
+    try:
+        for r, (cmd, env) in enumerate(rank_commands(n, argv, port)):
+            # ranks > 0 write to a file, not a pipe nobody drains (a rank that fills a 64-KiB pipe with warnings would block inside a collective)
+            log = None if r == 0 else tempfile.TemporaryFile(mode="w+")
+            logs.append(log)
+            procs.append(subprocess.Popen(cmd, env=env, stdout=log, stderr=None if r == 0 else subprocess.STDOUT, text=True,
+                                          start_new_session=True))
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    if r != 0:
+                        logs[r].seek(0)
+                        sys.stderr.write(f"[bench.py launcher] rank {r} exited with {code}:\n{logs[r].read()[-2000:]}\n")
+                    for o in alive:                      # exact PIDs we started, nothing by pattern
+                        procs[o].terminate()
+            if alive and time.time() - t_start > deadline_s:
+                sys.stderr.write(f"[bench.py launcher] ranks {sorted(alive)} still running after {deadline_s:.0f} s: tearing the job down\n")
+                rc = rc or 124
+                break
+            time.sleep(0.2)
+    except _Stop as e:
+        sys.stderr.write(f"[bench.py launcher] signal {e.args[0]}: stopping {sum(p.poll() is None for p in procs)} rank(s)\n")
+        rc = rc or 128 + int(e.args[0])
+    finally:
+        reap()
+        for sg, h in old_handlers.items():
+            try:
+                signal.signal(sg, h)
+            except (ValueError, OSError):
+                pass
+        for log in logs:
+            if log is not None:
+                log.close()
     return rc
 
 
@@ -590,8 +680,14 @@ def main():
                          f"starts the ranks itself)")
     if os.environ.get("MC_BENCH_LAUNCH_PROBE") == "1":
         # launcher self-test (tests/test_bench_launcher_cpu.py): a rank reports the environment it was started with and leaves, GPU untouched
-        print(json.dumps({"probe": True, "rank": rank, "local_rank": local, "world": world, "gpus": args.gpus,
-                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "steps": args.steps}), flush=True)
+        print(json.dumps({"probe": True, "rank": rank, "local_rank": local, "world": world, "gpus": args.gpus, "pid": os.getpid(),
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "steps": args.steps,
+                          "cpus": PINNED_CPUS}), flush=True)
+        pf = os.environ.get("MC_BENCH_PROBE_PIDFILE")
+        if pf:                                           # launcher clean-up tests: every rank leaves its pid, then waits to be stopped
+            with open(f"{pf}.{rank}", "w") as f:
+                f.write(str(os.getpid()))
+            time.sleep(float(os.environ.get("MC_BENCH_PROBE_SLEEP", "0")))
         return
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # MC_BENCH_SHARE_GPU=1 + MC_BENCH_BACKEND=gloo (functional test only, never a measurement): N ranks on a box with fewer GPUs - rank r

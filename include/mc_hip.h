@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 8
+#define MC_ABI_VERSION 9
 
 /* activation codes for mc_gemm_bf16 */
 #define MC_ACT_NONE 0
@@ -185,7 +185,7 @@ int mc_gemm_set_option(const char* name, int value);
 /* M <= 64 launches with more than 16 rows run gemm_rows_kernel (activations through LDS, K split over workgroups, fp32 slabs folded by the
  * last-arriving workgroup).  Its workspaces (16 x 50 MiB, one per launching stream so that concurrent streams share nothing) are allocated
  * at the first such launch made outside stream capture; a launch that finds no workspace (first launch ever is inside a capture, or a
- * ninth live stream) keeps the older skinny kernel, whose fp32 summation order differs.  Call this once before capturing when the process may
+ * seventeenth live stream) keeps the older skinny kernel, whose fp32 summation order differs.  Call this once before capturing when the process may
  * capture before it has launched eagerly (mc_llm_create does).  Options "rows_kernel" (default 1) and "rows_min_mb" (default 2 = more
  * than 16 rows) of mc_gemm_set_option switch the kernel off / move the threshold. */
 int mc_gemm_reserve_rows(void* stream);
@@ -304,6 +304,13 @@ int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t 
                              int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B, int H, int Hkv, int Lq,
                              int S, int D, int causal, int q_offset, float scale, const float* rel_table, int rel_stride, int rel_off,
                              const float* q_gate, float* lse, void* stream);
+/* The attention probabilities themselves (output_attentions=True: `attn_weights` of LocalLoraAttention.forward, multimodal_llama.py:295-312 -
+ * softmax in fp32 over the scaled, masked scores, cast to the model dtype): probs [B, H, Lq, S] bf16, row (b, h, i) = softmax_j(scale q_i.k_j)
+ * over the keys j < kv_lens[b] (NULL: S) that pass the causal test j <= i + q_offset (causal != 0) and the optional key_valid [B][kv_stride]
+ * bytes; masked entries are 0.  A debugging / analysis output, not on the generation path: one wave per (b, h, query) row, O(Lq S D). */
+int mc_attn_probs_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                       const int32_t* kv_lens, const void* key_valid, int64_t kv_stride, void* probs, int B, int H, int Hkv, int Lq, int S,
+                       int D, int causal, int q_offset, float scale, void* stream);
 int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* bytes);
 int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st, int64_t k_sh,
                         const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o, int64_t o_sb, void* workspace,
@@ -458,6 +465,13 @@ int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_
  * batch's attention mask when it is not a suffix mask - left-padded batches, masks with holes.  key_valid [B][row_stride >= Smax] bytes over
  * CACHE positions (generated positions must be 1).  A decode call with a mask runs one launch per kernel (no graph replay). */
 int mc_llm_set_key_mask(void* handle, const void* key_valid, int64_t row_stride);
+/* One-shot capture for the NEXT mc_llm_prefill call (forward(output_hidden_states / output_attentions), multimodal_llama.py:561-604, :676-688):
+ * hidden_snapshots (may be NULL) receives n_layers + 1 copies of the routed hidden state [M, hidden] bf16 - index 0 the input embeddings,
+ * index l + 1 the output of decoder layer l (un-normed; the reference's last tuple entry is the final norm of index n_layers, which the
+ * call returns in hidden_out); q_snapshots (may be NULL) receives every layer's rotated queries [B, Lq, H, D] bf16 in sequence order (with
+ * the layer's keys, which stay in the KV cache, they give the attention probabilities: mc_attn_probs_bf16).  A capturing call runs every
+ * layer for every row (no last-layer tail). */
+int mc_llm_set_capture(void* handle, void* hidden_snapshots, void* q_snapshots);
 int mc_llm_workspace_bytes(void* handle, int M, int B, int Lq, int64_t* bytes);
 /* Prefill over M rows in routed order.  group_start / group_adapter are HOST arrays (n_groups+1 / n_groups); the other
  * int32 arrays are device arrays: row_b/row_pos/row_t [M], out_map [B*Lq] (sequence slot -> routed row, -1 = padding),

@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -168,6 +168,8 @@ _SIGS.update({
     "mc_ckpt_scalar": [c_p, c_i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(c_i), C.POINTER(c_l), C.POINTER(C.c_double),
                        C.POINTER(c_p), C.POINTER(c_l)],
     "mc_llm_profile_read": [c_p, c_i, C.POINTER(C.c_double), C.POINTER(c_l)],
+    "mc_llm_set_capture": [c_p, c_p, c_p],
+    "mc_attn_probs_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
 })
 # optional symbols added by later ABI revisions are bound if present
 _OPTIONAL: dict = {}

@@ -744,6 +744,11 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
                                         int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
                                         const float* rel_table, int rel_stride, int rel_off, const float* q_gate, float* lse,
                                         void* stream) {
+    // the one-shot states are taken (and so cleared) BEFORE any argument check: a refused call consumes them too, they can never reach a later launch
+    const uint8_t* kv_once = nullptr; int64_t kv_once_sb = 0;
+    take_key_mask(kv_once, kv_once_sb);
+    const int b_inner_once = g_b_inner; const int64_t sbi_once = g_sbi;
+    g_b_inner = 0; g_sbi = 0;
     MC_CHECK_ARG(q && k && v && o, "mc_attn_prefill_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_prefill_bf16: head_dim %d not supported (64 or 128)", D);
     MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Lq > 0 && S > 0, "mc_attn_prefill_bf16: bad shape");
@@ -752,9 +757,8 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
     AttnParams p{(const bf16_t*)q, q_sb, q_st, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
                  (bf16_t*)o, o_row_stride, out_map, kv_lens, B, H, Hkv, Lq, S, causal, q_offset,
                  scale * 1.4426950408889634f, rel_table, q_gate, rel_stride, rel_off, lse};
-    take_key_mask(p.key_valid, p.key_valid_sb);
-    p.b_inner = g_b_inner; p.sbi = g_sbi;
-    g_b_inner = 0; g_sbi = 0;
+    p.key_valid = kv_once; p.key_valid_sb = kv_once_sb;
+    p.b_inner = b_inner_once; p.sbi = sbi_once;
     MC_CHECK_ARG(p.b_inner == 0 || (Lq <= 8 && S <= 8 && !rel_table && !p.key_valid && B % p.b_inner == 0),
                  "mc_attn_prefill_bf16: a two-level batch index (mc_attn_set_batch_split) is only defined for the Lq, S <= 8 kernel");
     hipStream_t s = (hipStream_t)stream;
@@ -825,6 +829,11 @@ extern "C" int mc_attn_prefill_dropout_bf16(const void* q, int64_t q_sb, int64_t
                                             void* o, int64_t o_row_stride, const int32_t* kv_lens, int B, int H, int Hkv, int Lq, int S, int D,
                                             int causal, int q_offset, float scale, float* lse, float dropout_p, unsigned long long seed,
                                             unsigned int stream_id, void* stream) {
+    const uint8_t* kv_once = nullptr; int64_t kv_once_sb = 0;
+    take_key_mask(kv_once, kv_once_sb);                    // one-shot states: consumed before any check (see mc_attn_prefill_lse_bf16)
+    const int b_inner_once = g_b_inner;
+    g_b_inner = 0; g_sbi = 0;
+    MC_CHECK_ARG(b_inner_once == 0, "mc_attn_prefill_dropout_bf16: a two-level batch index (mc_attn_set_batch_split) is not defined for this launch");
     MC_CHECK_ARG(q && k && v && o, "mc_attn_prefill_dropout_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_prefill_dropout_bf16: head_dim %d not supported (64 or 128)", D);
     MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Lq > 0 && S > 0 && S % 4 == 0, "mc_attn_prefill_dropout_bf16: bad shape (S must be a multiple of 4)");
@@ -836,7 +845,7 @@ extern "C" int mc_attn_prefill_dropout_bf16(const void* q, int64_t q_sb, int64_t
                  scale * 1.4426950408889634f, nullptr, nullptr, 0, 0, lse};
     const double t = (double)dropout_p * 4294967296.0;
     p.drop = AttnDropout{t >= 4294967295.0 ? 4294967295u : (uint32_t)t, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, 1.0f / (1.0f - dropout_p)};
-    take_key_mask(p.key_valid, p.key_valid_sb);
+    p.key_valid = kv_once; p.key_valid_sb = kv_once_sb;
     dim3 grid((Lq + 63) / 64, H, B);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) attn_prefill_kernel<128, false, 4, 1, true><<<grid, 256, 4 * 64 * 256, s>>>(p);
@@ -854,6 +863,79 @@ extern "C" int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, i
                                     H, Hkv, Lq, S, D, causal, q_offset, scale, rel_table, rel_stride, rel_off, q_gate, nullptr, stream);
 }
 
+// ------------------------------------------------------------------------------------------
+// output_attentions: the probabilities themselves (`attn_weights` of LocalLoraAttention.forward, multimodal_llama.py:295-312).  Not on the
+// generation path - the flash kernels above never materialise them - so this is the plain form: one wave per (b, h, query) row, a key per
+// lane, two sweeps over the keys (online max / sum, then exp(s - max) / sum rounded to the storage type).  Masked entries are exact zeros.
+struct ProbsParams {
+    const bf16_t* q; int64_t q_sb, q_st, q_sh; const bf16_t* k; int64_t k_sb, k_st, k_sh;
+    const int32_t* kv_lens; const uint8_t* key_valid; int64_t kv_stride; bf16_t* out;
+    int B, H, Hkv, Lq, S, causal, q_offset; float scale_log2;
+};
+template <int D>
+__global__ __launch_bounds__(256) void attn_probs_kernel(ProbsParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t qs[4][D];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4LL + wave;
+    const bool on = row < (int64_t)p.B * p.H * p.Lq;
+    const int64_t rr = on ? row : 0;
+    const int i = (int)(rr % p.Lq), h = (int)((rr / p.Lq) % p.H), b = (int)(rr / p.Lq / p.H);
+    const int hk = h / (p.H / p.Hkv);
+    if (lane < D / 8) *(bf16x8*)&qs[wave][lane * 8] = *(const bf16x8*)(p.q + b * p.q_sb + (int64_t)i * p.q_st + h * p.q_sh + lane * 8);
+    __syncthreads();
+    if (!on) return;
+    int limit = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
+    if (p.causal) limit = min(limit, i + p.q_offset + 1);
+    const bf16_t* kb = p.k + b * p.k_sb + hk * p.k_sh;
+    const uint8_t* kv = p.key_valid ? p.key_valid + b * p.kv_stride : nullptr;
+    auto score = [&](int j) -> float {
+        const bf16_t* kr = kb + (int64_t)j * p.k_st;
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) {
+            const bf16x8 kk = *(const bf16x8*)(kr + c * 8), qq = *(const bf16x8*)&qs[wave][c * 8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf((float)qq[e], (float)kk[e], a);
+        }
+        return a * p.scale_log2;
+    };
+    float m = NEG_BIG, l = 0.f;
+    for (int j = lane; j < limit; j += 64) {
+        if (kv && !kv[j]) continue;
+        const float sc = score(j);
+        const float mn = fmaxf(m, sc);
+        l = l * fast_exp2(m - mn) + fast_exp2(sc - mn);
+        m = mn;
+    }
+    const float mw = wave_max(m);
+    l = wave_sum(l * (m > NEG_BIG ? fast_exp2(m - mw) : 0.f));
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    bf16_t* orow = p.out + row * (int64_t)p.S;
+    for (int j = lane; j < p.S; j += 64) {
+        float pr = 0.f;
+        if (j < limit && !(kv && !kv[j])) pr = fast_exp2(score(j) - mw) * inv;
+        orow[j] = (bf16_t)pr;
+    }
+}
+
+extern "C" int mc_attn_probs_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                                  const int32_t* kv_lens, const void* key_valid, int64_t kv_stride, void* probs, int B, int H, int Hkv, int Lq, int S,
+                                  int D, int causal, int q_offset, float scale, void* stream) {
+    MC_CHECK_ARG(q && k && probs, "mc_attn_probs_bf16: null pointer");
+    MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_probs_bf16: head_dim %d not supported (64 or 128)", D);
+    MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Lq > 0 && S > 0, "mc_attn_probs_bf16: bad shape");
+    MC_CHECK_ARG((q_st % 8 | q_sh % 8 | k_st % 8 | k_sh % 8 | q_sb % 8 | k_sb % 8) == 0, "mc_attn_probs_bf16: strides must be multiples of 8 elements");
+    MC_CHECK_ARG(!key_valid || kv_stride >= S, "mc_attn_probs_bf16: key mask rows shorter than S");
+    ProbsParams p{(const bf16_t*)q, q_sb, q_st, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, kv_lens, (const uint8_t*)key_valid, kv_stride,
+                  (bf16_t*)probs, B, H, Hkv, Lq, S, causal, q_offset, scale * 1.4426950408889634f};
+    const int64_t rows = (int64_t)B * H * Lq;
+    MC_CHECK_ARG((rows + 3) / 4 < (1LL << 31), "mc_attn_probs_bf16: too many rows");
+    if (D == 128) attn_probs_kernel<128><<<(int)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(p);
+    else attn_probs_kernel<64><<<(int)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(p);
+    MC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* bytes) {
     *bytes = (int64_t)B * H * nsplit * (D + 2) * 4;
     return 0;
@@ -863,6 +945,8 @@ extern "C" int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, co
                                    int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
                                    int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S,
                                    int D, int nsplit, float scale, void* stream) {
+    const uint8_t* kv_once = nullptr; int64_t kv_once_sb = 0;
+    take_key_mask(kv_once, kv_once_sb);                    // consumed before any check
     MC_CHECK_ARG(q && k && v && o, "mc_attn_decode_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_decode_bf16: head_dim %d not supported (64 or 128)", D);
     MC_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || workspace), "mc_attn_decode_bf16: nsplit>1 needs a workspace");
@@ -870,7 +954,7 @@ extern "C" int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, co
     DecodeParams p{(const bf16_t*)q, q_sb, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
                    (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
                    nullptr, 0, nullptr, nullptr, nullptr, nullptr};
-    take_key_mask(p.key_valid, p.key_valid_sb);
+    p.key_valid = kv_once; p.key_valid_sb = kv_once_sb;
     dim3 grid(B * H, nsplit);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) {
@@ -891,6 +975,8 @@ static int attn_decode_rope_impl(const void* qkv, int64_t qkv_ld, const mc_slab_
                                  int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
                                  void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
                                  int nsplit, float scale, void* stream) {
+    const uint8_t* kv_once = nullptr; int64_t kv_once_sb = 0;
+    take_key_mask(kv_once, kv_once_sb);                    // consumed before any check
     MC_CHECK_ARG((qkv || sl) && cos_table && sin_table && k_cache && v_cache && o && kv_lens, "mc_attn_decode_rope_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_decode_rope_bf16: head_dim %d not supported (64 or 128)", D);
     MC_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || workspace), "mc_attn_decode_rope_bf16: nsplit>1 needs a workspace");
@@ -901,7 +987,7 @@ static int attn_decode_rope_impl(const void* qkv, int64_t qkv_ld, const mc_slab_
                    (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
                    (const bf16_t*)qkv, qkv_ld, cos_table, sin_table, (bf16_t*)k_cache, (bf16_t*)v_cache,
                    sl ? sl->slabs : nullptr, sl ? sl->ssp : nullptr, sl ? sl->S : 0, sl ? sl->N : 0, sl ? sl->K : 0, sl ? sl->rms_eps : 0.f};
-    take_key_mask(p.key_valid, p.key_valid_sb);
+    p.key_valid = kv_once; p.key_valid_sb = kv_once_sb;
     dim3 grid(B * H, nsplit);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) {
@@ -919,7 +1005,6 @@ extern "C" int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const f
                                         int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
                                         void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
                                         int nsplit, float scale, void* stream) {
-    MC_CHECK_ARG(qkv, "mc_attn_decode_rope_bf16: null pointer");
     return attn_decode_rope_impl(qkv, qkv_ld, nullptr, cos_table, sin_table, k_cache, k_sb, k_st, k_sh, v_cache, v_sb, v_st, v_sh, o, o_sb, workspace,
                                  kv_lens, B, H, Hkv, S, D, nsplit, scale, stream);
 }
@@ -929,7 +1014,6 @@ extern "C" int mc_attn_decode_rope_slabs_bf16(const mc_slab_ref* qkv_slabs, cons
                                               int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
                                               void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
                                               int nsplit, float scale, void* stream) {
-    MC_CHECK_ARG(qkv_slabs, "mc_attn_decode_rope_slabs_bf16: null pointer");
     return attn_decode_rope_impl(nullptr, 0, qkv_slabs, cos_table, sin_table, k_cache, k_sb, k_st, k_sh, v_cache, v_sb, v_st, v_sh, o, o_sb, workspace,
                                  kv_lens, B, H, Hkv, S, D, nsplit, scale, stream);
 }

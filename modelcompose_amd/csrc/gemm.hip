@@ -1388,6 +1388,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 // Optional live timing of the dominant kernel (gemm_tile256_kernel): HIP events recorded on the launch stream around every launch while
 // enabled (bench.py's roofline object).  Not graph-capturable; leave disabled in normal operation.
@@ -1608,15 +1609,17 @@ constexpr size_t kRowsSlabFloats = (size_t)12 << 20;          // 48 MiB of fp32 
 constexpr int kRowsMaxSplit = 8;
 constexpr size_t kRowsSsBytes = (size_t)kRowsMaxSplit * 64 * sizeof(float);
 std::vector<RowsWs> g_rows_ws;
+std::mutex g_rows_mu;                  // the slot table is touched from every launching thread (tower / pipeline streams, serving threads)
 constexpr int kRowsPool = 16;          // (round 4: 8 -> 16; default, capture, two pipeline and up to four tower streams already make 8)
 char* g_rows_pool = nullptr;
 }  // namespace
 
 // The workspace of a stream: a pool of kRowsPool equal workspaces is allocated at the first rows launch (or mc_gemm_reserve_rows) made
 // while the calling stream is not capturing; every stream that launches the kernel is given its own slot then (host bookkeeping only, so a
-// stream met for the first time during capture still gets one).  Concurrent streams never share slabs; a ninth stream, or a
+// stream met for the first time during capture still gets one).  Concurrent streams never share slabs; a stream beyond the pool, or a
 // first launch inside a capture, keeps the skinny kernel.
 static char* rows_workspace(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_rows_mu);
     for (auto& w : g_rows_ws) if (w.stream == s) return w.base;
     const size_t bytes = kRowsSsBytes + kRowsSlabFloats * sizeof(float);
     if (!g_rows_pool) {
@@ -1637,6 +1640,7 @@ static char* rows_workspace(hipStream_t s) {
 
 // a destroyed stream gives its slot back (its launches have completed: the caller synchronised before destroying it)
 extern "C" int mc_gemm_release_rows(void* stream) {
+    std::lock_guard<std::mutex> lock(g_rows_mu);
     for (size_t i = 0; i < g_rows_ws.size(); ++i)
         if (g_rows_ws[i].stream == (hipStream_t)stream) { g_rows_ws.erase(g_rows_ws.begin() + i); break; }
     return 0;
@@ -1916,7 +1920,9 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
             if (rounds >= 2 && rounds <= 40 && rem > 0 && rem <= 64) {
                 const int64_t m_keep = (rounds * 256) / tn;                        // m-tiles that fit the whole rounds
                 const int64_t rows_main = m_keep * 256;
-                if (m_keep > 0 && rows_main < M && tm - m_keep <= 3 && tile_ni(m_keep, N, false) == ni0 && use_tile256((int)rows_main, N, K)) {
+                // (the remainder must be large enough for the 128 x 128 kernel - the only one that is bit-identical to this one; 64 rows or fewer would
+                // be routed to the skinny / rows kernels, whose fp32 summation order differs)
+                if (m_keep > 0 && rows_main < M && M - rows_main > 64 && tm - m_keep <= 3 && tile_ni(m_keep, N, false) == ni0 && use_tile256((int)rows_main, N, K)) {
                     mc_gemm_args a1 = *a, a2 = *a;
                     a1.M = (int)rows_main;
                     const int64_t r0 = rows_main;

@@ -48,6 +48,11 @@ struct Llm {
     const void* call_key_mask = nullptr;     // ... while that call runs
     int64_t call_key_mask_stride = 0;
     bool fold_qkv = true;                    // decode: the q|k|v projection's split-K slabs are folded by the attention launch (no reduce launch)
+    // one-shot capture of the NEXT prefill (mc_llm_set_capture): cap_hidden receives n_layers + 1 snapshots of the routed hidden state
+    // (the embeddings, then every layer's output), cap_q every layer's rotated queries [B, Lq, H, D] - what forward(output_hidden_states /
+    // output_attentions) of the reference returns is built from them (multimodal_llama.py:561-604)
+    void* cap_hidden = nullptr;
+    void* cap_q = nullptr;
     int tail_adapter = -1;                   // >= 0: generate()'s prefill runs the last layer's attention + MLP for the last token of every
                                              // sequence only (all of them routed to this adapter); -1: every row (forward(), mixed adapters)
     // hipStreamBeginCapture is refused on the legacy null stream (torch's default current stream).  Callers that pass stream 0 have their
@@ -348,6 +353,13 @@ extern "C" int mc_llm_set_key_mask(void* handle, const void* key_valid, int64_t 
     return 0;
 }
 
+extern "C" int mc_llm_set_capture(void* handle, void* hidden_snapshots, void* q_snapshots) {
+    Llm* m = (Llm*)handle;
+    if (!m) { mc_set_error("mc_llm_set_capture: null handle"); return 1; }
+    m->cap_hidden = hidden_snapshots; m->cap_q = q_snapshots;
+    return 0;
+}
+
 extern "C" int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_k, float top_p) {
     Llm* m = (Llm*)handle;
     if (!m) { mc_set_error("mc_llm_set_sampling: null handle"); return 1; }
@@ -392,21 +404,35 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
     m->key_mask = nullptr; m->key_mask_stride = 0;
     struct MaskGuard { Llm* m; ~MaskGuard() { m->call_key_mask = nullptr; m->call_key_mask_stride = 0; (void)mc_attn_set_key_mask(nullptr, 0); } } mask_guard{m};
     const mc_llm_config& c = m->cfg;
+    // one-shot capture buffers: this call's, then gone (also on the error paths below)
+    char* cap_h = (char*)m->cap_hidden; char* cap_q = (char*)m->cap_q;
+    m->cap_hidden = nullptr; m->cap_q = nullptr;
+    const size_t snap_h = (size_t)M * c.hidden * 2, snap_q = (size_t)B * Lq * c.n_heads * c.head_dim * 2;
     Ws w = carve(c, M, B, Lq, (char*)workspace);
+    auto snapshot = [&](int l) -> int {               // after layer l (l = -1: the embeddings)
+        hipError_t e = hipSuccess;
+        if (cap_h) e = hipMemcpyAsync(cap_h + (size_t)(l + 1) * snap_h, x_routed, snap_h, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e == hipSuccess && cap_q && l >= 0) e = hipMemcpyAsync(cap_q + (size_t)l * snap_q, w.qseq, snap_q, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) { mc_set_error("mc_llm_prefill: capture copy: %s", hipGetErrorString(e)); return 2; }
+        return 0;
+    };
+    RUN(snapshot(-1));
     RUN(mc_rms_scale_bf16(x_routed, c.hidden, w.rs, M, c.hidden, c.rms_eps, stream));
     // generate() only reads the last token's hidden state of the LAST layer (lm_head on row -1, multimodal_llama.py:720 + greedy_search):
     // that layer still projects q|k|v for every row (the cache needs all keys), but its attention, o_proj and MLP run for the B last
     // tokens only - as a decode step would, reading the keys the projection just stored.  Needs all last tokens on one adapter.
-    const bool tail = m->tail_adapter >= 0 && !hidden_out && last_rows && kv_lens && (logits_out || next_ids) && B <= 512;
+    const bool tail = m->tail_adapter >= 0 && !hidden_out && last_rows && kv_lens && (logits_out || next_ids) && B <= 512 && !cap_h && !cap_q;
     const int tail_adapter = m->tail_adapter;
     // ONE-SHOT: the option is the caller's promise that every last_rows entry of THIS batch is routed to that adapter (last_rows lives on
     // the device; checking it here would cost a synchronising copy per prefill).  It is consumed by the call, so a promise made for one
     // batch can never be applied silently to the next: a caller that wants the tail path sets it before every prefill.
     m->tail_adapter = -1;
     const int full_layers = tail ? c.n_layers - 1 : c.n_layers;
-    for (int l = 0; l < full_layers; ++l)
+    for (int l = 0; l < full_layers; ++l) {
         RUN(layer_forward(m, l, (char*)x_routed, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
                           Lq, (char*)k_cache, (char*)v_cache, Smax, false, 1, nullptr, stream));
+        if (cap_h || cap_q) RUN(snapshot(l));
+    }
     if (tail) {
         const int l = c.n_layers - 1;
         const int64_t hd = c.hidden, D = c.head_dim, H = c.n_heads, Hkv = c.n_kv_heads;

@@ -155,6 +155,9 @@ class HipBeatsAudioEncoder:
     def forward(self, audio_inputs, audio_padding_mask=None):
         """(features (B, T, C), valid-token mask (B, T)) like BeatsAudioEncoder.forward (audio_encoder.py:37-40)."""
         c, dev = self.cfg, self.device
+        # a deferred refusal the caller of the PREVIOUS forward never collected (standalone use of the encoder: nothing calls check_pending
+        # for it) is raised now rather than never
+        self.check_pending()
         x = audio_inputs.to(dev, BF16)
         B, Fr, Mel = x.shape
         ps = c.input_patch_size

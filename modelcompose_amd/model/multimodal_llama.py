@@ -11,6 +11,7 @@ from __future__ import annotations
 import functools
 import os
 import threading
+import time
 
 import ctypes as C
 import math
@@ -388,6 +389,7 @@ class MultimodalLlamaForCausalLM:
         modalities are skipped: the reference runs their encoder on zeros only as a ZeRO-3 workaround (:203-206)
         and never uses the result."""
         feats, masks = {}, {}
+        t_issue0 = time.perf_counter()
         present = [m for m in self.modal_names if m != "default" and m in inputs]
         # Round 4 (`encode_streams`, default on; MC_ENC_STREAMS=0 / model.encode_streams = False: one stream): the towers are independent, and the
         # short ones run many launches of one or two rounds of tiles (BEATs: 288-384 tiles per GEMM) - on side streams their launches fill each
@@ -430,6 +432,17 @@ class MultimodalLlamaForCausalLM:
                 feats[modal] = fl[0] if len(fl) == 1 else torch.cat(fl, dim=0)
         for modal, f in feats.items():
             masks[modal] = torch.ones(f.shape[0], f.shape[1], device=f.device)
+        # host time spent ISSUING the towers' launches (several hundred per batch, from Python): bench.py reports it per batch so that a
+        # slowdown with 8 ranks on one host can be attributed
+        self.last_encode_issue_ms = (time.perf_counter() - t_issue0) * 1e3
+        # deferred input checks of the encoders (BEATs: a device padding mask that is not a suffix) are raised HERE, for every caller of this
+        # public method - not only for the ones that go on to _plan().  The read synchronises with the towers; generate() and
+        # forward() copy the ids to the host right after this call anyway, so the wait only moves.
+        if not torch.cuda.is_current_stream_capturing():
+            for modal in present:
+                chk = getattr(self.model.modal_encoders.get(modal), "check_pending", None)
+                if chk is not None:
+                    chk()
         return feats, masks
 
     def _encode_one(self, modal, x, prefix_tokens, suffix_tokens):
@@ -541,7 +554,7 @@ class MultimodalLlamaForCausalLM:
             self._cache[("ws", slot)] = ws
         return self._cache[key], ws
 
-    def _prefill(self, plan: SplicePlan, feats, max_new_tokens: int, want_hidden=False, want_logits=True, slot=0):
+    def _prefill(self, plan: SplicePlan, feats, max_new_tokens: int, want_hidden=False, want_logits=True, slot=0, capture=(False, False)):
         if getattr(self, "_dirty", True):
             self.finalize()
         cfg, dev = self.config, self.device
@@ -597,12 +610,19 @@ class MultimodalLlamaForCausalLM:
             if len(ads) == 1:
                 tail = int(ads[0])
         _lib.check(_lib.lib().mc_llm_set_option(self._handle, b"tail_adapter", tail), "mc_llm_set_option")
+        cap_h = cap_q = None
+        if capture[0]:                                            # forward(output_hidden_states): n_layers + 1 snapshots of the routed rows
+            cap_h = torch.empty(cfg.num_hidden_layers + 1, M, cfg.hidden_size, dtype=BF16, device=dev)
+        if capture[1]:                                            # forward(output_attentions): every layer's rotated queries, sequence order
+            cap_q = torch.empty(cfg.num_hidden_layers, B * Lmax, cfg.num_attention_heads * cfg.head_dim, dtype=BF16, device=dev)
+        if cap_h is not None or cap_q is not None:
+            _lib.check(_lib.lib().mc_llm_set_capture(self._handle, _ptr(cap_h), _ptr(cap_q)), "mc_llm_set_capture")
         _lib.check(_lib.lib().mc_llm_prefill(self._handle, _ptr(x), M, len(ga), gs.ctypes.data_as(C.c_void_p), ga.ctypes.data_as(C.c_void_p),
                                              _ptr(row_b), _ptr(row_t), _ptr(row_t), _ptr(out_map), _ptr(kv_lens), _ptr(last_rows), B, Lmax,
                                              _ptr(kc), _ptr(vc), Smax, _ptr(ws), _ptr(hidden), _ptr(logits), _ptr(next_ids), _stream()),
                    "mc_llm_prefill")
         return dict(plan=plan, layout=lay, kc=kc, vc=vc, ws=ws, Smax=Smax, logits=logits, next_ids=next_ids, hidden=hidden,
-                    kv_lens=kv_lens, out_map=out_map, slot=slot, key_valid=kmask)
+                    kv_lens=kv_lens, out_map=out_map, slot=slot, key_valid=kmask, cap_hidden=cap_h, cap_q=cap_q)
 
     def _decode(self, st, n_steps: int, out_ids: torch.Tensor, step0: int, want_logits=False):
         B = st["plan"].B
@@ -655,10 +675,14 @@ class MultimodalLlamaForCausalLM:
         inputs_embeds (B, L, hidden): the reference routes by modal_attention_mask, which its ForCausalLM.forward leaves unbound on this
         entry; here `modal_attention_mask` ({modal: bool (B, L)}, optional) routes the rows, default = every row on
         the `default` adapter.  cache_reserve: tokens of KV capacity beyond the prompt (default 256; the cache grows when it fills)."""
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / per-layer hidden states are never materialised on the HIP path")
+        cfg_ = self.config
+        output_attentions = bool(getattr(cfg_, "output_attentions", False) if output_attentions is None else output_attentions)          # :687-690
+        output_hidden_states = bool(getattr(cfg_, "output_hidden_states", False) if output_hidden_states is None else output_hidden_states)
         V = self.config.vocab_size
         if past_key_values is not None:
+            if output_attentions or output_hidden_states:
+                raise NotImplementedError("a cached decode step returns logits only: per-layer hidden states / attention maps are captured "
+                                          "by the prefill call (forward without past_key_values)")
             if not isinstance(past_key_values, HipPastKeyValues) or past_key_values.model is not self:
                 raise TypeError("past_key_values must be the HipPastKeyValues returned by this model's forward(use_cache=True)")
             if labels is not None or inputs_embeds is not None:
@@ -684,9 +708,28 @@ class MultimodalLlamaForCausalLM:
             feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
             plan = self._plan(input_ids, attention_mask, labels, modal_inputs, feats)
         reserve = max(0, min(reserve, self.config.max_position_embeddings - plan.Lmax))       # the rotary table bounds the cache
-        st = self._prefill(plan, feats, reserve, want_hidden=True, want_logits=False, slot=slot)
+        st = self._prefill(plan, feats, reserve, want_hidden=True, want_logits=False, slot=slot, capture=(output_hidden_states, output_attentions))
         st["mask_in_decode"] = mask_in_decode
         B, Lmax = plan.B, plan.Lmax
+        hidden_states = attentions = raw_last = None
+        if output_hidden_states:
+            # the reference's tuple (multimodal_llama.py:561-604): the input of every decoder layer, then the final norm of the last layer's
+            # output - n_layers + 1 tensors (B, L, hidden); padded slots are zero rows
+            seq = lambda rows: self._rows_to_sequence(rows, st["out_map"], B, Lmax)
+            hs = [seq(st["cap_hidden"][l]) for l in range(self.config.num_hidden_layers)]
+            raw_last = seq(st["cap_hidden"][self.config.num_hidden_layers])
+            hidden_states = tuple(hs) + (seq(st["hidden"]),)
+        if output_attentions:
+            # `attn_weights` of every layer (:295-312): softmax over the scaled, masked scores, (B, H, L, L) in the model dtype.  The flash
+            # kernels never form them; they are recomputed from the layer's rotated queries (captured) and its keys (in the KV cache)
+            c = self.config
+            H, Hkv, D = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+            S_ = st["Smax"]
+            atts = []
+            for l in range(c.num_hidden_layers):
+                atts.append(ops.attn_probs(st["cap_q"][l], st["kc"][l], B, H, Hkv, Lmax, Lmax, D, (Lmax * H * D, H * D, D), (Hkv * S_ * D, D, S_ * D),
+                                           causal=True, kv_lens=st["kv_lens"], key_valid=st["key_valid"]))
+            attentions = tuple(atts)
         lg_r = ops.linear(st["hidden"], self.lm_head, out_f32=True)                          # lm_head (:720), routed order
         logits = torch.zeros(B * Lmax, V, dtype=torch.float32, device=self.device)
         valid = st["out_map"] >= 0
@@ -700,7 +743,15 @@ class MultimodalLlamaForCausalLM:
             rows, _ = ops.ce_loss(logits.view(B * Lmax, V), tgt.view(-1), 1.0, want_grad=False)
             loss = rows.sum() / (tgt != IGNORE_INDEX).sum()                                   # nan when every target is ignored, as torch's CE
         pkv = HipPastKeyValues(self, st, plan.valid_lens) if use_cache else None
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv)
+        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv, hidden_states=hidden_states, attentions=attentions)
+        out.raw_last_hidden_state = raw_last                      # (extra, not in the reference's output): the last layer's output before the final norm
+        return out
+
+    def _rows_to_sequence(self, rows: torch.Tensor, out_map: torch.Tensor, B: int, Lmax: int) -> torch.Tensor:
+        """routed rows [M, hidden] -> (B, Lmax, hidden) in sequence order (slot without a row: zeros)."""
+        out = torch.empty(B * Lmax, rows.shape[-1], dtype=rows.dtype, device=rows.device)
+        ops.copy_rows(rows, out, B * Lmax, src_idx=out_map)
+        return out.view(B, Lmax, -1)
 
     # ---- cached decoding for external loops ----------------------------------------------------------------------------------
     def _new_slot(self):

@@ -249,6 +249,17 @@ def attn_prefill(q, k, v, out, B, H, Hkv, Lq, S, D, q_strides, k_strides, v_stri
     return out
 
 
+def attn_probs(q, k, B, H, Hkv, Lq, S, D, q_strides, k_strides, causal=True, q_offset=0, scale=None, kv_lens=None, key_valid=None, out=None):
+    """softmax(scale q k^T + mask) itself, (B, H, Lq, S) in the storage dtype (mc_attn_probs_bf16: output_attentions)."""
+    scale = (1.0 / math.sqrt(D)) if scale is None else scale
+    if out is None:
+        out = torch.empty(B, H, Lq, S, dtype=q.dtype, device=q.device)
+    _lib.check(_lib.lib().mc_attn_probs_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(kv_lens), _p(key_valid),
+                                             0 if key_valid is None else key_valid.stride(0), _p(out), B, H, Hkv, Lq, S, D,
+                                             1 if causal else 0, q_offset, scale, _stream()), "mc_attn_probs_bf16")
+    return out
+
+
 def attn_decode(q, k, v, out, B, H, Hkv, S, D, q_strides, k_strides, v_strides, o_sb, nsplit=1, workspace=None, scale=None,
                 kv_lens=None):
     scale = (1.0 / math.sqrt(D)) if scale is None else scale

@@ -283,38 +283,46 @@ def _tiny_clip_dir(tmp, hidden=32, layers=3, heads=4, inter=64, image=28, patch=
     return d, c
 
 
-def g4():
-    """Tiny end-to-end through the reference classes: CLIPVisionTower -> mlp2x_gelu -> splice -> 2-layer LLM."""
+def _g4_build(tmp):
+    """The tiny vision model and inputs of g4 (CLIPVisionTower -> mlp2x_gelu -> splice -> 2-layer LLM), built from the reference classes with
+    fixed seeds: g4 and g18 call it and get the same weights and inputs."""
     ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
     ce = refshim.import_ref("modelcompose.model.multimodal_encoder.clip_encoder")
     pb = refshim.import_ref("modelcompose.model.multimodal_projector.builder")
+    # dims the HIP path supports: head_dim 64, hidden % 64 == 0, vocab % 4 == 0
+    clip_dir, ccfg = _tiny_clip_dir(tmp, hidden=128, layers=3, heads=2, inter=256)
+    torch.manual_seed(14)
+    cfg = tiny_llm_config(ml, modal=("vision",), reset="default-vision=0.5", layers=2, prefix_tokens=2,
+                          hidden=128, heads=2, inter=192, vocab=128)
+    cfg.mm_vision_encoder = clip_dir
+    cfg.mm_vision_select_layer = -2
+    cfg.mm_vision_select_feature = "patch"
+    cfg.mm_projector_type = "mlp2x_gelu"
+    model = ml.MultimodalLlamaForCausalLM(cfg).eval()
+    args = types.SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature="patch")
+    tower = ce.CLIPVisionTower(clip_dir, args, delay_load=False)
+    pcfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=ccfg.hidden_size, hidden_size=cfg.hidden_size)
+    proj = pb.build_vision_projector(pcfg)
+    for p in proj.parameters():
+        p.data = torch.randn_like(p) * 0.1
+    model.model.modal_encoders = nn.ModuleDict({"vision": tower})
+    model.model.modal_projectors = nn.ModuleDict({"vision": proj})
+    _randomize_lora(model, 7)
+    model.eval()
+    B = 2
+    V = -200
+    g = torch.Generator().manual_seed(3)
+    ids = torch.cat([torch.ones(B, 1, dtype=torch.long), torch.randint(3, 97, (B, 4), generator=g),
+                     torch.full((B, 1), V), torch.full((B, 1), 13), torch.randint(3, 97, (B, 5), generator=g)], dim=1)
+    pixels = torch.randn(B, 3, 28, 28, generator=g)
+    return model, tower, cfg, ccfg, ids, pixels
+
+
+def g4():
+    """Tiny end-to-end through the reference classes: CLIPVisionTower -> mlp2x_gelu -> splice -> 2-layer LLM."""
     with tempfile.TemporaryDirectory() as tmp:
-        # dims the HIP path supports: head_dim 64, hidden % 64 == 0, vocab % 4 == 0
-        clip_dir, ccfg = _tiny_clip_dir(tmp, hidden=128, layers=3, heads=2, inter=256)
-        torch.manual_seed(14)
-        cfg = tiny_llm_config(ml, modal=("vision",), reset="default-vision=0.5", layers=2, prefix_tokens=2,
-                              hidden=128, heads=2, inter=192, vocab=128)
-        cfg.mm_vision_encoder = clip_dir
-        cfg.mm_vision_select_layer = -2
-        cfg.mm_vision_select_feature = "patch"
-        cfg.mm_projector_type = "mlp2x_gelu"
-        model = ml.MultimodalLlamaForCausalLM(cfg).eval()
-        args = types.SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature="patch")
-        tower = ce.CLIPVisionTower(clip_dir, args, delay_load=False)
-        pcfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=ccfg.hidden_size, hidden_size=cfg.hidden_size)
-        proj = pb.build_vision_projector(pcfg)
-        for p in proj.parameters():
-            p.data = torch.randn_like(p) * 0.1
-        model.model.modal_encoders = nn.ModuleDict({"vision": tower})
-        model.model.modal_projectors = nn.ModuleDict({"vision": proj})
-        _randomize_lora(model, 7)
-        model.eval()
-        B = 2
-        V = -200
-        g = torch.Generator().manual_seed(3)
-        ids = torch.cat([torch.ones(B, 1, dtype=torch.long), torch.randint(3, 97, (B, 4), generator=g),
-                         torch.full((B, 1), V), torch.full((B, 1), 13), torch.randint(3, 97, (B, 5), generator=g)], dim=1)
-        pixels = torch.randn(B, 3, 28, 28, generator=g)
+        model, tower, cfg, ccfg, ids, pixels = _g4_build(tmp)
+        B = ids.shape[0]
         n_new = 8
         with torch.no_grad():
             feats = tower(pixels)
@@ -346,6 +354,20 @@ def g4():
         d = json.loads(cfg_json(cfg, extra))
         d["mm_vision_encoder"] = "clip-tiny"
         _save("g4_e2e_vision", meta=np.array(json.dumps(d)), **arrays)
+
+
+def g18():
+    """forward(output_hidden_states=True, output_attentions=True) of the reference on g4's model and inputs (multimodal_llama.py:561-604,
+    :295-312, :676-745): the tuple of hidden states (input of every layer, then the final norm) and every layer's attention probabilities.
+    The weights are g4's (tests load them from g4_e2e_vision.npz); logits_prefill is stored again so that a test can tie the two fixtures."""
+    with tempfile.TemporaryDirectory() as tmp:
+        model, tower, cfg, ccfg, ids, pixels = _g4_build(tmp)
+        with torch.no_grad():
+            out = model(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool), modal_inputs={"vision": pixels},
+                        output_hidden_states=True, output_attentions=True, return_dict=True)
+        assert len(out.hidden_states) == cfg.num_hidden_layers + 1 and len(out.attentions) == cfg.num_hidden_layers
+        _save("g18_hidden_attn", input_ids=ids, logits_prefill=out.logits, hidden_states=torch.stack(list(out.hidden_states), 0),
+              attentions=torch.stack(list(out.attentions), 0))
 
 
 def g6():
@@ -1216,7 +1238,7 @@ def g16():
 
 
 GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5_clip": g5_clip, "g5_beats": g5_beats, "g5_qformer": g5_qformer, "g5_video": g5_video,
-          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g16": g16}
+          "g5_point": g5_point, "g5_imagebind": g5_imagebind, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g16": g16, "g18": g18}
 SLOW_GROUPS = {"g15": g15, "g17a": lambda: g17("a"), "g17b": lambda: g17("b"), "g17": g17}          # by name only
 
 

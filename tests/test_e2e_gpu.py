@@ -61,6 +61,35 @@ def test_g4_prefill_logits_and_greedy_ids(g4_model):
     assert torch.equal(got, a["gen_ids"]), (got, a["gen_ids"], _margins(a["step_logits"]))
 
 
+def test_output_hidden_states_and_attentions_match_the_reference(g4_model):
+    """forward(output_hidden_states=True, output_attentions=True) (multimodal_llama.py:561-604, :295-312, :676-745) against the reference's
+    own outputs on g4's model (tests/golden/g18_hidden_attn.npz, written by `python -m oracle.gen_golden g18`): the tuple of hidden states -
+    the input of every decoder layer, then the final norm of the last layer's output - and every layer's attention probabilities."""
+    model, a, meta, sd = g4_model
+    g18, _, _ = load_golden("g18_hidden_attn")
+    assert torch.equal(g18["input_ids"], a["input_ids"]) and torch.equal(g18["logits_prefill"], a["logits_prefill"])      # same model, same inputs
+    ids, px = a["input_ids"].cuda(), a["pixels"].cuda()
+    plain = model.forward(input_ids=ids, modal_inputs={"vision": px})
+    out = model.forward(input_ids=ids, modal_inputs={"vision": px}, output_hidden_states=True, output_attentions=True)
+    assert plain.hidden_states is None and plain.attentions is None
+    assert torch.equal(out.logits, plain.logits), "capturing must not change what is computed"
+    n_layers = meta["num_hidden_layers"]
+    assert isinstance(out.hidden_states, tuple) and len(out.hidden_states) == n_layers + 1 and len(out.attentions) == n_layers
+    ref_h, ref_a = g18["hidden_states"], g18["attentions"]
+    for l in range(n_layers + 1):
+        assert out.hidden_states[l].shape == ref_h[l].shape
+        # bf16 storage vs the fp32 reference (the embeddings are exact to one rounding)
+        within(f"11 hidden_states[{l}]", out.hidden_states[l], ref_h[l], 2 ** -8 if l == 0 else 1.2e-2)
+    for l in range(n_layers):
+        assert out.attentions[l].shape == ref_a[l].shape
+        got = out.attentions[l].float().cpu()
+        assert (got - ref_a[l]).abs().max().item() < 1.5e-2, (l, (got - ref_a[l]).abs().max().item())       # probabilities: absolute
+        assert (got[ref_a[l] == 0] == 0).all()                                                           # the causal zeros are exact zeros
+        assert (got.sum(-1) - 1).abs().max().item() < 2e-2
+    # the un-normed last layer output rides along (used by the per-layer parity test at depth)
+    assert out.raw_last_hidden_state.shape == out.hidden_states[-1].shape
+
+
 def _margins(ref_logits):
     top2 = ref_logits.topk(2, dim=-1).values
     return ((top2[..., 0] - top2[..., 1]) / ref_logits.abs().max()).tolist()
@@ -210,8 +239,9 @@ def test_limits_raise_like_the_reference(g4_model):
         model.generate(ids, modal_inputs={}, max_new_tokens=2)
     with pytest.raises(ValueError):                   # longer than the rotary table (max_position_embeddings)
         model.generate(ids, modal_inputs={"vision": a["pixels"].cuda()}, max_new_tokens=meta["max_position_embeddings"])
-    with pytest.raises(NotImplementedError):
-        model.forward(input_ids=ids, modal_inputs={"vision": a["pixels"].cuda()}, output_attentions=True)
+    out = model.forward(input_ids=ids, modal_inputs={"vision": a["pixels"].cuda()}, use_cache=True)
+    with pytest.raises(NotImplementedError):          # per-layer outputs belong to the prefill call, a cached step returns logits only
+        model.forward(input_ids=ids[:, -1:], past_key_values=out.past_key_values, output_hidden_states=True)
 
 
 def test_load_pretrained_model_from_checkpoint_directories(tmp_path):

@@ -33,8 +33,9 @@ def test_beats_encoder_matches_reference():
     assert rel_err(f2, a["features_nopad"]) < 2 ** -5
     # round 4: a DEVICE mask is analysed on the device (no host round trip: one launch pools the frame mask, writes the clip lengths,
     # zeroes the padded rows); a HOST mask on the host.  Same function: bitwise equal features and masks.
-    fh, mh = enc(a["fbank"].cuda(), a["padding_mask"])                   # host mask
     assert enc._pending_mask_check and not HipBeatsAudioEncoder(None, None, config=BeatsConfig(cfg))._pending_mask_check
+    fh, mh = enc(a["fbank"].cuda(), a["padding_mask"])                   # host mask (the forward first collects the pending device check)
+    assert not enc._pending_mask_check
     enc.check_pending()
     assert torch.equal(fh, f) and torch.equal(mh, mask)
     # padding that is not a suffix: refused at once for a host mask, at the deferred check for a device mask
@@ -48,6 +49,11 @@ def test_beats_encoder_matches_reference():
         enc.check_pending()
     enc(a["fbank"].cuda(), a["padding_mask"].cuda())
     enc.check_pending()                                                 # the flag was cleared: a good mask passes again
+    # a standalone user who never calls check_pending() still hears about it - at the encoder's next forward
+    enc(a["fbank"].cuda(), bad.cuda())
+    with pytest.raises(NotImplementedError):
+        enc(a["fbank"].cuda(), None)
+    enc(a["fbank"].cuda(), None)
 
 
 def test_qformer_projector_matches_reference():
