@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="time the oracle on ONE sample with all 32 decoder layers (35 GB of fp32 weights, several minutes of host time) instead of "
+                         "extrapolating from 1 and 8 layers: cpu_baseline.kind = 'port-measured'")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configs after the timed region")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (roofline objects become null)")
     ap.add_argument("--no-graph", action="store_true")
@@ -114,6 +117,10 @@ def parse():
                     help="informational, after the timed region: the same K batches through the pipelined loop with every large GEMM on the "
                          "186-register 192-column tiles (mc_gemm_set_option force_tile192), which leave room for the decode attention's waves "
                          "beside a resident GEMM workgroup")
+    ap.add_argument("--gather", default="ids", choices=["ids", "logits"],
+                    help="what the ranks all-gather per batch: the generated ids (default; what the reference's per-chunk answer files hold, "
+                         "MCUB-4.sh:60-70) or, as BASELINE.json's north_star words it, the step LOGITS [B, new_tokens, vocab] fp32 (the decode "
+                         "graph is still replayed: runtime option graph_logits)")
     ap.add_argument("--workload", default="iav", choices=["iav", "vision", "generate", "mcub4", "train"],
                     help="iav (default) = the metric's config; vision (alias generate) = configs[1]; mcub4 = configs[3]; train = configs[4], the "
                          "stage-2 finetune step (forward + backward + gradient all-reduce + AdamW)")
@@ -153,6 +160,31 @@ def workload_meta(name, layers):
 
 
 # ------------------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline_full(workload: str, new_tokens: int):
+    """The oracle on one sample of the workload at FULL depth, timed, nothing extrapolated (VERDICT r4 #6).  Needs ~40 GB of host memory."""
+    from modelcompose_amd import synthetic
+    from oracle import pipeline
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    modals, sentinels = WORKLOADS[workload][0], WORKLOADS[workload][1]
+    gen_dev = "cuda" if torch.cuda.is_available() else "cpu"
+    meta = workload_meta(workload, 32)
+    sd = synthetic.synthetic_state_dict(meta, device=gen_dev, seed=7, dtype=torch.float32)
+    sd = {k: v.cpu() for k, v in sd.items()}
+    om = pipeline.OracleModel.from_state_dict(sd, meta)
+    ids = synthetic.synthetic_prompt(1, sentinels)
+    mi = synthetic_inputs(modals, 1, gen_dev, 3)
+    mi = {k: ({kk: (vv.float().cpu() if vv.is_floating_point() else vv.cpu()) for kk, vv in v.items()} if isinstance(v, dict) else v.float().cpu())
+          for k, v in mi.items()}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        om.generate(ids, mi, max_new_tokens=new_tokens, ignore_eos=True)
+        full = time.perf_counter() - t0
+    return {"value": 1.0 / full, "unit": "samples/s", "cores": cores, "kind": "port-measured", "extrapolated": False,
+            "sample": f"oracle (torch fp32 CPU port of the reference path, batch 1 as the reference's eval loop) on ONE sample of the same workload "
+                      f"({WORKLOADS[workload][3]}, {new_tokens} greedy tokens), all 32 decoder layers, every encoder: {full:.1f} s, timed, no extrapolation"}
+
+
 def cpu_baseline(workload: str, new_tokens: int):
     """Oracle = CPU port of the reference algorithm (branch-form LocalLoRA on all tokens, mask-sum routing, every encoder), torch fp32.
     Bounded sample of the SAME workload: one sample (batch 1, the reference's eval batch), `new_tokens` greedy tokens, timed with 1 and
@@ -188,7 +220,15 @@ def cpu_baseline(workload: str, new_tokens: int):
     per_layer = max((times[hi] - times[lo]) / (hi - lo), 1e-9)
     fixed = max(times[lo] - lo * per_layer, 0.0)
     full = fixed + 32 * per_layer
-    return {"value": 1.0 / full, "unit": "samples/s", "cores": cores, "kind": "port",
+    measured = None
+    mpath = os.path.join(ROOT, "profiles", "cpu_baseline_full.json")          # a committed full-depth run of `--cpu-baseline-full` (same oracle, same sample)
+    if os.path.exists(mpath):
+        try:
+            measured = json.load(open(mpath))
+        except Exception:
+            measured = None
+    return {"value": 1.0 / full, "unit": "samples/s", "cores": cores, "kind": "port", "extrapolated": True,
+            "measured_full_depth_run": measured,
             "sample": f"oracle (torch fp32 CPU port of the reference path, batch 1 as the reference's eval loop) on one sample of the same "
                       f"workload ({WORKLOADS[workload][3]}, {new_tokens} greedy tokens), timed with {lo} and {hi} of 32 decoder layers "
                       f"({times[lo]:.1f}s, {times[hi]:.1f}s): per-layer cost x32 + measured fixed cost (all encoders, projectors, splice, "
@@ -204,9 +244,12 @@ def secondary_runs(new_tokens: int):
     synchronize bracket), whose JSON line is attached in compact form.  Not part of `value`."""
     import subprocess
     out = {}
-    for name, steps, warm in (("vision", 6, 2), ("mcub4", 4, 2), ("train", 10, 3)):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--steps", str(steps), "--warmup", str(warm),
-               "--no-cpu-baseline", "--no-secondary", "--new-tokens", str(new_tokens)] + ([] if name == "train" else ["--no-profile"])
+    # "iav_128": the headline workload at the REFERENCE's decode budget, max_new_tokens=128 (eval/model_multimodal_qa_loader.py:101; SURVEY §8d
+    # "report also 128"): the HBM-bound share of a step roughly triples
+    for name, steps, warm in (("iav_128", 3, 2), ("vision", 6, 2), ("mcub4", 4, 2), ("train", 10, 3)):
+        wl, nt = ("iav", 128) if name == "iav_128" else (name, new_tokens)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", str(steps), "--warmup", str(warm),
+               "--no-cpu-baseline", "--no-secondary", "--new-tokens", str(nt)] + ([] if name == "train" else ["--no-profile"])
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MC_BENCH_FORCE_DIST")}
         try:
             t0 = time.perf_counter()
@@ -429,7 +472,7 @@ def profiled_pass(model, step_fn, cfg, B, new_tokens, n_steps):
 # ------------------------------------------------------------------------------------------------------------------- generate workloads
 def generate_main(args, world, rank, local):
     from modelcompose_amd import _lib, synthetic
-    from modelcompose_amd.dist import gather_ids
+    from modelcompose_amd.dist import gather_ids, gather_logits
     from modelcompose_amd.model.builder import build_from_state_dict
     name = args.workload
     modals, sentinels, defB, msuffix, desc = WORKLOADS[name]
@@ -439,6 +482,15 @@ def generate_main(args, world, rank, local):
     meta = workload_meta(name, args.layers)
     sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
     model = build_from_state_dict(meta, sd, device=dev)
+    # the load-time composition (the path's "fused AXPY over state_dict tensors"): algorithmic bytes = W read ONCE per linear + one dense W' written
+    # per routed adapter + the LoRA factors, over the device time of the composition loop (events around it in finalize(); weights already in HBM)
+    compose_roofline = None
+    if getattr(model, "compose_ms", 0) and getattr(model, "compose_bytes", 0):
+        gbs = model.compose_bytes / model.compose_ms / 1e6
+        compose_roofline = {"bound": "hbm", "kernel": "compose_multi_kernel (W' = bf16((W + sum s B A) diag(g)) for every routed adapter, one pass per linear)",
+                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                            "bytes": model.compose_bytes, "ms": round(model.compose_ms, 3), "launches": int(model.compose_launches),
+                            "note": "one-time, at load; includes the small transposes of the LoRA A factors between the launches"}
     model.use_graph = not args.no_graph
     _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"use_graph", 0 if args.no_graph else 1), "set_option")
     del sd
@@ -450,9 +502,19 @@ def generate_main(args, world, rank, local):
     if "point" in modals:
         model.model.modal_encoders["point"].fps_start = torch.zeros(B, dtype=torch.long)
 
-    def step(**kw):
-        out = model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True, **kw)
+    want_lg = args.gather == "logits"
+    if want_lg:
+        _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"graph_logits", 1), "set_option")
+    gkw = {"return_step_logits": True} if want_lg else {}
+
+    def gather(out):
+        if want_lg:
+            out, lg = out
+            gather_logits(lg, world, force=DIST, equal_shapes=True)
         return gather_ids(out[:, ids.shape[1]:], world, force=DIST, equal_shapes=True)
+
+    def step(**kw):
+        return gather(model.generate(ids, modal_inputs=mi, max_new_tokens=args.new_tokens, ignore_eos=True, **gkw, **kw))
 
     def step_local(**kw):
         # rank 0's evidence passes run after the other ranks have left: no collective in them
@@ -468,8 +530,8 @@ def generate_main(args, world, rank, local):
             for _ in range(n):
                 step()
             return
-        for out in model.generate_pipelined(((ids, mi) for _ in range(n)), max_new_tokens=args.new_tokens, ignore_eos=True):
-            gather_ids(out[:, ids.shape[1]:], world, force=DIST, equal_shapes=True)
+        for out in model.generate_pipelined(((ids, mi) for _ in range(n)), max_new_tokens=args.new_tokens, ignore_eos=True, **gkw):
+            gather(out)
 
     # the pipelined loop alternates two generation pipelines (own KV cache, workspace, decode graph): both must have run once before the
     # timed region, whatever W the caller asked for
@@ -488,6 +550,8 @@ def generate_main(args, world, rank, local):
         if DIST or world > 1:
             torch.distributed.destroy_process_group()
         return
+    # host time spent issuing the towers' launches for the last timed batch (Python-issued: several hundred launches per batch and rank)
+    host_issue_ms = round(float(getattr(model, "last_encode_issue_ms", 0.0)), 2)
     feats, _ = model.encode_modal_inputs(mi, model.prefix_tokens, model.suffix_tokens)
     spliced = int(ids.shape[1] - len(sentinels) + sum(f.shape[1] for f in feats.values()))
     value = world * B * args.steps / dt
@@ -499,9 +563,9 @@ def generate_main(args, world, rank, local):
         "config": {"workload": f"{desc}; batch {B} per GPU, {spliced}-token spliced prompt, {args.new_tokens} greedy tokens",
                    "workload_name": name, "per_gpu_batch": B, "new_tokens": args.new_tokens, "layers": args.layers, "spliced_length": spliced,
                    "block_tokens": {m: int(f.shape[1]) for m, f in feats.items()}, "adapters": list(model.modal_names),
-                   "parallelism": f"dp{world}", "decode_graph_requested": not args.no_graph, "pipelined": bool(args.pipeline),
+                   "parallelism": f"dp{world}", "gathered": args.gather, "decode_graph_requested": not args.no_graph, "pipelined": bool(args.pipeline),
                    "pipeline_priming_steps": priming},
-        "roofline": None, "roofline_decode": None,
+        "roofline": None, "roofline_decode": None, "roofline_compose": compose_roofline,
     }
     del feats
     if not args.no_profile:
@@ -549,8 +613,10 @@ def generate_main(args, world, rank, local):
     torch.cuda.empty_cache()
     if world == 1 and not DIST and not args.no_secondary and name == "iav" and args.layers == 32:
         line["secondary"] = secondary_runs(args.new_tokens)
+    line["host"] = {"pinned_cpus": len(PINNED_CPUS) if PINNED_CPUS else None, "cpu_count": os.cpu_count(),
+                    "encode_issue_ms_last_batch": host_issue_ms}
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(name, args.new_tokens)
+        line["cpu_baseline"] = cpu_baseline_full(name, args.new_tokens) if args.cpu_baseline_full else cpu_baseline(name, args.new_tokens)
     print(json.dumps(line), flush=True)
     if DIST or world > 1:
         torch.distributed.destroy_process_group()

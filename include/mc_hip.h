@@ -53,7 +53,7 @@ int mc_compose_weight_bf16(const void* w_rowmajor, int64_t ldw, const void* cons
 /* As above with (a) col_scale fp32 [K] multiplied into the columns before the single bf16 rounding — folds the weight of the
  * LlamaRMSNorm that precedes the linear (multimodal_llama.py:405-406, :443, :462) into it — and (b) block interleaving: packed
  * 16-row block nb is written at block index nb*nb_stride + nb_offset (gate_proj / up_proj interleaved for the fused SwiGLU
- * epilogue of mc_gemm_ex_bf16).  (c) retention_parts (optional, device, 2 * ceil(ceil64(K)/256) * ceil(N/32) floats): per-workgroup
+ * epilogue of mc_gemm_ex_bf16).  (c) retention_parts (optional, device, mc_compose_retention_floats(N, K) floats): per-workgroup
  * partial sums {sum (W' - bf16(W c)) (dW c), sum (dW c)^2} over the elements the workgroup wrote - their ratio, summed by the caller,
  * is the share of the delta that survives the single bf16 rounding (1 for trained deltas; falls when |dW| is below half a bf16 step
  * of W: the reference's branch form, multimodal_llama.py:130-149, has no such rounding).                                        */
@@ -70,6 +70,23 @@ int mc_compose_weight_dither_bf16(const void* w_rowmajor, int64_t ldw, const voi
                                   const float* scales, int n_terms, int r, void* out_packed, void* out_rowmajor, int64_t ldo,
                                   int N, int K, const float* col_scale, int nb_stride, int nb_offset, float* retention_parts,
                                   uint32_t dither_seed, void* stream);
+
+/* ONE pass per linear for ALL routed adapters (round 5): the W tile is read once and every output o = 0 .. n_out - 1 is written from it,
+ * W'_o = bf16((W + sum over the terms m with bit m of term_mask[o] set of scale[m] B_m A_m) diag(col_scale)) - 1 read + n_out writes of W
+ * instead of n_out x (read + write).  For the 3-way composed model: terms = {default-vision, default-audio, default-video, vision, audio,
+ * video}, outputs = {default: the first three, vision, audio, video: one each} (LocalLoraLinear.forward, multimodal_llama.py:130-157).
+ * term_mask NULL = every term in every output; dither_seeds / retention_parts / out_rowmajor may be NULL or hold NULL / 0 entries;
+ * retention_parts[o] holds mc_compose_retention_floats(N, K) floats ({num, den} per workgroup, summed by the caller).  At most 8 terms,
+ * 6 outputs.  mc_compose_weight_{,ex_,dither_}bf16 are this call with one output. */
+typedef struct mc_compose_multi_args {
+    const void* w; int64_t ldw;
+    const void* const* at_list; const void* const* b_list; const float* scales; int n_terms, r;
+    int n_out; void* const* out_packed; void* const* out_rowmajor; const uint32_t* term_mask; const uint32_t* dither_seeds;
+    float* const* retention_parts;
+    int64_t ldo; int N, K; const float* col_scale; int nb_stride, nb_offset;
+} mc_compose_multi_args;
+int mc_compose_multi_bf16(const mc_compose_multi_args* args, void* stream);
+int mc_compose_retention_floats(int N, int K, int64_t* floats);
 
 /* ---- audio front-end: Kaldi log-mel filterbank + BEATs normalisation + zero padding (beats/audio_processor.py:143-170; replaces
  * torchaudio.compliance.kaldi.fbank, a third-party CPU dependency of the reference).  wav [B, wav_stride] fp32 at 16 kHz,
@@ -442,7 +459,9 @@ int mc_llm_destroy(void* handle);
  * (LlamaRotaryEmbedding of transformers 4.31, computed in fp32).                                                        */
 int mc_llm_set_weights(void* handle, const void* const* layer_w, const void* final_norm, const void* lm_head_packed,
                        const void* embed_table, const float* cos_table, const float* sin_table);
-/* options: "use_graph" (decode steps replayed from a hipGraph, default 1); "profile" (below); "tail_adapter" (default -1 = off; a >= 0: the
+/* options: "use_graph" (decode steps replayed from a hipGraph, default 1); "graph_logits" (default 0; 1: a mc_llm_decode call with logits_out
+ * still replays the graph and copies every step's logits out of the workspace between replays - the logits all-gather of an eval loop);
+ * "profile" (below); "tail_adapter" (default -1 = off; a >= 0: the
  * NEXT mc_llm_prefill call, if it asks for last-row logits / next ids only - hidden_out null - runs the LAST layer's attention, o_proj and
  * MLP for the last token of every sequence only, with adapter a's weights; the layer's q|k|v projection still covers every row, so the
  * KV cache is what the all-rows path writes.  ONE-SHOT: the value is the caller's promise that every last_rows entry of that batch lies

@@ -70,6 +70,14 @@ class GemmArgsC(C.Structure):
                 ("defer_reduce", c_p)]
 
 
+class ComposeMultiArgsC(C.Structure):
+    """struct mc_compose_multi_args (include/mc_hip.h)."""
+    _fields_ = [("w", c_p), ("ldw", c_l), ("at_list", C.POINTER(c_p)), ("b_list", C.POINTER(c_p)), ("scales", C.POINTER(c_f)), ("n_terms", c_i), ("r", c_i),
+                ("n_out", c_i), ("out_packed", C.POINTER(c_p)), ("out_rowmajor", C.POINTER(c_p)), ("term_mask", C.POINTER(C.c_uint32)),
+                ("dither_seeds", C.POINTER(C.c_uint32)), ("retention_parts", C.POINTER(c_p)), ("ldo", c_l), ("N", c_i), ("K", c_i), ("col_scale", c_p),
+                ("nb_stride", c_i), ("nb_offset", c_i)]
+
+
 class SlabRefC(C.Structure):
     """struct mc_slab_ref (include/mc_hip.h)."""
     _fields_ = [("slabs", c_p), ("ssp", c_p), ("S", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("rms_eps", c_f)]
@@ -169,6 +177,8 @@ _SIGS.update({
                        C.POINTER(c_p), C.POINTER(c_l)],
     "mc_llm_profile_read": [c_p, c_i, C.POINTER(C.c_double), C.POINTER(c_l)],
     "mc_llm_set_capture": [c_p, c_p, c_p],
+    "mc_compose_multi_bf16": [C.POINTER(ComposeMultiArgsC), c_p],
+    "mc_compose_retention_floats": [c_i, c_i, C.POINTER(c_l)],
     "mc_attn_probs_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
 })
 # optional symbols added by later ABI revisions are bound if present

@@ -48,125 +48,283 @@ __device__ __forceinline__ bf16_t compose_round(float v, uint32_t seed, int n, i
     return __builtin_bit_cast(bf16_t, hi);
 }
 
-// workgroup = 4 waves; tile = 32 rows (n) x 256 cols (k); wave w owns cols [64w, 64w+64)
-__global__ __launch_bounds__(256) void compose_kernel(ComposeParams p) {
+// Round 5: ONE pass per linear for ALL routed adapters.  The round-4 kernel ran once per adapter (4 launches per linear for the 3-way composed
+// model: 4 x (read W + write W')), read W in 8-byte pieces of 16 different rows per wave instruction and re-read it element by element for
+// the retention statistic: 0.8 TB/s.  Here a workgroup reads its W tile ONCE, with 16-byte loads, keeps it in registers, and writes every
+// adapter's W' from it - 1 read + n_out writes instead of n_out x (read + write) - each output as whole 1-KiB blocks of the packed layout
+// (16 bytes per lane: v_permlane16_swap pairs the two 16-column blocks of a lane pair, the exchange the GEMM epilogue uses).
+// workgroup = 4 waves; tile = 16 NR rows (n) x 256 cols (k); wave w owns cols [64w, 64w + 64)
+#define MC_MAX_OUTS 6
+
+struct ComposeMultiParams {
+    const bf16_t* w; int64_t ldw;            // may be null (-> pure delta)
+    const bf16_t* at[MC_MAX_TERMS];          // [K, r]
+    const bf16_t* bm[MC_MAX_TERMS];          // [N, r]
+    float scale[MC_MAX_TERMS];
+    int n_terms, r, n_out;
+    bf16_t* out_packed[MC_MAX_OUTS];         // [ceil16(N)/16][Kp/32][64][8] each
+    bf16_t* out_rowmajor[MC_MAX_OUTS];       // optional row-major copies (ld = ldo)
+    uint32_t term_mask[MC_MAX_OUTS];         // bit m: term m belongs to this output (summed in term order)
+    uint32_t dither_seed[MC_MAX_OUTS];       // 0: round to nearest even; else unbiased rounding (compose_round)
+    float* retention[MC_MAX_OUTS];           // optional per-output [gridDim.y][gridDim.x][2] partial sums (see mc_hip.h)
+    int64_t ldo;
+    int N, K, Kp;
+    const float* col_scale;                  // [K] fp32 or null
+    int nb_stride, nb_offset;
+};
+
+// FAST: K % 8 == 0 and 16-byte aligned rows of W / the row-major copies - every 8-element piece is loaded and stored whole, no per-element
+// guards (the shapes of the LLM); the general instantiation guards every element.
+// Loop order (register budget: 2 waves per SIMD): per output, per term, the term's A^T fragments of the wave's 64 columns are loaded ONCE
+// (RS x 4 fragments) and reused against the NR row blocks, whose B fragments stream through; a multi-term output keeps its running fp32
+// total in LDS (16 bytes per lane and 16 x 16 block, conflict-free), a single-term output never leaves the registers.
+template <int NR, bool FAST>
+__global__ __launch_bounds__(256, 2) void compose_multi_kernel(ComposeMultiParams p_by_value) {
+    // The argument block is read where it lies, in the kernarg segment: its arrays are indexed by the run-time output / term number, and a
+    // by-value aggregate indexed dynamically is first loaded whole into ~100 SGPRs (130 of them then spilled into vector registers, which in
+    // turn spilled to scratch); from memory each use is one scalar load with a computed offset.
+    (void)p_by_value;
+    const ComposeMultiParams& p = *(const ComposeMultiParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int RS = 4;                                  // k-steps of 32 along the rank held in registers at a time (r = 128: all of them)
+    __shared__ __attribute__((aligned(16))) f32x4 tots[4][NR][4][64];
+    __shared__ float red[MC_MAX_OUTS][4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c16 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.y * 32;
+    const int n0 = blockIdx.y * (16 * NR);
     const int k0 = blockIdx.x * 256 + wave * 64;
     const bool wave_on = k0 < p.Kp;
-    float ret_num = 0.f, ret_den = 0.f;
-    if (wave_on) {
-
-    f32x4 tot[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) tot[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int m = 0; m < p.n_terms; ++m) {
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bf16_t* at = p.at[m];
-        const bf16_t* bm = p.bm[m];
-        for (int rs = 0; rs < p.r; rs += 32) {
-            bf16x8 bf[2], af[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int n = min(n0 + i * 16 + c16, p.N - 1);
-                bf[i] = *(const bf16x8*)(bm + (int64_t)n * p.r + rs + g * 8);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int k = min(k0 + t * 16 + c16, p.K - 1);
-                af[t] = *(const bf16x8*)(at + (int64_t)k * p.r + rs + g * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf[i], acc[i][t], 0, 0, 0);
-        }
-        const float s = p.scale[m];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) tot[i][t] += acc[i][t] * s;
-    }
-    // D[k = 4g + reg][n = c16]
     const int kblocks = p.Kp >> 5;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int n = n0 + i * 16 + c16;
-        const int nb = n >> 4;
-        if (nb * 16 >= ((p.N + 15) & ~15)) continue;
+    const int np16 = (p.N + 15) & ~15;
+    // this lane's 16-byte piece of a block pair tp (blocks 2 tp, 2 tp + 1 of the wave's four 16-column blocks): 8 consecutive k of row n
+    const int k8off = (g & 1) * 16 + (g >> 1) * 8;
+    float cs[4][4];
+    if (wave_on) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int k = k0 + t * 16 + g * 4;
-            float r4[4] = {tot[i][t][0], tot[i][t][1], tot[i][t][2], tot[i][t][3]};
-            const bool inb = n < p.N;
-            if (p.w && inb) {
-                if (k + 3 < p.K) {
-                    const bf16x4 w4 = *(const bf16x4*)(p.w + (int64_t)n * p.ldw + k);
+            if (FAST) {
+                const f32x4 c4 = (p.col_scale && k < p.K) ? *(const f32x4*)(p.col_scale + k) : (f32x4){1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) r4[j] += (float)w4[j];
+                for (int j = 0; j < 4; ++j) cs[t][j] = c4[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cs[t][j] = p.col_scale ? p.col_scale[min(k + j, p.K - 1)] : 1.0f;
+            }
+        }
+    }
+    // W of row block i in the accumulator layout (lane: n = c16, k = 16 t + 4 g .. + 3): 16-byte loads of the 8 columns the lane will STORE,
+    // swapped back (the exchange is its own inverse).  The first output's loads come from HBM, the later ones find the tile in the L2 /
+    // Infinity Cache: W crosses the HBM interface once per linear.
+    auto load_w = [&](int i, bf16x4 (&wv)[4]) {
+        const int n = n0 + i * 16 + c16;
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            const int k = k0 + tp * 32 + k8off;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (p.w && n < p.N) {
+                if (FAST) {
+                    if (k < p.K) v = *(const u32x4*)(p.w + (int64_t)n * p.ldw + k);
                 } else {
+                    bf16x8 e;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (k + j < p.K) r4[j] += (float)p.w[(int64_t)n * p.ldw + k + j];
+                    for (int j = 0; j < 8; ++j) e[j] = (k + j < p.K) ? p.w[(int64_t)n * p.ldw + k + j] : (bf16_t)0.0f;
+                    v = __builtin_bit_cast(u32x4, e);
                 }
             }
-            if (p.col_scale) {
+            auto r0 = __builtin_amdgcn_permlane16_swap(v[0], v[2], false, false);
+            auto r1 = __builtin_amdgcn_permlane16_swap(v[1], v[3], false, false);
+            const u32x2 lo = {r0[0], r1[0]}, hi = {r0[1], r1[1]};
+            wv[2 * tp] = __builtin_bit_cast(bf16x4, lo);
+            wv[2 * tp + 1] = __builtin_bit_cast(bf16x4, hi);
+        }
+    };
+    for (int a = 0; a < p.n_out; ++a) {
+        float ret_num = 0.f, ret_den = 0.f;
+        if (wave_on) {
+            const uint32_t mask = p.term_mask[a];
+            const uint32_t seed = p.dither_seed[a];
+            const bool want_ret = p.retention[a] != nullptr && p.w != nullptr;
+            bf16_t* const outp = p.out_packed[a];
+            bf16_t* const outr = p.out_rowmajor[a];
+            const int last_m = mask ? 31 - __builtin_clz(mask) : -1;
+            const int first_m = mask ? __builtin_ctz(mask) : -1;
+            // the epilogue of row block i: total (fp32) + W, column scale, ONE rounding, store
+            auto finish = [&](int i, const f32x4 (&tot)[4]) {
+                const int n = n0 + i * 16 + c16;
+                const int nb = n >> 4;                           // wave-uniform (c16 < 16)
+                if (nb * 16 >= np16) return;
+                const bool inb = n < p.N;
+                bf16x4 wv[4];
+                load_w(i, wv);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (k + j < p.K) r4[j] *= p.col_scale[k + j];
-            }
-            bf16x4 o;
+                for (int tp = 0; tp < 2; ++tp) {
+                    bf16x4 o[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (inb && k + j < p.K) ? compose_round(r4[j], p.dither_seed, n, k + j) : (bf16_t)0.0f;
-            if (p.retention_parts && p.w && inb) {
-                // the composed weight against the base weight rounded the same way: the part of (W' - bf16(W c)) that lies along dW c
+                    for (int h = 0; h < 2; ++h) {
+                        const int t = 2 * tp + h;
+                        const int k = k0 + t * 16 + g * 4;
+                        float r4[4] = {tot[t][0], tot[t][1], tot[t][2], tot[t][3]};
+                        if (p.w && inb) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (k + j < p.K) {
-                        const float cs = p.col_scale ? p.col_scale[k + j] : 1.0f;
-                        const float wv = (float)p.w[(int64_t)n * p.ldw + k + j];
-                        const float d = tot[i][t][j] * cs;
-                        const float moved = (float)o[j] - (float)(bf16_t)(wv * cs);
-                        ret_num = fmaf(moved, d, ret_num);
-                        ret_den = fmaf(d, d, ret_den);
+                            for (int j = 0; j < 4; ++j) r4[j] += (float)wv[t][j];
+                        }
+                        if (p.col_scale) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) r4[j] *= cs[t][j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[h][j] = (inb && k + j < p.K) ? compose_round(r4[j], seed, n, k + j) : (bf16_t)0.0f;
+                        if (want_ret && inb) {
+                            // the composed weight against the base weight rounded the same way: the part of (W' - bf16(W c)) that lies along dW c
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (k + j < p.K) {
+                                    const float d = tot[t][j] * cs[t][j];
+                                    const float moved = (float)o[h][j] - (float)(bf16_t)((float)wv[t][j] * cs[t][j]);
+                                    ret_num = fmaf(moved, d, ret_num);
+                                    ret_den = fmaf(d, d, ret_den);
+                                }
+                        }
                     }
-            }
-            const int kb = k >> 5;
-            const int q = (k & 31) >> 3;
-            bf16_t* dst = p.out_packed + ((int64_t)(nb * p.nb_stride + p.nb_offset) * kblocks + kb) * 512 + ((q << 4) | (n & 15)) * 8 + (k & 7);
-            *(bf16x4*)dst = o;
-            if (p.out_rowmajor && inb) {
+                    // 16 bytes per lane: even g the 8 columns (g >> 1) * 8 .. of block 2 tp, odd g of block 2 tp + 1
+                    const u32x2 pa = __builtin_bit_cast(u32x2, o[0]), pb = __builtin_bit_cast(u32x2, o[1]);
+                    auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                    const u32x4 ov = {r0[0], r1[0], r0[1], r1[1]};
+                    const int k8 = k0 + tp * 32 + k8off;
+                    const int kb = k8 >> 5, q = (k8 & 31) >> 3;
+                    bf16_t* dst = outp + ((int64_t)(nb * p.nb_stride + p.nb_offset) * kblocks + kb) * 512 + ((q << 4) | (n & 15)) * 8;
+                    *(u32x4*)dst = ov;
+                    if (outr && inb) {
+                        if (FAST) {
+                            if (k8 < p.K) *(u32x4*)(outr + (int64_t)n * p.ldo + k8) = ov;
+                        } else {
+                            const bf16x8 e = __builtin_bit_cast(bf16x8, ov);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (k + j < p.K) p.out_rowmajor[(int64_t)n * p.ldo + k + j] = o[j];
+                            for (int j = 0; j < 8; ++j)
+                                if (k8 + j < p.K) outr[(int64_t)n * p.ldo + k8 + j] = e[j];
+                        }
+                    }
+                }
+            };
+            if (mask == 0) {                                     // no LoRA term: W' = bf16(W c)
+                const f32x4 zero[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+                for (int i = 0; i < NR; ++i) finish(i, zero);
+            }
+            const bool one_chunk = p.r <= 32 * RS;               // the whole rank fits the fragment registers: A^T is loaded once per term
+            for (int m = 0; m < p.n_terms; ++m) {
+                if (!((mask >> m) & 1u)) continue;
+                const bf16_t* at = p.at[m];
+                const bf16_t* bm = p.bm[m];
+                const float s = p.scale[m];
+                const bool first = m == first_m, last = m == last_m;
+                bf16x8 af[RS][4];
+                auto load_af = [&](int rs0) {
+#pragma unroll
+                    for (int q = 0; q < RS; ++q)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int k = min(k0 + t * 16 + c16, p.K - 1);
+                            af[q][t] = *(const bf16x8*)(at + (int64_t)k * p.r + min(rs0 + q * 32, p.r - 32) + g * 8);      // (steps beyond r are skipped below)
+                        }
+                };
+                if (one_chunk) load_af(0);
+#pragma unroll 1
+                for (int i = 0; i < NR; ++i) {
+                    const int n = min(n0 + i * 16 + c16, p.N - 1);
+                    f32x4 acc[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int rs0 = 0; rs0 < p.r; rs0 += 32 * RS) {
+                        if (!one_chunk) load_af(rs0);
+                        bf16x8 bf[RS];
+#pragma unroll
+                        for (int q = 0; q < RS; ++q) bf[q] = *(const bf16x8*)(bm + (int64_t)n * p.r + min(rs0 + q * 32, p.r - 32) + g * 8);
+#pragma unroll
+                        for (int q = 0; q < RS; ++q) {
+                            if (rs0 + q * 32 < p.r) {
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][t], bf[q], acc[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                    f32x4 tot[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        tot[t] = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : tots[wave][i][t][lane];
+                        tot[t] += acc[t] * s;
+                    }
+                    if (last) finish(i, tot);
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) tots[wave][i][t][lane] = tot[t];
+                    }
+                }
             }
         }
-    }
-    }
-    if (p.retention_parts) {
-        __shared__ float red[4][2];
+        if (p.retention[a]) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            ret_num += __shfl_xor(ret_num, o, 64);
-            ret_den += __shfl_xor(ret_den, o, 64);
-        }
-        if (lane == 0) { red[wave][0] = ret_num; red[wave][1] = ret_den; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float* dst = p.retention_parts + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
-            dst[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);            // fixed order: reproducible
-            dst[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+            for (int o = 32; o > 0; o >>= 1) {
+                ret_num += __shfl_xor(ret_num, o, 64);
+                ret_den += __shfl_xor(ret_den, o, 64);
+            }
+            if (lane == 0) { red[a][wave][0] = ret_num; red[a][wave][1] = ret_den; }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < p.n_out && p.retention[threadIdx.x]) {
+        const int a = threadIdx.x;
+        float* dst = p.retention[a] + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        dst[0] = (red[a][0][0] + red[a][1][0]) + (red[a][2][0] + red[a][3][0]);            // fixed order: reproducible
+        dst[1] = (red[a][0][1] + red[a][1][1]) + (red[a][2][1] + red[a][3][1]);
+    }
+}
+
+#define MC_COMPOSE_NR 4
+
+extern "C" int mc_compose_retention_floats(int N, int K, int64_t* floats) {
+    MC_CHECK_ARG(floats && N > 0 && K > 0, "mc_compose_retention_floats: bad arguments");
+    const int Kp = (K + 63) / 64 * 64;
+    *floats = 2LL * ((Kp + 255) / 256) * ((N + 16 * MC_COMPOSE_NR - 1) / (16 * MC_COMPOSE_NR));
+    return 0;
+}
+
+extern "C" int mc_compose_multi_bf16(const mc_compose_multi_args* a, void* stream) {
+    MC_CHECK_ARG(a && a->N > 0 && a->K > 0, "mc_compose_multi_bf16: bad arguments");
+    MC_CHECK_ARG(a->n_terms >= 0 && a->n_terms <= MC_MAX_TERMS, "mc_compose_multi_bf16: at most %d terms (got %d)", MC_MAX_TERMS, a->n_terms);
+    MC_CHECK_ARG(a->n_out >= 1 && a->n_out <= MC_MAX_OUTS, "mc_compose_multi_bf16: 1 .. %d outputs (got %d)", MC_MAX_OUTS, a->n_out);
+    MC_CHECK_ARG(a->n_terms == 0 || (a->r > 0 && a->r % 32 == 0), "mc_compose_multi_bf16: rank %d must be a multiple of 32 (pad A^T / B)", a->r);
+    MC_CHECK_ARG(!a->w || a->ldw % 4 == 0, "mc_compose_multi_bf16: ldw must be a multiple of 4");
+    MC_CHECK_ARG(a->nb_stride >= 1 && a->nb_offset >= 0 && a->nb_offset < a->nb_stride, "mc_compose_multi_bf16: bad block interleave %d/%d", a->nb_offset, a->nb_stride);
+    ComposeMultiParams p;
+    p.w = (const bf16_t*)a->w; p.ldw = a->ldw;
+    for (int i = 0; i < a->n_terms; ++i) {
+        MC_CHECK_ARG(a->at_list && a->b_list && a->scales && a->at_list[i] && a->b_list[i], "mc_compose_multi_bf16: null term %d", i);
+        p.at[i] = (const bf16_t*)a->at_list[i]; p.bm[i] = (const bf16_t*)a->b_list[i]; p.scale[i] = a->scales[i];
+    }
+    p.n_terms = a->n_terms; p.r = a->r; p.n_out = a->n_out;
+    for (int o = 0; o < MC_MAX_OUTS; ++o) {
+        const bool on = o < a->n_out;
+        MC_CHECK_ARG(!on || (a->out_packed && a->out_packed[o]), "mc_compose_multi_bf16: null output %d", o);
+        MC_CHECK_ARG(!on || !a->term_mask || (a->term_mask[o] >> a->n_terms) == 0, "mc_compose_multi_bf16: output %d names a term beyond n_terms", o);
+        p.out_packed[o] = on ? (bf16_t*)a->out_packed[o] : nullptr;
+        p.out_rowmajor[o] = on && a->out_rowmajor ? (bf16_t*)a->out_rowmajor[o] : nullptr;
+        p.term_mask[o] = on ? (a->term_mask ? a->term_mask[o] : ((1u << a->n_terms) - 1u)) : 0u;
+        p.dither_seed[o] = on && a->dither_seeds ? a->dither_seeds[o] : 0u;
+        p.retention[o] = on && a->retention_parts ? a->retention_parts[o] : nullptr;
+    }
+    p.ldo = a->ldo;
+    p.N = a->N; p.K = a->K; p.Kp = (a->K + 63) / 64 * 64;
+    p.col_scale = a->col_scale; p.nb_stride = a->nb_stride; p.nb_offset = a->nb_offset;
+    dim3 grid((p.Kp + 255) / 256, (a->N + 16 * MC_COMPOSE_NR - 1) / (16 * MC_COMPOSE_NR));
+    bool fast = a->K % 8 == 0 && (!a->w || (a->ldw % 8 == 0 && ((uintptr_t)a->w & 15) == 0)) && (!a->col_scale || ((uintptr_t)a->col_scale & 15) == 0);
+    for (int o = 0; o < a->n_out; ++o)
+        if (p.out_rowmajor[o] && (a->ldo % 8 || ((uintptr_t)p.out_rowmajor[o] & 15))) fast = false;
+    if (fast) compose_multi_kernel<MC_COMPOSE_NR, true><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else compose_multi_kernel<MC_COMPOSE_NR, false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    MC_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int mc_compose_weight_dither_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,
@@ -174,26 +332,15 @@ extern "C" int mc_compose_weight_dither_bf16(const void* w, int64_t ldw, const v
                                              int64_t ldo, int N, int K, const float* col_scale, int nb_stride, int nb_offset,
                                              float* retention_parts, uint32_t dither_seed, void* stream) {
     MC_CHECK_ARG(out_packed && N > 0 && K > 0, "mc_compose_weight_bf16: bad arguments");
-    MC_CHECK_ARG(n_terms >= 0 && n_terms <= MC_MAX_TERMS, "mc_compose_weight_bf16: at most %d terms (got %d)", MC_MAX_TERMS, n_terms);
-    MC_CHECK_ARG(n_terms == 0 || (r > 0 && r % 32 == 0), "mc_compose_weight_bf16: rank %d must be a multiple of 32 (pad A^T / B)", r);
-    MC_CHECK_ARG(!w || ldw % 4 == 0, "mc_compose_weight_bf16: ldw must be a multiple of 4");
-    MC_CHECK_ARG(nb_stride >= 1 && nb_offset >= 0 && nb_offset < nb_stride, "mc_compose_weight_ex_bf16: bad block interleave %d/%d", nb_offset, nb_stride);
-    ComposeParams p;
-    p.w = (const bf16_t*)w; p.ldw = ldw;
-    for (int i = 0; i < n_terms; ++i) {
-        MC_CHECK_ARG(at_list[i] && b_list[i], "mc_compose_weight_bf16: null term %d", i);
-        p.at[i] = (const bf16_t*)at_list[i]; p.bm[i] = (const bf16_t*)b_list[i]; p.scale[i] = scales[i];
-    }
-    p.n_terms = n_terms; p.r = r;
-    p.out_packed = (bf16_t*)out_packed; p.out_rowmajor = (bf16_t*)out_rowmajor; p.ldo = ldo;
-    p.N = N; p.K = K; p.Kp = (K + 63) / 64 * 64;
-    p.col_scale = col_scale; p.nb_stride = nb_stride; p.nb_offset = nb_offset;
-    p.retention_parts = retention_parts;
-    p.dither_seed = dither_seed;
-    dim3 grid((p.Kp + 255) / 256, (N + 31) / 32);
-    compose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    MC_CHECK_LAUNCH();
-    return 0;
+    mc_compose_multi_args a;
+    void* outs[1] = {out_packed};
+    void* rms[1] = {out_rowmajor};
+    float* rets[1] = {retention_parts};
+    uint32_t seeds[1] = {dither_seed};
+    a.w = w; a.ldw = ldw; a.at_list = at_list; a.b_list = b_list; a.scales = scales; a.n_terms = n_terms; a.r = r;
+    a.n_out = 1; a.out_packed = outs; a.out_rowmajor = rms; a.term_mask = nullptr; a.dither_seeds = seeds; a.retention_parts = rets;
+    a.ldo = ldo; a.N = N; a.K = K; a.col_scale = col_scale; a.nb_stride = nb_stride; a.nb_offset = nb_offset;
+    return mc_compose_multi_bf16(&a, stream);
 }
 
 extern "C" int mc_compose_weight_ex_bf16(const void* w, int64_t ldw, const void* const* at_list, const void* const* b_list,

@@ -47,6 +47,8 @@ struct Llm {
     int64_t key_mask_stride = 0;
     const void* call_key_mask = nullptr;     // ... while that call runs
     int64_t call_key_mask_stride = 0;
+    bool graph_logits = false;               // "graph_logits" option: a decode call that asks for step logits still replays the graph (the step's
+                                             // logits are copied out of the workspace between replays) instead of one launch per kernel
     bool fold_qkv = true;                    // decode: the q|k|v projection's split-K slabs are folded by the attention launch (no reduce launch)
     // one-shot capture of the NEXT prefill (mc_llm_set_capture): cap_hidden receives n_layers + 1 snapshots of the routed hidden state
     // (the embeddings, then every layer's output), cap_q every layer's rotated queries [B, Lq, H, D] - what forward(output_hidden_states /
@@ -293,6 +295,7 @@ extern "C" int mc_llm_set_option(void* handle, const char* name, int value) {
     Llm* m = (Llm*)handle;
     if (!m || !name) { mc_set_error("mc_llm_set_option: null argument"); return 1; }
     if (!strcmp(name, "use_graph")) { m->use_graph = value != 0; return 0; }
+    if (!strcmp(name, "graph_logits")) { m->graph_logits = value != 0; return 0; }
     if (!strcmp(name, "fold_qkv")) {
         if (m->fold_qkv != (value != 0)) {                       // captured decode graphs hold the other launch sequence
             for (int i = 0; i < Llm::kGraphs; ++i) m->gkey[i] = Llm::Key{};
@@ -522,7 +525,7 @@ extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids
     void* attn_ws = (char*)workspace + w.total;
     const int nsplit = decode_nsplit(c, B);
     hipStream_t s = (hipStream_t)stream;
-    if (m->use_graph && !logits_out && n_steps > 1 && !m->prof_on && !m->call_key_mask) {
+    if (m->use_graph && (!logits_out || m->graph_logits) && n_steps > 1 && !m->prof_on && !m->call_key_mask) {
         // graphs cannot be captured on the legacy null stream: run this call's launches on the handle's own stream, after everything the
         // caller has queued on stream 0 (ev_in) and before anything it queues afterwards (ev_out)
         hipStream_t gs = s;
@@ -589,6 +592,10 @@ extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids
             for (int i = 0; i < n_steps; ++i) {
                 hipError_t e = hipGraphLaunch(m->graph_exec[slot], gs);
                 if (e != hipSuccess) { mc_set_error("mc_llm_decode: hipGraphLaunch: %s", hipGetErrorString(e)); return 2; }
+                if (logits_out) {          // "graph_logits": the replayed step left its logits in the workspace
+                    e = hipMemcpyAsync(logits_out + (size_t)i * B * c.vocab, w.logits, (size_t)B * c.vocab * sizeof(float), hipMemcpyDeviceToDevice, gs);
+                    if (e != hipSuccess) { mc_set_error("mc_llm_decode: logits copy: %s", hipGetErrorString(e)); return 2; }
+                }
             }
             m->graph_active = 1;
             return hand_back();

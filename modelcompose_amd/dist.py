@@ -64,3 +64,44 @@ def gather_ids(ids: torch.Tensor, world_size: int, force: bool = False, pad_valu
     if any(r != Bm for r in rows):
         out = torch.cat([out[k * Bm:k * Bm + r] for k, r in enumerate(rows)], 0)
     return (out, rows) if return_rows else out
+
+
+def gather_rows(t: torch.Tensor, world_size: int, force: bool = False, equal_shapes: bool = False) -> torch.Tensor:
+    """All ranks' rows of a [rows, ...] tensor (any dtype; trailing dimensions equal on every rank) -> [sum_r rows_r, ...] in rank order.
+    Ranks may hold different row counts (the last chunk of `ceil(n/N)` is shorter or empty): the counts are exchanged first and the
+    padding rows dropped, as gather_ids does for the id matrix."""
+    if world_size == 1 and not force:
+        return t
+    import torch.distributed as dist
+    t = t.contiguous()
+    if t.is_cuda and dist.get_backend() == "gloo":
+        return gather_rows(t.cpu(), world_size, force=force, equal_shapes=equal_shapes).to(t.device)
+    tail = tuple(t.shape[1:])
+    if equal_shapes:
+        out = torch.empty((world_size * t.shape[0],) + tail, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out
+    mine = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = torch.empty(world_size, dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(counts, mine)
+    rows = [int(r) for r in counts.cpu()]
+    Bm = max(rows)
+    if Bm == 0:
+        return torch.empty((0,) + tail, dtype=t.dtype, device=t.device)
+    padded = t
+    if t.shape[0] != Bm:
+        padded = torch.zeros((Bm,) + tail, dtype=t.dtype, device=t.device)
+        padded[:t.shape[0]] = t
+    out = torch.empty((world_size * Bm,) + tail, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, padded)
+    if any(r != Bm for r in rows):
+        out = torch.cat([out[k * Bm:k * Bm + r] for k, r in enumerate(rows)], 0)
+    return out
+
+
+def gather_logits(logits: torch.Tensor, world_size: int, force: bool = False, equal_shapes: bool = False) -> torch.Tensor:
+    """BASELINE.json's north_star words the eval aggregation as an all-gather of LOGITS: every rank's step logits [B_r, T, V] fp32 ->
+    [sum_r B_r, T, V] in rank order (the reference itself aggregates text files, scripts/model_composition/test/MCUB-4.sh:60-70; gather_ids
+    moves what those files hold).  One RCCL all_gather_into_tensor over xGMI, T V 4 bytes per row."""
+    assert logits.dim() == 3, "gather_logits takes [rows, steps, vocab]"
+    return gather_rows(logits, world_size, force=force, equal_shapes=equal_shapes)

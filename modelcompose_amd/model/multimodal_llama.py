@@ -258,6 +258,34 @@ class MultimodalLlamaForCausalLM:
         _compose_into(w, tl, N, K, out, col_scale, nb_stride, nb_offset, retention=self._retention_parts.setdefault(adapter, []),
                       dither_seed=seed)
 
+    def _compose_linear_multi(self, prefix: str, adapters, outs, N: int, K: int, col_scale=None, nb_stride=1, nb_offset=0):
+        """The dense weights of one LocalLoRA linear for ALL routed adapters in one pass over W (round 5: W is read once, not once per
+        adapter): the union of the adapters' LoRA terms, one bit mask per output."""
+        dev = self.device
+        w = self._raw[f"{prefix}.weight"].to(dev, BF16)
+        keys, terms, masks = [], [], []
+        for ad, out in zip(adapters, outs):
+            self._composed.setdefault(ad, []).append((prefix, out, N, K, col_scale, nb_stride, nb_offset))
+            m = 0
+            for key, scale in composition_terms(self.config, ad, lambda key: self._has_lora(prefix, key)):
+                if not self._has_lora(prefix, key):
+                    continue                                         # e.g. 'default-point' never trained: contributes B = 0
+                tk = (key, float(scale))
+                if tk not in keys:
+                    keys.append(tk)
+                    terms.append((self._raw[f"{prefix}.lora_A.{key}.weight"].to(dev), self._raw[f"{prefix}.lora_B.{key}.weight"].to(dev), scale))
+                m |= 1 << keys.index(tk)
+            masks.append(m)
+        if len(terms) > 8 or len(outs) > 6:                          # beyond one launch's tables: per adapter
+            for ad, out in zip(adapters, outs):
+                self._composed[ad].pop()
+                self._compose_linear(prefix, ad, out, N, K, col_scale, nb_stride, nb_offset)
+            return
+        rets = [self._retention_parts.setdefault(ad, []) for ad in adapters]
+        _compose_multi_into(w, terms, masks, N, K, outs, col_scale, nb_stride, nb_offset, retentions=rets)
+        r = max((t[0].shape[0] for t in terms), default=0)
+        self.compose_bytes += 2.0 * N * K * (1 + len(outs)) + 2.0 * len(terms) * r * (N + K)
+
     def finalize(self):
         """Compose + pack every weight, create the C runtime handle."""
         cfg, dev = self.config, self.device
@@ -274,38 +302,49 @@ class MultimodalLlamaForCausalLM:
         qkv_n, Kp_h, Kp_i = (H + 2 * Hkv) * D, ops.ceil_to(Hd, 64), ops.ceil_to(I, 64)
         keep = []
         layer_ptrs = []
+        self.compose_bytes = 0.0                                     # algorithmic HBM bytes of the composition (bench.py's compose roofline)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         # adapters whose dense weights equal another adapter's (no LoRA terms at all) share storage with the base
         for l in range(Lyr):
-            base_cache = {}
-            for ai, ad in enumerate(names):
-                p = f"model.layers.{l}"
+            p = f"model.layers.{l}"
+            # input_layernorm / post_attention_layernorm weights (fp32) folded into the q|k|v and gate|up columns
+            g_in = raw[f"{p}.input_layernorm.weight"].to(dev, torch.float32).contiguous()
+            g_post = raw[f"{p}.post_attention_layernorm.weight"].to(dev, torch.float32).contiguous()
+            keep.extend([g_in, g_post])
+            owners = []                                              # adapters that get storage of their own (the first LoRA-less one stands for all)
+            base_owner = None
+            owner_of = {}
+            for ad in names:
                 has_any = any(composition_terms(cfg, ad, lambda key, pp=f"{p}.{blk}.{lin}": self._has_lora(pp, key))
                               for blk, lins in LINEARS for lin in lins)
-                if not has_any and "base" in base_cache:
-                    layer_ptrs.extend(base_cache["base"])
-                    continue
-                # input_layernorm / post_attention_layernorm weights (fp32) folded into the q|k|v and gate|up columns
-                g_in = raw[f"{p}.input_layernorm.weight"].to(dev, torch.float32).contiguous()
-                g_post = raw[f"{p}.post_attention_layernorm.weight"].to(dev, torch.float32).contiguous()
-                qkv = torch.empty(ops.packed_elems(qkv_n, Hd), dtype=BF16, device=dev)
-                off = 0
-                for lin, n in (("q_proj", H * D), ("k_proj", Hkv * D), ("v_proj", Hkv * D)):
-                    self._compose_linear(f"{p}.self_attn.{lin}", ad, qkv[off * Kp_h:(off + n) * Kp_h], n, Hd, col_scale=g_in)
-                    off += n
-                o = torch.empty(ops.packed_elems(Hd, H * D), dtype=BF16, device=dev)
-                self._compose_linear(f"{p}.self_attn.o_proj", ad, o, Hd, H * D)
-                # gate / up interleaved per 16-row block (gate even, up odd) for the fused SwiGLU epilogue
-                gu = torch.empty(ops.packed_elems(2 * I, Hd), dtype=BF16, device=dev)
-                self._compose_linear(f"{p}.mlp.gate_proj", ad, gu, I, Hd, col_scale=g_post, nb_stride=2, nb_offset=0)
-                self._compose_linear(f"{p}.mlp.up_proj", ad, gu, I, Hd, col_scale=g_post, nb_stride=2, nb_offset=1)
-                dn = torch.empty(ops.packed_elems(Hd, I), dtype=BF16, device=dev)
-                self._compose_linear(f"{p}.mlp.down_proj", ad, dn, Hd, I)
-                keep.extend([g_in, g_post])
-                ptrs = [qkv.data_ptr(), o.data_ptr(), gu.data_ptr(), dn.data_ptr()]
-                keep.extend([qkv, o, gu, dn])
                 if not has_any:
-                    base_cache["base"] = ptrs
-                layer_ptrs.extend(ptrs)
+                    if base_owner is None:
+                        base_owner = ad
+                        owners.append(ad)
+                    owner_of[ad] = base_owner
+                else:
+                    owners.append(ad)
+                    owner_of[ad] = ad
+            bufs = {}
+            for ad in owners:
+                bufs[ad] = dict(qkv=torch.empty(ops.packed_elems(qkv_n, Hd), dtype=BF16, device=dev),
+                                o=torch.empty(ops.packed_elems(Hd, H * D), dtype=BF16, device=dev),
+                                gu=torch.empty(ops.packed_elems(2 * I, Hd), dtype=BF16, device=dev),     # gate / up interleaved per 16-row block (gate even, up odd)
+                                dn=torch.empty(ops.packed_elems(Hd, I), dtype=BF16, device=dev))
+                keep.extend(bufs[ad].values())
+            off = 0
+            for lin, n in (("q_proj", H * D), ("k_proj", Hkv * D), ("v_proj", Hkv * D)):
+                self._compose_linear_multi(f"{p}.self_attn.{lin}", owners, [bufs[ad]["qkv"][off * Kp_h:(off + n) * Kp_h] for ad in owners], n, Hd, col_scale=g_in)
+                off += n
+            self._compose_linear_multi(f"{p}.self_attn.o_proj", owners, [bufs[ad]["o"] for ad in owners], Hd, H * D)
+            self._compose_linear_multi(f"{p}.mlp.gate_proj", owners, [bufs[ad]["gu"] for ad in owners], I, Hd, col_scale=g_post, nb_stride=2, nb_offset=0)
+            self._compose_linear_multi(f"{p}.mlp.up_proj", owners, [bufs[ad]["gu"] for ad in owners], I, Hd, col_scale=g_post, nb_stride=2, nb_offset=1)
+            self._compose_linear_multi(f"{p}.mlp.down_proj", owners, [bufs[ad]["dn"] for ad in owners], Hd, I)
+            for ad in names:
+                b = bufs[owner_of[ad]]
+                layer_ptrs.extend([b["qkv"].data_ptr(), b["o"].data_ptr(), b["gu"].data_ptr(), b["dn"].data_ptr()])
+        ev1.record()
         final_norm = raw["model.norm.weight"].to(dev, BF16).contiguous()
         self.lm_head = ops.pack_weight(raw["lm_head.weight"].to(dev))
         # rotary tables, fp32 (LlamaRotaryEmbedding 4.31: inv_freq and angles in fp32)
@@ -330,6 +369,10 @@ class MultimodalLlamaForCausalLM:
         self._final_norm = final_norm
         self._dirty = False
         torch.cuda.synchronize()
+        # device time of the composition loop (every launch of it, the small A^T transposes included; host-resident state dicts also pay their
+        # H2D copies here) and its launch count: 7 per layer (one per linear, all routed adapters from one read of W)
+        self.compose_ms = ev0.elapsed_time(ev1)
+        self.compose_launches = 7 * Lyr
         self._summarise_delta_retention()
         return self
 
@@ -1066,6 +1109,68 @@ def _cat_rows(parts: List[torch.Tensor]) -> torch.Tensor:
     return out
 
 
+def _retention_floats(N: int, K: int) -> int:
+    n = C.c_int64(0)
+    _lib.check(_lib.lib().mc_compose_retention_floats(N, K, C.byref(n)), "mc_compose_retention_floats")
+    return int(n.value)
+
+
+def _prep_terms(terms):
+    """[(A [r, K], B [N, r], scale)] -> (A^T list [K, rp], B list [N, rp], rp): bf16, the rank padded to a multiple of 32."""
+    ats, bs, r = [], [], 0
+    for (a, b, s) in terms:
+        r0 = a.shape[0]
+        rp = ops.ceil_to(r0, 32)
+        at = a.to(BF16).t().contiguous()
+        bb = b.to(BF16).contiguous()
+        if rp != r0:
+            at = torch.nn.functional.pad(at, (0, rp - r0))
+            bb = torch.nn.functional.pad(bb, (0, rp - r0))
+        if r and rp != r:
+            raise ValueError("the LoRA terms of one linear must share one (padded) rank")
+        r = rp
+        ats.append(at)
+        bs.append(bb)
+    return ats, bs, r
+
+
+def _compose_multi_into(w: torch.Tensor, terms, masks, N: int, K: int, outs, col_scale=None, nb_stride=1, nb_offset=0, retentions=None):
+    """ONE pass over W for every routed adapter of a linear (mc_compose_multi_bf16): output o = (W + sum of the terms named by masks[o])
+    diag(col_scale), packed into outs[o].  retentions: per output a list that receives this call's partial sums, or None."""
+    n, n_out = len(terms), len(outs)
+    ats, bs, r = _prep_terms(terms)
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    if N % 16 and nb_stride != 1:
+        raise ValueError("interleaved packing needs N to be a multiple of 16")
+    for o in outs:
+        if o.numel() != ops.packed_elems(N, K) * nb_stride:
+            raise ValueError("packed buffer has the wrong size")
+    parts = []
+    for oi in range(n_out):
+        pt = None
+        if retentions is not None and retentions[oi] is not None and masks[oi]:
+            pt = torch.empty(_retention_floats(N, K) // 2, 2, dtype=torch.float32, device=outs[oi].device)
+            retentions[oi].append(pt)
+        parts.append(pt)
+    a = _lib.ComposeMultiArgsC()
+    a.w, a.ldw = w.data_ptr(), w.stride(0)
+    a.at_list = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in ats])
+    a.b_list = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in bs])
+    a.scales = (C.c_float * max(n, 1))(*[float(t[2]) for t in terms])
+    a.n_terms, a.r, a.n_out = n, r, n_out
+    a.out_packed = (C.c_void_p * n_out)(*[o.data_ptr() for o in outs])
+    a.out_rowmajor = None
+    a.term_mask = (C.c_uint32 * n_out)(*[int(m) for m in masks])
+    a.dither_seeds = None
+    a.retention_parts = (C.c_void_p * n_out)(*[0 if pt is None else pt.data_ptr() for pt in parts])
+    a.ldo, a.N, a.K = 0, N, K
+    a.col_scale = 0 if col_scale is None else col_scale.data_ptr()
+    a.nb_stride, a.nb_offset = nb_stride, nb_offset
+    _lib.check(_lib.lib().mc_compose_multi_bf16(C.byref(a), _stream()), "mc_compose_multi_bf16")
+    return outs
+
+
 def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col_scale=None, nb_stride=1, nb_offset=0, retention=None,
                   dither_seed: int = 0):
     """W' = (W + Σ scale·B·A)·diag(col_scale) packed into the preallocated buffer `out` (16-row block nb at nb*nb_stride + nb_offset).
@@ -1095,7 +1200,7 @@ def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col
         raise ValueError("packed buffer has the wrong size")
     parts = None
     if retention is not None and n > 0:
-        parts = torch.empty(((ops.ceil_to(K, 64) + 255) // 256) * ((N + 31) // 32), 2, dtype=torch.float32, device=out.device)
+        parts = torch.empty(_retention_floats(N, K) // 2, 2, dtype=torch.float32, device=out.device)
         retention.append(parts)
     _lib.check(_lib.lib().mc_compose_weight_dither_bf16(_ptr(w), w.stride(0), at_arr, b_arr, sc, n, r, _ptr(out), None, 0, N, K,
                                                         _ptr(col_scale), nb_stride, nb_offset, _ptr(parts), int(dither_seed) & 0xFFFFFFFF,

@@ -139,6 +139,99 @@ def _rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, rnd: bool = Tru
     return bf(y) if rnd else y
 
 
+def _groups_of(adapter_masks, decode: bool, B: int, L: int):
+    """[(adapter, row indices or None)]: the routed groups of the flattened (B L) rows."""
+    if decode or adapter_masks is None:
+        return [("default", None)]
+    flat = {k: v.reshape(-1) for k, v in adapter_masks.items()}
+    groups = [(k, torch.nonzero(m).squeeze(1)) for k, m in flat.items() if bool(m.any())]
+    cover = torch.zeros(B * L, dtype=torch.long)
+    for _, rows in groups:
+        cover[rows] += 1
+    assert bool((cover == 1).all()), "adapter masks must be one-hot per token"
+    if len(groups) == 1:
+        groups = [(groups[0][0], None)]
+    return groups
+
+
+def _layer(dw: DeviceWeights, i: int, h: torch.Tensor, groups, cos, sin, B: int, L: int, R: dict, past=None, trace: Optional[dict] = None):
+    """One decoder layer over h (B L, hidden) with the HIP path's storage points (MultimodalLlamaDecoderLayer.forward,
+    multimodal_llama.py:408-468).  past: (k, v) of this layer or None.  Returns (h_out, (k, v))."""
+    cfg = dw.cfg
+    r = lambda name, t: bf(t) if R[name] else t
+    opx = (lambda t: t) if (R["resid_attn"] and R["resid_mlp"]) or not R["operand"] else bf      # GEMM operand of an fp32 stream
+    H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    eps = cfg.rms_norm_eps
+    decode = past is not None
+    scale = 1.0 / math.sqrt(D)
+    W = dw.layer(i, [g_[0] for g_ in groups])
+    rs = _rs(h, eps)
+    hx = opx(h)
+    q = r("qkv", _routed(hx, W, "q_proj", groups) * rs).view(B, L, H, D)
+    k = r("qkv", _routed(hx, W, "k_proj", groups) * rs).view(B, L, Hkv, D)
+    v = r("qkv", _routed(hx, W, "v_proj", groups) * rs).view(B, L, Hkv, D)
+    if trace is not None:
+        trace[f"{i}.rs"] = rs.clone()
+        trace[f"{i}.qkv"] = torch.cat([q.reshape(B * L, -1), k.reshape(B * L, -1), v.reshape(B * L, -1)], 1)
+    q, k = _rope(q, cos, sin, R["rope"]), _rope(k, cos, sin, R["rope"])
+    if trace is not None:
+        trace[f"{i}.q_rot"] = q.reshape(B * L, -1).clone()
+    q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)            # (B, H, L, D)
+    if decode:
+        k = torch.cat([past[0], k], dim=2)
+        v = torch.cat([past[1], v], dim=2)
+    present = (k, v)
+    rep = H // Hkv
+    kk = k if rep == 1 else k.repeat_interleave(rep, dim=1)
+    vv = v if rep == 1 else v.repeat_interleave(rep, dim=1)
+    s = torch.matmul(q, kk.transpose(2, 3)) * scale
+    if decode:
+        p = torch.softmax(s, dim=-1)
+        o = torch.matmul(p, vv)
+    else:
+        causal = torch.ones(L, L, dtype=torch.bool).tril()
+        s = s.masked_fill(~causal, float("-inf"))
+        m = s.max(dim=-1, keepdim=True).values
+        p = torch.exp(s - m)
+        o = torch.matmul(r("p", p), vv) / p.sum(-1, keepdim=True)
+    o = r("attn_out", o).transpose(1, 2).reshape(B * L, H * D)
+    h = r("resid_attn", h + _routed(o, W, "o_proj", groups))
+    if trace is not None:
+        trace[f"{i}.attn"] = o.clone()
+        trace[f"{i}.x1"] = h.clone()
+    rs = _rs(h, eps)
+    hx = opx(h)
+    g = r("gate_up", _routed(hx, W, "gate_proj", groups) * rs)
+    u = r("gate_up", _routed(hx, W, "up_proj", groups) * rs)
+    inter = r("inter", g / (1.0 + torch.exp(-g)) * u)
+    h = r("resid_mlp", h + _routed(inter, W, "down_proj", groups))
+    del W
+    if trace is not None:
+        trace[f"{i}.inter"] = inter.clone()
+        trace[f"{i}.x2"] = h.clone()
+    return h, present
+
+
+def _cos_sin(cfg, B: int, L: int, past_len: int):
+    D = cfg.head_dim
+    cos_t, sin_t = llm.rope_tables(D, max(cfg.max_position_embeddings, past_len + L), cfg.rope_theta)
+    half = D // 2
+    pos = torch.arange(past_len, past_len + L)
+    return cos_t[pos][:, :half][None].expand(B, L, half), sin_t[pos][:, :half][None].expand(B, L, half)
+
+
+def forward_layer(dw: DeviceWeights, i: int, x: torch.Tensor, adapter_masks: Optional[Dict[str, torch.Tensor]], rounding: Optional[dict] = None,
+                  trace: Optional[dict] = None) -> torch.Tensor:
+    """Prefill of decoder layer i ALONE on a given input x (B, L, hidden) fp32 holding bf16 values - the hidden state that enters the layer -
+    returning the layer's output (B, L, hidden).  For per-layer teacher-forced checks at depth (tests/test_fulldepth_parity_gpu.py): both
+    implementations are handed the same input of layer i, so their outputs differ by one layer's worth of rounding, not by i layers'."""
+    B, L, Hd = x.shape
+    groups = _groups_of(adapter_masks, False, B, L)
+    cos, sin = _cos_sin(dw.cfg, B, L, 0)
+    h, _ = _layer(dw, i, x.reshape(B * L, Hd), groups, cos, sin, B, L, _rounding(rounding), None, trace)
+    return h.view(B, L, Hd)
+
+
 def forward(dw: DeviceWeights, x: torch.Tensor, adapter_masks: Optional[Dict[str, torch.Tensor]], past_kv=None, last_only=False,
             trace: Optional[dict] = None, rounding: Optional[dict] = None):
     """x (B, L, hidden) fp32 holding bf16 values (spliced embeddings, or the embedding rows of one decode token).
@@ -147,77 +240,17 @@ def forward(dw: DeviceWeights, x: torch.Tensor, adapter_masks: Optional[Dict[str
     cfg = dw.cfg
     R = _rounding(rounding)
     r = lambda name, t: bf(t) if R[name] else t
-    opx = (lambda t: t) if (R["resid_attn"] and R["resid_mlp"]) or not R["operand"] else bf      # GEMM operand of an fp32 stream
     B, L, Hd = x.shape
-    H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     eps = cfg.rms_norm_eps
     decode = past_kv is not None
     past_len = past_kv[0][0].shape[2] if decode else 0
-    if decode or adapter_masks is None:
-        groups = [("default", None)]
-    else:
-        flat = {k: v.reshape(-1) for k, v in adapter_masks.items()}
-        groups = [(k, torch.nonzero(m).squeeze(1)) for k, m in flat.items() if bool(m.any())]
-        cover = torch.zeros(B * L, dtype=torch.long)
-        for _, rows in groups:
-            cover[rows] += 1
-        assert bool((cover == 1).all()), "adapter masks must be one-hot per token"
-        if len(groups) == 1:
-            groups = [(groups[0][0], None)]
-    cos_t, sin_t = llm.rope_tables(D, max(cfg.max_position_embeddings, past_len + L), cfg.rope_theta)
-    half = D // 2
-    pos = torch.arange(past_len, past_len + L)
-    cos = cos_t[pos][:, :half][None].expand(B, L, half)
-    sin = sin_t[pos][:, :half][None].expand(B, L, half)
+    groups = _groups_of(adapter_masks, decode, B, L)
+    cos, sin = _cos_sin(cfg, B, L, past_len)
     h = x.reshape(B * L, Hd)
     presents = []
-    scale = 1.0 / math.sqrt(D)
     for i in range(cfg.num_hidden_layers):
-        W = dw.layer(i, [g_[0] for g_ in groups])
-        rs = _rs(h, eps)
-        hx = opx(h)
-        q = r("qkv", _routed(hx, W, "q_proj", groups) * rs).view(B, L, H, D)
-        k = r("qkv", _routed(hx, W, "k_proj", groups) * rs).view(B, L, Hkv, D)
-        v = r("qkv", _routed(hx, W, "v_proj", groups) * rs).view(B, L, Hkv, D)
-        if trace is not None:
-            trace[f"{i}.rs"] = rs.clone()
-            trace[f"{i}.qkv"] = torch.cat([q.reshape(B * L, -1), k.reshape(B * L, -1), v.reshape(B * L, -1)], 1)
-        q, k = _rope(q, cos, sin, R["rope"]), _rope(k, cos, sin, R["rope"])
-        if trace is not None:
-            trace[f"{i}.q_rot"] = q.reshape(B * L, -1).clone()
-        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)            # (B, H, L, D)
-        if decode:
-            k = torch.cat([past_kv[i][0], k], dim=2)
-            v = torch.cat([past_kv[i][1], v], dim=2)
-        presents.append((k, v))
-        rep = H // Hkv
-        kk = k if rep == 1 else k.repeat_interleave(rep, dim=1)
-        vv = v if rep == 1 else v.repeat_interleave(rep, dim=1)
-        s = torch.matmul(q, kk.transpose(2, 3)) * scale
-        if decode:
-            p = torch.softmax(s, dim=-1)
-            o = torch.matmul(p, vv)
-        else:
-            causal = torch.ones(L, L, dtype=torch.bool).tril()
-            s = s.masked_fill(~causal, float("-inf"))
-            m = s.max(dim=-1, keepdim=True).values
-            p = torch.exp(s - m)
-            o = torch.matmul(r("p", p), vv) / p.sum(-1, keepdim=True)
-        o = r("attn_out", o).transpose(1, 2).reshape(B * L, H * D)
-        h = r("resid_attn", h + _routed(o, W, "o_proj", groups))
-        if trace is not None:
-            trace[f"{i}.attn"] = o.clone()
-            trace[f"{i}.x1"] = h.clone()
-        rs = _rs(h, eps)
-        hx = opx(h)
-        g = r("gate_up", _routed(hx, W, "gate_proj", groups) * rs)
-        u = r("gate_up", _routed(hx, W, "up_proj", groups) * rs)
-        inter = r("inter", g / (1.0 + torch.exp(-g)) * u)
-        h = r("resid_mlp", h + _routed(inter, W, "down_proj", groups))
-        del W
-        if trace is not None:
-            trace[f"{i}.inter"] = inter.clone()
-            trace[f"{i}.x2"] = h.clone()
+        h, present = _layer(dw, i, h, groups, cos, sin, B, L, R, past_kv[i] if decode else None, trace)
+        presents.append(present)
     hid = h.view(B, L, Hd)
     if last_only:
         hid = hid[:, -1:]

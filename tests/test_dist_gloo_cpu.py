@@ -162,3 +162,47 @@ def test_two_rank_bucketed_gradient_allreduce():
     cover = sorted((lo, hi) for _, lo, hi in ranges)
     assert cover[0][0] == 0 and cover[-1][1] == 67 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
     assert torch.equal(g, torch.arange(67, dtype=torch.float32) * 3)   # rank 0 (x1) + rank 1 (x2)
+
+
+# ------------------------------------------------------------------------------------------------------------------- round 5
+def _soak_worker(rank, world, port, ret, n_samples, rounds):
+    """An eval job in miniature on `world` gloo ranks: the reference's ceil(n / N) chunks (uneven, the last ranks short or EMPTY), per batch a
+    gather of the ids (ragged lengths) AND of the step logits (north_star's wording), many rounds back to back."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from modelcompose_amd.dist import gather_ids, gather_logits, split_list
+    V, T = 16, 3
+    ok = True
+    for rd in range(rounds):
+        samples = list(range(rd * 1000, rd * 1000 + n_samples))
+        chunks = split_list(samples, world)                       # the reference's rule: ceil(n / N) per chunk, possibly fewer than N chunks
+        mine = chunks[rank] if rank < len(chunks) else []         # (its get_chunk raises for a rank without one, model_multimodal_qa_loader.py:31-33)
+        ids = torch.tensor([[s * 10 + t for t in range(T)] for s in mine], dtype=torch.int64).reshape(len(mine), T)
+        lg = torch.tensor([[[float(s) + 0.001 * t + 0.01 * v for v in range(V)] for t in range(T)] for s in mine], dtype=torch.float32).reshape(len(mine), T, V)
+        all_ids = gather_ids(ids, world)
+        all_lg = gather_logits(lg, world)
+        exp_ids = torch.tensor([[s * 10 + t for t in range(T)] for s in samples], dtype=torch.int64)
+        exp_lg = torch.tensor([[[float(s) + 0.001 * t + 0.01 * v for v in range(V)] for t in range(T)] for s in samples], dtype=torch.float32)
+        ok = ok and torch.equal(all_ids, exp_ids) and torch.equal(all_lg, exp_lg)
+    ret.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_soak_with_uneven_chunks_and_an_empty_rank():
+    """8 ranks on one host (what the driver's SCALE run starts), 19 samples -> ceil(19 / 8) = 3 per rank: ranks 0-5 hold 3, rank 6
+    holds 1, rank 7 NONE; every rank must see the reference's `cat` order (eval/model_multimodal_qa_loader.py:25-33) for ids and logits,
+    20 rounds in a row."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_soak_worker, args=(r, world, port, q, 19, 20)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got == [(r, True) for r in range(world)]

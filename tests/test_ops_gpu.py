@@ -344,6 +344,44 @@ def test_compose_weight_dense_merge(ops, N, K, r, nt):
     close_bf16(y, yb, rel=2 ** -6)
 
 
+@pytest.mark.parametrize("N,K,r", [(4096, 4096, 128), (352, 1024, 64), (100, 200, 32), (64, 100, 32), (11008, 4096, 128)])
+def test_compose_multi_one_pass_equals_one_launch_per_adapter(ops, N, K, r):
+    """Round 5 (mc_compose_multi_bf16): ONE pass over W writes every routed adapter's dense weight - the 3-way composed model's four adapters
+    from six LoRA terms (default = default-vision + default-audio + default-video, multimodal_llama.py:130-149; vision / audio / video =
+    their own term, :150-157), with the RMSNorm column factor and the gate / up block interleave.  Bit for bit what one launch per adapter
+    writes (same MFMA chain per term, same term order, one rounding), and the retention statistics of each output agree."""
+    import ctypes as C
+    from modelcompose_amd import _lib
+    from modelcompose_amd.model.multimodal_llama import _compose_into, _compose_multi_into
+    w = dev(rand_bf(N, K, scale=0.02, seed=60))
+    terms = [(dev(rand_bf(r, K, scale=K ** -0.5, seed=61 + i)), dev(rand_bf(N, r, scale=0.01, seed=71 + i)), 0.5 + 0.25 * i) for i in range(6)]
+    masks = [0b000111, 0b001000, 0b010000, 0b100000, 0]                  # default, vision, audio, video, and an adapter without LoRA (= base)
+    g = (1.0 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(5))).float().cuda()
+    for stride, off in ((1, 0), (2, 1)):
+        if stride == 2 and N % 16:
+            continue
+        n_el = ops.packed_elems(N, K) * stride
+        outs = [torch.zeros(n_el, dtype=BF, device="cuda") for _ in masks]
+        rets = [[] for _ in masks]
+        _compose_multi_into(w, terms, masks, N, K, outs, col_scale=g, nb_stride=stride, nb_offset=off, retentions=rets)
+        for oi, m in enumerate(masks):
+            single = torch.zeros(n_el, dtype=BF, device="cuda")
+            r1 = []
+            _compose_into(w, [t for i, t in enumerate(terms) if (m >> i) & 1], N, K, single, col_scale=g, nb_stride=stride, nb_offset=off, retention=r1)
+            assert torch.equal(outs[oi], single), (N, K, oi, stride)
+            if m:
+                a_, b_ = rets[oi][0].double().sum(0).cpu(), r1[0].double().sum(0).cpu()
+                assert abs(a_[0] / a_[1] - b_[0] / b_[1]) < 1e-4
+            else:
+                assert not rets[oi]
+    # and against the fp32 formula (one bf16 rounding away)
+    got = ops.unpack_weight(ops.PackedWeight(_compose_multi_into(w, terms, masks[:1], N, K, [torch.zeros(ops.packed_elems(N, K), dtype=BF, device="cuda")])[0], N, K))
+    ref = w.float().cpu()
+    for a, b, sc in terms[:3]:
+        ref = ref + sc * (b.float().cpu() @ a.float().cpu())
+    close_bf16(got, ref, rel=2 ** -8)
+
+
 def _interleave_gate_up(wg, wu):
     """[I, K] gate / up -> [2I, K] with 16-row blocks alternating gate, up (layout expected by the swiglu epilogue)."""
     I, K = wg.shape
