@@ -31,6 +31,11 @@ extern "C" {
 const char* mc_last_error(void);
 int mc_abi_version(void);
 int mc_device_info(int* cu_count, int64_t* hbm_bytes, char* arch, int arch_len);
+/* The 16-bit storage element of this build: MC_DTYPE_BF16 (libmc_hip.so - BASELINE.json's dtype, the headline) or MC_DTYPE_F16
+ * (libmc_hip_f16.so: the SAME sources and entry points instantiated on IEEE half, fp32 accumulation unchanged - the reference's own
+ * inference dtype, model/builder.py:41, :162, :185, kept as the parity instrument: 8x finer mantissa at the same MFMA rate).  Every
+ * `_bf16` entry point below takes / returns that element type in the f16 build; fp32 and integer interfaces are unchanged. */
+int mc_storage_dtype(void);
 
 /* ---- weights ---------------------------------------------------------------------------------------
  * Packed layout (see csrc/gemm.hip): [ceil16(N)/16][ceil64(K)/32][64 lanes][8] bf16, zero padded.        */

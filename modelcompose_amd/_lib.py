@@ -6,9 +6,53 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
+# The same sources instantiated on IEEE-half storage (csrc/common.h, -DMC_STORAGE_F16): the reference's own inference dtype
+# (modelcompose/model/builder.py:41, :162, :185), kept as the parity instrument.  One storage dtype per process: MC_STORAGE_DTYPE=fp16 in
+# the environment, or set_storage_dtype("fp16") before anything is built.
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libmc_hip_f16.so")}
 ABI_VERSION = 9
+_DTYPE_CODES = {"bf16": 1, "fp16": 2}                        # MC_DTYPE_BF16 / MC_DTYPE_F16 of mc_hip.h
 
+
+def _norm_dtype(name) -> str:
+    n = str(name).replace("torch.", "").lower()
+    if n in ("bf16", "bfloat16"):
+        return "bf16"
+    if n in ("fp16", "f16", "float16", "half"):
+        return "fp16"
+    raise ValueError(f"storage dtype must be bf16 or fp16, not {name!r}")
+
+
+_storage = _norm_dtype(os.environ.get("MC_STORAGE_DTYPE", "bf16"))
+_libs: dict = {}
 _lib = None
+
+
+def storage_name() -> str:
+    return _storage
+
+
+def storage_dtype():
+    """torch dtype of the 16-bit storage element of the library this process uses."""
+    import torch
+    return torch.float16 if _storage == "fp16" else torch.bfloat16
+
+
+def set_storage_dtype(name) -> str:
+    """Select the library instantiation for this process: "bf16" (default, the headline) or "fp16".  Rebinds the storage dtype constant of
+    every loaded module of the package; objects built before the switch keep their tensors and must not be used after it."""
+    global _storage, _lib
+    import sys
+    new = _norm_dtype(name)
+    if new != _storage:
+        _storage = new
+        _lib = None
+    dt = storage_dtype()
+    for mname, mod in list(sys.modules.items()):
+        if mname.startswith("modelcompose_amd") and mod is not None and hasattr(mod, "BF16"):
+            mod.BF16 = dt
+    return _storage
+
 
 c_p = C.c_void_p
 c_i = C.c_int
@@ -18,6 +62,7 @@ c_f = C.c_float
 # name -> argtypes  (every function returns int status unless noted)
 _SIGS = {
     "mc_abi_version": [],
+    "mc_storage_dtype": [],
     "mc_device_info": [C.POINTER(c_i), C.POINTER(c_l), C.c_char_p, c_i],
     "mc_packed_weight_elems": [c_i, c_i, C.POINTER(c_l)],
     "mc_pack_weight_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
@@ -197,6 +242,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    if _storage in _libs:
+        _lib = _libs[_storage]
+        return _lib
+    LIB_PATH = LIB_PATHS[_storage]
     if not os.path.exists(LIB_PATH):
         raise MCError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       f"(or `make -C modelcompose_amd/csrc`). There is no CPU fallback.")
@@ -216,7 +265,10 @@ def lib():
         fn.restype = c_i
     v = L.mc_abi_version()
     if v != ABI_VERSION:
-        raise MCError(f"libmc_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild")
+        raise MCError(f"{os.path.basename(LIB_PATH)} ABI version {v} != expected {ABI_VERSION}; rebuild")
+    if L.mc_storage_dtype() != _DTYPE_CODES[_storage]:
+        raise MCError(f"{os.path.basename(LIB_PATH)} was built for storage dtype code {L.mc_storage_dtype()}, expected {_storage}; rebuild")
+    _libs[_storage] = L
     _lib = L
     return L
 

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int nq = 0; nq < NQ; ++nq) s[nq][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kb & 1][ks], qf[nq][ks], s[nq][kb], 0, 0, 0);
+                for (int nq = 0; nq < NQ; ++nq) s[nq][kb] = mc_mfma_16x16x32(kfr[kb & 1][ks], qf[nq][ks], s[nq][kb]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -376,9 +376,9 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
                 // (128-byte rows, D = 64: two rows per bank line, 8 rows x 2 chunks of a group -> chunk ^ (2 * ((row >> 1) & 3)))
                 const int sw_lo = (CH == 16) ? (chv ^ ((key_lo & 7) << 1)) : (chv ^ (((key_lo >> 1) & 3) << 1));
                 const int sw_hi = (CH == 16) ? (chv ^ ((key_hi & 7) << 1)) : (chv ^ (((key_hi >> 1) & 3) << 1));
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                const bf16x4 lo = mc_ds_read_tr16(
                     (__attribute__((address_space(3))) bf16x4*)(char*)(vl + key_lo * ROWB + sw_lo * 16 + (tp & 1) * 8));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                const bf16x4 hi = mc_ds_read_tr16(
                     (__attribute__((address_space(3))) bf16x4*)(char*)(vl + key_hi * ROWB + sw_hi * 16 + (tp & 1) * 8));
                 bf16x8 vf;
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
             for (int i = 0; i < GV; ++i) {
                 const int f = grp * GV + i, pr = f / DB, db = f % DB;
 #pragma unroll
-                for (int nq = 0; nq < NQ; ++nq) oacc[nq][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[grp & 1][i], pf[nq][pr], oacc[nq][db], 0, 0, 0);
+                for (int nq = 0; nq < NQ; ++nq) oacc[nq][db] = mc_mfma_16x16x32(vfr[grp & 1][i], pf[nq][pr], oacc[nq][db]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
                 const int off = row * ROWB + swz<D>(ks * 4 + g, row) * 16;
                 const bf16x8 kf = *(const bf16x8*)(k_sw + off);
                 const bf16x8 vf = *(const bf16x8*)(v_sw + off);
-                s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-                dp[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp[kb], 0, 0, 0);
+                s[kb] = mc_mfma_16x16x32(kf, qf[ks], s[kb]);
+                dp[kb] = mc_mfma_16x16x32(vf, dof[ks], dp[kb]);
             }
         }
         bf16x8 dsf[2];
@@ -182,14 +182,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
             const int key_hi = (2 * pr + 1) * 16 + g * 4 + tq;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                const bf16x4 lo = mc_ds_read_tr16(
                     (__attribute__((address_space(3))) bf16x4*)(k_sw + tr_off<D>(key_lo, db, tp)));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                const bf16x4 hi = mc_ds_read_tr16(
                     (__attribute__((address_space(3))) bf16x4*)(k_sw + tr_off<D>(key_hi, db, tp)));
                 bf16x8 kf;
                 kf[0] = lo[0]; kf[1] = lo[1]; kf[2] = lo[2]; kf[3] = lo[3];
                 kf[4] = hi[0]; kf[5] = hi[1]; kf[6] = hi[2]; kf[7] = hi[3];
-                acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf[pr], acc[db], 0, 0, 0);
+                acc[db] = mc_mfma_16x16x32(kf, dsf[pr], acc[db]);
             }
         }
     }
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
                 const int off = row * ROWB + swz<D>(ks * 4 + g, row) * 16;
                 const bf16x8 qf = *(const bf16x8*)(q_sw + off);
                 const bf16x8 of = *(const bf16x8*)(o_sw + off);
-                s[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], s[qb], 0, 0, 0);
-                dp[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, vf[ks], dp[qb], 0, 0, 0);
+                s[qb] = mc_mfma_16x16x32(qf, kf[ks], s[qb]);
+                dp[qb] = mc_mfma_16x16x32(of, vf[ks], dp[qb]);
             }
         }
         // lane owns key column c, queries 16qb + 4g + r
@@ -309,15 +309,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const int off_lo = tr_off<D>(r_lo, db, tp), off_hi = tr_off<D>(r_hi, db, tp);
-                const bf16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(o_sw + off_lo));
-                const bf16x4 ohi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(o_sw + off_hi));
-                const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(q_sw + off_lo));
-                const bf16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(q_sw + off_hi));
+                const bf16x4 olo = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(o_sw + off_lo));
+                const bf16x4 ohi = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(o_sw + off_hi));
+                const bf16x4 qlo = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(q_sw + off_lo));
+                const bf16x4 qhi = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(q_sw + off_hi));
                 bf16x8 of, qf;
                 of[0] = olo[0]; of[1] = olo[1]; of[2] = olo[2]; of[3] = olo[3]; of[4] = ohi[0]; of[5] = ohi[1]; of[6] = ohi[2]; of[7] = ohi[3];
                 qf[0] = qlo[0]; qf[1] = qlo[1]; qf[2] = qlo[2]; qf[3] = qlo[3]; qf[4] = qhi[0]; qf[5] = qhi[1]; qf[6] = qhi[2]; qf[7] = qhi[3];
-                accv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, pf[pr], accv[db], 0, 0, 0);
-                acck[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf[pr], acck[db], 0, 0, 0);
+                accv[db] = mc_mfma_16x16x32(of, pf[pr], accv[db]);
+                acck[db] = mc_mfma_16x16x32(qf, dsf[pr], acck[db]);
             }
         }
     }

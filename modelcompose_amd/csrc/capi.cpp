@@ -15,6 +15,12 @@ void mc_set_error(const char* fmt, ...) {
 
 extern "C" const char* mc_last_error(void) { return g_err; }
 extern "C" int mc_abi_version(void) { return MC_ABI_VERSION; }
+// the 16-bit storage element this build of the library was instantiated on (MC_DTYPE_BF16: libmc_hip.so, MC_DTYPE_F16: libmc_hip_f16.so)
+#ifdef MC_STORAGE_F16
+extern "C" int mc_storage_dtype(void) { return MC_DTYPE_F16; }
+#else
+extern "C" int mc_storage_dtype(void) { return MC_DTYPE_BF16; }
+#endif
 
 extern "C" int mc_device_info(int* cu_count, int64_t* hbm_bytes, char* arch, int arch_len) {
     int dev = 0;

@@ -3,14 +3,44 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit STORAGE element of this build of the library.  libmc_hip.so: bfloat16 (BASELINE.json's dtype, the headline).  libmc_hip_f16.so:
+// the same sources instantiated on IEEE half (-DMC_STORAGE_F16) - the reference's own inference dtype (modelcompose/model/builder.py:41,
+// :162, :185: torch_dtype=torch.float16), 8x finer mantissa at the same MFMA rate (v_mfma_f32_16x16x32_f16): the parity instrument.  The
+// name bf16_t / bf16xN is kept for the element type in both; every kernel converts through float, so nothing else depends on the format
+// (the one bit-level routine, compose_round, has a form per format).
+#ifdef MC_STORAGE_F16
+typedef _Float16 bf16_t;
+typedef _Float16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MC_STORAGE_IS_F16 1
+#define mc_mfma_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#else
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MC_STORAGE_IS_F16 0
+#define mc_mfma_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ds_read_b64_tr_b16 (the transposing LDS read: V / K / activation fragments straight from row-major tiles) for the build's storage element
+typedef __attribute__((address_space(3))) void mc_lds_void;
+#if MC_STORAGE_IS_F16
+typedef __fp16 mc_tr4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ bf16x4 mc_ds_read_tr16(mc_lds_void* p) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) mc_tr4*)p));
+}
+#else
+typedef __bf16 mc_tr4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+__device__ __forceinline__ bf16x4 mc_ds_read_tr16(mc_lds_void* p) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) mc_tr4*)p));
+}
+#endif
 
 #define MC_WAVE 64
 

@@ -40,12 +40,30 @@ __device__ __forceinline__ uint32_t compose_hash(uint32_t x) {
 
 __device__ __forceinline__ bf16_t compose_round(float v, uint32_t seed, int n, int k) {
     if (seed == 0) return (bf16_t)v;
+#if MC_STORAGE_IS_F16
+    // IEEE half: the two neighbours of v on the half grid are its nearest value and the next one on the other side of v; v is rounded to the
+    // farther one with probability = its distance from the nearer one over the spacing (unbiased: E = v)
+    const bf16_t h0 = (bf16_t)v;
+    const float f0 = (float)h0;
+    if (f0 == v || !(fabsf(v) < 65504.0f)) return h0;                            // on the grid, or nothing finite beyond it
+    uint16_t b0 = __builtin_bit_cast(uint16_t, h0);
+    const bool away = fabsf(f0) < fabsf(v);                                       // v lies beyond h0 (away from zero)
+    uint16_t b1;
+    if ((b0 & 0x7fffu) == 0) b1 = (uint16_t)((v < 0.f ? 0x8000u : 0u) | 1u);      // from (signed) zero: the smallest subnormal towards v
+    else b1 = away ? (uint16_t)(b0 + 1) : (uint16_t)(b0 - 1);
+    const bf16_t h1 = __builtin_bit_cast(bf16_t, b1);
+    const float f1 = (float)h1;
+    const float frac = (v - f0) / (f1 - f0);                                      // in (0, 0.5]: how far v sits from its nearest neighbour
+    const uint32_t r = compose_hash(seed ^ compose_hash((uint32_t)n * 0x9E3779B1U + (uint32_t)k)) & 0xFFFFU;
+    return ((float)r + 0.5f) * (1.0f / 65536.0f) < frac ? h1 : h0;
+#else
     uint32_t bits = __builtin_bit_cast(uint32_t, v);
     if ((bits & 0x7f800000U) == 0x7f800000U || (bits & 0x7fff0000U) == 0x7f7f0000U) return (bf16_t)v;   // inf / nan, and the largest finite bf16 (the carry would make it inf): as the plain cast
     const uint32_t r = compose_hash(seed ^ compose_hash((uint32_t)n * 0x9E3779B1U + (uint32_t)k)) & 0xFFFFU;
     bits += r;                                                                // sign-magnitude: the magnitude goes up with probability frac / 2^16
     const uint16_t hi = (uint16_t)(bits >> 16);
     return __builtin_bit_cast(bf16_t, hi);
+#endif
 }
 
 // Round 5: ONE pass per linear for ALL routed adapters.  The round-4 kernel ran once per adapter (4 launches per linear for the 3-way composed
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void compose_multi_kernel(ComposeMultiParam
                         for (int q = 0; q < RS; ++q) {
                             if (rs0 + q * 32 < p.r) {
 #pragma unroll
-                                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][t], bf[q], acc[t], 0, 0, 0);
+                                for (int t = 0; t < 4; ++t) acc[t] = mc_mfma_16x16x32(af[q][t], bf[q], acc[t]);
                             }
                         }
                     }

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const bf16_t* __restr
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mc_mfma_16x16x32(wf[kk][i], xf[kk][j], acc[i][j]);
         };
         // 12 reads in flight (lgkmcnt is a 4-bit counter), k-step 0 computes while k-step 1's fragments land
         ldx(0); ldw(0); ldx(1);
@@ -493,7 +493,7 @@ __device__ __forceinline__ void g2_tile(char* smem, int t, int wave, int woff, i
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
-                    acc[nh][i][mh][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][kk], xf[mh][jj][kk], acc[nh][i][mh][jj], 0, 0, 0);
+                    acc[nh][i][mh][jj] = mc_mfma_16x16x32(wf[i][kk], xf[mh][jj][kk], acc[nh][i][mh][jj]);
         if constexpr ((ABL & 64) != 0) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int b = 0; b < MB; ++b) acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][r], xf[u][b], acc[r][b], 0, 0, 0);
+                for (int b = 0; b < MB; ++b) acc[r][b] = mc_mfma_16x16x32(wf[u][r], xf[u][b], acc[r][b]);
         // (unconditional: a branch in the streaming loop costs the load pipelining far more than these 8 FMAs per fragment)
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
             bf16x8 wf = __builtin_nontemporal_load((const bf16x8*)wptr[r]);
             wptr[r] += 512;
 #pragma unroll
-            for (int b = 0; b < MB; ++b) acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[b], acc[r][b], 0, 0, 0);
+            for (int b = 0; b < MB; ++b) acc[r][b] = mc_mfma_16x16x32(wf, xf[b], acc[r][b]);
         }
     }
     if constexpr (FOLD) {
@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int r = 0; r < RW; ++r)
 #pragma unroll
-                for (int b = 0; b < MB; ++b) acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kb][r], xf[b], acc[r][b], 0, 0, 0);
+                for (int b = 0; b < MB; ++b) acc[r][b] = mc_mfma_16x16x32(wf[kb][r], xf[b], acc[r][b]);
             if (more) {
 #pragma unroll
                 for (int r = 0; r < RW; ++r) wf[kb][r] = __builtin_nontemporal_load((const bf16x8*)(wptr[r] + kb * 512));

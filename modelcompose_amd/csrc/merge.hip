@@ -13,15 +13,15 @@
 
 template <typename T> __device__ __forceinline__ float ld_f(const T* p, int64_t i);
 template <> __device__ __forceinline__ float ld_f<float>(const float* p, int64_t i) { return p[i]; }
-template <> __device__ __forceinline__ float ld_f<bf16_t>(const bf16_t* p, int64_t i) { return (float)p[i]; }
+template <> __device__ __forceinline__ float ld_f<__bf16>(const __bf16* p, int64_t i) { return (float)p[i]; }
 template <> __device__ __forceinline__ float ld_f<__half>(const __half* p, int64_t i) { return __half2float(p[i]); }
 template <typename T> __device__ __forceinline__ float rnd_t(float v);
 template <> __device__ __forceinline__ float rnd_t<float>(float v) { return v; }
-template <> __device__ __forceinline__ float rnd_t<bf16_t>(float v) { return (float)(bf16_t)v; }
+template <> __device__ __forceinline__ float rnd_t<__bf16>(float v) { return (float)(__bf16)v; }
 template <> __device__ __forceinline__ float rnd_t<__half>(float v) { return __half2float(__float2half(v)); }
 template <typename T> __device__ __forceinline__ void st_t(T* p, int64_t i, float v);
 template <> __device__ __forceinline__ void st_t<float>(float* p, int64_t i, float v) { p[i] = v; }
-template <> __device__ __forceinline__ void st_t<bf16_t>(bf16_t* p, int64_t i, float v) { p[i] = (bf16_t)v; }
+template <> __device__ __forceinline__ void st_t<__bf16>(__bf16* p, int64_t i, float v) { p[i] = (__bf16)v; }
 template <> __device__ __forceinline__ void st_t<__half>(__half* p, int64_t i, float v) { p[i] = __float2half(v); }
 
 #define TIES_BINS 2048
@@ -109,7 +109,7 @@ static int ties_launch(int which, const void* x, int64_t ld, int64_t d, int n, i
 #define TIES_DISPATCH(...)                                                                                  \
     do {                                                                                                    \
         if (dtype == MC_DTYPE_F32) ties_launch<float>(__VA_ARGS__);                                         \
-        else if (dtype == MC_DTYPE_BF16) ties_launch<bf16_t>(__VA_ARGS__);                                  \
+        else if (dtype == MC_DTYPE_BF16) ties_launch<__bf16>(__VA_ARGS__);                                    \
         else if (dtype == MC_DTYPE_F16) ties_launch<__half>(__VA_ARGS__);                                   \
         else { mc_set_error("ties: unsupported dtype code %d", dtype); return 1; }                          \
     } while (0)
@@ -183,7 +183,7 @@ extern "C" int mc_merge_metrics(const void* x, int dtype, int64_t ld, int64_t d,
     MC_CHECK_ARG(x && partial && d > 0 && n >= 2, "mc_merge_metrics: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MC_DTYPE_F32) merge_metrics_kernel<float><<<METRIC_BLOCKS, 256, 0, s>>>((const float*)x, ld, d, n, thr, partial);
-    else if (dtype == MC_DTYPE_BF16) merge_metrics_kernel<bf16_t><<<METRIC_BLOCKS, 256, 0, s>>>((const bf16_t*)x, ld, d, n, thr, partial);
+    else if (dtype == MC_DTYPE_BF16) merge_metrics_kernel<__bf16><<<METRIC_BLOCKS, 256, 0, s>>>((const __bf16*)x, ld, d, n, thr, partial);
     else if (dtype == MC_DTYPE_F16) merge_metrics_kernel<__half><<<METRIC_BLOCKS, 256, 0, s>>>((const __half*)x, ld, d, n, thr, partial);
     else { mc_set_error("mc_merge_metrics: unsupported dtype code %d", dtype); return 1; }
     MC_CHECK_LAUNCH();

@@ -575,18 +575,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int colb = (wp * 32 + i * 16 + tp * 4) * 2;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(la + r_lo * TN_ROWB + colb));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(la + r_hi * TN_ROWB + colb));
+                const bf16x4 lo = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(la + r_lo * TN_ROWB + colb));
+                const bf16x4 hi = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(la + r_hi * TN_ROWB + colb));
                 fa[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 const int colq = (wq * 32 + i * 16 + tp * 4) * 2;
-                const bf16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lb + r_lo * TN_ROWB + colq));
-                const bf16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lb + r_hi * TN_ROWB + colq));
+                const bf16x4 lo2 = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(lb + r_lo * TN_ROWB + colq));
+                const bf16x4 hi2 = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(lb + r_hi * TN_ROWB + colq));
                 fb[i] = (bf16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mc_mfma_16x16x32(fa[i], fb[j], acc[i][j]);
         }
     }
     // D[row = 4g + r][col = c16] of the (i, j) block: out[p0 + wp*32 + i*16 + 4g + r][q0 + wq*32 + j*16 + c16]
@@ -672,17 +672,17 @@ __global__ __launch_bounds__(256) void gemm_tn_wide_kernel(TnParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ca = (pa0 + i * 16 + tp * 4) * 2, cb = (qb0 + i * 16 + tp * 4) * 2;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(la + r_lo * SA + ca));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(la + r_hi * SA + ca));
+                const bf16x4 lo = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(la + r_lo * SA + ca));
+                const bf16x4 hi = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(la + r_hi * SA + ca));
                 fa[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const bf16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lb + r_lo * SB + cb));
-                const bf16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lb + r_hi * SB + cb));
+                const bf16x4 lo2 = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(lb + r_lo * SB + cb));
+                const bf16x4 hi2 = mc_ds_read_tr16((__attribute__((address_space(3))) bf16x4*)(lb + r_hi * SB + cb));
                 fb[i] = (bf16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mc_mfma_16x16x32(fa[i], fb[j], acc[i][j]);
         }
     }
     float* dst = p.splits > 1 ? p.slabs + ((int64_t)(prob * p.splits + split) * p.P) * p.Q : p.out[prob];

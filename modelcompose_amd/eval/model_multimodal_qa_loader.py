@@ -16,6 +16,7 @@ import uuid
 
 import torch
 
+from .. import _lib
 from .. import conversation as conversation_lib
 from ..conversation import SeparatorStyle, conv_templates
 from ..data import ChunkedMultimodalDataset, DataCollatorForSupervisedDataset
@@ -66,7 +67,7 @@ def eval_model(args, loaded=None):
     def batches():
         for batch in loader:
             input_ids = batch["input_ids"].to(model.device)
-            modal_inputs = _to_device(batch["modal_inputs"], model.device, torch.bfloat16) if "modal_inputs" in batch else {}
+            modal_inputs = _to_device(batch["modal_inputs"], model.device, _lib.storage_dtype()) if "modal_inputs" in batch else {}
             meta.append(input_ids)
             # batch 1 (the reference): no mask, as the reference's generate() call.  Batched: the collator right-pads the prompts; the mask
             # gives every row its own length, so each row generates exactly what it would alone

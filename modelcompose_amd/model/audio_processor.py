@@ -47,17 +47,18 @@ class HipBeatsAudioProcessor:
         self._mel = torch.from_numpy(mel).contiguous().to(self.device)
         self._lo, self._hi = torch.from_numpy(lo).to(self.device), torch.from_numpy(hi).to(self.device)
 
-    def fbank(self, waveforms: torch.Tensor, n_samples: torch.Tensor, frames_out: int, out_dtype=torch.bfloat16) -> torch.Tensor:
+    def fbank(self, waveforms: torch.Tensor, n_samples: torch.Tensor, frames_out: int, out_dtype=None) -> torch.Tensor:
         """waveforms [B, T] fp32 in [-1, 1] on the device, n_samples [B] int32 -> normalised log-mel [B, frames_out, 128]."""
         if not waveforms.is_cuda:
             raise ValueError("waveforms must be a device (HIP) tensor; this path has no CPU fallback")
         w = waveforms.to(torch.float32).contiguous()
         B = w.shape[0]
+        out_dtype = _lib.storage_dtype() if out_dtype is None else out_dtype
         out = torch.empty(B, frames_out, 128, dtype=out_dtype, device=w.device)
-        p16 = out.data_ptr() if out_dtype == torch.bfloat16 else None
+        p16 = out.data_ptr() if out_dtype == _lib.storage_dtype() else None
         p32 = out.data_ptr() if out_dtype == torch.float32 else None
         if p16 is None and p32 is None:
-            raise ValueError("out_dtype must be bfloat16 or float32")
+            raise ValueError("out_dtype must be the library's storage dtype (bfloat16; float16 in the fp16 build) or float32")
         _lib.check(_lib.lib().mc_fbank_f32(w.data_ptr(), n_samples.to(w.device, torch.int32).data_ptr(), w.stride(0), B, self._win.data_ptr(),
                                            self._mel.data_ptr(), self._lo.data_ptr(), self._hi.data_ptr(), float(2 ** 15), self.fbank_mean,
                                            self.fbank_std, p16, p32, frames_out, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
@@ -80,7 +81,7 @@ class HipBeatsAudioProcessor:
         if wav.dim() == 2:
             wav = wav.mean(0) if wav.shape[0] == 2 else wav[0]
         if wav.dim() != 1 or wav.numel() == 0:
-            return torch.zeros(self.n_frames * self.frame_length, 128, dtype=torch.bfloat16, device=self.device), \
+            return torch.zeros(self.n_frames * self.frame_length, 128, dtype=_lib.storage_dtype(), device=self.device), \
                 torch.zeros(self.n_frames * self.frame_length, dtype=torch.bool, device=self.device)
         wav = wav.to(self.device, torch.float32)
         T = wav.numel()
@@ -90,6 +91,6 @@ class HipBeatsAudioProcessor:
         else:
             rows = ((m + (m % self.frame_length)) // self.frame_length) * self.frame_length        # pads by the remainder (:164-168)
         if rows == 0:
-            return torch.zeros(0, 128, dtype=torch.bfloat16, device=self.device), torch.zeros(0, dtype=torch.bool, device=self.device)
+            return torch.zeros(0, 128, dtype=_lib.storage_dtype(), device=self.device), torch.zeros(0, dtype=torch.bool, device=self.device)
         fb = self.fbank(wav.view(1, -1), torch.tensor([T], dtype=torch.int32), rows)[0]
         return fb, torch.zeros(rows, dtype=torch.bool, device=self.device)

@@ -90,9 +90,15 @@ def get_model_name_from_path(model_path: str) -> str:
     return parts[-1]
 
 
-def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto", device="cuda"):
+def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto", device="cuda", *,
+                          torch_dtype=None):
+    """torch_dtype (extension; the reference hard-codes torch.float16, builder.py:41): None = the process's storage dtype (bf16 unless
+    MC_STORAGE_DTYPE=fp16); torch.float16 / "fp16" selects the IEEE-half instantiation of the library for the whole process."""
     if load_8bit or load_4bit:
         raise NotImplementedError("bitsandbytes quantised loading (builder.py:30-39) is out of scope of the HIP path")
+    if torch_dtype is not None:
+        from .. import _lib
+        _lib.set_storage_dtype(torch_dtype)
     if "multimodal" not in model_name.lower():
         raise ValueError(f"model name '{model_name}' does not contain 'multimodal': only the composed-model branch "
                          f"(builder.py:138-185) is implemented")
@@ -123,8 +129,14 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     return tokenizer, model, modal_processors, context_len
 
 
-def build_from_state_dict(meta: dict, sd: Dict[str, torch.Tensor], device="cuda") -> MultimodalLlamaForCausalLM:
-    """Construct a model from an in-memory reference-grammar state dict (tests, smoke, synthetic benchmarks)."""
+def build_from_state_dict(meta: dict, sd: Dict[str, torch.Tensor], device="cuda", dtype=None) -> MultimodalLlamaForCausalLM:
+    """Construct a model from an in-memory reference-grammar state dict (tests, smoke, synthetic benchmarks).
+    dtype: None = the process's storage dtype (bf16 unless MC_STORAGE_DTYPE=fp16 / set_storage_dtype); "fp16" / torch.float16 selects the
+    IEEE-half instantiation of the library - the reference's own inference dtype (model/builder.py:41, :162, :185) - for the WHOLE process:
+    one storage dtype per process, so models built before with the other one must not be used any more."""
+    if dtype is not None:
+        from .. import _lib
+        _lib.set_storage_dtype(dtype)
     known = set(MultimodalConfig._defaults)
     cfg = MultimodalConfig(**{k: v for k, v in meta.items() if k in known or k.startswith("mm_") or k.startswith("local_")})
     model = MultimodalLlamaForCausalLM(cfg, device=device)

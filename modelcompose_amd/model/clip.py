@@ -17,9 +17,9 @@ import torch
 
 from ..checkpoint_io import load_tensors
 
-from .. import ops
+from .. import _lib, ops
 
-BF16 = torch.bfloat16
+BF16 = _lib.storage_dtype()      # the library's 16-bit storage element: bf16, or fp16 with MC_STORAGE_DTYPE=fp16 (_lib.set_storage_dtype)
 
 
 class ClipVisionConfig:

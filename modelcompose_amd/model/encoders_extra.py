@@ -18,10 +18,10 @@ import torch
 
 from ..checkpoint_io import load_nested, load_tensors
 
-from .. import ops
+from .. import _lib, ops
 from .clip import _strip
 
-BF16 = torch.bfloat16
+BF16 = _lib.storage_dtype()      # the library's 16-bit storage element: bf16, or fp16 with MC_STORAGE_DTYPE=fp16 (_lib.set_storage_dtype)
 
 
 def _pw(sd, w, b=None, dev="cuda"):

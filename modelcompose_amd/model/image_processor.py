@@ -125,7 +125,7 @@ class HipCLIPImageProcessor:
         p = lambda t: None if t is None else t.data_ptr()
         _lib.check(_lib.lib().mc_image_preprocess_u8(
             img.data_ptr(), h, w, ch, cw, off_y, off_x, bg, p(bh), p(kh), ksh, p(bv), p(kv), ksv, rh, rw, top, left, crop_h, crop_w, mean, std,
-            tmp.data_ptr(), out.data_ptr() if self.out_dtype == torch.bfloat16 else None,
+            tmp.data_ptr(), out.data_ptr() if self.out_dtype == _lib.storage_dtype() else None,
             out.data_ptr() if self.out_dtype == torch.float32 else None, p(u8), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
             "mc_image_preprocess_u8")
         return (out, u8) if out_u8 else out

@@ -25,7 +25,7 @@ from ..constants import IGNORE_INDEX, MODAL_TOKEN_INDEXES
 from .config import MultimodalConfig, adapter_plan, composition_terms, infer_modals
 from .splice import SplicePlan, plan_splice, routed_layout
 
-BF16 = torch.bfloat16
+BF16 = _lib.storage_dtype()      # the library's 16-bit storage element: bf16, or fp16 with MC_STORAGE_DTYPE=fp16 (_lib.set_storage_dtype)
 
 
 # Side streams are shared by every model instance of the process (one set per device): the library keeps per-stream state - the split-K

@@ -22,8 +22,9 @@ def sample_frame_ids(duration: int, num_frames: int = 8) -> np.ndarray:
 
 
 class HipLanguageBindVideoProcessor:
-    def __init__(self, num_frames: int = 8, size: int = 224, device="cuda", out_dtype=torch.bfloat16):
-        self.num_frames, self.size, self.device, self.out_dtype = num_frames, size, torch.device(device), out_dtype
+    def __init__(self, num_frames: int = 8, size: int = 224, device="cuda", out_dtype=None):
+        self.num_frames, self.size, self.device = num_frames, size, torch.device(device)
+        self.out_dtype = _lib.storage_dtype() if out_dtype is None else out_dtype
 
     def transform(self, frames_u8: torch.Tensor, flip: bool = False) -> torch.Tensor:
         """frames_u8 [T, H, W, 3] uint8 -> [3, T, size, size].  `flip`: the reference's transform ends with
@@ -44,7 +45,7 @@ class HipLanguageBindVideoProcessor:
         out = torch.empty(3, T, s, s, dtype=self.out_dtype, device=self.device)
         mean, std = (C.c_float * 3)(*OPENAI_DATASET_MEAN), (C.c_float * 3)(*OPENAI_DATASET_STD)
         _lib.check(_lib.lib().mc_video_preprocess_u8(f.data_ptr(), T, H, W, rh, rw, top, left, s, 1 if flip else 0, mean, std,
-                                                     out.data_ptr() if self.out_dtype == torch.bfloat16 else None,
+                                                     out.data_ptr() if self.out_dtype == _lib.storage_dtype() else None,
                                                      out.data_ptr() if self.out_dtype == torch.float32 else None,
                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mc_video_preprocess_u8")
         return out

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 
 ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3, "relu": 4}
-BF16 = torch.bfloat16
+BF16 = _lib.storage_dtype()      # the library's 16-bit storage element: bf16, or fp16 with MC_STORAGE_DTYPE=fp16 (_lib.set_storage_dtype)
 
 
 def _stream():
@@ -22,7 +22,9 @@ def _p(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
-def _req(t: torch.Tensor, dtype=BF16, name="tensor"):
+def _req(t: torch.Tensor, dtype="storage", name="tensor"):
+    if isinstance(dtype, str):
+        dtype = BF16                                       # the library's storage element (rebound by _lib.set_storage_dtype)
     if not t.is_cuda:
         raise ValueError(f"{name} must be a device (HIP) tensor; this path has no CPU fallback")
     if dtype is not None and t.dtype != dtype:

@@ -28,6 +28,7 @@ from typing import Callable, Dict, Iterator, List, Optional
 import numpy as np
 import torch
 
+from .. import _lib
 from ..constants import DEFAULT_IMAGE_TOKEN, IMAGE_TOKEN_INDEX
 
 server_error_msg = "**NETWORK ERROR DUE TO HIGH TRAFFIC. PLEASE REGENERATE OR REFRESH THIS PAGE.**"      # modelcompose/utils.py:11
@@ -64,8 +65,8 @@ class ContinuousBatcher:
         dev = model.device
         shape = (cfg.num_hidden_layers, self.B, cfg.num_key_value_heads, self.Smax, cfg.head_dim)
         with torch.inference_mode(False):
-            self.kc = torch.zeros(shape, dtype=torch.bfloat16, device=dev)
-            self.vc = torch.zeros(shape, dtype=torch.bfloat16, device=dev)
+            self.kc = torch.zeros(shape, dtype=_lib.storage_dtype(), device=dev)
+            self.vc = torch.zeros(shape, dtype=_lib.storage_dtype(), device=dev)
             self.kv_lens = torch.ones(self.B, dtype=torch.int32, device=dev)          # idle rows: a one-token context
             self.next_ids = torch.zeros(self.B, dtype=torch.int64, device=dev)
             self.out = torch.zeros(self.B, 1, dtype=torch.int64, device=dev)
@@ -308,7 +309,7 @@ class ModelWorker:
                 pixels = process_images(images, self.image_processor, model.config)
             if isinstance(pixels, list):
                 pixels = torch.stack(pixels, 0)
-            modal_inputs["vision"] = pixels.to(model.device, dtype=torch.bfloat16)
+            modal_inputs["vision"] = pixels.to(model.device, dtype=_lib.storage_dtype())
             enc = model.get_model().get_modal_encoder("vision")
             num_image_tokens = prompt.count(DEFAULT_IMAGE_TOKEN) * int(getattr(enc, "num_patches", 0))
         temperature = float(params.get("temperature", 1.0))

@@ -20,9 +20,9 @@ from typing import Dict, List
 
 import torch
 
-from .. import ops
+from .. import _lib, ops
 
-BF16 = torch.bfloat16
+BF16 = _lib.storage_dtype()      # the library's 16-bit storage element: bf16, or fp16 with MC_STORAGE_DTYPE=fp16 (_lib.set_storage_dtype)
 F32 = torch.float32
 
 

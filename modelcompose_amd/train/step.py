@@ -32,7 +32,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from ..constants import IGNORE_INDEX
 from ..model.config import MultimodalConfig, adapter_plan, infer_modals
 from ..model.multimodal_llama import MultimodalLlamaForCausalLM
@@ -40,7 +40,7 @@ from ..model.encoders_extra import HipQformerProjector
 from ..model.projector import HipMlpProjector
 from .buckets import bucket_ranges
 
-BF16 = torch.bfloat16
+BF16 = _lib.storage_dtype()      # the library's 16-bit storage element: bf16, or fp16 with MC_STORAGE_DTYPE=fp16 (_lib.set_storage_dtype)
 F32 = torch.float32
 # linears that read the same activation share one rank-projection GEMM: their A matrices are stored stacked ("A_in")
 GROUPS = (("attn_in", (("self_attn", "q_proj"), ("self_attn", "k_proj"), ("self_attn", "v_proj"))),

@@ -36,6 +36,33 @@ def test_header_symbols_are_exported_and_bound(lib):
     assert L.mc_abi_version() == lib.ABI_VERSION
 
 
+def test_the_fp16_instantiation_exports_the_same_abi(lib):
+    """libmc_hip_f16.so = the same sources on IEEE-half storage (csrc/common.h; the reference's own dtype, model/builder.py:41): same entry
+    points, same ABI version, and it says which storage element it was built on."""
+    import subprocess
+    import sys
+    assert os.path.exists(lib.LIB_PATHS["fp16"]), "make -C modelcompose_amd/csrc builds both libraries"
+    L = lib.lib()
+    assert lib.storage_name() == "bf16" and L.mc_storage_dtype() == 1
+    # one storage dtype per process: the other library is checked in a child interpreter
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from modelcompose_amd import _lib\n"
+            "import torch\n"
+            "assert _lib.storage_name() == 'fp16' and _lib.storage_dtype() == torch.float16\n"
+            "L = _lib.lib()\n"
+            "assert L.mc_storage_dtype() == 2 and L.mc_abi_version() == _lib.ABI_VERSION\n"
+            "from modelcompose_amd import ops\n"
+            "from modelcompose_amd.model import multimodal_llama as mm\n"
+            "assert ops.BF16 == torch.float16 and mm.BF16 == torch.float16\n"
+            "import modelcompose_amd\n"
+            "modelcompose_amd.set_storage_dtype('bf16')\n"
+            "assert ops.BF16 == torch.bfloat16 and mm.BF16 == torch.bfloat16 and _lib.lib().mc_storage_dtype() == 1\n"
+            "print('ok')\n") % ROOT
+    env = dict(os.environ, MC_STORAGE_DTYPE="fp16")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_argument_errors_do_not_touch_the_gpu(lib):
     L = lib.lib()
     # null pointers / bad shapes are rejected before any HIP call

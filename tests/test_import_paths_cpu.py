@@ -42,8 +42,10 @@ def test_signatures_match_the_reference_surface():
     from modelcompose.model import LlavaLlamaForCausalLM, MultimodalConfig, MultimodalLlamaForCausalLM
     from modelcompose.model.builder import load_pretrained_model
     # builder.py:27
-    assert _params(load_pretrained_model) == ["model_path", "model_base", "model_name", "load_8bit", "load_4bit", "device_map", "device"]
     sig = inspect.signature(load_pretrained_model)
+    assert [k for k, v in sig.parameters.items() if v.kind == v.POSITIONAL_OR_KEYWORD] == ["model_path", "model_base", "model_name", "load_8bit", "load_4bit",
+                                                                                           "device_map", "device"]
+    assert [k for k, v in sig.parameters.items() if v.kind == v.KEYWORD_ONLY] == ["torch_dtype"]        # extension: the reference hard-codes float16 (:41)
     assert sig.parameters["device_map"].default == "auto" and sig.parameters["device"].default == "cuda"
     assert LlavaLlamaForCausalLM is MultimodalLlamaForCausalLM and MultimodalLlamaForCausalLM.config_class is MultimodalConfig
     M = MultimodalLlamaForCausalLM
