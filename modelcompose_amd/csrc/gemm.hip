@@ -602,6 +602,198 @@ __device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc
         }
 }
 
+// Everything a 256-row tile does with its accumulators (acc[nh][i][mh][jj]: wave (wave_n, wave_m) owns output columns n0 + 2 NI 16 wave_n ...
+// and rows m0 + 64 wave_m ...) - the epilogue of gemm_tile256_kernel (which keeps its own inlined copy: routing that kernel through this
+// function changed hipcc's register allocation of its main loop, 0 -> 24 spilled VGPRs) as a function, for gemm_tile2_kernel.
+template <int ABL, int NI, int WN = 2>
+__device__ __forceinline__ void g2_epilogue_all(const Epilogue& ep, f32x4 (&acc)[2][4][2][2], int m0, int n0, int M, int N, int wave_m, int wave_n,
+                                                int c16, int q4) {
+    constexpr int NT = NI * 32 * WN;              // tile width: WN wave columns of 2 NI 16 weight rows
+    // Epilogue.  bf16 outputs whose tile lies inside N take the wide path (16-byte stores of block pairs, the row factor loaded once per
+    // row, ALL residual values of the lane requested before the first store: one exposed memory latency per tile instead of one per row -
+    // a workgroup owns its CU, so nothing else runs while its epilogue waits); everything else the 8-byte path.
+    const bool wide = !ep.out_f32 && (n0 + NT <= N) && (ep.ldo % 8 == 0) && ((uintptr_t)ep.out % 16 == 0) && (NI % 2 == 0);
+    if constexpr (NI == 4) {
+        if (wide && ep.rope.q_out) {
+            // RoPE + scatter (what rope_kv_kernel does to the stored q|k|v row): the values are rounded to bf16 first, exactly as the unfused
+            // route stores them, then rotated in fp32 and rounded again.  A wave's 128 columns are one head.
+            const Epilogue::Rope& rp = ep.rope;
+            const int nw = n0 + wave_n * 128;
+            const int head = nw >> 7;
+            const bool rot = head < rp.H + rp.Hkv;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
+                    const bool live = m < M;
+                    const int mc = live ? m : (M - 1);
+                    const float a = ep.row_scale ? ep.alpha * ep.row_scale[mc] : ep.alpha;
+                    const int b = rp.row_b[mc], pos = rp.row_pos[mc], tq = rp.row_t[mc];
+                    const bool put = live && b >= 0;
+                    bf16_t* drow;
+                    if (head < rp.H) drow = rp.q_out + ((int64_t)(b * rp.Lq + tq) * rp.H + head) * 128;
+                    else if (rot) drow = rp.k_cache + (((int64_t)b * rp.Hkv + (head - rp.H)) * rp.Smax + pos) * 128;
+                    else drow = rp.v_cache + (((int64_t)b * rp.Hkv + (head - rp.H - rp.Hkv)) * rp.Smax + pos) * 128;
+                    const float* cr = rp.cosT + (int64_t)pos * 64 + q4 * 4;
+                    const float* sr = rp.sinT + (int64_t)pos * 64 + q4 * 4;
+                    bf16x4 v1[4], v2[4];                   // block i: first-half / second-half values of d = 16 i + 4 q4 ..
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v1[i] = epilogue_vals4<0, -1, 0>(ep, a, nw + i * 16 + q4 * 4, acc[0][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
+                        v2[i] = epilogue_vals4<0, -1, 0>(ep, a, nw + 64 + i * 16 + q4 * 4, acc[1][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
+                    }
+                    if (rot) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 c = *(const f32x4*)(cr + i * 16), sn = *(const f32x4*)(sr + i * 16);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float r1, r2;
+                                mc_rope_pair((float)v1[i][j], (float)v2[i][j], c[j], sn[j], r1, r2);
+                                v1[i][j] = (bf16_t)r1; v2[i][j] = (bf16_t)r2;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        u32x2 pa = __builtin_bit_cast(u32x2, v1[i]), pb = __builtin_bit_cast(u32x2, v1[i + 1]);
+                        auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                        const u32x4 o1 = {r0[0], r1[0], r0[1], r1[1]};
+                        if (put) *(u32x4*)(drow + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o1;
+                        pa = __builtin_bit_cast(u32x2, v2[i]); pb = __builtin_bit_cast(u32x2, v2[i + 1]);
+                        r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                        r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                        const u32x4 o2 = {r0[0], r1[0], r0[1], r1[1]};
+                        if (put) *(u32x4*)(drow + 64 + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o2;
+                    }
+                }
+            return;
+        }
+    }
+    const bool has_res = wide && !ep.swiglu && ep.residual != nullptr;
+    const int actc = ep.act == MC_ACT_NONE ? 0 : ((ep.act == MC_ACT_QUICK_GELU || ep.act == MC_ACT_SILU) ? 1 : (ep.act == MC_ACT_GELU ? 3 : 2));
+    const float act_k = ep.act == MC_ACT_QUICK_GELU ? 1.702f : 1.0f;
+    bf16x4 res[2][2][2][NI];
+    // residual rows in 16-byte loads (round 3): the lane reads the 8 columns it will STORE (the layout behind the epilogue's
+    // v_permlane16_swap) and swaps them back into the accumulator layout - the exchange is its own inverse; half the load instructions
+    const bool res16 = has_res && NI % 2 == 0 && ep.ldr % 8 == 0 && ((uintptr_t)ep.residual % 16 == 0) && !(ABL & 1024);
+    if (res16) {
+        if constexpr (NI % 2 == 0) {
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int mc = min(m0 + wave_m * 64 + mh * 32 + jj * 16 + c16, M - 1);
+                    const bf16_t* rrow = ep.residual + (int64_t)mc * ep.ldr + n0 + wave_n * (2 * NI * 16) + (q4 & 1) * 16 + (q4 >> 1) * 8;
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int i = 0; i < NI; i += 2) {
+                            const u32x4 v = *(const u32x4*)(rrow + nh * (NI * 16) + i * 16);
+                            auto r0 = __builtin_amdgcn_permlane16_swap(v[0], v[2], false, false);
+                            auto r1 = __builtin_amdgcn_permlane16_swap(v[1], v[3], false, false);
+                            const u32x2 lo = {r0[0], r1[0]}, hi = {r0[1], r1[1]};
+                            res[mh][jj][nh][i] = __builtin_bit_cast(bf16x4, lo);
+                            res[mh][jj][nh][i + 1] = __builtin_bit_cast(bf16x4, hi);
+                        }
+                }
+        }
+    } else if (has_res) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int mc = min(m0 + wave_m * 64 + mh * 32 + jj * 16 + c16, M - 1);
+                const bf16_t* rrow = ep.residual + (int64_t)mc * ep.ldr + n0 + wave_n * (2 * NI * 16) + q4 * 4;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) res[mh][jj][nh][i] = *(const bf16x4*)(rrow + nh * (NI * 16) + i * 16);
+            }
+    }
+    if constexpr (NI % 2 == 0) {
+        if (wide && !ep.swiglu) {
+            // the common combinations get their own straight-line instantiation; the rest decide bias / residual per call
+#define G2_EPI(A, B, R) g2_epilogue_wide<A, B, R, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k)
+            const bool hb = ep.bias != nullptr;
+            if (ep.ss_parts && NI == 4 && actc == 0 && !hb && has_res) g2_epilogue_wide<0, 0, 1, NI, true>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);   // LLM o / down + next norm's factor
+            else if (ep.ss_parts && NI == 4 && actc == 0) g2_epilogue_wide<0, -1, -1, NI, true>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
+            else if (actc == 0 && !hb && !has_res) G2_EPI(0, 0, 0);            // LLM q|k|v (without the RoPE route), plain projections
+            else if (actc == 0 && !hb && has_res) G2_EPI(0, 0, 1);        // LLM o / down
+            else if (actc == 0 && hb && !has_res) G2_EPI(0, 1, 0);        // encoder q|k|v
+            else if (actc == 0 && hb && has_res) G2_EPI(0, 1, 1);         // encoder out / fc2
+            else if (actc == 1 && hb && !has_res) G2_EPI(1, 1, 0);        // encoder fc1 (QuickGELU)
+            else if (actc == 1) G2_EPI(1, -1, -1);
+            else if (actc == 3) G2_EPI(3, -1, -1);                        // BEATs / point-cloud fc1 (exact GELU)
+            else G2_EPI(2, -1, -1);
+#undef G2_EPI
+            return;
+        }
+    }
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
+            const bool live = m < M;                   // depends on c16 only: the lane pairs of a swap are live together
+            const int mc = live ? m : (M - 1);
+            if (wide) {
+                const float a = ep.row_scale ? ep.alpha * ep.row_scale[mc] : ep.alpha;
+                if (ep.swiglu) {
+                    // gate / up blocks alternate along N: input blocks (f, f+1) -> output block f/2; output blocks f/2 and f/2+1 are adjacent
+                    bf16_t* orow = (bf16_t*)ep.out + (int64_t)mc * ep.ldo + ((n0 + wave_n * (2 * NI * 16)) >> 1);
+#pragma unroll
+                    for (int f = 0; f < 2 * NI; f += 4) {
+                        const bf16x4 lo = swiglu_vals4(a, acc[f / NI][f % NI][mh][jj], acc[(f + 1) / NI][(f + 1) % NI][mh][jj]);
+                        const bf16x4 hi = swiglu_vals4(a, acc[(f + 2) / NI][(f + 2) % NI][mh][jj], acc[(f + 3) / NI][(f + 3) % NI][mh][jj]);
+                        u32x2 pa = __builtin_bit_cast(u32x2, lo), pb = __builtin_bit_cast(u32x2, hi);
+                        auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        if (live) *(u32x4*)(orow + (f >> 1) * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
+                    }
+                    continue;
+                }
+                const int nw = n0 + wave_n * (2 * NI * 16);
+                bf16_t* orow = (bf16_t*)ep.out + (int64_t)mc * ep.ldo + nw;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int i = 0; i < NI; i += 2) {
+                        const int nb = nh * (NI * 16) + i * 16;
+                        const bf16x4 lo = epilogue_vals4(ep, a, nw + nb + q4 * 4, acc[nh][i][mh][jj], has_res, res[mh][jj][nh][i]);
+                        const bf16x4 hi = epilogue_vals4(ep, a, nw + nb + 16 + q4 * 4, acc[nh][i + 1][mh][jj], has_res, res[mh][jj][nh][i + 1]);
+                        u32x2 pa = __builtin_bit_cast(u32x2, lo), pb = __builtin_bit_cast(u32x2, hi);
+                        auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        if (live) *(u32x4*)(orow + nb + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
+                    }
+                continue;
+            }
+            if (!live) continue;
+            if (ep.swiglu) {
+                // gate / up blocks alternate along N: consecutive block pairs of this wave's 2*NI blocks (a pair may straddle the nh halves
+                // when NI is odd; both halves are this lane's registers)
+#pragma unroll
+                for (int f = 0; f < 2 * NI; f += 2) {
+                    const int n = n0 + wave_n * (2 * NI * 16) + f * 16;
+                    if (n + 16 < N) epilogue_store4_swiglu(ep, m, (n >> 1) + q4 * 4, acc[f / NI][f % NI][mh][jj], acc[(f + 1) / NI][(f + 1) % NI][mh][jj]);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int n = n0 + wave_n * (2 * NI * 16) + nh * (NI * 16) + i * 16 + q4 * 4;
+                    if (n < N) epilogue_store4(ep, m, n, acc[nh][i][mh][jj]);
+                }
+        }
+}
+
 // rows of one launch may belong to several adapter groups (routed LocalLoRA order): group g owns rows [row_start[g], row_start[g+1])
 // = m-tiles [tile_start[g], tile_start[g+1]) and multiplies against its own composed weight
 struct G2Groups {
@@ -992,6 +1184,126 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
                     if (n < N) epilogue_store4(ep, m, n, acc[nh][i][mh][jj]);
                 }
         }
+}
+
+// ------------------------------------------------------------------------------------------
+// large-M kernel, second tile economy (round 5): 256 (tokens) x 128 (weight rows) x 32 tiles, 4 waves, TWO workgroups per CU
+// ------------------------------------------------------------------------------------------
+// gemm_tile256_kernel owns its CU (8 waves x 256 registers, 128 KiB of LDS): while a tile's epilogue drains its 128 KiB of stores at the
+// CU's store rate (14-16 B/clk: 4.3-4.9 us) and the next tile's prologue waits for its first K-tiles, the matrix pipe idles - 7 % of a
+// K = 4096 tile, 28 % at K = 1024 (the encoder shapes) - and a persistent form that would overlap them does not fit the register file
+// (DESIGN.md §4).  Here two INDEPENDENT workgroups share a CU (4 waves x 256 registers and 72 KiB of LDS each): one's epilogue / prologue /
+// barrier wait runs beside the other's main loop with no schedule to hand-align, at the price of 1.5x the LDS-DMA bytes per FLOP
+// ((1/256 + 1/128) against 2/256).
+//   wave w: rows m0 + 64 w .. + 63, all 128 columns - the per-wave tile (and so the accumulator layout, acc[nh][i][mh][jj], and every
+//           epilogue: g2_epilogue_all) of gemm_tile256_kernel; results are bit-identical (same 16x16x32 MFMA chain over k per element).
+//   LDS:    3 stages x (W 8 KiB | X 16 KiB), one stage = one 32-deep K-step.  W: the packed weight's 1-KiB fragment blocks as they lie in
+//           HBM (8 pieces, 2 per wave, read back lane-linear).  X: 16 rows x 64 bytes per 1-KiB piece (4 per wave - the wave's OWN rows),
+//           16-byte chunk c of row r stored in slot c ^ (2 * ((r >> 3) & 1)): the 16-lane groups of a ds_read_b128 then cover all 64 banks.
+//   loop:   [counted vmcnt: step t landed] s_barrier [6 LDS-DMA for step t + 2] [12 fragment reads] [32 MFMA]   - one barrier per K-step,
+//           two steps of DMA in flight across it (never vmcnt(0) in the loop).
+#define T2_STAGE 24576
+#define T2_XOFF 8192
+
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void gemm_tile2_kernel(const bf16_t* __restrict__ x, int64_t ldx, G2Groups grp, int N, int K, Epilogue ep,
+                                                            int tiles_m, int tiles_n, int raster) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int nwg = tiles_m * tiles_n;
+    int tm, tn;
+    g2_map_tile(blockIdx.x, nwg, tiles_m, tiles_n, raster, tm, tn);
+    int m0, M;
+    const bf16_t* wp;
+    g2_group_of(grp, tm, m0, M, wp);
+    const int n0 = tn * 128;
+    const int kblocks = K >> 5;
+    const int nblocks = (N + 15) >> 4;
+    const int nt = K >> 5;                        // K-steps of 32
+
+    // per-lane DMA sources (byte offsets at K-step 0) - W pieces 2w, 2w + 1 of the stage's 8; X pieces 4w .. 4w + 3 of its 16 (own rows)
+    const char* wbase = (const char*)wp;
+    const char* xbase = (const char*)x;
+    uint32_t wsrc[2], xsrc[4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int nb = min((n0 >> 4) + wave * 2 + e, nblocks - 1);
+        wsrc[e] = (uint32_t)(((int64_t)nb * kblocks * 512 + lane * 8) * 2);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = wave * 64 + r * 16 + (lane >> 2);
+        const int ch = (lane & 3) ^ (((lane >> 5) & 1) << 1);                 // slot (lane & 3) of row (lane >> 2) holds chunk slot ^ 2 * ((row >> 3) & 1)
+        xsrc[r] = (uint32_t)(((int64_t)min(m0 + row, M - 1) * ldx + ch * 8) * 2);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+    auto stage = [&](int t) {                     // K-step t -> stage t % 3
+        const uint32_t sb = lds0 + (uint32_t)((t % 3) * T2_STAGE);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) g2_dma16s(wbase + (int64_t)t * 1024, wsrc[e], sb + (uint32_t)((wave * 2 + e) * 1024));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g2_dma16s(xbase + (int64_t)t * 64, xsrc[r], sb + (uint32_t)(T2_XOFF + (wave * 4 + r) * 1024));
+    };
+    // fragment read offsets inside a stage
+    const int woff = lane * 16;
+    const int xoff = T2_XOFF + wave * 4096 + c16 * 64 + ((q4 ^ (((c16 >> 3) & 1) << 1)) * 16);
+
+    f32x4 acc[2][4][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0);
+    if (nt > 1) stage(1);
+    __builtin_amdgcn_s_waitcnt(0xC07F);           // every scalar (kernel-argument) load retired before the loop (see gemm_tile256_kernel)
+    for (int t = 0; t < nt; ++t) {
+        // step t has landed when at most step t + 1's six pieces are still in flight
+        if (t + 1 < nt) g2_waitvm<6>(); else g2_waitvm<0>();
+        __builtin_amdgcn_s_barrier();             // every wave's W pieces of step t are in; every wave has finished reading step t - 1
+        // placement of the step's six LDS-DMA instructions (A/B builds, same results): ABL & 3 = 0 in front of the fragment reads, 1 behind
+        // them, 2 inside the MFMA stream (one behind every fifth MFMA)
+        const bool more = t + 2 < nt;
+        if ((ABL & 3) == 0 && more) stage(t + 2);             // into the stage step t - 1 was read from
+        const char* sb = smem + (t % 3) * T2_STAGE;
+        bf16x8 wf[2][4], xf[2][2];
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) xf[mh][jj] = *(const bf16x8*)(sb + xoff + (mh * 2 + jj) * 1024);
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[nh][i] = *(const bf16x8*)(sb + woff + (nh * 4 + i) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((ABL & 3) == 1 && more) stage(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t sb2 = lds0 + (uint32_t)(((t + 2) % 3) * T2_STAGE);
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) acc[nh][i][mh][jj] = mc_mfma_16x16x32(wf[nh][i], xf[mh][jj], acc[nh][i][mh][jj]);
+                if ((ABL & 3) == 2 && more) {
+                    const int c = nh * 4 + i;                  // 8 groups of four MFMAs: a DMA behind groups 1 .. 6
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c == 1 || c == 2) g2_dma16s(wbase + (int64_t)(t + 2) * 1024, wsrc[c - 1], sb2 + (uint32_t)((wave * 2 + c - 1) * 1024));
+                    else if (c >= 3 && c <= 6) g2_dma16s(xbase + (int64_t)(t + 2) * 64, xsrc[c - 3], sb2 + (uint32_t)(T2_XOFF + (wave * 4 + c - 3) * 1024));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    g2_epilogue_all<ABL, 4, 1>(ep, acc, m0, n0, M, N, wave, 0, c16, q4);
 }
 
 #define SK_WAVES 8
@@ -1429,6 +1741,12 @@ static bool g_tile192 = true;
 static bool g_force192 = false;
 static thread_local bool g_in_tail = false, g_force128 = false;      // mc_gemm_ex_bf16's tail split (below)
 static bool g_tail_split = false;     // measured +-0 on the encode stage (in-process A/B 127.0-127.7 vs 127.2-127.5 ms): off by default
+// "tile2" option (round 5): 0 = gemm_tile256_kernel for every large launch; 1 = gemm_tile2_kernel (256 x 128 tiles, two workgroups per CU) for
+// every launch the 256-column instantiation would take; 2 = for launches with K <= "tile2_max_k" only (the encoder shapes, where the
+// 256 x 256 kernel's per-tile prologue + epilogue are 28 % of a tile).  Results are bit-identical either way.
+static int g_tile2 = 0;
+static int g_tile2_max_k = 2048;
+static int g_tile2_variant = 0;
 static bool g_raster_auto = true;          // "raster_shared" option
 static bool g_rows_on = true;              // "rows_kernel" option: M <= 64 launches with ceil(M / 16) >= "rows_min_mb" take gemm_rows_kernel
 static int g_rows_min_mb = 2;
@@ -1441,6 +1759,9 @@ static int g_raster_min_tiles = 1024;      // launches with at least this many t
 // device, samples/s  overlap + 256: 33.4, overlap + 192: 31.8, no overlap + 192: 32.8, no overlap + 256: 31.1)
 extern "C" int mc_gemm_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tile192")) { g_tile192 = value != 0; return 0; }
+    if (name && !strcmp(name, "tile2")) { g_tile2 = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+    if (name && !strcmp(name, "tile2_max_k")) { g_tile2_max_k = value; return 0; }
+    if (name && !strcmp(name, "tile2_variant")) { g_tile2_variant = value; return 0; }
     if (name && !strcmp(name, "force_tile192")) { g_force192 = value != 0; return 0; }
     if (name && !strcmp(name, "tail_split")) { g_tail_split = value != 0; return 0; }
     if (name && !strcmp(name, "raster_shared")) { g_raster_auto = value != 0; return 0; }
@@ -1730,7 +2051,25 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     // debug word bits 3-5: 8 = timing-only ablation without the LDS-DMA (wrong results); 40 = correct results + clock stamps around the main
     // loop (mc_gemm_clock_read); 56 = A/B builds, picked by bits 12-14.  (The round-1 ablations "no fragment reads" / "DMA re-reads K-tiles
     // 0/1" and the launch_bounds(512,1) build are no longer instantiated: ABL bits 1, 2, 4 - their results are in DESIGN.md.)
-    if (ni == 3) {
+    const bool tile2 = ni == 4 && !((g_gemm_dbg >> 3) & 7) && (g_tile2 == 1 || (g_tile2 == 2 && K <= g_tile2_max_k));
+    if (tile2) {
+        static bool attr2_set = false;
+        const int lds2 = 3 * T2_STAGE;
+        if (!attr2_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_tile2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            (void)hipFuncSetAttribute((const void*)gemm_tile2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            (void)hipFuncSetAttribute((const void*)gemm_tile2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            attr2_set = true;
+        }
+        const int tn2 = (N + 127) / 128;
+        int r2 = raster & 255;                                       // the n-slab width counts 256-column tiles: twice as many 128-column ones
+        if ((raster >> 8) & 255) r2 |= (min(255, 2 * ((raster >> 8) & 255))) << 8;
+        switch (g_tile2_variant) {                                   // "tile2_variant" option: where the K-step's DMA instructions sit (kernel comment)
+            case 1: gemm_tile2_kernel<1><<<tiles_m * tn2, 256, lds2, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tn2, r2); break;
+            case 2: gemm_tile2_kernel<2><<<tiles_m * tn2, 256, lds2, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tn2, r2); break;
+            default: gemm_tile2_kernel<0><<<tiles_m * tn2, 256, lds2, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tn2, r2); break;
+        }
+    } else if (ni == 3) {
         gemm_tile256_kernel<0, 3, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);
     } else switch ((g_gemm_dbg >> 3) & 7) {
         case 1: G2_LAUNCH(1); break;

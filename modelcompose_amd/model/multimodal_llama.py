@@ -164,6 +164,7 @@ class MultimodalLlamaForCausalLM:
         self._keep = []                                                # device tensors referenced by the C handle
         self._cache = {}
         self._lock = threading.RLock()                                 # see _serialised
+        self._compose_events = None
         self.use_graph = True
 
     # ------------------------------------------------------------------ reference accessors
@@ -282,7 +283,7 @@ class MultimodalLlamaForCausalLM:
                 self._compose_linear(prefix, ad, out, N, K, col_scale, nb_stride, nb_offset)
             return
         rets = [self._retention_parts.setdefault(ad, []) for ad in adapters]
-        _compose_multi_into(w, terms, masks, N, K, outs, col_scale, nb_stride, nb_offset, retentions=rets)
+        _compose_multi_into(w, terms, masks, N, K, outs, col_scale, nb_stride, nb_offset, retentions=rets, events=self._compose_events)
         r = max((t[0].shape[0] for t in terms), default=0)
         self.compose_bytes += 2.0 * N * K * (1 + len(outs)) + 2.0 * len(terms) * r * (N + K)
 
@@ -305,6 +306,7 @@ class MultimodalLlamaForCausalLM:
         self.compose_bytes = 0.0                                     # algorithmic HBM bytes of the composition (bench.py's compose roofline)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+        self._compose_events = []
         # adapters whose dense weights equal another adapter's (no LoRA terms at all) share storage with the base
         for l in range(Lyr):
             p = f"model.layers.{l}"
@@ -372,7 +374,11 @@ class MultimodalLlamaForCausalLM:
         # device time of the composition loop (every launch of it, the small A^T transposes included; host-resident state dicts also pay their
         # H2D copies here) and its launch count: 7 per layer (one per linear, all routed adapters from one read of W)
         self.compose_ms = ev0.elapsed_time(ev1)
-        self.compose_launches = 7 * Lyr
+        self.compose_launches = len(self._compose_events)
+        # the composition kernel's own time: HIP events around each of its launches (the loop above is host-bound: per linear a dozen small
+        # torch ops - the A^T transposes of the LoRA factors, allocations - sit between two launches)
+        self.compose_kernel_ms = sum(a.elapsed_time(b) for a, b in self._compose_events)
+        self._compose_events = None
         self._summarise_delta_retention()
         return self
 
@@ -1134,7 +1140,7 @@ def _prep_terms(terms):
     return ats, bs, r
 
 
-def _compose_multi_into(w: torch.Tensor, terms, masks, N: int, K: int, outs, col_scale=None, nb_stride=1, nb_offset=0, retentions=None):
+def _compose_multi_into(w: torch.Tensor, terms, masks, N: int, K: int, outs, col_scale=None, nb_stride=1, nb_offset=0, retentions=None, events=None):
     """ONE pass over W for every routed adapter of a linear (mc_compose_multi_bf16): output o = (W + sum of the terms named by masks[o])
     diag(col_scale), packed into outs[o].  retentions: per output a list that receives this call's partial sums, or None."""
     n, n_out = len(terms), len(outs)
@@ -1167,7 +1173,13 @@ def _compose_multi_into(w: torch.Tensor, terms, masks, N: int, K: int, outs, col
     a.ldo, a.N, a.K = 0, N, K
     a.col_scale = 0 if col_scale is None else col_scale.data_ptr()
     a.nb_stride, a.nb_offset = nb_stride, nb_offset
+    if events is not None:                                        # (start, end) pair per launch: the kernel's own device time (bench.py's compose roofline)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.lib().mc_compose_multi_bf16(C.byref(a), _stream()), "mc_compose_multi_bf16")
+    if events is not None:
+        e1.record()
+        events.append((e0, e1))
     return outs
 
 

@@ -78,8 +78,9 @@ def test_output_hidden_states_and_attentions_match_the_reference(g4_model):
     ref_h, ref_a = g18["hidden_states"], g18["attentions"]
     for l in range(n_layers + 1):
         assert out.hidden_states[l].shape == ref_h[l].shape
-        # bf16 storage vs the fp32 reference (the embeddings are exact to one rounding)
-        within(f"11 hidden_states[{l}]", out.hidden_states[l], ref_h[l], 2 ** -8 if l == 0 else 1.2e-2)
+        # bf16 storage vs the fp32 reference (entry 0 = the spliced embeddings: text rows exact to one rounding, the image block as far
+        # from fp32 as the bf16 CLIP tower + projector: measured 5.6e-3)
+        within(f"11 hidden_states[{l}]", out.hidden_states[l], ref_h[l], 1.2e-2)
     for l in range(n_layers):
         assert out.attentions[l].shape == ref_a[l].shape
         got = out.attentions[l].float().cpu()

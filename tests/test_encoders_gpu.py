@@ -25,6 +25,7 @@ def test_beats_encoder_matches_reference():
     enc = HipBeatsAudioEncoder(None, None, config=BeatsConfig(cfg))
     enc.load_state_dict(sd)
     f, mask = enc(a["fbank"].cuda(), a["padding_mask"].cuda())
+    assert enc._pending_mask_check and not HipBeatsAudioEncoder(None, None, config=BeatsConfig(cfg))._pending_mask_check      # a device mask defers its check
     assert torch.equal(mask.cpu(), ~a["pooled_mask"])
     valid = ~a["pooled_mask"]
     # padded positions are don't-care (never attended, ignored by the caller: multimodal_arch.py:233-235)
@@ -33,8 +34,7 @@ def test_beats_encoder_matches_reference():
     assert rel_err(f2, a["features_nopad"]) < 2 ** -5
     # round 4: a DEVICE mask is analysed on the device (no host round trip: one launch pools the frame mask, writes the clip lengths,
     # zeroes the padded rows); a HOST mask on the host.  Same function: bitwise equal features and masks.
-    assert enc._pending_mask_check and not HipBeatsAudioEncoder(None, None, config=BeatsConfig(cfg))._pending_mask_check
-    fh, mh = enc(a["fbank"].cuda(), a["padding_mask"])                   # host mask (the forward first collects the pending device check)
+    fh, mh = enc(a["fbank"].cuda(), a["padding_mask"])                   # host mask (every forward first collects a pending device check)
     assert not enc._pending_mask_check
     enc.check_pending()
     assert torch.equal(fh, f) and torch.equal(mh, mask)

@@ -368,10 +368,13 @@ def _ulps(d, o):
     return (d - o).abs() / ulp
 
 
-# measured on MI355X (profiles/r05_parity.json) x ~2: the layer's output is the residual stream - bf16(x1 + down(...)), x1 = bf16(x + o(...)) -
-# so a flipped rounding upstream moves an output element by at most a few of ITS ulps
-LAYER_MAX_ULPS = 4.0
-LAYER_FRAC_OVER_1 = 2e-2
+# the layer's output is the residual stream - bf16(x1 + down(...)), x1 = bf16(x + o(...)) - so a flipped rounding upstream moves an output
+# element by at most a few of ITS ulps.  Measured on MI355X (profiles/r05_parity.json): layer 0 (the stream is still as small as the layer's
+# own contribution: rms 1.6 -> 2.8) max 4 ulps, 2.1 % of the elements over 1 ulp; layers 8 / 16 / 24 / 31 (rms 6.7 ... 12.9) max 3 ulps,
+# 1.1e-3 / 1.9e-4 / 2.2e-4 / 2.2e-4 over 1 ulp.  Bounds ~2x.
+LAYER_MAX_ULPS = 6.0
+LAYER_FRAC_OVER_1 = {0: 4e-2}
+LAYER_FRAC_OVER_1_DEEP = 2.5e-3
 
 
 def test_every_probed_layer_is_exact_to_rounding_on_its_own_input(model32):
@@ -407,7 +410,8 @@ def test_every_probed_layer_is_exact_to_rounding_on_its_own_input(model32):
                        "rms_in": hs[l].pow(2).mean().sqrt().item(), "rms_out": d.pow(2).mean().sqrt().item(),
                        "rel_err": ((d - o).abs().max() / o.abs().max()).item()}
         print("layer", l, rep[str(l)])
-    REPORT["per_layer_teacher_forced"] = {"layers": rep, "bound_max_ulps": LAYER_MAX_ULPS, "bound_frac_over_1ulp": LAYER_FRAC_OVER_1, "tokens": int(hs[0].shape[1])}
+    REPORT["per_layer_teacher_forced"] = {"layers": rep, "bound_max_ulps": LAYER_MAX_ULPS, "bound_frac_over_1ulp_layer0": LAYER_FRAC_OVER_1[0],
+                                          "bound_frac_over_1ulp_deeper": LAYER_FRAC_OVER_1_DEEP, "tokens": int(hs[0].shape[1])}
     _dump()
     for l, r_ in rep.items():
-        assert r_["max_ulps"] <= LAYER_MAX_ULPS and r_["frac_over_1ulp"] <= LAYER_FRAC_OVER_1, (l, r_)
+        assert r_["max_ulps"] <= LAYER_MAX_ULPS and r_["frac_over_1ulp"] <= LAYER_FRAC_OVER_1.get(int(l), LAYER_FRAC_OVER_1_DEEP), (l, r_)

@@ -135,6 +135,85 @@ def test_gemm_tile256_ab_builds_are_bit_identical(ops):
     close_bf16(outs["shipped"], x.float() @ ops.unpack_weight(pw).float().t() + r.float())
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_gemm_tile2_two_workgroups_per_cu_is_bit_identical(ops, variant):
+    """Round 5: gemm_tile2_kernel (256 x 128 x 32 tiles, 4 waves, two workgroups per CU, 3-stage LDS-DMA ring; mc_gemm_set_option "tile2") runs
+    the same 16x16x32 MFMA chain over k for every output element as gemm_tile256_kernel and shares its epilogues: every route must give
+    the same BITS - plain / bias + activation + residual, fp32 output, SwiGLU, the next norm's factor (rms_out), RoPE + cache scatter, routed
+    adapter groups with ragged edges in M and N - for each placement of the K-step's DMA instructions (tile2_variant)."""
+    from modelcompose_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(100 + variant)
+    rb = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(BF).cuda()
+
+    def both(fn):
+        outs = []
+        for on in (0, 1):
+            _lib.check(L.mc_gemm_set_option(b"tile2", on), "tile2")
+            _lib.check(L.mc_gemm_set_option(b"tile2_variant", variant), "tile2_variant")
+            L.mc_gemm_debug(4)                                   # the 256-row kernels whatever the tile count
+            try:
+                outs.append(fn())
+            finally:
+                L.mc_gemm_debug(0)
+                _lib.check(L.mc_gemm_set_option(b"tile2", 0), "tile2")
+                _lib.check(L.mc_gemm_set_option(b"tile2_variant", 0), "tile2_variant")
+        return outs
+    # (a) bias + activation + residual, fp32 output; ragged M, N not a multiple of the tile, short and long K
+    for (M, N, K) in ((700, 1024, 64), (16500, 4096, 4096), (2731, 1000, 1024), (300, 520, 128)):
+        x, w, b, r = rb(M, K), rb(N, K, sc=K ** -0.5), rb(N), rb(M, N)
+        pw = ops.pack_weight(w, b)
+        a, c = both(lambda: (ops.linear(x, pw, act="gelu", residual=r), ops.linear(x, pw, out_f32=True), ops.linear(x, pw, act="quick_gelu")))
+        for u, v in zip(a, c):
+            assert torch.equal(u, v), (M, N, K)
+        close_bf16(c[0], F.gelu(x.float() @ w.float().t() + b.float()) + r.float())
+    # (b) SwiGLU + row factor; rms_out; grouped rows
+    K, I = 512, 1408
+    sizes = (700, 1300, 90)
+    gs = [0, 700, 2000, 2090]
+    M = gs[-1]
+    x = rb(M, K)
+    rs = ops.rms_scale(x, 1e-5)
+    wgu = [ops.pack_weight(_interleave_gate_up(rb(I, K, sc=K ** -0.5), rb(I, K, sc=K ** -0.5))) for _ in sizes]
+    a, c = both(lambda: ops.linear_grouped(x, wgu, gs, row_scale=rs, swiglu=True))
+    assert torch.equal(a, c) and a.shape == (M, I)
+    wo = [ops.pack_weight(rb(1024, K, sc=K ** -0.5)) for _ in sizes]
+    res = rb(M, 1024)
+
+    def with_rms():
+        f = torch.full((M,), -1.0, dtype=torch.float32, device="cuda")
+        return ops.linear_grouped(x, wo, gs, residual=res, rms_out=f, rms_out_eps=1e-5), f
+    a, c = both(with_rms)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    # (c) q|k|v projection with RoPE + cache scatter in the epilogue (D = 128: the register route)
+    D, H, Hkv = 128, 4, 4
+    N = (H + 2 * Hkv) * D
+    M = 1500
+    Bq, Lq, Smax = 3, 520, 560
+    x = rb(M, 1024)
+    wq = [ops.pack_weight(rb(N, 1024, sc=0.05))]
+    slots = torch.randperm(Bq * Lq, generator=g)[:M]
+    row_b, row_t = (slots // Lq).to(torch.int32), (slots % Lq).to(torch.int32)
+    row_pos = (row_t + 7 * row_b).to(torch.int32)
+    row_b[::17] = -1
+    row_b, row_t, row_pos = row_b.cuda(), row_t.cuda(), row_pos.cuda()
+    ang = torch.arange(Smax + 32, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(64, dtype=torch.float32) / 64))[None]
+    cos, sin = ang.cos().cuda().contiguous(), ang.sin().cuda().contiguous()
+
+    def qkv():
+        q = torch.full((Bq * Lq, H * D), 3.0, dtype=BF, device="cuda")
+        k = torch.full((Bq, Hkv, Smax, D), 5.0, dtype=BF, device="cuda")
+        v = torch.full((Bq, Hkv, Smax, D), 7.0, dtype=BF, device="cuda")
+        rope = ops.rope_scatter(row_b, row_pos, row_t, cos, sin, q, k, v, H, Hkv, D, Lq, Smax)
+        scratch = torch.full((M, N), 9.0, dtype=BF, device="cuda")
+        ops.linear_grouped(x, wq, [0, M], rope=rope, out=scratch)
+        return q, k, v
+    a, c = both(qkv)
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)
+    assert (c[0] != 3.0).any()
+
+
 @pytest.mark.parametrize("M", [8, 300])
 @pytest.mark.parametrize("act", ["none", "gelu", "quick_gelu", "silu"])
 def test_gemm_epilogue_bias_act_residual(ops, M, act):
