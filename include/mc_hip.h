@@ -402,6 +402,10 @@ int mc_sample_step_f32(const float* logits, int64_t ld, int64_t* next_ids, int64
                        int step_const, const uint32_t* seed_ptr, unsigned long long seed_const, int M, int N, float temperature, int top_k,
                        float top_p, const float* uniform_in, float* probs_out, int64_t ldp, void* stream);
 
+/* out[m][n] = logits[m][n] - logsumexp_n(logits[m]) (fp32): the scoring step of beam search (generate(num_beams > 1): transformers 4.31
+ * beam_search, forwarded by eval/model_multimodal_qa_loader.py:94-102) */
+int mc_log_softmax_f32(const float* logits, int64_t ld, float* out, int64_t ldo, int M, int N, void* stream);
+
 /* ---- checkpoint files (csrc/ckpt_reader.cpp) --------------------------------------------------------------------------------
  * Replaces torch.load / safetensors in load_pretrained_model (model/builder.py:148, :157-168): adapter_model.bin, non_lora_trainables.bin,
  * mm_projector.bin, the base model's (sharded) pytorch_model-*.bin or *.safetensors, encoder checkpoints.  mc_ckpt_open maps the file and

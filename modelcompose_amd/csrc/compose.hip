@@ -167,13 +167,11 @@ __global__ __launch_bounds__(256, 2) void compose_multi_kernel(ComposeMultiParam
             const int last_m = mask ? 31 - __builtin_clz(mask) : -1;
             const int first_m = mask ? __builtin_ctz(mask) : -1;
             // the epilogue of row block i: total (fp32) + W, column scale, ONE rounding, store
-            auto finish = [&](int i, const f32x4 (&tot)[4]) {
+            auto finish = [&](int i, const f32x4 (&tot)[4], const bf16x4 (&wv)[4]) {
                 const int n = n0 + i * 16 + c16;
                 const int nb = n >> 4;                           // wave-uniform (c16 < 16)
                 if (nb * 16 >= np16) return;
                 const bool inb = n < p.N;
-                bf16x4 wv[4];
-                load_w(i, wv);
 #pragma unroll
                 for (int tp = 0; tp < 2; ++tp) {
                     bf16x4 o[2];
@@ -228,17 +226,26 @@ __global__ __launch_bounds__(256, 2) void compose_multi_kernel(ComposeMultiParam
             if (mask == 0) {                                     // no LoRA term: W' = bf16(W c)
                 const f32x4 zero[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
-                for (int i = 0; i < NR; ++i) finish(i, zero);
+                for (int i = 0; i < NR; ++i) {
+                    bf16x4 wv0[4];
+                    load_w(i, wv0);
+                    finish(i, zero, wv0);
+                }
             }
-            const bool one_chunk = p.r <= 32 * RS;               // the whole rank fits the fragment registers: A^T is loaded once per term
+            // One term pass = every load it needs issued back to back (the term's A^T fragments, the B fragments of ALL row blocks and, on an
+            // output's last term, the W pieces the epilogue adds), then the MFMA chains: one exposed memory latency per pass instead of one per
+            // row block (round 5, first version: 0.85 TB/s - each wave waited ~2 us for four 16-byte loads sixteen times per tile).
+            // Ranks beyond 32 RS are processed in chunks of 32 RS, the chunk sums added in fp32 (r <= 128: one chunk, one MFMA chain).
+            const int n_chunks = (p.r + 32 * RS - 1) / (32 * RS);
             for (int m = 0; m < p.n_terms; ++m) {
                 if (!((mask >> m) & 1u)) continue;
                 const bf16_t* at = p.at[m];
                 const bf16_t* bm = p.bm[m];
                 const float s = p.scale[m];
-                const bool first = m == first_m, last = m == last_m;
-                bf16x8 af[RS][4];
-                auto load_af = [&](int rs0) {
+                for (int ch = 0; ch < n_chunks; ++ch) {
+                    const int rs0 = ch * 32 * RS;
+                    const bool first = m == first_m && ch == 0, last = m == last_m && ch == n_chunks - 1;
+                    bf16x8 af[RS][4];
 #pragma unroll
                     for (int q = 0; q < RS; ++q)
 #pragma unroll
@@ -246,37 +253,48 @@ __global__ __launch_bounds__(256, 2) void compose_multi_kernel(ComposeMultiParam
                             const int k = min(k0 + t * 16 + c16, p.K - 1);
                             af[q][t] = *(const bf16x8*)(at + (int64_t)k * p.r + min(rs0 + q * 32, p.r - 32) + g * 8);      // (steps beyond r are skipped below)
                         }
-                };
-                if (one_chunk) load_af(0);
+                    // row blocks in groups of NG: the group's B fragments and W pieces are requested together (a real loop over the groups keeps
+                    // the register count at two waves per SIMD; fully unrolled, hipcc spilled 186 registers)
+                    constexpr int NG = 2;
 #pragma unroll 1
-                for (int i = 0; i < NR; ++i) {
-                    const int n = min(n0 + i * 16 + c16, p.N - 1);
-                    f32x4 acc[4];
+                    for (int ig = 0; ig < NR; ig += NG) {
+                        bf16x8 bf[NG][RS];
+                        bf16x4 wv[NG][4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    for (int rs0 = 0; rs0 < p.r; rs0 += 32 * RS) {
-                        if (!one_chunk) load_af(rs0);
-                        bf16x8 bf[RS];
+                        for (int j = 0; j < NG; ++j) {
+                            const int n = min(n0 + (ig + j) * 16 + c16, p.N - 1);
 #pragma unroll
-                        for (int q = 0; q < RS; ++q) bf[q] = *(const bf16x8*)(bm + (int64_t)n * p.r + min(rs0 + q * 32, p.r - 32) + g * 8);
+                            for (int q = 0; q < RS; ++q) bf[j][q] = *(const bf16x8*)(bm + (int64_t)n * p.r + min(rs0 + q * 32, p.r - 32) + g * 8);
+                        }
+                        if (last) {
 #pragma unroll
-                        for (int q = 0; q < RS; ++q) {
-                            if (rs0 + q * 32 < p.r) {
+                            for (int j = 0; j < NG; ++j) load_w(ig + j, wv[j]);
+                        }
 #pragma unroll
-                                for (int t = 0; t < 4; ++t) acc[t] = mc_mfma_16x16x32(af[q][t], bf[q], acc[t]);
+                        for (int j = 0; j < NG; ++j) {
+                            const int i = ig + j;
+                            f32x4 acc[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int q = 0; q < RS; ++q) {
+                                if (rs0 + q * 32 < p.r) {
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) acc[t] = mc_mfma_16x16x32(af[q][t], bf[j][q], acc[t]);
+                                }
+                            }
+                            f32x4 tot[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                tot[t] = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : tots[wave][i][t][lane];
+                                tot[t] += acc[t] * s;
+                            }
+                            if (last) finish(i, tot, wv[j]);
+                            else {
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) tots[wave][i][t][lane] = tot[t];
                             }
                         }
-                    }
-                    f32x4 tot[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        tot[t] = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : tots[wave][i][t][lane];
-                        tot[t] += acc[t] * s;
-                    }
-                    if (last) finish(i, tot);
-                    else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) tots[wave][i][t][lane] = tot[t];
                     }
                 }
             }

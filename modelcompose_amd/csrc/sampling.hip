@@ -245,3 +245,33 @@ extern "C" int mc_sample_step_f32(const float* logits, int64_t ld, int64_t* next
     MC_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// log_softmax over fp32 rows: the scoring step of beam search (transformers 4.31 generation/utils.py beam_search:
+// next_token_scores = log_softmax(next_token_logits) - eval/model_multimodal_qa_loader.py:94-102 forwards --num_beams).  One workgroup per
+// row, two sweeps (max, sum of exp) then the write; fp32 throughout, fixed reduction order.
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, int64_t ld, float* __restrict__ out, int64_t ldo, int N) {
+    __shared__ float red[16];
+    const float* r = x + (int64_t)blockIdx.x * ld;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < N; i += 256) m = fmaxf(m, r[i]);
+    m = wave_max(m);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) s += __expf(r[i] - m);
+    const float tot = block_sum(s, red + 4);
+    const float lse = m + __logf(tot);
+    float* o = out + (int64_t)blockIdx.x * ldo;
+    for (int i = threadIdx.x; i < N; i += 256) o[i] = r[i] - lse;
+}
+
+extern "C" int mc_log_softmax_f32(const float* logits, int64_t ld, float* out, int64_t ldo, int M, int N, void* stream) {
+    MC_CHECK_ARG(logits && out && M > 0 && N > 0, "mc_log_softmax_f32: bad arguments");
+    log_softmax_kernel<<<M, 256, 0, (hipStream_t)stream>>>(logits, ld, out, ldo, N);
+    MC_CHECK_LAUNCH();
+    return 0;
+}

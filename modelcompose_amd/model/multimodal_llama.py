@@ -891,11 +891,12 @@ class MultimodalLlamaForCausalLM:
         prompt followed by the new ids, rows that hit EOS are padded with pad_token_id (transformers greedy_search / sample).
         do_sample=True applies transformers 4.31's warpers in their order (temperature, top_k - GenerationConfig default 50, pass
         top_k=0 to disable - then top_p) and draws with a Philox stream keyed by `seed` (kwarg; default: drawn from torch's global
-        generator, so torch.manual_seed makes runs repeatable).  Beam search is not implemented."""
+        generator, so torch.manual_seed makes runs repeatable).  num_beams > 1: beam search (_beam_search; kwargs length_penalty, early_stopping)."""
         if num_beams not in (None, 1):
-            # (the reference cannot run it either on multimodal samples: transformers 4.31 expands input_ids num_beams times but not the
-            # modal_inputs dict, and the splice loop runs out of feature items - multimodal_arch.py:343-346 - IndexError)
-            raise NotImplementedError("beam search (num_beams > 1) is not implemented on the HIP path")
+            if do_sample or kw.get("streamer") is not None or kw.get("stopping_criteria") or kw.get("forced_ids") is not None or return_step_logits:
+                raise NotImplementedError("beam search runs greedy-scored, without streamer / stopping criteria / step logits")
+            return self._beam_search(input_ids, modal_inputs or {}, attention_mask, int(num_beams), max_new_tokens,
+                                     float(kw.pop("length_penalty", 1.0)), bool(kw.pop("early_stopping", False)), ignore_eos)
         sampling = None
         if do_sample:
             T = 1.0 if temperature is None else float(temperature)
@@ -1027,6 +1028,99 @@ class MultimodalLlamaForCausalLM:
         if return_step_logits:
             return res, torch.cat(step_logits, 0).transpose(0, 1)[:, :new.shape[1]]
         return res
+
+    def _beam_search(self, input_ids, modal_inputs, attention_mask, k, max_new_tokens, length_penalty, early_stopping, ignore_eos):
+        """generate(num_beams = k > 1): transformers 4.31's beam_search + BeamSearchScorer (the loop eval/model_multimodal_qa_loader.py:94-102
+        reaches through --num_beams; restated and pinned in oracle/beam.py).  The prompt is prefilled ONCE per sample and its KV cache rows
+        are replicated k times (the reference expands input_ids k-fold and prefills k copies - and, on samples with modal tokens, fails in
+        its splice loop because modal_inputs is not expanded with them, multimodal_arch.py:343-346; here those samples work).  Every step is
+        one cached decode step of the runtime over the B k beam rows; the scoring (log-softmax) is a kernel, the candidate bookkeeping - 2k
+        candidates per sample and step - is the scorer's host logic, the cache rows follow their beams by a device gather per step."""
+        import types
+        dev = self.device
+        eos, pad = (None if ignore_eos else self.config.eos_token_id), self.config.pad_token_id
+        pad = self.config.eos_token_id if pad is None else pad
+        feats, _ = self.encode_modal_inputs(modal_inputs, self.prefix_tokens, self.suffix_tokens)
+        plan = self._plan(input_ids, attention_mask, None, modal_inputs, feats)
+        if not plan.mask_is_suffix:
+            raise NotImplementedError("beam search with a non-suffix attention mask")
+        st0 = self._prefill(plan, feats, max_new_tokens, want_logits=True, slot=("beam", 0))
+        B, Smax = plan.B, st0["Smax"]
+        Bk = B * k
+        (kc, vc), ws = self._buffers(Bk, Smax, Bk, 1, slot=("beam", 1))
+        (kc2, vc2), _ = self._buffers(Bk, Smax, Bk, 1, slot=("beam", 2))
+        rep = torch.arange(B, device=dev).repeat_interleave(k)
+        torch.index_select(st0["kc"], 1, rep, out=kc)
+        torch.index_select(st0["vc"], 1, rep, out=vc)
+        lens = np.repeat(plan.valid_lens, k).astype(np.int32)
+        next_ids = torch.zeros(Bk, dtype=torch.int64, device=dev)
+        st = dict(plan=types.SimpleNamespace(B=Bk, valid_lens=lens), kc=kc, vc=vc, ws=ws, Smax=Smax, next_ids=next_ids,
+                  kv_lens=torch.from_numpy(lens).to(dev), slot=("beam", 1), key_valid=None)
+        scratch = torch.zeros(Bk, 1, dtype=torch.int64, device=dev)
+        ids = input_ids.cpu().repeat_interleave(k, dim=0)
+        L0 = ids.shape[1]
+        max_len = L0 + max_new_tokens
+        scores = torch.zeros(B, k, dtype=torch.float32)
+        scores[:, 1:] = -1e9
+        scores = scores.view(-1)
+        from ..beam import BeamHypotheses
+        hyps = [BeamHypotheses(k, length_penalty, early_stopping) for _ in range(B)]
+        done = [False] * B
+        logits = st0["logits"].index_select(0, rep)                   # every beam of a sample starts from the prompt's last-position logits
+        step = 0
+        V = self.config.vocab_size
+        while True:
+            cur_len = ids.shape[1]
+            logp = ops.log_softmax(logits)
+            cand = (logp + scores.to(dev)[:, None]).view(B, k * V)
+            top_s, top_i = torch.topk(cand, 2 * k, dim=1, largest=True, sorted=True)
+            top_s, top_i = top_s.cpu(), top_i.cpu()
+            top_beam, top_tok = top_i // V, top_i % V
+            nxt_scores = torch.zeros(B, k)
+            nxt_tok = torch.zeros(B, k, dtype=torch.long)
+            nxt_idx = torch.zeros(B, k, dtype=torch.long)
+            for b in range(B):
+                if done[b]:
+                    nxt_scores[b], nxt_tok[b], nxt_idx[b] = 0.0, pad, b * k
+                    continue
+                n = 0
+                for rank in range(2 * k):
+                    tok, sc, src = int(top_tok[b, rank]), float(top_s[b, rank]), b * k + int(top_beam[b, rank])
+                    if eos is not None and tok == eos:
+                        if rank >= k:
+                            continue
+                        hyps[b].add(ids[src].clone(), sc)
+                    else:
+                        nxt_scores[b, n], nxt_tok[b, n], nxt_idx[b, n] = sc, tok, src
+                        n += 1
+                    if n == k:
+                        break
+                done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+            scores = nxt_scores.view(-1)
+            sel = nxt_idx.view(-1)
+            ids = torch.cat([ids[sel], nxt_tok.view(-1, 1)], dim=1)
+            if all(done) or ids.shape[1] >= max_len:
+                break
+            if not torch.equal(sel, torch.arange(Bk)):                # the cache rows follow their beams
+                sel_d = sel.to(dev)
+                torch.index_select(st["kc"], 1, sel_d, out=kc2)
+                torch.index_select(st["vc"], 1, sel_d, out=vc2)
+                (st["kc"], kc2), (st["vc"], vc2) = (kc2, st["kc"]), (vc2, st["vc"])
+            next_ids.copy_(nxt_tok.view(-1))
+            logits = self._decode(st, 1, scratch, step, want_logits=True)[0]
+            step += 1
+        for b in range(B):
+            if not done[b]:
+                for j in range(k):
+                    hyps[b].add(ids[b * k + j], float(scores[b * k + j]))
+        best = [h.best() for h in hyps]
+        out_len = min(max(int(x.shape[0]) for x in best) + 1, max_len)
+        out = torch.full((B, out_len), pad, dtype=torch.long)
+        for b, x in enumerate(best):
+            out[b, :x.shape[0]] = x
+            if eos is not None and x.shape[0] < out_len:
+                out[b, x.shape[0]] = eos
+        return out.to(dev)
 
     @torch.no_grad()
     def generate_pipelined(self, batches, **kw):

@@ -301,6 +301,14 @@ def argmax(logits_f32, out=None):
     return out
 
 
+def log_softmax(logits_f32, out=None):
+    """mc_log_softmax_f32: rows of fp32 logits -> log-probabilities (beam search scoring)."""
+    M, N = logits_f32.shape
+    out = torch.empty(M, N, dtype=torch.float32, device=logits_f32.device) if out is None else out
+    _lib.check(_lib.lib().mc_log_softmax_f32(_p(logits_f32), logits_f32.stride(0), _p(out), out.stride(0), M, N, _stream()), "mc_log_softmax_f32")
+    return out
+
+
 def sample_step(logits_f32, temperature=1.0, top_k=0, top_p=1.0, seed=0, step=0, uniform=None, want_probs=False):
     """One sampled token per row of logits [M, V] fp32 (HF warper order: temperature, top-k, top-p, multinomial).  Returns ids int64 [M]
     (and the final probabilities [M, V] when want_probs)."""

@@ -206,6 +206,43 @@ def test_g8_four_modality_composed_model_matches_reference():
     assert torch.equal(got, a["gen_ids"]), (got, a["gen_ids"], _margins(a["step_logits"]))
 
 
+@pytest.mark.parametrize("k,lp", [(2, 1.0), (3, 1.0), (3, 0.0)])
+def test_beam_search_equals_the_restated_transformers_loop(g4_model, k, lp):
+    """generate(num_beams=k) (eval/model_multimodal_qa_loader.py:94-102 forwards --num_beams) against oracle/beam.py - transformers 4.31's
+    beam_search + BeamSearchScorer restated and pinned against the installed transformers (tests/test_beam_cpu.py) - driven by the fp32 oracle
+    model on the same prompts: an image prompt (the reference itself fails on those: it expands input_ids k-fold but not modal_inputs,
+    multimodal_arch.py:343-346) and a text-only batch.  Sequences must be equal unless the oracle's own candidate ranking had a near-tie."""
+    from oracle import beam, pipeline
+    model, a, meta, sd = g4_model
+    om = pipeline.OracleModel.from_state_dict(sd, meta)
+    n_new = 6
+    eos, pad = meta.get("eos_token_id", 2), meta.get("pad_token_id", 0)
+
+    def run(ids, mi_dev, mi_cpu):
+        got = model.generate(ids.cuda(), modal_inputs=mi_dev, num_beams=k, max_new_tokens=n_new, length_penalty=lp).cpu()
+
+        def last_logits(rows):
+            mi = {m: v.repeat_interleave(rows.shape[0] // ids.shape[0], 0) for m, v in mi_cpu.items()}
+            with torch.no_grad():
+                lg, _, _ = om.prefill(rows, mi, last_only=True)
+            return lg[:, -1]
+        want = beam.beam_search(last_logits, ids, k, n_new, eos, pad, length_penalty=lp)
+        return got, want
+    got, want = run(a["input_ids"], {"vision": a["pixels"].cuda()}, {"vision": a["pixels"]})
+    assert got.shape[0] == want.shape[0] == a["input_ids"].shape[0]
+    assert torch.equal(got[:, :a["input_ids"].shape[1]], a["input_ids"])
+    assert got.shape == want.shape and torch.equal(got, want), (got, want)
+    g = torch.Generator().manual_seed(7)
+    txt = torch.cat([torch.ones(3, 1, dtype=torch.long), torch.randint(3, 97, (3, 7), generator=g)], 1)
+    got, want = run(txt, {}, {})
+    assert got.shape == want.shape and torch.equal(got, want), (got, want)
+    # one beam is the greedy loop
+    g1 = model.generate(txt.cuda(), modal_inputs={}, num_beams=1, max_new_tokens=n_new).cpu()
+    b1 = beam.beam_search(lambda rows: om.prefill(rows, {}, last_only=True)[0][:, -1], txt, 1, n_new, eos, pad)
+    n = min(g1.shape[1], b1.shape[1])
+    assert torch.equal(g1[:, :n], b1[:, :n])
+
+
 def test_ragged_and_text_only_batch_equals_per_sample_oracle(g4_model):
     """Edge cases of the splice / decode path: a batch whose samples have different spliced lengths (one of them text only, no image
     block).  Positions are per sample on the HIP path, so every sample must reproduce the oracle run on that sample alone
