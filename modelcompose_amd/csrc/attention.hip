@@ -423,6 +423,245 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_prefill_kernel(AttnParams p) 
 }
 
 // ------------------------------------------------------------------------------------------
+// Prefill attention on the 32x32x16 MFMA (round 5) - the LLM's launches: head_dim 128, no relative-position bias, no dropout, no per-key mask.
+// ------------------------------------------------------------------------------------------
+// The kernel above is ISSUE-bound (round-4 counters: each wave issuing 44 % of its cycles, the matrix pipe 41.6 % busy): per 64-key tile and
+// wave it issues 64 v_mfma_f32_16x16x32 - each holds the SIMD's vector issue port for 8 of its 16 cycles - beside ~250 softmax VALU
+// instructions and 48 LDS reads.  The 32x32x16 shape does the same FLOPs in 32 instructions that hold the port for 8 of their 32 cycles:
+// 768 free issue cycles per tile for the same softmax.  Same algorithm, other fragment maps (cdna_hip_programming.md §3):
+//   S^T[key][q] = K . Q^T   A = K rows (lane r = key, half h: d = 16 ks + 8 h + j), B = Q^T (lane r = query, same d); the 32 x 32 result has the
+//                           QUERY on the lane (r) and 16 keys (reg & 3) + 8 (reg >> 2) + 4 h in the registers: row statistics are in-lane + ONE
+//                           v_permlane32_swap across the halves.
+//   O^T[d][q] += V^T . P^T  P^T is the accumulator tile used as the next B operand: registers 8 s .. 8 s + 7 -> bf16 = the fragment of k-step s,
+//                           whose element j of half h is key 16 s + 8 (j >> 2) + 4 h + (j & 3); V^T (A operand, lane r = d) takes the same keys:
+//                           two transposing reads of 4 keys each (ds_read_b64_tr_b16: rows 16 s + 4 h .. + 3 and + 8).  O^T keeps the query on
+//                           the lane, so the (rare) rescale and the final 1 / l are per-lane multiplies.
+// One workgroup = 4 waves x 32 queries; K / V tiles of 64 keys, double-buffered by LDS-DMA, both XOR-swizzled by
+// chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)) (conflict-free for the row reads of K and the transposing reads of V of this shape).
+// The online softmax (deferred maximum, P rounded to the storage type before P.V, fp32 row sums) is the one of attn_prefill_kernel: results
+// agree with it to fp32 summation order (the P.V sums run over the keys in another order); tests bound both against the fp32 reference.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_prefill32_kernel(AttnParams p) {
+    constexpr int D = 128, ROWB = 256, TILE = 64 * ROWB, KS = D / 16, DB = D / 32, QB = 128, WQ = 32;
+    extern __shared__ __attribute__((aligned(16))) char lds[];               // [buffer][K | V] = 4 x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int qblk, hd, b;
+    {   // XCD-aware block order (see attn_prefill_kernel)
+        const int nx = gridDim.x, ny = gridDim.y;
+        const int total = nx * ny * (int)gridDim.z;
+        const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, idx = lin >> 3;
+        const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        qblk = nx - 1 - v % nx;
+        hd = (v / nx) % ny;
+        b = v / (nx * ny);
+    }
+    const int hk = hd / (p.H / p.Hkv);
+    const int q0 = qblk * QB + wave * WQ;
+    const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
+    const int tq_row = min(q0 + r, p.Lq - 1);
+    const int q_abs = q0 + r + p.q_offset;
+
+    bf16x8 qf[KS];
+    {
+        const bf16_t* qp = p.q + b * p.q_sb + (int64_t)tq_row * p.q_st + hd * p.q_sh + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));          // retired here, not on the first MFMA inside the loop
+    }
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    int last_key = kvlen;
+    if (CAUSAL) last_key = min(last_key, qblk * QB + QB - 1 + p.q_offset + 1);
+    const int ntiles = (last_key + 63) / 64;
+    const bf16_t* kbase = p.k + b * p.k_sb + hk * p.k_sh;
+    const bf16_t* vbase = p.v + b * p.v_sb + hk * p.v_sh;
+
+    // staging: 4 rows x 256 B per 1-KiB DMA instruction, wave w stages rows 16 w .. 16 w + 15 of K and of V (4 + 4 instructions)
+    const int srow = lane >> 4, sch = lane & 15;
+    uint32_t koff[4], voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 16 + i * 4 + srow;
+        const int sw = sch ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        koff[i] = (uint32_t)(((int64_t)row * p.k_st + sw * 8) * 2);
+        voff[i] = (uint32_t)(((int64_t)row * p.v_st + sw * 8) * 2);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    auto stage = [&](int kt, int buf) {
+        const bf16_t* kt_k = kbase + (int64_t)kt * 64 * p.k_st;
+        const bf16_t* kt_v = vbase + (int64_t)kt * 64 * p.v_st;
+        const uint32_t l0 = lds0 + (uint32_t)(buf * (2 * TILE));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dma16si(kt_k, koff[i], l0 + (uint32_t)((wave * 16 + i * 4) * ROWB));
+            dma16si(kt_v, voff[i], l0 + (uint32_t)(TILE + (wave * 16 + i * 4) * ROWB));
+        }
+    };
+    if (ntiles > 0) stage(0, 0);
+
+    // loop-invariant LDS offsets.  K row read: row = 32 kb + r, chunk 2 ks + h.  V transposing read: 16-lane group gi = lane >> 4 covers the
+    // d columns 16 (gi & 1) .. + 15 of a 32-wide d block; its lane 4 q + p supplies row (key base + q), columns 4 p .. 4 p + 3
+    const int li = lane & 15, tq = li >> 2, tp = li & 3, dhalf = (lane >> 4) & 1;
+    const float scale = p.scale_log2e;
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        const char* kl = lds + buf * (2 * TILE);
+        const char* vl = kl + TILE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // causal: a tile that starts after this wave's last query contributes nothing (only the upper waves of a block reach the block's last
+        // key tile); the wave still takes part in the staging (ONE staging site: a second copy of its eight DMA instructions and their
+        // address registers pushed the kernel over the register limit) and in the barrier
+        const bool idle_tile = CAUSAL && kt * 64 > q0 + WQ - 1 + p.q_offset;
+        // ---- S^T = K . Q^T : two 32-key blocks, 8 k-steps of 16 over the head dim; K fragments fetched four k-steps ahead
+        f32x16 s[2];
+        bf16x8 kfr[2][4];
+        if (!idle_tile) {
+        auto ldk = [&](int grp, bf16x8 (&dst)[4]) {           // grp = 2 kb + (ks >> 2)
+            const int kb = grp >> 1, ks0 = (grp & 1) * 4;
+            const int row = kb * 32 + r;
+            const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = *(const bf16x8*)(kl + row * ROWB + (((ks0 + i) * 2 + h) ^ f) * 16);
+        };
+        ldk(0, kfr[0]);
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            if (grp < 3) ldk(grp + 1, kfr[(grp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((grp & 1) == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[grp >> 1][e] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[grp >> 1] = mc_mfma_32x32x16(kfr[grp & 1][i], qf[(grp & 1) * 4 + i], s[grp >> 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        }
+        if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1);          // behind K.Q^T, in front of the softmax's VALU-only stretch
+        if (idle_tile) continue;
+        // ---- online softmax: this lane's query against keys 64 kt + 32 kb + (e & 3) + 8 (e >> 2) + 4 h
+        const bool need_mask = (kt * 64 + 63 >= kvlen) || (CAUSAL && kt * 64 + 63 > q0 + p.q_offset);
+        constexpr float RESC = 8.0f;
+        float tmax = NEG_BIG;
+        if (need_mask) {                                       // masked scores are replaced in place by -3e38: they lose every maximum and exp2 to 0
+            // key = 64 kt + 4 h + c with the compile-time c = 32 kb + (e & 3) + 8 (e >> 2): ONE per-lane limit, compared with constants (the
+            // thresholds must not become 32 hoisted registers: the kernel sits at the register limit of two waves per SIMD)
+            int lim = kvlen - 1 - kt * 64 - 4 * h;
+            if (CAUSAL) lim = min(lim, q_abs - kt * 64 - 4 * h);
+            asm volatile("" : "+v"(lim));
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[kb][e] = (kb * 32 + (e & 3) + 8 * (e >> 2)) <= lim ? s[kb][e] : -3.0e38f;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, s[kb][e]);
+        {
+            auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            tmax = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));
+        }
+        tmax = tmax > NEG_BIG ? tmax * scale : NEG_BIG;       // the scale is positive: the maximum commutes with it (no valid key yet: stays NEG_BIG)
+        if (__builtin_amdgcn_ballot_w64(tmax > m_run + RESC) != 0) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = fast_exp2(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+        }
+        bf16x8 pf[2][2];
+        {
+            const float nm = -m_run;
+            float lsum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = fast_exp2(fmaf(s[kb][e], scale, nm));
+                    lsum += pv;
+                    pf[kb][e >> 3][e & 7] = (bf16_t)pv;
+                }
+            l_run += lsum;
+        }
+        // ---- O^T += V^T . P^T : per (key block kb, k-step st of 16 keys) and d block db one fragment = two transposing reads
+        bf16x8 vfr[2][2];
+        auto ldv = [&](int grp, bf16x8 (&dst)[2]) {           // grp = (kb * 2 + st) * 2 + (db >> 1): fragments db = 2 (grp & 1), + 1
+            const int ksx = grp >> 1;                          // kb * 2 + st
+            const int key0 = (ksx >> 1) * 32 + (ksx & 1) * 16 + 4 * h + tq;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int db = (grp & 1) * 2 + i;
+                const int ch = db * 4 + dhalf * 2 + (tp >> 1);
+                const int ka = key0, kb_ = key0 + 8;
+                const int fa = ((ka & 3) << 2) | ((ka >> 2) & 3), fb = ((kb_ & 3) << 2) | ((kb_ >> 2) & 3);
+                const bf16x4 lo = mc_ds_read_tr16((mc_lds_void*)(vl + ka * ROWB + ((ch ^ fa) * 16) + (tp & 1) * 8));
+                const bf16x4 hi = mc_ds_read_tr16((mc_lds_void*)(vl + kb_ * ROWB + ((ch ^ fb) * 16) + (tp & 1) * 8));
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                dst[i] = vf;
+            }
+        };
+        ldv(0, vfr[0]);
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) {
+            if (grp < 7) ldv(grp + 1, vfr[(grp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ksx = grp >> 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int db = (grp & 1) * 2 + i;
+                oacc[db] = mc_mfma_32x32x16(vfr[grp & 1][i], pf[ksx >> 1][ksx & 1], oacc[db]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- finalize
+    {
+        auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        const float l = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int t = q0 + r;
+        if (p.lse && t < p.Lq && h == 0) p.lse[((int64_t)b * p.H + hd) * p.Lq + t] = l > 0.f ? m_run + log2f(l) : NEG_BIG;
+        int64_t row = -1;
+        if (t < p.Lq) row = p.out_map ? p.out_map[b * p.Lq + t] : (int64_t)b * p.Lq + t;
+        bf16_t* op = p.o + (row < 0 ? 0 : row) * p.o_row_stride + hd * D;
+        // oacc[db][e]: d = 32 db + 8 (e >> 2) + 4 h + (e & 3).  v_permlane32_swap pairs the d groups 2 g, 2 g + 1 of the two halves so that the
+        // lower half stores the 8 consecutive d of group 2 g and the upper half those of group 2 g + 1: 16 bytes per lane and store
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq += 2) {
+                bf16x4 a4, b4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a4[e] = (bf16_t)(oacc[db][gq * 4 + e] * inv); b4[e] = (bf16_t)(oacc[db][(gq + 1) * 4 + e] * inv); }
+                const u32x2 pa = __builtin_bit_cast(u32x2, a4), pb = __builtin_bit_cast(u32x2, b4);
+                auto r0 = __builtin_amdgcn_permlane32_swap(pa[0], pb[0], false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(pa[1], pb[1], false, false);
+                // lower half: r0[0], r1[0] = own group gq (d + 0 .. 3), r0[1], r1[1] = the upper half's group gq (d + 4 .. 7)
+                // upper half: r0[0], r1[0] = the lower half's group gq + 1 (d + 0 .. 3), r0[1], r1[1] = own group gq + 1 (d + 4 .. 7)
+                const u32x4 ov = {r0[0], r1[0], r0[1], r1[1]};
+                if (row >= 0) *(u32x4*)(op + db * 32 + (gq + h) * 8) = ov;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // tiny sequences (Lq, S <= 8): the temporal attention of LanguageBind-Video (languagebind/video/modeling_video.py:105-130: every patch
 // position attends over its t = 8 frames - 4112 sequences x 16 heads of 8 x 8 scores per clip batch).  The flash kernel above spends a
 // 64 x 64 MFMA tile and two 64-row LDS stages on each of them (4 TFLOP/s, 260 us per layer); this is a memory-bound problem: q, k, v read
@@ -791,8 +1030,12 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
         // K fragment reads at the top of the tile: +1 % (debug bit 6: at the top, as every other shape does)
         else if (g_attn_dbg & 64) attn_prefill_kernel<128, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
         else if (p.key_valid) attn_prefill_kernel<128, false, 4, 2, false, 1><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
-        else if (S % 64 == 0 && 64LL * k_st * 2 + 256 < (1LL << 31) && 64LL * v_st * 2 + 256 < (1LL << 31))     // the LLM's launches: no per-key mask, whole key tiles
-            attn_prefill_kernel<128, false, 4, 2, false, 1, false, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+        else if (S % 64 == 0 && 64LL * k_st * 2 + 256 < (1LL << 31) && 64LL * v_st * 2 + 256 < (1LL << 31)) {   // the LLM's launches: no per-key mask, whole key tiles
+            // round 5: the 32x32x16 kernel (debug bit 7 keeps the 16x16x32 one for A/B)
+            if (g_attn_dbg & 128) attn_prefill_kernel<128, false, 4, 2, false, 1, false, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+            else if (causal) attn_prefill32_kernel<true><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+            else attn_prefill32_kernel<false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+        }
         else attn_prefill_kernel<128, false, 4, 2, false, 1, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);      // no per-key mask: its loads and branches compiled out
         MC_CHECK_LAUNCH();
         return 0;

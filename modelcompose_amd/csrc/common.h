@@ -15,6 +15,7 @@ typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MC_STORAGE_IS_F16 1
 #define mc_mfma_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define mc_mfma_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #else
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -22,8 +23,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MC_STORAGE_IS_F16 0
 #define mc_mfma_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define mc_mfma_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

@@ -307,7 +307,11 @@ def _ref_attn(q, k, v, causal, q_offset, kv_lens, scale):
 
 
 @pytest.mark.parametrize("D,H,Hkv,L,S,causal", [(128, 4, 4, 70, 70, True), (128, 8, 2, 200, 200, True), (64, 4, 4, 577, 577, False),
-                                                (64, 3, 3, 9, 9, False), (128, 2, 2, 33, 97, True), (64, 2, 2, 32, 300, False)])
+                                                (64, 3, 3, 9, 9, False), (128, 2, 2, 33, 97, True), (64, 2, 2, 32, 300, False),
+                                                # head_dim 128, whole 64-key tiles, more than 64 queries: the 32x32x16 kernel (round 5) - grouped
+                                                # key / value heads, a query offset, ragged key counts, a query count that is not a multiple of 128
+                                                (128, 8, 2, 200, 256, True), (128, 4, 4, 300, 320, False), (128, 2, 2, 130, 192, True),
+                                                (128, 4, 4, 515, 576, True)])
 def test_attn_prefill(ops, D, H, Hkv, L, S, causal):
     B = 2
     q = rand_bf(B, L, H, D, seed=9)
@@ -322,6 +326,31 @@ def test_attn_prefill(ops, D, H, Hkv, L, S, causal):
     ref = ref.transpose(1, 2).reshape(B * L, H * D)
     # P is rounded to bf16 before P·V (2^-9 relative per term) and the output once more: 2^-6 of the output scale
     close_bf16(out, ref, rel=2 ** -6)
+
+
+def test_attn_prefill_32x32_kernel_out_map_and_lse(ops):
+    """The 32x32x16 kernel's routed output map (rows scattered, -1 = skipped) and its log2-sum-exp output (the backward's input)."""
+    from modelcompose_amd import _lib
+    B, H, D, L, S = 2, 4, 128, 260, 320
+    q, k, v = rand_bf(B, L, H, D, seed=31), rand_bf(B, H, S, D, seed=32), rand_bf(B, H, S, D, seed=33)
+    perm = torch.randperm(B * L, generator=torch.Generator().manual_seed(3)).int()
+    perm[5] = -1
+    out = torch.full((B * L, H * D), 9.0, dtype=BF, device="cuda")
+    lse = torch.zeros(B, H, L, dtype=torch.float32, device="cuda")
+    ops.attn_prefill_lse(dev(q), dev(k), dev(v), out, lse, B, H, L, S, D, (L * H * D, H * D, D), (H * S * D, D, S * D), (H * S * D, D, S * D), H * D, True)
+    ref = _ref_attn(q.float().transpose(1, 2), k.float(), v.float(), True, 0, None, 1 / math.sqrt(D)).transpose(1, 2).reshape(B * L, H * D)
+    close_bf16(out, ref, rel=2 ** -6)
+    sc = (q.float().transpose(1, 2) @ k.float().transpose(-1, -2)) / math.sqrt(D)
+    sc = sc.masked_fill(torch.arange(S)[None, None, None, :] > torch.arange(L)[None, None, :, None], float("-inf"))
+    want = torch.logsumexp(sc, -1) / math.log(2.0)
+    assert (lse.cpu() - want).abs().max().item() < 2e-3
+    out2 = torch.full((B * L, H * D), 9.0, dtype=BF, device="cuda")
+    ops.attn_prefill(dev(q), dev(k), dev(v), out2, B, H, H, L, S, D, (L * H * D, H * D, D), (H * S * D, D, S * D), (H * S * D, D, S * D), H * D, True,
+                     out_map=dev(perm))
+    keep = perm >= 0
+    assert torch.equal(out2[dev(perm[keep].long())], out[dev(keep)])
+    skipped_dst = sorted(set(range(B * L)) - set(perm[keep].tolist()))
+    assert bool((out2[dev(torch.tensor(skipped_dst))] == 9.0).all())
 
 
 def test_attn_prefill_out_map_and_qkv_fused_layout(ops):
@@ -803,7 +832,7 @@ def test_prefill_attention_128_query_workgroups_match_64_query_ones(causal):
     v = torch.randn(B, H, S, D, generator=g).to(torch.bfloat16).cuda()
     lens = torch.tensor([L, 900], dtype=torch.int32, device="cuda")
     outs = []
-    for dbg in (1, 0):
+    for dbg in (1, 128):                      # (bit 7: the 16x16x32 kernel family; the default for this shape is the 32x32x16 kernel since round 5)
         _lib.lib().mc_attn_debug(dbg)
         out = torch.zeros(B * L, H * D, dtype=torch.bfloat16, device="cuda")
         ops.attn_prefill(q, k, v, out, B, H, H, L, S, D, (L * H * D, H * D, D), (H * S * D, D, S * D), (H * S * D, D, S * D), H * D, causal, kv_lens=lens)
@@ -836,11 +865,21 @@ def test_long_prefill_attention_shapes_are_bit_identical_and_right(causal, L, S,
         ops.attn_prefill(q, k, v, out, B, H, H, L, S, D, (L * H * D, H * D, D), (H * S * D, D, S * D), (H * S * D, D, S * D), H * D, causal, kv_lens=kl)
         _lib.lib().mc_attn_debug(0)
         return out
-    stag = run(0)
+    stag = run(128)                           # bit 7: the 16x16x32 family (round 5 made the 32x32x16 kernel the default of this shape)
     assert torch.equal(stag, run(2)), "4-wave != 8-wave kernel"
     assert torch.equal(stag, run(4)), "two query blocks per wave != one"
     for _ in range(5):
-        assert torch.equal(stag, run(0)), "not reproducible run to run"
+        assert torch.equal(stag, run(128)), "not reproducible run to run"
+    # round 5: the shipped 32x32x16 kernel - same online softmax, other fragment maps, P.V summed over the keys in another order: equal to
+    # the 16x16x32 family to fp32 summation order (a bf16 output element differs by at most 2 ulp of the tensor's scale), bitwise reproducible
+    new = run(0)
+    for _ in range(5):
+        assert torch.equal(new, run(0)), "32x32x16 kernel not reproducible run to run"
+    dd = (new.float() - stag.float()).abs()
+    scale_ = stag.float().abs().max().item()
+    assert dd.max().item() <= 2 ** -7 * scale_, (dd.max().item(), scale_)
+    assert (dd > 0).float().mean().item() < 0.25
+    stag = new
     # and it is the right function: fp32 softmax attention of the bf16 inputs for one (batch, head)
     b_, h_ = 1, 7
     n = int(lens[b_])
