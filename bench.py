@@ -426,11 +426,22 @@ def profiled_pass(model, step_fn, cfg, B, new_tokens, n_steps):
                                f"{tj.get('algorithmic_bytes_per_launch')})")
         except Exception:
             traffic = None
+    by_class = {}
+    for cname, (k0_, k1_) in (("decoder_layers_K_ge_4096", (4096, 1 << 30)), ("encoder_towers_K_lt_4096", (0, 4095))):
+        ms_c, fl_c, n_c = C.c_double(0), C.c_double(0), C.c_int64(0)
+        L.mc_gemm_profile_read_range(k0_, k1_, C.byref(ms_c), C.byref(fl_c), C.byref(n_c))
+        if n_c.value:
+            a_c = fl_c.value / max(ms_c.value, 1e-9) / 1e9
+            by_class[cname] = {"achieved": round(a_c, 2), "frac": round(a_c / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "launches": int(n_c.value),
+                               "ms_per_step": round(ms_c.value / n_steps, 3)}
     roofline = {"bound": "mfma", "kernel": "gemm_tile256_kernel", "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": int(n.value), "avg_launch_us": round(ms.value / max(n.value, 1) * 1e3, 2),
                 "avg_flops_per_launch": fl.value / max(n.value, 1), "avg_algorithmic_bytes_per_launch": by.value / max(n.value, 1),
-                "share_of_step": round(ms.value / n_steps / max(sum(stages.values()), 1e-9), 4)}
+                "share_of_step": round(ms.value / n_steps / max(sum(stages.values()), 1e-9), 4),
+                # the same events split by the launch's reduction length: the Vicuna decoder's four linears (K = 4096 / 11008) and the
+                # encoder towers' (K = 768 / 1024: a tile's prologue + store-bound epilogue weigh 28 % there against 7 %)
+                "by_class": by_class}
     # ---- decode roofline: algorithmic bytes of one step = every decoder weight + lm_head once, K and V of every cached key once
     Hd, I, V, Ln, H, D = cfg["hidden"], cfg["inter"], cfg["vocab"], cfg["layers"], cfg["heads"], cfg["head_dim"]
     wbytes = {"qkv_gemm": 2.0 * 3 * Hd * Hd, "o_gemm": 2.0 * Hd * Hd, "gate_up_gemm": 2.0 * 2 * I * Hd, "down_gemm": 2.0 * Hd * I,

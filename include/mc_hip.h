@@ -214,6 +214,7 @@ int mc_gemm_reserve_rows(void* stream);
 int mc_gemm_release_rows(void* stream);   /* before destroying a stream that launched GEMMs: gives its workspace slot back */
 int mc_gemm_profile_enable(int on);
 int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches);
+int mc_gemm_profile_read_range(int k_min, int k_max, double* total_ms, double* total_flops, int64_t* launches);   /* launches with k_min <= K <= k_max */
 int mc_gemm_profile_read_bytes(double* total_bytes);   /* algorithmic HBM bytes (operands read once, output written once) of the same launches */
 /* diagnostic: shader clock (GHz) held across the 256x256 kernel's main loop, median over the first n_wg workgroups of the last launch made
  * with mc_gemm_debug(40) (correct results, stamped build) */

@@ -77,6 +77,7 @@ _SIGS = {
     "mc_gemm_profile_enable": [c_i],
     "mc_gemm_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)],
     "mc_gemm_profile_read_bytes": [C.POINTER(C.c_double)],
+    "mc_gemm_profile_read_range": [c_i, c_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)],
     "mc_gemm_clock_read": [c_i, C.POINTER(C.c_double)],
     "mc_attn_debug": [c_i],
     "mc_gemm_set_option": [C.c_char_p, c_i],

@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // Optional live timing of the dominant kernel (gemm_tile256_kernel): HIP events recorded on the launch stream around every launch while
 // enabled (bench.py's roofline object).  Not graph-capturable; leave disabled in normal operation.
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; int K; };
 bool g_prof_on = false;
 int g_gemm_dbg = 0;
 std::vector<ProfRec> g_prof;
@@ -1836,6 +1836,25 @@ extern "C" int mc_gemm_clock_read(int n_wg, double* ghz) {
     if (r.empty()) { mc_set_error("mc_gemm_clock_read: no stamps recorded"); return 2; }
     std::sort(r.begin(), r.end());
     *ghz = r[r.size() / 2];
+    return 0;
+}
+
+// the same sums over the launches with k_min <= K <= k_max only (bench.py: the decoder layers' launches, K >= 4096, apart from the encoder
+// towers', K <= 1024, whose per-tile prologue + epilogue weigh 4x more)
+extern "C" int mc_gemm_profile_read_range(int k_min, int k_max, double* total_ms, double* total_flops, int64_t* launches) {
+    double ms = 0.0, fl = 0.0;
+    int64_t n = 0;
+    for (auto& r : g_prof) {
+        if (r.K < k_min || r.K > k_max) continue;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) { mc_set_error("mc_gemm_profile_read_range: %s", hipGetErrorString(e)); return 2; }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        ms += t; fl += r.flops; ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = n;
     return 0;
 }
 
@@ -2037,6 +2056,7 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     if (g_prof_on) {
         (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);
         rec.flops = 2.0 * M_total * (double)N * K;
+        rec.K = K;
         // algorithmic HBM bytes: x and every group's W read once, the output written once (half as wide with the fused SwiGLU),
         // the residual read once
         rec.bytes = 2.0 * ((double)M_total * K + (double)grp.n * N * K + (double)M_total * (a->swiglu ? N / 2 : N) * (a->out_f32 ? 2 : 1) +
