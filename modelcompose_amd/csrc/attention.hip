@@ -1032,7 +1032,10 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
         else if (p.key_valid) attn_prefill_kernel<128, false, 4, 2, false, 1><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
         else if (S % 64 == 0 && 64LL * k_st * 2 + 256 < (1LL << 31) && 64LL * v_st * 2 + 256 < (1LL << 31)) {   // the LLM's launches: no per-key mask, whole key tiles
             // round 5: the 32x32x16 kernel (debug bit 7 keeps the 16x16x32 one for A/B)
-            if (g_attn_dbg & 128) attn_prefill_kernel<128, false, 4, 2, false, 1, false, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+            // (measured, profiles/r05_probes/attn32_ab.json: causal L = 683 +12 %, 2048 +6 %, 2793 +1 %; bidirectional L = 2304 -1.5 %: the
+            // bidirectional launches keep the 16x16x32 kernel unless debug bit 8 asks for the new one)
+            if ((g_attn_dbg & 128) || (!causal && !(g_attn_dbg & 256)))
+                attn_prefill_kernel<128, false, 4, 2, false, 1, false, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
             else if (causal) attn_prefill32_kernel<true><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
             else attn_prefill32_kernel<false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
         }

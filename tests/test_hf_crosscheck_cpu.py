@@ -137,32 +137,52 @@ def test_shim_rotary_and_rmsnorm_equal_installed_transformers(hf):
     assert torch.equal(llm.decoder_attention_mask(am, 2, 10, 0) == 0, allowed)
 
 
+REF_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[2])
+from oracle import gen_golden, llm, refshim
+z = np.load(sys.argv[1])
+arr = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("sd::")}
+sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
+torch.manual_seed(0)
+cfg = gen_golden.tiny_llm_config(ml, modal=("vision",), reset="default-vision=0.5", layers=2, hidden=64, heads=4, inter=128, vocab=128)
+cfg.max_position_embeddings = 64
+model = ml.MultimodalLlamaForCausalLM(cfg).eval()
+missing, unexpected = model.load_state_dict(sd, strict=False)
+assert not unexpected and all("lora_" in k or "prefix_tokens" in k or "suffix_tokens" in k for k in missing), (missing, unexpected)
+with torch.no_grad():
+    for n, p in model.named_parameters():
+        if ".lora_B." in n:
+            p.zero_()        # untrained LoRA (peft 0.4.0 initialises B = 0; the installed transformers' post_init re-draws every nn.Linear)
+def close(a, b, tol=2e-5):
+    err = (a - b).abs().max().item() / b.abs().max().item()
+    assert err < tol, err
+ids = arr["input_ids"]
+left = arr["mask_left"].bool()
+with torch.no_grad():
+    o = model(input_ids=ids, attention_mask=torch.ones(2, 10, dtype=torch.bool), use_cache=True)
+    close(o.logits, arr["logits_full"])
+    o2 = model(input_ids=arr["next_ids"][:, None], attention_mask=torch.ones(2, 11, dtype=torch.bool), past_key_values=o.past_key_values, use_cache=True)
+    close(o2.logits[:, -1], arr["logits_step"])
+    ol = model(input_ids=ids, attention_mask=left)
+    close(ol.logits[left], arr["logits_left"][left])
+    # and the restatement against the shimmed reference on EVERY position, masked rows included (same mask arithmetic on both sides)
+    cfg_o = llm.LLMConfig(vocab_size=128, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                          max_position_embeddings=64, rms_norm_eps=1e-5, lora_r=4, lora_alpha=8, lora_strategy=None, modal_names=("default",),
+                          reset_scaling_weights=None, pad_token_id=0, eos_token_id=2)
+    hl, _ = llm.model_forward(sd, cfg_o, input_ids=ids, attention_mask=left)
+    close(llm.lm_logits(hl, sd), ol.logits)
+print("ok")
+'''
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/modelcompose"), reason="the reference sources exist in the build container only")
-def test_shimmed_reference_equals_installed_transformers_and_the_oracle(hf):
-    """The unmodified reference model class, made importable by the shim, with the SAME base weights and untrained LoRA (B = 0)."""
-    from oracle import gen_golden, llm, refshim
+def test_shimmed_reference_equals_installed_transformers_and_the_oracle(hf, tmp_path):
+    """The unmodified reference model class, made importable by the shim, with the SAME base weights and untrained LoRA (B = 0).  In a child
+    interpreter: the shim replaces sys.modules['modelcompose'] and names inside transformers - neither may leak into the other tests."""
     arr, sd = hf
-    ml = refshim.import_ref("modelcompose.model.language_model.multimodal_llama")
-    torch.manual_seed(0)
-    cfg = gen_golden.tiny_llm_config(ml, modal=("vision",), reset="default-vision=0.5", layers=2, hidden=64, heads=4, inter=128, vocab=128)
-    cfg.max_position_embeddings = 64
-    model = ml.MultimodalLlamaForCausalLM(cfg).eval()
-    missing, unexpected = model.load_state_dict(sd, strict=False)
-    assert not unexpected and all("lora_" in k or "prefix_tokens" in k or "suffix_tokens" in k for k in missing), (missing, unexpected)
-    with torch.no_grad():
-        for n, p in model.named_parameters():
-            if ".lora_B." in n:
-                p.zero_()                                 # untrained LoRA (peft 0.4.0 initialises B = 0; the installed transformers' post_init
-                                                          # re-draws every nn.Linear): the branches add exact zeros
-    ids = arr["input_ids"]
-    left = arr["mask_left"].bool()
-    with torch.no_grad():
-        o = model(input_ids=ids, attention_mask=torch.ones(2, 10, dtype=torch.bool), use_cache=True)
-        _close(o.logits, arr["logits_full"])
-        o2 = model(input_ids=arr["next_ids"][:, None], attention_mask=torch.ones(2, 11, dtype=torch.bool), past_key_values=o.past_key_values, use_cache=True)
-        _close(o2.logits[:, -1], arr["logits_step"])
-        ol = model(input_ids=ids, attention_mask=left)
-        _close(ol.logits[left], arr["logits_left"][left])
-        # and the restatement against the shimmed reference on EVERY position, masked rows included (same mask arithmetic on both sides)
-        hl, _ = llm.model_forward(sd, _cfg(), input_ids=ids, attention_mask=left)
-        _close(llm.lm_logits(hl, sd), ol.logits)
+    path = str(tmp_path / "hf_in.npz")
+    np.savez(path, **{k: v.numpy() for k, v in arr.items()}, **{"sd::" + k: v.numpy() for k, v in sd.items()})
+    r = subprocess.run([sys.executable, "-c", REF_SCRIPT, path, ROOT], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]

@@ -313,7 +313,9 @@ def _ref_attn(q, k, v, causal, q_offset, kv_lens, scale):
                                                 (128, 8, 2, 200, 256, True), (128, 4, 4, 300, 320, False), (128, 2, 2, 130, 192, True),
                                                 (128, 4, 4, 515, 576, True)])
 def test_attn_prefill(ops, D, H, Hkv, L, S, causal):
+    from modelcompose_amd import _lib
     B = 2
+    _lib.lib().mc_attn_debug(256)              # bidirectional head_dim-128 launches too on the 32x32x16 kernel (they default to the 16x16x32 one)
     q = rand_bf(B, L, H, D, seed=9)
     k = rand_bf(B, Hkv, S, D, seed=10)
     v = rand_bf(B, Hkv, S, D, seed=11)
@@ -323,6 +325,7 @@ def test_attn_prefill(ops, D, H, Hkv, L, S, causal):
     ops.attn_prefill(dev(q), dev(k), dev(v), out, B, H, Hkv, L, S, D, (L * H * D, H * D, D), (Hkv * S * D, D, S * D),
                      (Hkv * S * D, D, S * D), H * D, causal, q_off, kv_lens=dev(kv_lens))
     ref = _ref_attn(q.float().transpose(1, 2), k.float(), v.float(), causal, q_off, kv_lens, 1 / math.sqrt(D))
+    _lib.lib().mc_attn_debug(0)
     ref = ref.transpose(1, 2).reshape(B * L, H * D)
     # P is rounded to bf16 before P·V (2^-9 relative per term) and the output once more: 2^-6 of the output scale
     close_bf16(out, ref, rel=2 ** -6)
@@ -860,7 +863,7 @@ def test_long_prefill_attention_shapes_are_bit_identical_and_right(causal, L, S,
     kl = torch.tensor(lens, dtype=torch.int32, device="cuda")
 
     def run(dbg):
-        _lib.lib().mc_attn_debug(dbg)
+        _lib.lib().mc_attn_debug(dbg if dbg else 256)          # 0 -> the 32x32x16 kernel, also for the bidirectional case (bit 8)
         out = torch.zeros(B * L, H * D, dtype=torch.bfloat16, device="cuda")
         ops.attn_prefill(q, k, v, out, B, H, H, L, S, D, (L * H * D, H * D, D), (H * S * D, D, S * D), (H * S * D, D, S * D), H * D, causal, kv_lens=kl)
         _lib.lib().mc_attn_debug(0)

@@ -13,7 +13,8 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("gemm_tile256_kernel", "gemm_tile_kernel", "attn_prefill_kernel", "attn_decode_kernel", "gemm_skinny2_kernel")
+KEEP = ("gemm_tile256_kernel", "gemm_tile_kernel", "gemm_tile2_kernel", "attn_prefill_kernel", "attn_prefill32_kernel", "attn_decode_kernel", "gemm_skinny2_kernel",
+        "gemm_rows_kernel", "compose_multi_kernel")
 
 
 def short(name):
