@@ -11,6 +11,7 @@
 // Operands: Bm [N, r] row-major (checkpoint layout of lora_B), At [K, r] row-major (= lora_A transposed once
 // on load; r contiguous so both fragments are 16-byte loads).
 #include "common.h"
+#include <stdlib.h>
 
 #define MC_MAX_TERMS 8
 
@@ -96,7 +97,15 @@ struct ComposeMultiParams {
 // Loop order (register budget: 2 waves per SIMD): per output, per term, the term's A^T fragments of the wave's 64 columns are loaded ONCE
 // (RS x 4 fragments) and reused against the NR row blocks, whose B fragments stream through; a multi-term output keeps its running fp32
 // total in LDS (16 bytes per lane and 16 x 16 block, conflict-free), a single-term output never leaves the registers.
-template <int NR, bool FAST>
+// WT: the outputs' 16-byte stores written THROUGH (sc1: the line is not kept in the XCD's L2).  A launch writes n_out times the bytes it reads;
+// kept in the write-back L2 that stream evicts the LoRA factors every tile re-reads (12 x 1 MiB against a 4-MiB L2), which then come from the
+// Infinity Cache over the fabric - measured with plain stores: 0.9 TB/s, the fabric-side re-reads 3-5 x the algorithmic bytes.
+__device__ __forceinline__ void compose_store16(void* p, u32x4 v, bool wt) {
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *(u32x4*)p = v;
+}
+
+template <int NR, bool FAST, bool WT>
 __global__ __launch_bounds__(256, 2) void compose_multi_kernel(ComposeMultiParams p_by_value) {
     // The argument block is read where it lies, in the kernarg segment: its arrays are indexed by the run-time output / term number, and a
     // by-value aggregate indexed dynamically is first loaded whole into ~100 SGPRs (130 of them then spilled into vector registers, which in
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void compose_multi_kernel(ComposeMultiParam
                     const int k8 = k0 + tp * 32 + k8off;
                     const int kb = k8 >> 5, q = (k8 & 31) >> 3;
                     bf16_t* dst = outp + ((int64_t)(nb * p.nb_stride + p.nb_offset) * kblocks + kb) * 512 + ((q << 4) | (n & 15)) * 8;
-                    *(u32x4*)dst = ov;
+                    compose_store16(dst, ov, WT);
                     if (outr && inb) {
                         if (FAST) {
                             if (k8 < p.K) *(u32x4*)(outr + (int64_t)n * p.ldo + k8) = ov;
@@ -357,8 +366,11 @@ extern "C" int mc_compose_multi_bf16(const mc_compose_multi_args* a, void* strea
     bool fast = a->K % 8 == 0 && (!a->w || (a->ldw % 8 == 0 && ((uintptr_t)a->w & 15) == 0)) && (!a->col_scale || ((uintptr_t)a->col_scale & 15) == 0);
     for (int o = 0; o < a->n_out; ++o)
         if (p.out_rowmajor[o] && (a->ldo % 8 || ((uintptr_t)p.out_rowmajor[o] & 15))) fast = false;
-    if (fast) compose_multi_kernel<MC_COMPOSE_NR, true><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else compose_multi_kernel<MC_COMPOSE_NR, false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    static int wt = -1;                                 // MC_COMPOSE_WT=0: plain (write-back) output stores, for A/B
+    if (wt < 0) { const char* e = getenv("MC_COMPOSE_WT"); wt = (e && e[0] == '0') ? 0 : 1; }
+    if (fast && wt) compose_multi_kernel<MC_COMPOSE_NR, true, true><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else if (fast) compose_multi_kernel<MC_COMPOSE_NR, true, false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else compose_multi_kernel<MC_COMPOSE_NR, false, false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
     MC_CHECK_LAUNCH();
     return 0;
 }

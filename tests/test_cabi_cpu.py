@@ -152,7 +152,7 @@ def test_hot_kernels_do_not_spill():
         k = ks[name]
         assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
         assert k["vgpr_count"] + k["agpr_count"] <= 256, k          # two waves per SIMD
-    k = ks["_Z20compose_multi_kernelILi4ELb1EEv18ComposeMultiParams"]          # (a few scalar spills into vector lanes are harmless; scratch is not)
+    k = ks["_Z20compose_multi_kernelILi4ELb1ELb1EEv18ComposeMultiParams"]          # (a few scalar spills into vector lanes are harmless; scratch is not)
     assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] + k["agpr_count"] <= 256, k
     for name, k in ks.items():                                     # the decode GEMMs: every instantiation
         if name.startswith("_Z16gemm_rows_kernel"):
