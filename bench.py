@@ -111,6 +111,9 @@ def parse():
                     "(MultimodalLlamaForCausalLM.generate_pipelined, eval/model_multimodal_qa_loader.py --pipeline); every step still is one full "
                     "batch, all K batches start and finish inside the timed region")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one generate() call per step, nothing overlapped")
+    ap.add_argument("--decode-cus", type=int, default=None,
+                    help="pipelined loop: CUs reserved for the decode chain (model.decode_cus; multiple of 8, 0 = no partition; default: the model's "
+                         "own default / MC_DECODE_CUS)")
     ap.add_argument("--no-overlap", action="store_true", help="debug only (train): weight-gradient / rank-projection GEMMs on the main stream")
     ap.add_argument("--gemm-debug", type=int, default=0, help="debug only: mc_gemm_debug word (A/B of kernel variants)")
     ap.add_argument("--ab-tile192", action="store_true",
@@ -493,6 +496,8 @@ def generate_main(args, world, rank, local):
     meta = workload_meta(name, args.layers)
     sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
     model = build_from_state_dict(meta, sd, device=dev)
+    if args.decode_cus is not None:
+        model.decode_cus = args.decode_cus
     # the load-time composition (the path's "fused AXPY over state_dict tensors"): algorithmic bytes = W read ONCE per linear + one dense W' written
     # per routed adapter + the LoRA factors, over the device time of the composition loop (events around it in finalize(); weights already in HBM)
     compose_roofline = None
@@ -578,7 +583,8 @@ def generate_main(args, world, rank, local):
                    "workload_name": name, "per_gpu_batch": B, "new_tokens": args.new_tokens, "layers": args.layers, "spliced_length": spliced,
                    "block_tokens": {m: int(f.shape[1]) for m, f in feats.items()}, "adapters": list(model.modal_names),
                    "parallelism": f"dp{world}", "gathered": args.gather, "decode_graph_requested": not args.no_graph, "pipelined": bool(args.pipeline),
-                   "pipeline_priming_steps": priming},
+                   "pipeline_priming_steps": priming,
+                   "decode_cus": int(getattr(model, "decode_cus", os.environ.get("MC_DECODE_CUS", "0")) or 0) if args.pipeline else 0},
         "roofline": None, "roofline_decode": None, "roofline_compose": compose_roofline,
     }
     del feats

@@ -36,6 +36,11 @@ int mc_device_info(int* cu_count, int64_t* hbm_bytes, char* arch, int arch_len);
  * inference dtype, model/builder.py:41, :162, :185, kept as the parity instrument: 8x finer mantissa at the same MFMA rate).  Every
  * `_bf16` entry point below takes / returns that element type in the f16 build; fp32 and integer interfaces are unchanged. */
 int mc_storage_dtype(void);
+/* A HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (hipExtStreamCreateWithCUMask; consecutive CU indices are dealt
+ * round-robin over the XCDs, so a multiple of 8 takes the same number from every XCD).  No reference counterpart: the reference runs one
+ * CUDA stream; this serves generate_pipelined's decode / prefill CU partition (model_multimodal_qa_loader.py:94-102 is the loop it feeds). */
+int mc_stream_create_cu_range(int first_cu, int n_cus, void** stream);
+int mc_stream_destroy(void* stream);
 
 /* ---- weights ---------------------------------------------------------------------------------------
  * Packed layout (see csrc/gemm.hip): [ceil16(N)/16][ceil64(K)/32][64 lanes][8] bf16, zero padded.        */

@@ -64,6 +64,8 @@ _SIGS = {
     "mc_abi_version": [],
     "mc_storage_dtype": [],
     "mc_device_info": [C.POINTER(c_i), C.POINTER(c_l), C.c_char_p, c_i],
+    "mc_stream_create_cu_range": [c_i, c_i, C.POINTER(c_p)],
+    "mc_stream_destroy": [c_p],
     "mc_packed_weight_elems": [c_i, c_i, C.POINTER(c_l)],
     "mc_pack_weight_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_unpack_weight_bf16": [c_p, c_p, c_i, c_i, c_p],

@@ -34,12 +34,26 @@ BF16 = _lib.storage_dtype()      # the library's 16-bit storage element: bf16, o
 _STREAM_POOLS: Dict = {}
 
 
-def _shared_streams(device, kind: str, n: int):
-    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), kind)
+def _shared_streams(device, kind: str, n: int, cu_range=None):
+    """cu_range = (first_cu, n_cus): streams restricted to those CUs (mc_stream_create_cu_range; generate_pipelined's decode_cus mode)."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (idx, kind, cu_range)
     pool = _STREAM_POOLS.setdefault(key, [])
     while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=device))
+        if cu_range is None:
+            pool.append(torch.cuda.Stream(device=device))
+        else:
+            h = C.c_void_p()
+            with torch.cuda.device(idx):
+                _lib.check(_lib.lib().mc_stream_create_cu_range(int(cu_range[0]), int(cu_range[1]), C.byref(h)), "mc_stream_create_cu_range")
+            pool.append(torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx)))      # lives as long as the process (shared pool)
     return pool[:n]
+
+
+def _cu_count() -> int:
+    n = C.c_int(0)
+    _lib.check(_lib.lib().mc_device_info(C.byref(n), None, None, 0), "mc_device_info")
+    return n.value
 
 
 def _serialised(fn):
@@ -467,7 +481,7 @@ class MultimodalLlamaForCausalLM:
                 feats[modal] = self._encode_one(modal, x, prefix_tokens, suffix_tokens)
         else:
             cur = torch.cuda.current_stream()
-            pool = _shared_streams(self.device, "encode", len(work))
+            pool = _shared_streams(self.device, "encode", len(work), getattr(self, "_prefill_cu_range", None))
             parts = {}
             for (modal, x), st in zip(work, pool):
                 st.wait_stream(cur)
@@ -922,6 +936,7 @@ class MultimodalLlamaForCausalLM:
         # stage_events (dict, optional): receives torch.cuda.Event pairs recorded on the current stream around the three stages, as
         # {"encode": (e0, e1), "prefill": (e1, e2), "decode": (e2, e3)} (bench.py: stage times and the decode roofline)
         stage_events = kw.pop("stage_events", None)
+        dstream = kw.pop("decode_stream", None)
 
         def mark():
             if stage_events is None:
@@ -947,87 +962,100 @@ class MultimodalLlamaForCausalLM:
         e2 = mark()
         if prefill_done is not None:
             prefill_done.record()                                  # generate_pipelined: the other pipeline's prefill may start now
-        B = plan.B
-        out = self._cache.get(("out_ids", slot, B, max_new_tokens))   # persistent for the same reason as next_ids (the result is a copy)
-        if out is None:
-            with torch.inference_mode(False):
-                out = torch.zeros(B, max_new_tokens, dtype=torch.int64, device=self.device)
-            self._cache[("out_ids", slot, B, max_new_tokens)] = out
-        else:
-            out.zero_()
-        if sampling is not None:                                  # first token: same rule, RNG counter -1 (decode steps count from 0)
-            st["next_ids"].copy_(ops.sample_step(st["logits"], sampling[0], sampling[1], sampling[2], seed=sampling[3], step=-1))
-            st["sampling"] = sampling
-        out[:, 0] = st["next_ids"]
-        step_logits = [st["logits"][None]] if return_step_logits else None
-        eos, pad = self.config.eos_token_id, self.config.pad_token_id
-        pad = eos if pad is None else pad
-        done_at = max_new_tokens
-        # transformers' per-token hooks (serve/model_worker.py:160-185, eval/model_vqa*.py): streamer.put(prompt) then put(new ids) per
-        # step and end(); stopping_criteria(ids so far, scores) -> True stops every row.  Either one switches to one launch per token.
-        ids_dev = input_ids.to(self.device)
-        stopped_at = None
-
-        def hooks(n_done):                                       # n_done new tokens are in out[:, :n_done]
-            nonlocal stopped_at
-            if streamer is not None:
-                streamer.put(out[:, n_done - 1].cpu())
-            if criteria and stopped_at is None:
-                seq = torch.cat([ids_dev, out[:, :n_done]], dim=1)
-                if any(bool(c(seq, None)) for c in criteria):
-                    stopped_at = n_done
-            return stopped_at is not None
-
-        per_token = streamer is not None or bool(criteria)
-        if streamer is not None:
-            streamer.put(input_ids.cpu())
-        halted = hooks(1) if per_token else False
-        if forced is not None:
-            if sampling is not None or per_token or not ignore_eos:
-                raise ValueError("forced_ids is a greedy, ignore_eos=True, hook-free mode")
-            forced = forced.to(self.device, torch.int64)
-            for s_ in range(max_new_tokens - 1):
-                st["next_ids"].copy_(forced[:, s_])
-                lg = self._decode(st, 1, out[:, 1:], s_, want_logits=return_step_logits)
-                if return_step_logits:
-                    step_logits.append(lg)
-        elif max_new_tokens > 1 and not halted:
-            if ignore_eos and not per_token:
-                lg = self._decode(st, max_new_tokens - 1, out[:, 1:], 0, want_logits=return_step_logits)
-                if return_step_logits:
-                    step_logits.append(lg)
+        # decode_stream (generate_pipelined's CU partition): everything from here on - the decode steps and the result's assembly - is issued on
+        # that stream, ordered after the prefill; the caller's stream then waits for it (the slot's buffers are reused by its next prefill)
+        dctx = None
+        if dstream is not None:
+            slot_stream = torch.cuda.current_stream()
+            dstream.wait_stream(slot_stream)
+            dctx = torch.cuda.stream(dstream)
+            dctx.__enter__()
+        try:
+            B = plan.B
+            out = self._cache.get(("out_ids", slot, B, max_new_tokens))   # persistent for the same reason as next_ids (the result is a copy)
+            if out is None:
+                with torch.inference_mode(False):
+                    out = torch.zeros(B, max_new_tokens, dtype=torch.int64, device=self.device)
+                self._cache[("out_ids", slot, B, max_new_tokens)] = out
             else:
-                chunk, s = (1 if per_token else 16), 0
-                while s < max_new_tokens - 1:
-                    n = min(chunk, max_new_tokens - 1 - s)
-                    lg = self._decode(st, n, out[:, 1:], s, want_logits=return_step_logits)
+                out.zero_()
+            if sampling is not None:                                  # first token: same rule, RNG counter -1 (decode steps count from 0)
+                st["next_ids"].copy_(ops.sample_step(st["logits"], sampling[0], sampling[1], sampling[2], seed=sampling[3], step=-1))
+                st["sampling"] = sampling
+            out[:, 0] = st["next_ids"]
+            step_logits = [st["logits"][None]] if return_step_logits else None
+            eos, pad = self.config.eos_token_id, self.config.pad_token_id
+            pad = eos if pad is None else pad
+            done_at = max_new_tokens
+            # transformers' per-token hooks (serve/model_worker.py:160-185, eval/model_vqa*.py): streamer.put(prompt) then put(new ids) per
+            # step and end(); stopping_criteria(ids so far, scores) -> True stops every row.  Either one switches to one launch per token.
+            ids_dev = input_ids.to(self.device)
+            stopped_at = None
+
+            def hooks(n_done):                                       # n_done new tokens are in out[:, :n_done]
+                nonlocal stopped_at
+                if streamer is not None:
+                    streamer.put(out[:, n_done - 1].cpu())
+                if criteria and stopped_at is None:
+                    seq = torch.cat([ids_dev, out[:, :n_done]], dim=1)
+                    if any(bool(c(seq, None)) for c in criteria):
+                        stopped_at = n_done
+                return stopped_at is not None
+
+            per_token = streamer is not None or bool(criteria)
+            if streamer is not None:
+                streamer.put(input_ids.cpu())
+            halted = hooks(1) if per_token else False
+            if forced is not None:
+                if sampling is not None or per_token or not ignore_eos:
+                    raise ValueError("forced_ids is a greedy, ignore_eos=True, hook-free mode")
+                forced = forced.to(self.device, torch.int64)
+                for s_ in range(max_new_tokens - 1):
+                    st["next_ids"].copy_(forced[:, s_])
+                    lg = self._decode(st, 1, out[:, 1:], s_, want_logits=return_step_logits)
                     if return_step_logits:
                         step_logits.append(lg)
-                    s += n
-                    if per_token and hooks(1 + s):
-                        break
-                    if not ignore_eos and bool(((out[:, :1 + s] == eos).any(dim=1)).all()):   # host sync once per chunk
-                        break
-        if streamer is not None:
-            streamer.end()
-        if stage_events is not None:
-            stage_events.update(encode=(e0, e1), prefill=(e1, e2), decode=(e2, mark()), spliced_lens=plan.valid_lens.copy())
-        if stopped_at is not None:
-            out = out[:, :stopped_at]
-            done_at = stopped_at
-        new = out
-        if not ignore_eos:
-            is_eos = new == eos
-            after = (is_eos.cumsum(1) - is_eos.long()) > 0                           # strictly after the first EOS
-            new = torch.where(after, torch.full_like(new, pad), new)
-            fin = is_eos.any(1)
-            if bool(fin.all()):
-                done_at = int((is_eos.float().argmax(1) + 1).max().item())
-            new = new[:, :done_at]
-        res = torch.cat([input_ids.to(self.device), new], dim=1)
-        if return_step_logits:
-            return res, torch.cat(step_logits, 0).transpose(0, 1)[:, :new.shape[1]]
-        return res
+            elif max_new_tokens > 1 and not halted:
+                if ignore_eos and not per_token:
+                    lg = self._decode(st, max_new_tokens - 1, out[:, 1:], 0, want_logits=return_step_logits)
+                    if return_step_logits:
+                        step_logits.append(lg)
+                else:
+                    chunk, s = (1 if per_token else 16), 0
+                    while s < max_new_tokens - 1:
+                        n = min(chunk, max_new_tokens - 1 - s)
+                        lg = self._decode(st, n, out[:, 1:], s, want_logits=return_step_logits)
+                        if return_step_logits:
+                            step_logits.append(lg)
+                        s += n
+                        if per_token and hooks(1 + s):
+                            break
+                        if not ignore_eos and bool(((out[:, :1 + s] == eos).any(dim=1)).all()):   # host sync once per chunk
+                            break
+            if streamer is not None:
+                streamer.end()
+            if stage_events is not None:
+                stage_events.update(encode=(e0, e1), prefill=(e1, e2), decode=(e2, mark()), spliced_lens=plan.valid_lens.copy())
+            if stopped_at is not None:
+                out = out[:, :stopped_at]
+                done_at = stopped_at
+            new = out
+            if not ignore_eos:
+                is_eos = new == eos
+                after = (is_eos.cumsum(1) - is_eos.long()) > 0                           # strictly after the first EOS
+                new = torch.where(after, torch.full_like(new, pad), new)
+                fin = is_eos.any(1)
+                if bool(fin.all()):
+                    done_at = int((is_eos.float().argmax(1) + 1).max().item())
+                new = new[:, :done_at]
+            res = torch.cat([input_ids.to(self.device), new], dim=1)
+            if return_step_logits:
+                return res, torch.cat(step_logits, 0).transpose(0, 1)[:, :new.shape[1]]
+            return res
+        finally:
+            if dctx is not None:
+                dctx.__exit__(None, None, None)
+                slot_stream.wait_stream(dstream)
 
     def _beam_search(self, input_ids, modal_inputs, attention_mask, k, max_new_tokens, length_penalty, early_stopping, ignore_eos):
         """generate(num_beams = k > 1): transformers 4.31's beam_search + BeamSearchScorer (the loop eval/model_multimodal_qa_loader.py:94-102
@@ -1131,28 +1159,46 @@ class MultimodalLlamaForCausalLM:
         units.  Same tokens as sequential generate() calls; host syncs inside generate() (EOS checks without ignore_eos) shorten the
         overlap but do not break it."""
         cur = torch.cuda.current_stream()
-        streams = _shared_streams(self.device, "pipeline", 2)
-        pending = None
-        last_prefill = None
-        for i, item in enumerate(batches):
-            input_ids, modal_inputs = item[0], item[1]
-            am = item[2] if len(item) > 2 else None                # optional right-padding mask of the batch
-            slot = i & 1
-            s = streams[slot]
-            s.wait_stream(cur)                                     # inputs produced on the caller's stream
-            if last_prefill is not None:
-                s.wait_event(last_prefill)
-            ev = torch.cuda.Event()
-            with torch.cuda.stream(s):
-                out = self.generate(input_ids, modal_inputs=modal_inputs, attention_mask=am, slot=slot, prefill_done=ev, **kw)
-            last_prefill = ev
+        # decode_cus (attribute / MC_DECODE_CUS, default 0 = off; a multiple of 8): the CU partition.  Two streams at equal priority do not
+        # overlap a GEMM with a decode chain - every decode launch (5 per layer and token, each 20-350 us) waits for a GEMM tile (~30 us) to
+        # leave a CU, and a GEMM workgroup owns its CU's whole register file - so the decode steps run on a stream restricted to `decode_cus`
+        # CUs (the same number from every XCD) and the encoders + prefill on streams restricted to the OTHER CUs: the HBM-bound chain keeps a few
+        # load paths of its own, the MFMA-bound one loses decode_cus / 256 of its matrix units.
+        dcus = int(getattr(self, "decode_cus", os.environ.get("MC_DECODE_CUS", "0")) or 0)
+        dstream = None
+        self._prefill_cu_range = None
+        if dcus > 0:
+            total = _cu_count()
+            if dcus % 8 or dcus >= total:
+                raise ValueError(f"decode_cus={dcus}: a multiple of 8 below the device's {total} CUs")
+            self._prefill_cu_range = (dcus, total - dcus)
+            dstream = _shared_streams(self.device, "decode", 1, (0, dcus))[0]
+            kw = dict(kw, decode_stream=dstream)
+        streams = _shared_streams(self.device, "pipeline", 2, self._prefill_cu_range)
+        try:
+            pending = None
+            last_prefill = None
+            for i, item in enumerate(batches):
+                input_ids, modal_inputs = item[0], item[1]
+                am = item[2] if len(item) > 2 else None                # optional right-padding mask of the batch
+                slot = i & 1
+                s = streams[slot]
+                s.wait_stream(cur)                                     # inputs produced on the caller's stream
+                if last_prefill is not None:
+                    s.wait_event(last_prefill)
+                ev = torch.cuda.Event()
+                with torch.cuda.stream(s):
+                    out = self.generate(input_ids, modal_inputs=modal_inputs, attention_mask=am, slot=slot, prefill_done=ev, **kw)
+                last_prefill = ev
+                if pending is not None:
+                    pending[1].synchronize()
+                    yield pending[0]
+                pending = (out, s)
             if pending is not None:
                 pending[1].synchronize()
                 yield pending[0]
-            pending = (out, s)
-        if pending is not None:
-            pending[1].synchronize()
-            yield pending[0]
+        finally:
+            self._prefill_cu_range = None
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):
         """multimodal_llama.py:747-767 (kept for API parity; generate() does not call it)."""

@@ -120,8 +120,8 @@ def test_generate_eos_padding_and_reference_shape(g4_model):
     res = model.generate(ids, modal_inputs={"vision": a["pixels"].cuda()}, max_new_tokens=6, do_sample=False, temperature=0,
                          num_beams=1, use_cache=True)
     assert res.dtype == torch.int64 and res.shape[0] == ids.shape[0] and res.shape[1] <= ids.shape[1] + 6
-    with pytest.raises(NotImplementedError):
-        model.generate(ids, modal_inputs={"vision": a["pixels"].cuda()}, num_beams=2)
+    with pytest.raises(NotImplementedError):                  # beam search is greedy-scored only (round 5: num_beams > 1 itself is built)
+        model.generate(ids, modal_inputs={"vision": a["pixels"].cuda()}, num_beams=2, do_sample=True, temperature=0.7)
     # the loader's default (--temperature 0.2 -> do_sample=True, model_multimodal_qa_loader.py:96-99) runs on the sampled path
     res = model.generate(ids, modal_inputs={"vision": a["pixels"].cuda()}, max_new_tokens=6, do_sample=True, temperature=0.2, top_p=None)
     assert res.dtype == torch.int64 and res.shape[0] == ids.shape[0] and res.shape[1] <= ids.shape[1] + 6
@@ -218,24 +218,44 @@ def test_beam_search_equals_the_restated_transformers_loop(g4_model, k, lp):
     n_new = 6
     eos, pad = meta.get("eos_token_id", 2), meta.get("pad_token_id", 0)
 
+    def pad_to(x, n):
+        return torch.cat([x, torch.full((x.shape[0], n - x.shape[1]), pad, dtype=x.dtype)], 1) if x.shape[1] < n else x
+
     def run(ids, mi_dev, mi_cpu):
         got = model.generate(ids.cuda(), modal_inputs=mi_dev, num_beams=k, max_new_tokens=n_new, length_penalty=lp).cpu()
+        rep = lambda d, rows: {m: v.repeat_interleave(rows.shape[0] // ids.shape[0], 0) for m, v in d.items()}
 
-        def last_logits(rows):
-            mi = {m: v.repeat_interleave(rows.shape[0] // ids.shape[0], 0) for m, v in mi_cpu.items()}
-            with torch.no_grad():
-                lg, _, _ = om.prefill(rows, mi, last_only=True)
-            return lg[:, -1]
-        want = beam.beam_search(last_logits, ids, k, n_new, eos, pad, length_penalty=lp)
-        return got, want
-    got, want = run(a["input_ids"], {"vision": a["pixels"].cuda()}, {"vision": a["pixels"]})
+        def oracle_logits(noise=0.0, seed=0):
+            gen = torch.Generator().manual_seed(seed)
+
+            def f(rows):
+                with torch.no_grad():
+                    lg, _, _ = om.prefill(rows, rep(mi_cpu, rows), last_only=True)
+                l = lg[:, -1]
+                return l + noise * l.abs().max() * torch.randn(l.shape, generator=gen) if noise else l
+            return f
+
+        def hip_logits(rows):                                  # the device model's own logits (a fresh prefill of every beam row)
+            return model.forward(input_ids=rows.cuda(), modal_inputs=rep(mi_dev, rows)).logits[:, -1].float().cpu()
+        bs = lambda f: beam.beam_search(f, ids, k, n_new, eos, pad, length_penalty=lp)
+        W = ids.shape[1] + n_new
+        # (1) the beam bookkeeping in isolation: the restated loop driven by the DEVICE model's logits must give the device's sequences
+        want_dev = bs(hip_logits)
+        assert torch.equal(pad_to(got, W), pad_to(want_dev, W)), (got, want_dev)
+        # (2) against the fp32 oracle model: equal on every row whose oracle result is stable under noise of the fixture's logit tolerance
+        # (1.2e-2 of the logit scale, test_g4_*): a hypothesis that an EOS candidate of rank k - 1 vs k decides is a near-tie
+        want = bs(oracle_logits())
+        noisy = [pad_to(bs(oracle_logits(1.2e-2, sd_)), W) for sd_ in range(4)]
+        stable = torch.tensor([all(torch.equal(nz[b], pad_to(want, W)[b]) for nz in noisy) for b in range(ids.shape[0])])
+        assert torch.equal(pad_to(got, W)[stable], pad_to(want, W)[stable]), (got, want, stable)
+        return got, want, stable
+    got, want, st_img = run(a["input_ids"], {"vision": a["pixels"].cuda()}, {"vision": a["pixels"]})
     assert got.shape[0] == want.shape[0] == a["input_ids"].shape[0]
     assert torch.equal(got[:, :a["input_ids"].shape[1]], a["input_ids"])
-    assert got.shape == want.shape and torch.equal(got, want), (got, want)
     g = torch.Generator().manual_seed(7)
     txt = torch.cat([torch.ones(3, 1, dtype=torch.long), torch.randint(3, 97, (3, 7), generator=g)], 1)
-    got, want = run(txt, {}, {})
-    assert got.shape == want.shape and torch.equal(got, want), (got, want)
+    got, want, st_txt = run(txt, {}, {})
+    assert int(st_img.sum()) + int(st_txt.sum()) >= (len(st_img) + len(st_txt) + 1) // 2       # the comparison with the fp32 oracle is not vacuous
     # one beam is the greedy loop
     g1 = model.generate(txt.cuda(), modal_inputs={}, num_beams=1, max_new_tokens=n_new).cpu()
     b1 = beam.beam_search(lambda rows: om.prefill(rows, {}, last_only=True)[0][:, -1], txt, 1, n_new, eos, pad)

@@ -107,8 +107,8 @@ def test_generate_with_sampling_end_to_end():
     assert torch.equal(model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=n, ignore_eos=True), greedy)
     with pytest.raises(ValueError):
         model.generate(ids, modal_inputs={"vision": px}, do_sample=True, temperature=0.0, max_new_tokens=2)
-    with pytest.raises(NotImplementedError):
-        model.generate(ids, modal_inputs={"vision": px}, num_beams=3, max_new_tokens=2)
+    with pytest.raises(NotImplementedError):                  # beam search scores greedily: the two modes do not combine
+        model.generate(ids, modal_inputs={"vision": px}, num_beams=3, do_sample=True, temperature=0.7, max_new_tokens=2)
 
 
 def test_generate_streamer_and_stopping_criteria_hooks():

@@ -24,6 +24,11 @@ def main():
     if os.environ.get("MC_GEMM_DEBUG"):                      # A/B builds of the kernel under the counters (e.g. 12344 = without the next-tile L2 warm-up)
         from modelcompose_amd import _lib
         _lib.lib().mc_gemm_debug(int(os.environ["MC_GEMM_DEBUG"]))
+    if os.environ.get("MC_GEMM_OPTIONS"):                    # e.g. "raster_slab=8,raster_auto=0" (tools/pmc_clock_vs_traffic.sh)
+        from modelcompose_amd import _lib
+        for kv in os.environ["MC_GEMM_OPTIONS"].split(","):
+            k, v = kv.split("=")
+            _lib.check(_lib.lib().mc_gemm_set_option(k.encode(), int(v)), "mc_gemm_set_option " + kv)
     import bench
     B = int(sys.argv[2]) if len(sys.argv) > 2 else bench.WORKLOADS["iav"][2]
     Hd, I = 4096, 11008

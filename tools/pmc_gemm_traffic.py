@@ -1,6 +1,6 @@
 """profiles/traffic.json from the standalone layer-GEMM PMC passes (tools/pmc_gemm_layer.sh):
 
-    python tools/pmc_gemm_traffic.py <fetch csv> <write csv> <launches json> <tag>
+    python tools/pmc_gemm_traffic.py <fetch csv> <write csv> <launches json> <tag> [out json, default profiles/traffic.json]
 
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch of gemm_tile256_kernel: on gfx950 FETCH_SIZE tallies the 128-byte
 requests of wide coalesced reads at 64 bytes (MI355X_MICROARCH.md, HBM section) and both counters are in KiB.  The counters sit on the
@@ -39,7 +39,7 @@ def main():
                     "mc_llm_prefill launches them), measured standalone by tools/pmc_gemm_layer.sh: rocprofv3 --pmc aborts (SIGSEGV inside the "
                     "profiler, ROCm 7.2) on the full img+audio+video bench.py process; encoder launches of the same kernel are not included",
            "method": __doc__.split("\n\n")[-1].replace("\n", " ")}
-    json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+    json.dump(out, open(sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic.json", "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k not in ("method", "scope")}, indent=1))
 
 
