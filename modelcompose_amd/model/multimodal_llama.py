@@ -1099,6 +1099,8 @@ class MultimodalLlamaForCausalLM:
         V = self.config.vocab_size
         while True:
             cur_len = ids.shape[1]
+            if getattr(self, "_beam_trace", None) is not None:       # tests / tools: (beam rows so far, the logits they are scored with) per step
+                self._beam_trace.append((ids.clone(), logits.float().cpu()))
             logp = ops.log_softmax(logits)
             cand = (logp + scores.to(dev)[:, None]).view(B, k * V)
             top_s, top_i = torch.topk(cand, 2 * k, dim=1, largest=True, sorted=True)
