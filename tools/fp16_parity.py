@@ -11,6 +11,9 @@ tests start as a child process.
 cases:  g4 / g8      the reference's own tiny fixtures (tests/golden): prefill + step logits, greedy ids
         fulldepth8   the metric's model, 32 layers, eight unscreened rows of image + audio + video (tests/golden/g17): logits of 17
                      teacher-forced steps against the fp32 branch-form oracle, argmax agreement, free-running tokens matched per row
+        small_delta  the two-layer real-width vision model with LoRA B scaled to |dW| / |W| ~ 2^-9.3 (tests/test_fullwidth_parity_gpu.py::
+                     test_small_delta_*): HIP(delta) - HIP(B = 0) projected on the fp32 branch-form oracle's difference, 17 teacher-forced
+                     steps - the share of a small delta that arrives, and the rounding noise beside it, in this storage dtype
 Prints one JSON object."""
 from __future__ import annotations
 
@@ -27,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
-    ap.add_argument("--case", nargs="+", default=["g4"], choices=["g4", "g8", "fulldepth8"])
+    ap.add_argument("--case", nargs="+", default=["g4"], choices=["g4", "g8", "fulldepth8", "small_delta"])
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     import numpy as np
@@ -68,6 +71,47 @@ def main():
                                   "ids_matching": int((got == arr["gen_ids"]).sum())}
             del model
             torch.cuda.empty_cache()
+        elif case == "small_delta":
+            import warnings
+            import fullwidth_cases as fc
+            from oracle import pipeline, splice
+            meta, sd, ids, mi = fc.build_case("configs1_vision", lora_b_std=0.01 / 64)
+            w = sd["model.layers.0.self_attn.q_proj.weight"].float()
+            dw = 2.0 * sd["model.layers.0.self_attn.q_proj.lora_B.default.weight"].float() @ sd["model.layers.0.self_attn.q_proj.lora_A.default.weight"].float()
+            mid = cast(mi)
+            sdf = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+            sd_zero = {k: (torch.zeros_like(v) if ".lora_B." in k else v) for k, v in sd.items()}
+
+            def hip(state, forced=None):
+                with warnings.catch_warnings(record=True) as wl:
+                    warnings.simplefilter("always")
+                    model = build_from_state_dict(meta, state)
+                feats, _ = model.encode_modal_inputs(mid, model.prefix_tokens, model.suffix_tokens)
+                res, lg = model.generate(ids.cuda(), modal_inputs=mid, max_new_tokens=fc.N_NEW, ignore_eos=True, return_step_logits=True,
+                                         **({"forced_ids": forced} if forced is not None else {}))
+                o = (lg.float().cpu(), {m: f.float().cpu() for m, f in feats.items()},
+                     {"final": dict(model.delta_retention), "rne": dict(getattr(model, "delta_retention_rne", {})), "dithered": list(getattr(model, "delta_dithered", []))},
+                     [str(w_.message) for w_ in wl if issubclass(w_.category, RuntimeWarning)])
+                del model
+                torch.cuda.empty_cache()
+                return o
+            _, fb, _, _ = hip(sd)
+            with torch.no_grad():
+                o32 = pipeline.OracleModel.from_state_dict(sdf, meta)
+                ids_r, lg_r = o32.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True, feats_blocks=fb)
+                o0 = pipeline.OracleModel.from_state_dict({k: (torch.zeros_like(v) if ".lora_B." in k else v) for k, v in sdf.items()}, meta)
+                _, lg_0 = o0.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True, feats_blocks=fb, forced_ids=ids_r)
+            forced = ids_r[:, :fc.N_NEW - 1]
+            lg, _, retention, warned = hip(sd, forced)
+            lg_h0, _, _, _ = hip(sd_zero, forced)
+            dH, dO = (lg - lg_h0).double(), (lg_r - lg_0).double()
+            c = ((dH * dO).sum() / (dO * dO).sum()).item()
+            rep["cases"][case] = {"dw_over_w": (dw.abs().mean() / w.abs().mean()).item(), "rows": int(ids.shape[0]), "steps": fc.N_NEW,
+                                  "delta_projection_hip_on_oracle": c,
+                                  "delta_projection_per_step": ((dH * dO).sum((0, 2)) / (dO * dO).sum((0, 2))).tolist(),
+                                  "orthogonal_residual_over_effect": ((dH - c * dO).norm() / dO.norm()).item(),
+                                  "delta_effect_on_logits": rel(lg_0, lg_r), "logit_err_vs_branch_form": rel(lg, lg_r),
+                                  "compose_retention_per_adapter": retention, "warned": warned}
         else:
             import fullwidth_cases as fc
             z = np.load(os.path.join(ROOT, "tests", "golden", "g17_fulldepth_iav8.npz"))
