@@ -662,6 +662,281 @@ __global__ __launch_bounds__(256, 2) void attn_prefill32_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same kernel, SOFTWARE-PIPELINED inside the wave over 32-key half tiles (round 5, second step).
+// ------------------------------------------------------------------------------------------
+// attn_prefill32_kernel runs K.Q^T -> softmax -> P.V of a tile in dependency order: its matrix pipe is 46 % busy (profiles/r05_pmc) because a
+// wave's MFMAs wait for its own softmax and the other wave of the SIMD is, more often than not, in the same phase.  Here the scores of the
+// NEXT 32-key half tile are issued into the matrix pipe in front of the exponentials of the CURRENT one - independent instruction streams of
+// one wave, interleaved by the scheduler (sched_group_barrier: one MFMA per seven VALU) - so the exp2 / FMA / convert stretch (~300 cycles)
+// runs UNDER the 256 MFMA cycles instead of behind them; only P.V (which needs P) still follows.  Granularity 32 keys so that the two score
+// blocks in flight are the two halves the unpipelined kernel already holds (no extra registers): the online softmax takes its maximum per
+// half tile (same deferred-maximum rule).  Staging: the K ring runs one tile ahead of the V ring (K(t+1) is needed while V(t) is read), two
+// buffers each, two barriers per tile: top - V(t) landed, every wave done with tile t-1 -> V(t+1) may be staged; mid - K(t+1) landed, every
+// wave done with the first half -> K(t+2) may be staged.  Counted waits: a wave's outstanding DMA batches alternate V / K, vmcnt(4) retires
+// the older one.  Results agree with attn_prefill32_kernel to fp32 rounding (the maxima are taken over other key groups).
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_prefill32p_kernel(AttnParams p) {
+    constexpr int D = 128, ROWB = 256, TILE = 64 * ROWB, KS = D / 16, DB = D / 32, QB = 128, WQ = 32;
+    extern __shared__ __attribute__((aligned(16))) char lds[];               // K ring [2][16 KiB] | V ring [2][16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int qblk, hd, b;
+    {   // XCD-aware block order (see attn_prefill_kernel)
+        const int nx = gridDim.x, ny = gridDim.y;
+        const int total = nx * ny * (int)gridDim.z;
+        const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, idx = lin >> 3;
+        const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        qblk = nx - 1 - v % nx;
+        hd = (v / nx) % ny;
+        b = v / (nx * ny);
+    }
+    const int hk = hd / (p.H / p.Hkv);
+    const int q0 = qblk * QB + wave * WQ;
+    const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
+    const int tq_row = min(q0 + r, p.Lq - 1);
+    const int q_abs = q0 + r + p.q_offset;
+
+    bf16x8 qf[KS];
+    {
+        const bf16_t* qp = p.q + b * p.q_sb + (int64_t)tq_row * p.q_st + hd * p.q_sh + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+    }
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    int last_key = kvlen;
+    if (CAUSAL) last_key = min(last_key, qblk * QB + QB - 1 + p.q_offset + 1);
+    const int ntiles = (last_key + 63) / 64;
+    const bf16_t* kbase = p.k + b * p.k_sb + hk * p.k_sh;
+    const bf16_t* vbase = p.v + b * p.v_sb + hk * p.v_sh;
+
+    const int srow = lane >> 4, sch = lane & 15;
+    uint32_t koff[4], voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 16 + i * 4 + srow;
+        const int sw = sch ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        koff[i] = (uint32_t)(((int64_t)row * p.k_st + sw * 8) * 2);
+        voff[i] = (uint32_t)(((int64_t)row * p.v_st + sw * 8) * 2);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    // tiles past the last one are staged as copies of the last (valid memory, never read): every batch has its four instructions, which is
+    // what the counted waits below count
+    auto stage_k = [&](int kt) {
+        const bf16_t* src = kbase + (int64_t)min(kt, ntiles - 1) * 64 * p.k_st;
+        const uint32_t l0 = lds0 + (uint32_t)((kt & 1) * TILE);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16si(src, koff[i], l0 + (uint32_t)((wave * 16 + i * 4) * ROWB));
+    };
+    auto stage_v = [&](int kt) {
+        const bf16_t* src = vbase + (int64_t)min(kt, ntiles - 1) * 64 * p.v_st;
+        const uint32_t l0 = lds0 + (uint32_t)(2 * TILE + (kt & 1) * TILE);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16si(src, voff[i], l0 + (uint32_t)((wave * 16 + i * 4) * ROWB));
+    };
+    const int li = lane & 15, tq = li >> 2, tp = li & 3, dhalf = (lane >> 4) & 1;
+    const float scale = p.scale_log2e;
+    constexpr float RESC = 8.0f;
+
+    // LDS addresses with ONE per-lane register per operand: the swizzle is an XOR of the 16-byte chunk index with a per-row key f, and every
+    // chunk index is (compile-time part) ^ (per-lane part) with disjoint bits, so address = (per-lane word ^ compile-time word) + compile-time
+    // row offset + tile buffer: a v_xor with an immediate per read instead of a hoisted address register per read (48 of them otherwise).
+    //   K row 32 kb + r, chunk 2 ks + h, f = ((r & 3) << 2) | ((r >> 2) & 3)   (32 kb leaves bits 0 - 3 of the row alone)
+    const uint32_t k_lane = (uint32_t)(r * ROWB) | (uint32_t)(((((r & 3) << 2) | ((r >> 2) & 3)) ^ h) << 4);
+    //   V row key = 32 (ksx >> 1) + 16 (ksx & 1) + 8 hi + 4 h + tq, f = (tq << 2) | ((h + 2 hi) & 3) = ((tq << 2) | h) ^ (2 hi),
+    //   chunk 4 db + 2 dhalf + (tp >> 1), + 8 bytes for odd tp
+    const uint32_t v_lane = (uint32_t)((4 * h + tq) * ROWB) | (uint32_t)(((((tq << 2) | h) ^ (dhalf * 2 + (tp >> 1))) << 4) | ((tp & 1) * 8));
+    auto ldk = [&](uint32_t kl, int kb, int g, bf16x8 (&dst)[4]) {          // kl: LDS byte address of the K tile buffer
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t a = (k_lane ^ (uint32_t)((g * 4 + i) * 32)) + kl;
+            dst[i] = *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(a + (uint32_t)(kb * 32 * ROWB));
+        }
+    };
+    // V^T fragments of (tile buffer vl, 16-key step ksx = 2 kb + st), d blocks 2 g, 2 g + 1
+    auto ldv = [&](uint32_t vl, int ksx, int g, bf16x8 (&dst)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int db = g * 2 + i;
+            const uint32_t row0 = (uint32_t)(((ksx >> 1) * 32 + (ksx & 1) * 16) * ROWB);
+            const uint32_t alo = (v_lane ^ (uint32_t)(db * 64)) + vl, ahi = (v_lane ^ (uint32_t)(db * 64 + 32)) + vl;
+            const bf16x4 lo = mc_ds_read_tr16((mc_lds_void*)(uintptr_t)(alo + row0));
+            const bf16x4 hi = mc_ds_read_tr16((mc_lds_void*)(uintptr_t)(ahi + row0 + 8 * ROWB));
+            bf16x8 vf;
+            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+            vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+            dst[i] = vf;
+        }
+    };
+    // one half tile: softmax of sc (the raw scores of keys 64 kt + 32 kb + (e & 3) + 8 (e >> 2) + 4 h), the NEXT half's scores (keys block nkb of
+    // the tile in buffer nkl) issued beside its exponentials when `next`, then O^T += V^T . P^T
+    auto half = [&](int kt, int kb, f32x16& sc, uint32_t vl, bool next, uint32_t nkl, int nkb, f32x16& sn) {
+        const int key_lo = kt * 64 + kb * 32;
+        const bool need_mask = (key_lo + 31 >= kvlen) || (CAUSAL && key_lo + 31 > q0 + p.q_offset);
+        if (need_mask) {
+            int lim = kvlen - 1 - key_lo - 4 * h;
+            if (CAUSAL) lim = min(lim, q_abs - key_lo - 4 * h);
+            asm volatile("" : "+v"(lim));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[e] = ((e & 3) + 8 * (e >> 2)) <= lim ? sc[e] : -3.0e38f;
+        }
+        bf16x8 kfa[4];
+        if (next) ldk(nkl, nkb, 0, kfa);
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sc[e]);
+        {
+            auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            tmax = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));
+        }
+        tmax = tmax > NEG_BIG ? tmax * scale : NEG_BIG;
+        if (__builtin_amdgcn_ballot_w64(tmax > m_run + RESC) != 0) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = fast_exp2(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+        }
+        bf16x8 pf[2];
+        bf16x8 vfr[2][2];
+        const float nm = -m_run;
+        float lsum = 0.f;
+        if (next) {
+            // ONE scheduling region: the second K fragment group, the 8 MFMAs of the next half's scores, this half's exponentials and the
+            // first V fragment reads; the group barriers deal one MFMA per seven VALU instructions
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sn[e] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sn = mc_mfma_32x32x16(kfa[i], qf[i], sn);
+            ldk(nkl, nkb, 1, kfa);                                 // the same registers: these reads follow the four MFMAs that consume the first group
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sn = mc_mfma_32x32x16(kfa[i], qf[4 + i], sn);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = fast_exp2(fmaf(sc[e], scale, nm));
+                lsum += pv;
+                pf[e >> 3][e & 7] = (bf16_t)pv;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            }
+            ldv(vl, kb * 2, 0, vfr[0]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = fast_exp2(fmaf(sc[e], scale, nm));
+                lsum += pv;
+                pf[e >> 3][e & 7] = (bf16_t)pv;
+            }
+            ldv(vl, kb * 2, 0, vfr[0]);
+        }
+        l_run += lsum;
+        // ---- O^T += V^T . P^T over the half's two 16-key steps: fragment groups (st, d-block pair) one ahead of their MFMAs
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            if (grp < 3) ldv(vl, kb * 2 + ((grp + 1) >> 1), (grp + 1) & 1, vfr[(grp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int db = (grp & 1) * 2 + i;
+                oacc[db] = mc_mfma_32x32x16(vfr[grp & 1][i], pf[grp >> 1], oacc[db]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (ntiles > 0) {
+        stage_k(0); stage_v(0); stage_k(1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x16 s_cur, s_nxt;
+        {                                                          // the first half's scores, nothing to hide them under (tile 0 is active for every wave)
+            bf16x8 kf0[4], kf1[4];
+            ldk(lds0, 0, 0, kf0);
+            ldk(lds0, 0, 1, kf1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s_cur[e] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_cur = mc_mfma_32x32x16(kf0[i], qf[i], s_cur);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_cur = mc_mfma_32x32x16(kf1[i], qf[4 + i], s_cur);
+        }
+        // tiles [0, n_act) carry keys this wave's queries may see (causal: the tiles behind its last query are a suffix); the wave still
+        // takes part in the staging and the barriers of the others.  The last active tile's second half has no successor: peeled, so that the
+        // loop body is ONE path (a `next` flag inside it made hipcc merge the two score blocks through copies and spill)
+        int n_act = ntiles;
+        if (CAUSAL) n_act = min(ntiles, (q0 + WQ - 1 + p.q_offset) / 64 + 1);
+        auto tile = [&](int kt, auto last) {
+            const uint32_t kl = lds0 + (uint32_t)((kt & 1) * TILE);
+            const uint32_t kl_next = lds0 + (uint32_t)(((kt + 1) & 1) * TILE);
+            const uint32_t vl = lds0 + (uint32_t)(2 * TILE + (kt & 1) * TILE);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // V(kt) has landed (K(kt + 1) may still be in flight)
+            __builtin_amdgcn_s_barrier();
+            stage_v(kt + 1);
+            half(kt, 0, s_cur, vl, true, kl, 1, s_nxt);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // K(kt + 1) has landed (V(kt + 1) may still be in flight)
+            __builtin_amdgcn_s_barrier();
+            stage_k(kt + 2);
+            half(kt, 1, s_nxt, vl, !decltype(last)::value, kl_next, 0, s_cur);
+        };
+        for (int kt = 0; kt < n_act - 1; ++kt) tile(kt, std::false_type{});
+        if (n_act > 0) tile(n_act - 1, std::true_type{});
+        for (int kt = n_act; kt < ntiles; ++kt) {                  // idle tiles: staging and barriers only
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage_v(kt + 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage_k(kt + 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the dummy tail batches: no DMA may land in LDS after the workgroup has left
+    }
+    // ---- finalize (as attn_prefill32_kernel)
+    {
+        auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        const float l = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int t = q0 + r;
+        if (p.lse && t < p.Lq && h == 0) p.lse[((int64_t)b * p.H + hd) * p.Lq + t] = l > 0.f ? m_run + log2f(l) : NEG_BIG;
+        int64_t row = -1;
+        if (t < p.Lq) row = p.out_map ? p.out_map[b * p.Lq + t] : (int64_t)b * p.Lq + t;
+        bf16_t* op = p.o + (row < 0 ? 0 : row) * p.o_row_stride + hd * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq += 2) {
+                bf16x4 a4, b4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a4[e] = (bf16_t)(oacc[db][gq * 4 + e] * inv); b4[e] = (bf16_t)(oacc[db][(gq + 1) * 4 + e] * inv); }
+                const u32x2 pa = __builtin_bit_cast(u32x2, a4), pb = __builtin_bit_cast(u32x2, b4);
+                auto r0 = __builtin_amdgcn_permlane32_swap(pa[0], pb[0], false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(pa[1], pb[1], false, false);
+                const u32x4 ov = {r0[0], r1[0], r0[1], r1[1]};
+                if (row >= 0) *(u32x4*)(op + db * 32 + (gq + h) * 8) = ov;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // tiny sequences (Lq, S <= 8): the temporal attention of LanguageBind-Video (languagebind/video/modeling_video.py:105-130: every patch
 // position attends over its t = 8 frames - 4112 sequences x 16 heads of 8 x 8 scores per clip batch).  The flash kernel above spends a
 // 64 x 64 MFMA tile and two 64-row LDS stages on each of them (4 TFLOP/s, 260 us per layer); this is a memory-bound problem: q, k, v read
@@ -1036,6 +1311,8 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
             // bidirectional launches keep the 16x16x32 kernel unless debug bit 8 asks for the new one)
             if ((g_attn_dbg & 128) || (!causal && !(g_attn_dbg & 256)))
                 attn_prefill_kernel<128, false, 4, 2, false, 1, false, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+            else if (causal && (g_attn_dbg & 512)) attn_prefill32p_kernel<true><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+            else if (!causal && (g_attn_dbg & 512)) attn_prefill32p_kernel<false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
             else if (causal) attn_prefill32_kernel<true><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
             else attn_prefill32_kernel<false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
         }

@@ -882,8 +882,17 @@ def test_long_prefill_attention_shapes_are_bit_identical_and_right(causal, L, S,
     scale_ = stag.float().abs().max().item()
     assert dd.max().item() <= 2 ** -7 * scale_, (dd.max().item(), scale_)
     assert (dd > 0).float().mean().item() < 0.25
-    stag = new
-    # and it is the right function: fp32 softmax attention of the bf16 inputs for one (batch, head)
+    # round 5, second step: the software-pipelined instantiation (debug bit 9; the next half tile's scores issued under this one's
+    # exponentials, maxima per 32-key half tile): the same function to fp32 rounding, bitwise reproducible
+    pip = run(512 | 256)
+    for _ in range(5):
+        assert torch.equal(pip, run(512 | 256)), "pipelined 32x32x16 kernel not reproducible run to run"
+    # (its running maximum moves at other keys, so P = bf16(exp2(s - m)) is rounded at other scales: the fp32 sums differ by ~2^-9 relative -
+    # one output ulp - on most elements, where the unpipelined kernels differ by summation order only)
+    dd = (pip.float() - new.float()).abs()
+    assert dd.max().item() <= 2 ** -7 * scale_, (dd.max().item(), scale_)
+    assert (dd > 2 ** -9 * scale_).float().mean().item() < 0.05                  # beyond a quarter of the tolerance: rare
+    # and they are the right function: fp32 softmax attention of the bf16 inputs for one (batch, head)
     b_, h_ = 1, 7
     n = int(lens[b_])
     qs, ks, vs = q[b_, :, h_].float(), k[b_, h_, :n].float(), v[b_, h_, :n].float()
@@ -891,9 +900,10 @@ def test_long_prefill_attention_shapes_are_bit_identical_and_right(causal, L, S,
     if causal:
         sc = sc.masked_fill(torch.arange(n, device="cuda")[None, :] > torch.arange(L, device="cuda")[:, None], float("-inf"))
     ref = torch.softmax(sc, -1) @ vs
-    got = stag.view(B, L, H, D)[b_, :, h_].float()
     rows = torch.isfinite(ref).all(-1)
-    assert (got[rows] - ref[rows]).abs().max().item() <= 2 ** -6 * ref[rows].abs().max().item()
+    for out_ in (new, pip):
+        got = out_.view(B, L, H, D)[b_, :, h_].float()
+        assert (got[rows] - ref[rows]).abs().max().item() <= 2 ** -6 * ref[rows].abs().max().item()
 
 
 @pytest.mark.parametrize("M", [17, 33, 48, 64])
