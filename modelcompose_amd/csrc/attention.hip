@@ -674,7 +674,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill32_kernel(AttnParams p) {
 // buffers each, two barriers per tile: top - V(t) landed, every wave done with tile t-1 -> V(t+1) may be staged; mid - K(t+1) landed, every
 // wave done with the first half -> K(t+2) may be staged.  Counted waits: a wave's outstanding DMA batches alternate V / K, vmcnt(4) retires
 // the older one.  Results agree with attn_prefill32_kernel to fp32 rounding (the maxima are taken over other key groups).
-template <bool CAUSAL>
+// ABL (timing-only ablations, wrong results; debug bits 10 - 13 = this mask): 1 = half of the K / V fragment reads skipped (what a wave with twice the
+// queries would read per MFMA), 2 = no LDS-DMA after the prologue (the tiles in LDS are re-used), 4 = no softmax arithmetic (P = the raw scores
+// converted), 8 = no barriers and no waits for the DMA
+template <bool CAUSAL, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_prefill32p_kernel(AttnParams p) {
     constexpr int D = 128, ROWB = 256, TILE = 64 * ROWB, KS = D / 16, DB = D / 32, QB = 128, WQ = 32;
     extern __shared__ __attribute__((aligned(16))) char lds[];               // K ring [2][16 KiB] | V ring [2][16 KiB]
@@ -735,51 +738,81 @@ __global__ __launch_bounds__(256, 2) void attn_prefill32p_kernel(AttnParams p) {
         const bf16_t* src = kbase + (int64_t)min(kt, ntiles - 1) * 64 * p.k_st;
         const uint32_t l0 = lds0 + (uint32_t)((kt & 1) * TILE);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16si(src, koff[i], l0 + (uint32_t)((wave * 16 + i * 4) * ROWB));
+        for (int i = 0; i < 4; ++i) if (!(ABL & 2) || kt < 2) dma16si(src, koff[i], l0 + (uint32_t)((wave * 16 + i * 4) * ROWB));
     };
     auto stage_v = [&](int kt) {
         const bf16_t* src = vbase + (int64_t)min(kt, ntiles - 1) * 64 * p.v_st;
         const uint32_t l0 = lds0 + (uint32_t)(2 * TILE + (kt & 1) * TILE);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16si(src, voff[i], l0 + (uint32_t)((wave * 16 + i * 4) * ROWB));
+        for (int i = 0; i < 4; ++i) if (!(ABL & 2) || kt < 2) dma16si(src, voff[i], l0 + (uint32_t)((wave * 16 + i * 4) * ROWB));
     };
     const int li = lane & 15, tq = li >> 2, tp = li & 3, dhalf = (lane >> 4) & 1;
     const float scale = p.scale_log2e;
     constexpr float RESC = 8.0f;
 
-    // LDS addresses with ONE per-lane register per operand: the swizzle is an XOR of the 16-byte chunk index with a per-row key f, and every
-    // chunk index is (compile-time part) ^ (per-lane part) with disjoint bits, so address = (per-lane word ^ compile-time word) + compile-time
-    // row offset + tile buffer: a v_xor with an immediate per read instead of a hoisted address register per read (48 of them otherwise).
+    // LDS addresses: the swizzle is an XOR of the 16-byte chunk index with a per-row key f, and every chunk index is (compile-time part) ^
+    // (per-lane part) with disjoint bits, so address = (per-lane word ^ compile-time word) + compile-time row offset + tile buffer.  The 8 + 8
+    // XOR-ed per-lane words are loop invariants (16 registers); rows, key blocks and - the loop being unrolled over the two ring buffers - the
+    // buffer itself are IMMEDIATE offsets of the read: no address arithmetic in the loop (the first version of this kernel spent 50 VALU
+    // instructions per tile on it, a quarter of all).
     //   K row 32 kb + r, chunk 2 ks + h, f = ((r & 3) << 2) | ((r >> 2) & 3)   (32 kb leaves bits 0 - 3 of the row alone)
-    const uint32_t k_lane = (uint32_t)(r * ROWB) | (uint32_t)(((((r & 3) << 2) | ((r >> 2) & 3)) ^ h) << 4);
     //   V row key = 32 (ksx >> 1) + 16 (ksx & 1) + 8 hi + 4 h + tq, f = (tq << 2) | ((h + 2 hi) & 3) = ((tq << 2) | h) ^ (2 hi),
     //   chunk 4 db + 2 dhalf + (tp >> 1), + 8 bytes for odd tp
-    const uint32_t v_lane = (uint32_t)((4 * h + tq) * ROWB) | (uint32_t)(((((tq << 2) | h) ^ (dhalf * 2 + (tp >> 1))) << 4) | ((tp & 1) * 8));
-    auto ldk = [&](uint32_t kl, int kb, int g, bf16x8 (&dst)[4]) {          // kl: LDS byte address of the K tile buffer
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    lds_cptr kad[KS], vad[2 * DB];
+    {
+        const uint32_t k_lane = (uint32_t)(r * ROWB) | (uint32_t)(((((r & 3) << 2) | ((r >> 2) & 3)) ^ h) << 4);
+        const uint32_t v_lane = (uint32_t)((4 * h + tq) * ROWB) | (uint32_t)(((((tq << 2) | h) ^ (dhalf * 2 + (tp >> 1))) << 4) | ((tp & 1) * 8));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t a = (k_lane ^ (uint32_t)((g * 4 + i) * 32)) + kl;
-            dst[i] = *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(a + (uint32_t)(kb * 32 * ROWB));
-        }
+        for (int c = 0; c < KS; ++c) kad[c] = (lds_cptr)(uintptr_t)((k_lane ^ (uint32_t)(c * 32)) + lds0);
+#pragma unroll
+        for (int c = 0; c < 2 * DB; ++c) vad[c] = (lds_cptr)(uintptr_t)((v_lane ^ (uint32_t)(c * 32)) + lds0);     // c = 2 db + hi
+    }
+    // K fragments: tile buffer at byte offset KOFF (compile time), key block kb, k-steps 4 g .. 4 g + 3
+    auto ldk = [&](auto koff_, auto kb_, int g, bf16x8 (&dst)[4]) {
+        constexpr int off = decltype(koff_)::value + decltype(kb_)::value * 32 * ROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = *(const __attribute__((address_space(3))) bf16x8*)(kad[g * 4 + i] + off);
     };
-    // V^T fragments of (tile buffer vl, 16-key step ksx = 2 kb + st), d blocks 2 g, 2 g + 1
-    auto ldv = [&](uint32_t vl, int ksx, int g, bf16x8 (&dst)[2]) {
+    // V^T fragments: tile buffer at byte offset VOFF, 16-key step ksx = 2 kb + st (compile time after unrolling), d blocks 2 g, 2 g + 1
+    auto ldv = [&](auto voff_, int ksx, int g, bf16x8 (&dst)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int db = g * 2 + i;
-            const uint32_t row0 = (uint32_t)(((ksx >> 1) * 32 + (ksx & 1) * 16) * ROWB);
-            const uint32_t alo = (v_lane ^ (uint32_t)(db * 64)) + vl, ahi = (v_lane ^ (uint32_t)(db * 64 + 32)) + vl;
-            const bf16x4 lo = mc_ds_read_tr16((mc_lds_void*)(uintptr_t)(alo + row0));
-            const bf16x4 hi = mc_ds_read_tr16((mc_lds_void*)(uintptr_t)(ahi + row0 + 8 * ROWB));
+            const int row0 = decltype(voff_)::value + ((ksx >> 1) * 32 + (ksx & 1) * 16) * ROWB;
+            const bf16x4 lo = mc_ds_read_tr16((mc_lds_void*)(vad[2 * db] + row0));
+            const bf16x4 hi = mc_ds_read_tr16((mc_lds_void*)(vad[2 * db + 1] + row0 + 8 * ROWB));
             bf16x8 vf;
             vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
             vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
             dst[i] = vf;
         }
     };
-    // one half tile: softmax of sc (the raw scores of keys 64 kt + 32 kb + (e & 3) + 8 (e >> 2) + 4 h), the NEXT half's scores (keys block nkb of
-    // the tile in buffer nkl) issued beside its exponentials when `next`, then O^T += V^T . P^T
-    auto half = [&](int kt, int kb, f32x16& sc, uint32_t vl, bool next, uint32_t nkl, int nkb, f32x16& sn) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // exponentials of one half tile, two scores per instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32)
+    auto exps = [&](const f32x16& sc, float nm, bf16x8 (&pf)[2]) -> float {
+        if (ABL & 4) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pf[e >> 3][e & 7] = (bf16_t)sc[e];
+            return 1.0f;
+        }
+        const f32x2 sc2 = {scale, scale}, nm2 = {nm, nm};
+        f32x2 ls = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const f32x2 t = __builtin_elementwise_fma((f32x2){sc[e], sc[e + 1]}, sc2, nm2);
+            const f32x2 pv = {fast_exp2(t[0]), fast_exp2(t[1])};
+            ls += pv;
+            pf[e >> 3][e & 7] = (bf16_t)pv[0];
+            pf[e >> 3][(e & 7) + 1] = (bf16_t)pv[1];
+        }
+        return ls[0] + ls[1];
+    };
+    // one half tile: softmax of sc (the raw scores of keys 64 kt + 32 kb + (e & 3) + 8 (e >> 2) + 4 h), the NEXT half's scores (key block nkb of
+    // the tile at byte offset NKOFF) issued beside its exponentials when NEXT, then O^T += V^T . P^T
+    auto half = [&](int kt, auto kb_, f32x16& sc, auto voff_, auto next_, auto nkoff_, auto nkb_, f32x16& sn) {
+        constexpr int kb = decltype(kb_)::value;
+        constexpr bool next = decltype(next_)::value;
         const int key_lo = kt * 64 + kb * 32;
         const bool need_mask = (key_lo + 31 >= kvlen) || (CAUSAL && key_lo + 31 > q0 + p.q_offset);
         if (need_mask) {
@@ -790,13 +823,18 @@ __global__ __launch_bounds__(256, 2) void attn_prefill32p_kernel(AttnParams p) {
             for (int e = 0; e < 16; ++e) sc[e] = ((e & 3) + 8 * (e >> 2)) <= lim ? sc[e] : -3.0e38f;
         }
         bf16x8 kfa[4];
-        if (next) ldk(nkl, nkb, 0, kfa);
-        float tmax = NEG_BIG;
+        if (next) ldk(nkoff_, nkb_, 0, kfa);
+        float tmax = sc[0];                                        // (scores are finite or -3e38: no NaN to quieten, v_max3 as is)
+        if (!(ABL & 4)) {
+        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tmax) : "v"(sc[1]), "v"(sc[2]));
 #pragma unroll
-        for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sc[e]);
+        for (int e = 3; e < 15; e += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tmax) : "v"(sc[e]), "v"(sc[e + 1]));
+        asm("v_max_f32 %0, %0, %1" : "+v"(tmax) : "v"(sc[15]));
         {
             auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-            tmax = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));
+            float o_ = __uint_as_float(sw_[1]);
+            tmax = __uint_as_float(sw_[0]);
+            asm("v_max_f32 %0, %0, %1" : "+v"(tmax) : "v"(o_));
         }
         tmax = tmax > NEG_BIG ? tmax * scale : NEG_BIG;
         if (__builtin_amdgcn_ballot_w64(tmax > m_run + RESC) != 0) {
@@ -809,52 +847,41 @@ __global__ __launch_bounds__(256, 2) void attn_prefill32p_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
         }
+        }
         bf16x8 pf[2];
         bf16x8 vfr[2][2];
         const float nm = -m_run;
-        float lsum = 0.f;
         if (next) {
             // ONE scheduling region: the second K fragment group, the 8 MFMAs of the next half's scores, this half's exponentials and the
-            // first V fragment reads; the group barriers deal one MFMA per seven VALU instructions
+            // first V fragment reads; the group barriers deal one MFMA per five VALU instructions
 #pragma unroll
             for (int e = 0; e < 16; ++e) sn[e] = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) sn = mc_mfma_32x32x16(kfa[i], qf[i], sn);
-            ldk(nkl, nkb, 1, kfa);                                 // the same registers: these reads follow the four MFMAs that consume the first group
+            if (!(ABL & 1)) ldk(nkoff_, nkb_, 1, kfa);              // the same registers: these reads follow the four MFMAs that consume the first group
 #pragma unroll
             for (int i = 0; i < 4; ++i) sn = mc_mfma_32x32x16(kfa[i], qf[4 + i], sn);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = fast_exp2(fmaf(sc[e], scale, nm));
-                lsum += pv;
-                pf[e >> 3][e & 7] = (bf16_t)pv;
-            }
+            l_run += exps(sc, nm, pf);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
             }
-            ldv(vl, kb * 2, 0, vfr[0]);
+            ldv(voff_, kb * 2, 0, vfr[0]);
         } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = fast_exp2(fmaf(sc[e], scale, nm));
-                lsum += pv;
-                pf[e >> 3][e & 7] = (bf16_t)pv;
-            }
-            ldv(vl, kb * 2, 0, vfr[0]);
+            l_run += exps(sc, nm, pf);
+            ldv(voff_, kb * 2, 0, vfr[0]);
         }
-        l_run += lsum;
         // ---- O^T += V^T . P^T over the half's two 16-key steps: fragment groups (st, d-block pair) one ahead of their MFMAs
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
-            if (grp < 3) ldv(vl, kb * 2 + ((grp + 1) >> 1), (grp + 1) & 1, vfr[(grp + 1) & 1]);
+            if (grp < 3 && (!(ABL & 1) || grp == 0)) ldv(voff_, kb * 2 + ((grp + 1) >> 1), (grp + 1) & 1, vfr[(grp + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -869,10 +896,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill32p_kernel(AttnParams p) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         f32x16 s_cur, s_nxt;
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 1> I1;
         {                                                          // the first half's scores, nothing to hide them under (tile 0 is active for every wave)
             bf16x8 kf0[4], kf1[4];
-            ldk(lds0, 0, 0, kf0);
-            ldk(lds0, 0, 1, kf1);
+            ldk(I0{}, I0{}, 0, kf0);
+            ldk(I0{}, I0{}, 1, kf1);
 #pragma unroll
             for (int e = 0; e < 16; ++e) s_cur[e] = 0.f;
 #pragma unroll
@@ -882,25 +911,29 @@ __global__ __launch_bounds__(256, 2) void attn_prefill32p_kernel(AttnParams p) {
         }
         // tiles [0, n_act) carry keys this wave's queries may see (causal: the tiles behind its last query are a suffix); the wave still
         // takes part in the staging and the barriers of the others.  The last active tile's second half has no successor: peeled, so that the
-        // loop body is ONE path (a `next` flag inside it made hipcc merge the two score blocks through copies and spill)
+        // loop body is ONE path (a `next` flag inside it made hipcc merge the two score blocks through copies and spill); the loop is
+        // unrolled over the two ring buffers so that the buffer is a compile-time offset of every LDS read
         int n_act = ntiles;
         if (CAUSAL) n_act = min(ntiles, (q0 + WQ - 1 + p.q_offset) / 64 + 1);
-        auto tile = [&](int kt, auto last) {
-            const uint32_t kl = lds0 + (uint32_t)((kt & 1) * TILE);
-            const uint32_t kl_next = lds0 + (uint32_t)(((kt + 1) & 1) * TILE);
-            const uint32_t vl = lds0 + (uint32_t)(2 * TILE + (kt & 1) * TILE);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // V(kt) has landed (K(kt + 1) may still be in flight)
-            __builtin_amdgcn_s_barrier();
+        auto tile = [&](int kt, auto par_, auto last) {
+            constexpr int par = decltype(par_)::value;
+            typedef std::integral_constant<int, par * TILE> KOFF;
+            typedef std::integral_constant<int, (1 - par) * TILE> KOFF_NEXT;
+            typedef std::integral_constant<int, 2 * TILE + par * TILE> VOFF;
+            if (!(ABL & 8)) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // V(kt) has landed (K(kt + 1) may still be in flight)
             stage_v(kt + 1);
-            half(kt, 0, s_cur, vl, true, kl, 1, s_nxt);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // K(kt + 1) has landed (V(kt + 1) may still be in flight)
-            __builtin_amdgcn_s_barrier();
+            half(kt, I0{}, s_cur, VOFF{}, std::true_type{}, KOFF{}, I1{}, s_nxt);
+            if (!(ABL & 8)) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // K(kt + 1) has landed (V(kt + 1) may still be in flight)
             stage_k(kt + 2);
-            half(kt, 1, s_nxt, vl, !decltype(last)::value, kl_next, 0, s_cur);
+            half(kt, I1{}, s_nxt, VOFF{}, std::integral_constant<bool, !decltype(last)::value>{}, KOFF_NEXT{}, I0{}, s_cur);
         };
-        for (int kt = 0; kt < n_act - 1; ++kt) tile(kt, std::false_type{});
-        if (n_act > 0) tile(n_act - 1, std::true_type{});
-        for (int kt = n_act; kt < ntiles; ++kt) {                  // idle tiles: staging and barriers only
+        int kt = 0;
+        for (; kt + 1 < n_act - 1; kt += 2) { tile(kt, I0{}, std::false_type{}); tile(kt + 1, I1{}, std::false_type{}); }
+        if (kt < n_act - 1) { tile(kt, I0{}, std::false_type{}); ++kt; }      // (kt is even here: the pairs start at 0)
+        if (n_act > 0) {
+            if (kt & 1) tile(kt, I1{}, std::true_type{}); else tile(kt, I0{}, std::true_type{});
+        }
+        for (kt = n_act; kt < ntiles; ++kt) {                      // idle tiles: staging and barriers only
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             stage_v(kt + 1);
@@ -1311,6 +1344,19 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
             // bidirectional launches keep the 16x16x32 kernel unless debug bit 8 asks for the new one)
             if ((g_attn_dbg & 128) || (!causal && !(g_attn_dbg & 256)))
                 attn_prefill_kernel<128, false, 4, 2, false, 1, false, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+            else if (causal && ((g_attn_dbg >> 10) & 15)) {        // timing-only ablations (wrong results)
+                const dim3 gr((Lq + 127) / 128, H, B);
+                switch ((g_attn_dbg >> 10) & 15) {
+                    case 1: attn_prefill32p_kernel<true, 1><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
+                    case 2: attn_prefill32p_kernel<true, 2><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
+                    case 3: attn_prefill32p_kernel<true, 3><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
+                    case 4: attn_prefill32p_kernel<true, 4><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
+                    case 8: attn_prefill32p_kernel<true, 8><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
+                    case 10: attn_prefill32p_kernel<true, 10><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
+                    case 7: attn_prefill32p_kernel<true, 7><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
+                    default: attn_prefill32p_kernel<true, 15><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
+                }
+            }
             else if (causal && (g_attn_dbg & 512)) attn_prefill32p_kernel<true><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
             else if (!causal && (g_attn_dbg & 512)) attn_prefill32p_kernel<false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
             else if (causal) attn_prefill32_kernel<true><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
