@@ -214,7 +214,9 @@ int mc_gemm_set_option(const char* name, int value);
  * at the first such launch made outside stream capture; a launch that finds no workspace (first launch ever is inside a capture, or a
  * seventeenth live stream) keeps the older skinny kernel, whose fp32 summation order differs.  Call this once before capturing when the process may
  * capture before it has launched eagerly (mc_llm_create does).  Options "rows_kernel" (default 1) and "rows_min_mb" (default 2 = more
- * than 16 rows) of mc_gemm_set_option switch the kernel off / move the threshold. */
+ * than 16 rows) of mc_gemm_set_option switch the kernel off / move the threshold.  "rows_fold" (round 5, default 0): a split launch folds
+ * its slabs itself - sc1 stores, one agent-scope add per workgroup, the last adder of a row group sums the S slabs in slice order with sc1
+ * loads and runs the epilogue (no fence, no second launch; bit-identical to the rows_reduce_kernel path; measured 5-12 % slower, so off). */
 int mc_gemm_reserve_rows(void* stream);
 int mc_gemm_release_rows(void* stream);   /* before destroying a stream that launched GEMMs: gives its workspace slot back */
 int mc_gemm_profile_enable(int on);

@@ -1498,11 +1498,35 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_
 // slices read different lines.  With S > 1 the fp32 partial sums go to slabs [S][M][N] and rows_reduce_kernel adds them in slice order
 // (deterministic) and applies the epilogue.  The RMS factor (rms_eps) comes from the x tiles as they are staged: each element is squared
 // once per workgroup; with S > 1 the slice sums are combined by the reduce kernel, in slice order.
+// Round 5: the slab fold INSIDE the launch ("rows_fold", cnt != nullptr).  Every workgroup of a split launch writes its partial sums with
+// sc1 stores, waits for them (s_waitcnt vmcnt(0) in every storing wave, then the workgroup barrier), and one lane adds 1 to the row group's
+// counter with an agent-scope atomic; the workgroup whose add returns S - 1 is the last of its group: its waves read ALL S slabs of the group
+// with sc1 loads (behind the barrier the adding wave joins), sum them in slice order and run the epilogue - the protocol MI355X_MICROARCH.md
+// lists as measured-valid without fences (table "hand-offs measured with sc1 loads", first row: one agent-scope add per storing workgroup, the
+// last adder consumes; hipMalloc memory; one workgroup per CU - enforced here by an LDS pad).  Same sums in the same order as
+// rows_reduce_kernel: bit-identical outputs, one launch less per GEMM (the fence-based fold of round 2 cost 2 - 10 x: no fence here).
+__device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_sc1_f(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 ld_sc1(const float* p) {          // the caller waits (s_waitcnt vmcnt) before it uses the value
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ float ld_sc1_f(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+constexpr int kFoldMaxS = 8;                 // = kRowsMaxSplit (host side)
+
 template <int MB, int RW, int KT>
 __global__ __launch_bounds__(512) void gemm_rows_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, int M, int N,
-                                                        int K, Epilogue ep, float* __restrict__ slabs, float* __restrict__ ssp) {
+                                                        int K, Epilogue ep, float* __restrict__ slabs, float* __restrict__ ssp,
+                                                        float* __restrict__ ssp_g, unsigned int* __restrict__ cnt) {
     __shared__ __attribute__((aligned(16))) bf16x8 xs[2][KT][MB][64];
     __shared__ float rowss[MB * 16];
+    __shared__ int last_flag;
     constexpr int CH = KT * 4;                             // 16-byte chunks per tile row (KT k-blocks of 32 columns)
     constexpr int RPP = 512 / CH;                          // rows per staging pass
     constexpr int XP = (MB * 16 + RPP - 1) / RPP;
@@ -1612,17 +1636,112 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const bf16_t* __restrict
         // partial sums of slice y into slab y (16 floats per lane quarter and row); rows_reduce_kernel adds the slabs in slice order and
         // applies the epilogue.  (A last-arriver fold inside this kernel was measured 2 - 10x slower: device-scope release / acquire
         // fences write back and invalidate the XCD's whole L2 on this multi-die part.)
+        const bool fold = cnt != nullptr;
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
             for (int b = 0; b < MB; ++b) {
                 const int m = b * 16 + c16, n = (nb0 + r) * 16 + q4 * 4;
-                if (m < M && n < N) *(f32x4*)(slabs + ((int64_t)y * M + m) * N + n) = acc[r][b];
+                float* sp = slabs + ((int64_t)y * M + m) * N + n;
+                if (m < M && n < N) { if (fold) st_sc1(sp, acc[r][b]); else *(f32x4*)sp = acc[r][b]; }
             }
-        if (want_rms && blockIdx.x == 0) {                 // every row group squares the same x slice: group 0 reports it
-            __syncthreads();
-            if (tid < MB * 16) ssp[y * 64 + tid] = rowss[tid];
+        if (!fold) {
+            if (want_rms && blockIdx.x == 0) {             // every row group squares the same x slice: group 0 reports it
+                __syncthreads();
+                if (tid < MB * 16) ssp[y * 64 + tid] = rowss[tid];
+            }
+            return;
         }
+        // ---- fold inside the launch
+        if (want_rms) {                                    // this group's own copy of the slice's sums of squares (its last workgroup reads them)
+            __syncthreads();
+            if (tid < MB * 16) st_sc1_f(ssp_g + ((int64_t)blockIdx.x * S + y) * 64 + tid, rowss[tid]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier the signalling lane waits behind
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(cnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(S - 1);
+            if (last) __hip_atomic_store(cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch on this stream
+            last_flag = last;
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        // every load of the hand-off is issued before the first wait (slices in batches of four: one memory round trip per batch, not per slice);
+        // the sums run in slice order whatever order the data arrives in
+        float facf[MB];
+        float ssq[kFoldMaxS][MB];
+        if (want_rms) {
+#pragma unroll
+            for (int k = 0; k < kFoldMaxS; ++k)
+#pragma unroll
+                for (int b = 0; b < MB; ++b) ssq[k][b] = k < S ? ld_sc1_f(ssp_g + ((int64_t)blockIdx.x * S + k) * 64 + b * 16 + c16) : 0.f;
+        }
+        const float* sp0[RW][MB];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+                const int m = b * 16 + c16, n = (nb0 + r) * 16 + q4 * 4;
+                const bool ok = m < M && n < N;
+                sp0[r][b] = slabs + (int64_t)(ok ? m : 0) * N + (ok ? n : 0);
+            }
+        const int64_t sstride = (int64_t)M * N;
+        for (int k0 = 0; k0 < S; k0 += 4) {
+            f32x4 nx[4][RW][MB];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int b = 0; b < MB; ++b) nx[kk][r][b] = ld_sc1(sp0[r][b] + (int64_t)min(k0 + kk, S - 1) * sstride);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int b = 0; b < MB; ++b) {
+                        asm volatile("" : "+v"(nx[kk][r][b]));
+                        if (k0 + kk == 0) acc[r][b] = nx[kk][r][b];
+                        else if (k0 + kk < S) acc[r][b] += nx[kk][r][b];
+                    }
+        }
+        if (want_rms) {
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < kFoldMaxS; ++k) { asm volatile("" : "+v"(ssq[k][b])); if (k < S) t += ssq[k][b]; }
+                facf[b] = rsqrtf(t / (float)K + ep.rms_eps);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < MB; ++b) facf[b] = 1.0f;
+        }
+        if (ep.swiglu) {
+            if constexpr (RW % 2 == 0) {
+#pragma unroll
+                for (int r = 0; r < RW; r += 2)
+#pragma unroll
+                    for (int b = 0; b < MB; ++b) {
+                        const int m = b * 16 + c16, nb = nb0 + r;
+                        Epilogue e2 = ep;
+                        e2.alpha = ep.alpha * facf[b];
+                        if (m < M && (nb + 1) * 16 < N) epilogue_store4_swiglu(e2, m, (nb >> 1) * 16 + q4 * 4, acc[r][b], acc[r + 1][b]);
+                    }
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+                const int m = b * 16 + c16, n = (nb0 + r) * 16 + q4 * 4;
+                Epilogue e2 = ep;
+                e2.alpha = ep.alpha * facf[b];
+                if (m < M && n < N) epilogue_store4(e2, m, n, acc[r][b]);
+            }
         return;
     }
     __syncthreads();
@@ -1748,6 +1867,11 @@ static int g_tile2 = 0;
 static int g_tile2_max_k = 2048;
 static int g_tile2_variant = 0;
 static bool g_raster_auto = true;          // "raster_shared" option
+// "rows_fold" option: split launches of the rows kernel fold their slabs themselves (no rows_reduce_kernel launch).  OFF: measured SLOWER than the
+// reduce launch - the decode chain of 32 layers as a replayed graph 126.6 (loads per slice) / 133.3 (loads batched) against 118.8-120.9 us per layer
+// (tools/probes/rows_fold_ab.py, profiles/r05_probes/rows_fold_ab.json): without a fence the hand-off is three dependent trips to memory in EVERY
+// workgroup's tail (sc1 stores acknowledged -> agent-scope add returned -> sc1 loads), which a kernel boundary does in one
+static bool g_rows_fold = false;
 static bool g_rows_on = true;              // "rows_kernel" option: M <= 64 launches with ceil(M / 16) >= "rows_min_mb" take gemm_rows_kernel
 static int g_rows_min_mb = 2;
 static int g_raster_slab = 32;             // "raster_slab" option: tile columns per n-slab of the shared-m-group raster (0 = no slabs)
@@ -1768,6 +1892,7 @@ extern "C" int mc_gemm_set_option(const char* name, int value) {
     if (name && !strcmp(name, "raster_slab")) { g_raster_slab = value < 0 ? 0 : (value > 255 ? 255 : value); g_raster_slab_min = 0; return 0; }
     if (name && !strcmp(name, "raster_min_tiles")) { g_raster_min_tiles = value; return 0; }
     if (name && !strcmp(name, "rows_kernel")) { g_rows_on = value != 0; return 0; }
+    if (name && !strcmp(name, "rows_fold")) { g_rows_fold = value != 0; return 0; }
     if (name && !strcmp(name, "rows_min_mb")) { g_rows_min_mb = value; return 0; }
     mc_set_error("mc_gemm_set_option: unknown option '%s'", name ? name : "(null)");
     return 1;
@@ -1948,6 +2073,10 @@ struct RowsWs { hipStream_t stream; char* base; };
 constexpr size_t kRowsSlabFloats = (size_t)12 << 20;          // 48 MiB of fp32 slabs: S x M x N <= 12 Mi (8 x 64 x 22016 fits)
 constexpr int kRowsMaxSplit = 8;
 constexpr size_t kRowsSsBytes = (size_t)kRowsMaxSplit * 64 * sizeof(float);
+constexpr int kRowsMaxGroups = 512;                            // row groups of a launch that may fold its slabs itself ("rows_fold")
+constexpr size_t kRowsSspGBytes = (size_t)kRowsMaxGroups * kRowsMaxSplit * 64 * sizeof(float);
+constexpr size_t kRowsCntBytes = (size_t)kRowsMaxGroups * sizeof(unsigned int);
+constexpr size_t kRowsWsBytes = kRowsSsBytes + kRowsSlabFloats * sizeof(float) + kRowsSspGBytes + kRowsCntBytes;
 std::vector<RowsWs> g_rows_ws;
 std::mutex g_rows_mu;                  // the slot table is touched from every launching thread (tower / pipeline streams, serving threads)
 constexpr int kRowsPool = 16;          // (round 4: 8 -> 16; default, capture, two pipeline and up to four tower streams already make 8)
@@ -1961,12 +2090,15 @@ char* g_rows_pool = nullptr;
 static char* rows_workspace(hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_rows_mu);
     for (auto& w : g_rows_ws) if (w.stream == s) return w.base;
-    const size_t bytes = kRowsSsBytes + kRowsSlabFloats * sizeof(float);
+    const size_t bytes = kRowsWsBytes;
     if (!g_rows_pool) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
         char* base = nullptr;
         if (hipMalloc((void**)&base, bytes * kRowsPool) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        for (int i = 0; i < kRowsPool; ++i)                        // the fold's arrival counters start (and are left) at zero
+            (void)hipMemset(base + bytes * i + (bytes - kRowsCntBytes), 0, kRowsCntBytes);
+        (void)hipDeviceSynchronize();
         g_rows_pool = base;
     }
     for (int i = 0; i < kRowsPool; ++i) {
@@ -2015,19 +2147,33 @@ static int rows_split(int groups, int rw, int nblocks, int kblocks, int kt, int 
     return bs;
 }
 
+template <int MB, int RW, int KT>
+static void launch_rows_k(dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K, const Epilogue& ep,
+                          float* slabs, float* ssp, float* ssp_g, unsigned int* cnt) {
+    // the fold's hand-off is measured at ONE workgroup per CU: an LDS pad keeps a second one off the CU (static: the x tiles + 68 bytes)
+    constexpr int stat = 2 * KT * MB * 64 * 16 + MB * 16 * 4 + 4;
+    const int pad = cnt ? (82 * 1024 > stat ? 82 * 1024 - stat : 0) : 0;
+    static bool attr = false;
+    if (pad && !attr) { (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<MB, RW, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024); attr = true; }
+    gemm_rows_kernel<MB, RW, KT><<<grid, 512, pad, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
+}
+
 template <int MB>
 static void launch_rows(int RW, int kt, dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K, const Epilogue& ep,
                         char* ws, bool skip_reduce = false) {
     float* ssp = (float*)ws;
     float* slabs = (float*)(ws + kRowsSsBytes);
+    const bool fold = g_rows_fold && grid.y > 1 && !skip_reduce && (int)grid.x <= kRowsMaxGroups;
+    float* ssp_g = fold ? (float*)(ws + kRowsSsBytes + kRowsSlabFloats * sizeof(float)) : nullptr;
+    unsigned int* cnt = fold ? (unsigned int*)(ws + kRowsWsBytes - kRowsCntBytes) : nullptr;
     if (kt == 8) {
-        if (RW == 2) gemm_rows_kernel<MB, 2, 8><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
-        else gemm_rows_kernel<MB, 1, 8><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
+        if (RW == 2) launch_rows_k<MB, 2, 8>(grid, s, x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
+        else launch_rows_k<MB, 1, 8>(grid, s, x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
     } else {
-        if (RW == 2) gemm_rows_kernel<MB, 2, 4><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
-        else gemm_rows_kernel<MB, 1, 4><<<grid, 512, 0, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp);
+        if (RW == 2) launch_rows_k<MB, 2, 4>(grid, s, x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
+        else launch_rows_k<MB, 1, 4>(grid, s, x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
     }
-    if (grid.y > 1 && !skip_reduce) {
+    if (grid.y > 1 && !skip_reduce && !fold) {
         const int64_t total = (int64_t)M * ((ep.swiglu ? N >> 1 : N) >> 2);
         rows_reduce_kernel<<<(int)min((int64_t)1024, (total + 255) / 256), 256, 0, s>>>(slabs, ssp, (int)grid.y, M, N, K, ep);
     }

@@ -944,6 +944,13 @@ def test_rows_gemm_kernel_every_split_and_epilogue(M, N, K):
                         assert (got - base).abs().max().item() <= 1e-5 * exact.abs().max().item()
                         f32_by_split[S] = got
                     assert torch.equal(got, ops.linear_ex(x, pw, **kw))
+                    if S > 1:
+                        # round 5: the slab fold inside the launch (option "rows_fold": sc1 stores, one agent-scope add per workgroup, the last
+                        # adder sums the slabs in slice order) gives BITWISE what the separate rows_reduce_kernel launch gives, every time
+                        _lib.check(L.mc_gemm_set_option(b"rows_fold", 1), "rows_fold")
+                        for _ in range(6):
+                            assert torch.equal(got, ops.linear_ex(x, pw, **kw)), f"{name} S={S}: in-launch fold != reduce launch"
+                        _lib.check(L.mc_gemm_set_option(b"rows_fold", 0), "rows_fold")
         L.mc_gemm_debug(0)
         # the automatic choice inside a captured graph (stream met for the first time during capture) equals the eager launch
         eager = ops.linear_ex(x, pw, rms_eps=1e-5)
@@ -964,6 +971,56 @@ def test_rows_gemm_kernel_every_split_and_epilogue(M, N, K):
         assert (old - f32_by_split[1]).abs().max().item() <= 1e-5 * plain.abs().max().item()
     finally:
         L.mc_gemm_debug(0)
+        L.mc_gemm_set_option(b"rows_fold", 0)
+
+
+def test_rows_gemm_in_launch_fold_race_screen():
+    """The four decode GEMMs of the headline model (48 rows; q|k|v, o with residual, gate|up with SwiGLU + folded RMS, down with residual) back
+    to back as the decode step launches them, 300 rounds on the compute stream and 100 more with a second stream hammering HBM beside them:
+    every output of every round is bitwise the reduce-launch path's.  (The fold's hand-off has no fence: sc1 stores -> s_waitcnt -> barrier ->
+    one agent-scope add; the last adder's waves read with sc1 loads.  A stale read would show here as a differing round.)"""
+    from modelcompose_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(77)
+    Hd, I, M = 4096, 11008, 48
+    mk = lambda n, k: ops.pack_weight((torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16).cuda())
+    wq, wo, wg, wd = mk(3 * Hd, Hd), mk(Hd, Hd), mk(2 * I, Hd), mk(Hd, I)
+    x = torch.randn(M, Hd, generator=g).to(torch.bfloat16).cuda()
+    att = torch.randn(M, Hd, generator=g).to(torch.bfloat16).cuda()
+
+    def chain():
+        q = ops.linear_ex(x, wq, rms_eps=1e-5)
+        h1 = ops.linear_ex(att, wo, residual=x)
+        it = ops.linear_ex(h1, wg, rms_eps=1e-5, swiglu=True)
+        h2 = ops.linear_ex(it, wd, residual=h1)
+        return q, h1, it, h2
+    try:
+        _lib.check(L.mc_gemm_set_option(b"rows_fold", 0), "rows_fold")
+        ref = chain()
+        _lib.check(L.mc_gemm_set_option(b"rows_fold", 1), "rows_fold")
+        bad = 0
+        for _ in range(300):
+            bad += sum(int(not torch.equal(a, b)) for a, b in zip(chain(), ref))
+        big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        side = torch.cuda.Stream()
+        for _ in range(100):
+            with torch.cuda.stream(side):
+                big.add_(1.0)
+            bad += sum(int(not torch.equal(a, b)) for a, b in zip(chain(), ref))
+        torch.cuda.synchronize()
+        assert bad == 0, f"{bad} outputs of the in-launch fold differ from the reduce-launch path"
+        # and inside a graph, replayed
+        outs = [torch.empty_like(t) for t in ref]
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for o_, t in zip(outs, chain()):
+                o_.copy_(t)
+        for _ in range(50):
+            gr.replay()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(outs, ref))
+    finally:
+        L.mc_gemm_set_option(b"rows_fold", 0)
 
 
 @pytest.mark.parametrize("D,H,Hkv,sizes", [(128, 8, 8, (700, 1300)), (128, 4, 2, (2100,)), (64, 8, 8, (900, 1200)), (128, 8, 8, (40, 30)), (128, 8, 8, (1700, 0, 1500))])
