@@ -111,15 +111,10 @@ def parse():
                     "(MultimodalLlamaForCausalLM.generate_pipelined, eval/model_multimodal_qa_loader.py --pipeline); every step still is one full "
                     "batch, all K batches start and finish inside the timed region")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one generate() call per step, nothing overlapped")
-    ap.add_argument("--decode-cus", type=int, default=None,
-                    help="pipelined loop: CUs reserved for the decode chain (model.decode_cus; multiple of 8, 0 = no partition; default: the model's "
-                         "own default / MC_DECODE_CUS)")
     ap.add_argument("--no-overlap", action="store_true", help="debug only (train): weight-gradient / rank-projection GEMMs on the main stream")
-    ap.add_argument("--gemm-debug", type=int, default=0, help="debug only: mc_gemm_debug word (A/B of kernel variants)")
-    ap.add_argument("--ab-tile192", action="store_true",
-                    help="informational, after the timed region: the same K batches through the pipelined loop with every large GEMM on the "
-                         "186-register 192-column tiles (mc_gemm_set_option force_tile192), which leave room for the decode attention's waves "
-                         "beside a resident GEMM workgroup")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"],
+                    help="16-bit storage element of the run: bf16 (BASELINE.json's dtype, the headline) or fp16 - the reference's own inference dtype "
+                         "(modelcompose/model/builder.py:41, :162, :185); selects libmc_hip_f16.so for the whole process (MC_STORAGE_DTYPE)")
     ap.add_argument("--gather", default="ids", choices=["ids", "logits"],
                     help="what the ranks all-gather per batch: the generated ids (default; what the reference's per-chunk answer files hold, "
                          "MCUB-4.sh:60-70) or, as BASELINE.json's north_star words it, the step LOGITS [B, new_tokens, vocab] fp32 (the decode "
@@ -140,18 +135,20 @@ def synthetic_inputs(modals, B, dev, seed):
     g = torch.Generator(device=dev).manual_seed(seed)
     rnd = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
     mi = {}
+    from modelcompose_amd import _lib
+    st = _lib.storage_dtype()                       # the library's 16-bit storage element (bf16, or fp16 with --dtype fp16)
     if "vision" in modals:
-        mi["vision"] = rnd(B, 3, 336, 336).to(torch.bfloat16)
+        mi["vision"] = rnd(B, 3, 336, 336).to(st)
     if "audio" in modals:
         fbank = rnd(B, 1024, 128) * 0.5
         fbank[:, 998:] = 0
-        mi["audio"] = {"audio_inputs": fbank.to(torch.bfloat16), "audio_padding_mask": torch.zeros(B, 1024, dtype=torch.bool, device=dev)}
+        mi["audio"] = {"audio_inputs": fbank.to(st), "audio_padding_mask": torch.zeros(B, 1024, dtype=torch.bool, device=dev)}
     if "video" in modals:
-        mi["video"] = rnd(B, 3, 8, 224, 224).to(torch.bfloat16)
+        mi["video"] = rnd(B, 3, 8, 224, 224).to(st)
     if "point" in modals:
         xyz = rnd(B, 8192, 3)
         xyz = xyz / xyz.norm(dim=-1, keepdim=True).clamp_min(1e-6) * torch.rand(B, 8192, 1, generator=g, device=dev) ** (1 / 3)
-        mi["point"] = torch.cat([xyz, torch.rand(B, 8192, 3, generator=g, device=dev)], -1).to(torch.bfloat16)
+        mi["point"] = torch.cat([xyz, torch.rand(B, 8192, 3, generator=g, device=dev)], -1).to(st)
     return mi
 
 
@@ -230,6 +227,14 @@ def cpu_baseline(workload: str, new_tokens: int):
             measured = json.load(open(mpath))
         except Exception:
             measured = None
+    live = {"value": 1.0 / full, "seconds_per_sample": round(full, 1), "extrapolated": True, "cores": cores,
+            "how": f"this run, this host: {lo} and {hi} of 32 decoder layers timed ({times[lo]:.1f}s, {times[hi]:.1f}s), per-layer cost x32 + measured fixed cost"}
+    if measured and measured.get("value"):
+        # the number of record is the MEASURED full-depth run (nothing extrapolated); the bounded live sample of this run
+        # stays beside it as the cross-check that this host is in the same regime (python bench.py --cpu-baseline-full re-measures it: ~3 min)
+        return {"value": measured["value"], "unit": "samples/s", "cores": measured.get("cores", cores), "kind": "port", "extrapolated": False,
+                "sample": measured.get("sample"), "measured_by": "profiles/cpu_baseline_full.json (python bench.py --cpu-baseline-full on an MI355X box's host)",
+                "live_check": live}
     return {"value": 1.0 / full, "unit": "samples/s", "cores": cores, "kind": "port", "extrapolated": True,
             "measured_full_depth_run": measured,
             "sample": f"oracle (torch fp32 CPU port of the reference path, batch 1 as the reference's eval loop) on one sample of the same "
@@ -249,10 +254,14 @@ def secondary_runs(new_tokens: int):
     out = {}
     # "iav_128": the headline workload at the REFERENCE's decode budget, max_new_tokens=128 (eval/model_multimodal_qa_loader.py:101; SURVEY §8d
     # "report also 128"): the HBM-bound share of a step roughly triples
-    for name, steps, warm in (("iav_128", 3, 2), ("vision", 6, 2), ("mcub4", 4, 2), ("train", 10, 3)):
-        wl, nt = ("iav", 128) if name == "iav_128" else (name, new_tokens)
+    # "iav_fp16": the headline workload on the reference's own storage dtype (fp16: builder.py:41, :162, :185), with its roofline objects
+    # "iav_b1_128": the reference's eval geometry - batch 1, 128 greedy tokens, one generate() call per sample, nothing overlapped
+    #               (eval/model_multimodal_qa_loader.py:49-52, :94-102): time to first token, time per token, the M = 1 decode roofline
+    for name, steps, warm in (("iav_fp16", 4, 2), ("iav_b1_128", 4, 2), ("iav_128", 3, 2), ("vision", 6, 2), ("mcub4", 4, 2), ("train", 10, 3)):
+        wl, nt = ("iav", 128) if name in ("iav_128", "iav_b1_128") else (("iav", new_tokens) if name == "iav_fp16" else (name, new_tokens))
+        extra = {"iav_fp16": ["--dtype", "fp16"], "iav_b1_128": ["--batch", "1", "--no-pipeline"], "train": []}.get(name, ["--no-profile"])
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", str(steps), "--warmup", str(warm),
-               "--no-cpu-baseline", "--no-secondary", "--new-tokens", str(nt)] + ([] if name == "train" else ["--no-profile"])
+               "--no-cpu-baseline", "--no-secondary", "--new-tokens", str(nt)] + extra
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MC_BENCH_FORCE_DIST")}
         try:
             t0 = time.perf_counter()
@@ -267,8 +276,13 @@ def secondary_runs(new_tokens: int):
                          "config": {k: v for k, v in j["config"].items() if k in ("workload", "per_gpu_batch", "new_tokens", "layers", "spliced_length",
                                                                                  "pipelined", "parallelism", "trainable_params")},
                          "wall_s_incl_model_build": round(time.perf_counter() - t0, 1)}
-            if j.get("roofline"):
-                out[name]["roofline"] = j["roofline"]
+            for k in ("roofline", "roofline_decode", "stages_ms", "sequential", "pipelined"):
+                if j.get(k):
+                    out[name][k] = j[k]
+            if name == "iav_b1_128" and j.get("stages_ms"):
+                stg = j["stages_ms"]
+                out[name]["ms_to_first_token"] = round(stg["encode"] + stg["prefill"], 3)
+                out[name]["ms_per_token"] = round(stg["decode"] / max(nt - 1, 1), 4)
         except Exception as e:                                           # evidence only: never lose the headline line to it
             out[name] = {"error": repr(e)[:300]}
     return out
@@ -294,6 +308,11 @@ def train_step_flops(meta, B, L, n_targets, n_img_tokens):
     proj = B * n_img_tokens * 2.0 * (D * Hd + Hd * Hd) * 3 - B * n_img_tokens * 2.0 * D * Hd      # fwd + wgrad + dgrad, no dgrad into the frozen tower
     return {"base_linears": base, "attention": attn, "lora": lora, "lm_head": head, "clip": clip, "projector": proj,
             "total": base + attn + lora + head + clip + proj}
+
+
+def _lib_name():
+    from modelcompose_amd import _lib
+    return _lib.storage_name()
 
 
 def train_main(args, world, rank, local):
@@ -378,7 +397,7 @@ def train_main(args, world, rank, local):
         print(json.dumps({
             "metric": "samples/sec (whole node) stage-2 finetune step, composed Vicuna-7B", "value": round(world * B * args.steps / dt, 4),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _lib_name(), "data": "synthetic",
             "config": {"workload": "configs[4]: stage-2 finetune step, vision LocalLoRA Vicuna-7B (r128, default+vision adapters), "
                                    f"batch {B} per GPU, 683-token sequences, fwd+bwd+all-reduce+AdamW", "per_gpu_batch": B,
                        "layers": args.layers, "parallelism": f"ddp{world}", "trainable_params": int(st.n_params),
@@ -455,7 +474,7 @@ def profiled_pass(model, step_fn, cfg, B, new_tokens, n_steps):
     kv_bytes_layer = kv_keys * H * D * 2 * 2.0
     step_bytes = Ln * (wbytes["qkv_gemm"] + wbytes["o_gemm"] + wbytes["gate_up_gemm"] + wbytes["down_gemm"] + kv_bytes_layer) + wbytes["lm_head_gemm"]
     step_ms = stages["decode"] / max(n_dec, 1)
-    dec = {"bound": "hbm", "kernel": "decode step (5 launches per layer - plus one slab-reduce launch behind each split GEMM at batches above 16 - + lm_head + argmax, hipGraph replay)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+    dec = {"bound": "hbm", "kernel": "decode step (5 launches per layer + lm_head + argmax, hipGraph replay)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
            "achieved": round(step_bytes / max(step_ms, 1e-9) / 1e6, 1), "frac": round(step_bytes / max(step_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
            "bytes_per_step": step_bytes, "ms_per_step": round(step_ms, 4), "graph_active": bool(graph_active),
            "avg_keys_per_sequence": round(kv_keys / B, 1)}
@@ -496,8 +515,6 @@ def generate_main(args, world, rank, local):
     meta = workload_meta(name, args.layers)
     sd = synthetic.synthetic_state_dict(meta, device=dev, seed=1234)
     model = build_from_state_dict(meta, sd, device=dev)
-    if args.decode_cus is not None:
-        model.decode_cus = args.decode_cus
     # the load-time composition (the path's "fused AXPY over state_dict tensors"): algorithmic bytes = W read ONCE per linear + one dense W' written
     # per routed adapter + the LoRA factors, over the device time of the composition loop (events around it in finalize(); weights already in HBM)
     compose_roofline = None
@@ -578,13 +595,12 @@ def generate_main(args, world, rank, local):
         "metric": f"samples/sec (whole node) composed-Vicuna-7B greedy gen, {msuffix}",
         "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": _lib.storage_name(), "data": "synthetic",
         "config": {"workload": f"{desc}; batch {B} per GPU, {spliced}-token spliced prompt, {args.new_tokens} greedy tokens",
                    "workload_name": name, "per_gpu_batch": B, "new_tokens": args.new_tokens, "layers": args.layers, "spliced_length": spliced,
                    "block_tokens": {m: int(f.shape[1]) for m, f in feats.items()}, "adapters": list(model.modal_names),
                    "parallelism": f"dp{world}", "gathered": args.gather, "decode_graph_requested": not args.no_graph, "pipelined": bool(args.pipeline),
-                   "pipeline_priming_steps": priming,
-                   "decode_cus": int(getattr(model, "decode_cus", os.environ.get("MC_DECODE_CUS", "0")) or 0) if args.pipeline else 0},
+                   "pipeline_priming_steps": priming},
         "roofline": None, "roofline_decode": None, "roofline_compose": compose_roofline,
     }
     del feats
@@ -612,23 +628,6 @@ def generate_main(args, world, rank, local):
             "value": round(B * args.steps / dtp, 4), "unit": "samples/s", "ms_per_step": round(dtp / args.steps * 1e3, 3),
             "note": ("bench.py --no-pipeline: one generate() call per batch, nothing overlapped; same tokens" if was else
                      "bench.py --pipeline: decode of batch i overlapped with encoders + prefill of batch i+1; same tokens")}
-    if world == 1 and args.ab_tile192:
-        L_ = _lib.lib()
-        was = args.pipeline
-        args.pipeline = True
-        res = {}
-        for tag, on in (("tile256", 0), ("tile192", 1), ("tile256_again", 0)):
-            _lib.check(L_.mc_gemm_set_option(b"force_tile192", on), "force_tile192")
-            run_steps(2)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run_steps(args.steps)
-            torch.cuda.synchronize()
-            dtp = time.perf_counter() - t0
-            res[tag] = {"value": round(B * args.steps / dtp, 4), "ms_per_step": round(dtp / args.steps * 1e3, 3)}
-        _lib.check(L_.mc_gemm_set_option(b"force_tile192", 0), "force_tile192")
-        args.pipeline = was
-        line["ab_tile192_pipelined"] = res
     del model
     torch.cuda.empty_cache()
     if world == 1 and not DIST and not args.no_secondary and name == "iav" and args.layers == 32:
@@ -754,6 +753,8 @@ def launch_ranks(n: int, argv: list[str], deadline_s: float | None = None) -> in
 
 def main():
     args = parse()
+    if args.dtype:                                   # before anything imports the package: one storage dtype (one library) per process
+        os.environ["MC_STORAGE_DTYPE"] = args.dtype
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -790,9 +791,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gemm_debug:
-        from modelcompose_amd import _lib as _l
-        _l.lib().mc_gemm_debug(args.gemm_debug)
     if args.workload == "train":
         return train_main(args, world, rank, local)
     return generate_main(args, world, rank, local)

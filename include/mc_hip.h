@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 9
+#define MC_ABI_VERSION 10
 
 /* activation codes for mc_gemm_bf16 */
 #define MC_ACT_NONE 0
@@ -36,11 +36,6 @@ int mc_device_info(int* cu_count, int64_t* hbm_bytes, char* arch, int arch_len);
  * inference dtype, model/builder.py:41, :162, :185, kept as the parity instrument: 8x finer mantissa at the same MFMA rate).  Every
  * `_bf16` entry point below takes / returns that element type in the f16 build; fp32 and integer interfaces are unchanged. */
 int mc_storage_dtype(void);
-/* A HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (hipExtStreamCreateWithCUMask; consecutive CU indices are dealt
- * round-robin over the XCDs, so a multiple of 8 takes the same number from every XCD).  No reference counterpart: the reference runs one
- * CUDA stream; this serves generate_pipelined's decode / prefill CU partition (model_multimodal_qa_loader.py:94-102 is the loop it feeds). */
-int mc_stream_create_cu_range(int first_cu, int n_cus, void** stream);
-int mc_stream_destroy(void* stream);
 
 /* ---- weights ---------------------------------------------------------------------------------------
  * Packed layout (see csrc/gemm.hip): [ceil16(N)/16][ceil64(K)/32][64 lanes][8] bf16, zero padded.        */
@@ -149,13 +144,10 @@ int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, const void* b
  * multimodal_llama.py:405-406, when the norm weight has been folded into W by mc_compose_weight_ex_bf16).
  * swiglu: the packed weight interleaves gate_proj / up_proj per 16-row block (block 2j = gate rows 16j.., block 2j+1 = up rows
  * 16j..); out is [M, N/2] bf16 = silu(gate) * up (LocalLoraMLP.forward, multimodal_llama.py:381-388).
- * split_k > 1 (M <= 64 only): K is split over workgroups; slice s stores its fp32 partial sums (x row_scale x alpha) in slab s
- * of out = fp32 [split_k][M][ldo]; mc_residual_rms_bf16 adds the slabs in order into the hidden state (no atomics).
- * rms_eps > 0 (M <= 64, no row_scale): the kernel computes the RMSNorm factor rsqrt(mean_k x[m][k]^2 + rms_eps) of every row from the x
- * fragments it streams anyway and uses it as row_scale - the decode path needs no separate normalisation pass.
- * split_k < 0 (M > 64): "auto" - launches that would leave most CUs idle (few output tiles, long K: the LoRA rank projections of the
- * finetune step) are split along K into library-owned fp32 slabs, summed in fixed order, then given the normal epilogue.          */
-struct mc_slab_ref;
+ * rms_eps > 0 (strip family, no row_scale): the kernel computes the RMSNorm factor rsqrt(mean_k x[m][k]^2 + rms_eps) of every row from the
+ * x fragments it streams anyway and uses it as row_scale - the decode path needs no separate normalisation pass.
+ * split_k: 1, or < 0 (tile family) = "auto" - launches that would leave most CUs idle (few output tiles, long K: the LoRA rank projections
+ * of the finetune step) are split along K into library-owned fp32 slabs, summed in fixed order, then given the normal epilogue.     */
 typedef struct mc_gemm_args {
     const void* x; int64_t ldx; const void* w_packed; const void* bias; const void* residual; int64_t ldr;
     void* out; int64_t ldo; int M, N, K; int act; int out_f32; float alpha, beta;
@@ -167,19 +159,15 @@ typedef struct mc_gemm_args {
                                            * (LlamaRMSNorm, multimodal_llama.py:405-406), without the separate mc_rms_scale_bf16 pass: the
                                            * 256x256 kernel's epilogue leaves one sum of squares per row and 128-column chunk, a small
                                            * launch adds them in column order; other routes run mc_rms_scale_bf16 after the GEMM */
-    struct mc_slab_ref* defer_reduce;     /* non-null (round 3): a launch that the library splits along K into fp32 slabs (16 < M <= 64, plain
-                                           * bf16 output: no bias / activation / residual / SwiGLU) may SKIP its slab-reduce launch and describe
-                                           * the slabs here instead (S > 0); `out` is then NOT written and the consumer folds the slabs itself
-                                           * (mc_attn_decode_rope_bf16 takes the q|k|v projection this way: one launch less per decoder layer
-                                           * and step).  S = 0 on return: the launch wrote `out` as usual.  The slabs belong to the launching
-                                           * stream's workspace and are valid until that stream's next M <= 64 GEMM launch */
+    int family;                           /* which kernel family runs the launch (round 6).  The two families add the products of a row in
+                                           * different fp32 orders, each in ONE order whatever M is, so a caller that needs a row's bits not
+                                           * to depend on how many other rows share its launch (the eval loader batches a question
+                                           * differently at 1 and at 8 GPUs) pins the family: MC_GEMM_AUTO (0) = strip kernel for M <= 64,
+                                           * tile kernels above; MC_GEMM_STRIP (1) = the M <= 64 strip kernel always, larger M as slices of
+                                           * 64 rows (decode steps, lm_head, the last-token tail of a prefill); MC_GEMM_TILE (2) = the
+                                           * 128x128 / 256x256 tile kernels always, which are bit-identical to each other (prefill, encoders) */
 } mc_gemm_args;
-typedef struct mc_slab_ref {
-    const float* slabs;                   /* [S][M][N] fp32 partial sums, slice-major */
-    const float* ssp;                     /* [S][64] per-slice sums of squares of the x rows (rms_eps > 0), else unused */
-    int S, M, N, K;
-    float rms_eps;                        /* > 0: row m of the product is scaled by rsqrt(sum_s ssp[s][m] / K + rms_eps) */
-} mc_slab_ref;
+enum { MC_GEMM_AUTO = 0, MC_GEMM_STRIP = 1, MC_GEMM_TILE = 2 };
 /* RoPE + scatter fused into the q|k|v projection (LlamaAttention.forward, multimodal_llama.py:281-312: rotate q and k, append k / v to the
  * cache): output row r (absolute row index of the launch, as in mc_rope_kv_bf16) belongs to sequence row_b[r] (< 0: padding, skipped), is
  * query row_t[r] of this call and sits at cache position row_pos[r].  N must be (H + 2 Hkv) D.  With D = 128, an even head count and a
@@ -201,31 +189,19 @@ int mc_gemm_ex_bf16(const mc_gemm_args* args, void* stream);
 int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, const int32_t* group_start, const void* const* w_packed, void* stream);
 
 /* live HIP-event timing of the large-M GEMM kernel on its launch stream (bench.py roofline) */
-int mc_gemm_debug(int flags);          /* diagnostics only (bit 0: every workgroup computes tile (0,0)) */
 /* library-wide GEMM policy: "tile192" (default 1) lets the large-M kernel use 192-column tiles when they fill the 256 CUs better than
- * 256-column ones (under-filled launches); 0 = callers that run other work beside such launches keep the wider tile;
- * "raster_shared" (default 1): launches of >= 1024 tiles deal their 32-tile blocks round-robin over the XCDs (all XCDs on one m-group);
- * "raster_slab" (default 32, applied to launches of more than 64 tile columns; setting it applies it to every launch wider than the
- * value; 0 = off): with the shared raster the tile columns go in slabs of that many, slab outermost, so that a slab of W stays in the
- * Infinity Cache across the sweep over M.  None of these changes results. */
+ * 256-column ones (under-filled launches); 0 = callers that run other work beside such launches keep the wider tile.  Does not change
+ * results.  (Kernel A/B variants, forced tile shapes and the raster parameters live in the probes build only: csrc/Makefile `probes`.) */
 int mc_gemm_set_option(const char* name, int value);
-/* M <= 64 launches with more than 16 rows run gemm_rows_kernel (activations through LDS, K split over workgroups, fp32 slabs folded by the
- * last-arriving workgroup).  Its workspaces (16 x 50 MiB, one per launching stream so that concurrent streams share nothing) are allocated
- * at the first such launch made outside stream capture; a launch that finds no workspace (first launch ever is inside a capture, or a
- * seventeenth live stream) keeps the older skinny kernel, whose fp32 summation order differs.  Call this once before capturing when the process may
- * capture before it has launched eagerly (mc_llm_create does).  Options "rows_kernel" (default 1) and "rows_min_mb" (default 2 = more
- * than 16 rows) of mc_gemm_set_option switch the kernel off / move the threshold.  "rows_fold" (round 5, default 0): a split launch folds
- * its slabs itself - sc1 stores, one agent-scope add per workgroup, the last adder of a row group sums the S slabs in slice order with sc1
- * loads and runs the epilogue (no fence, no second launch; bit-identical to the rows_reduce_kernel path; measured 5-12 % slower, so off). */
-int mc_gemm_reserve_rows(void* stream);
-int mc_gemm_release_rows(void* stream);   /* before destroying a stream that launched GEMMs: gives its workspace slot back */
+/* Scratch of the tile kernels' rms_out route (16 x 48 MiB, one slot per launching stream so that concurrent streams share nothing),
+ * allocated at the first use made outside stream capture.  Call reserve once before capturing when the process may capture before it
+ * has launched eagerly (mc_llm_create does); release before destroying a stream that launched GEMMs (gives its slot back). */
+int mc_gemm_reserve_workspace(void* stream);
+int mc_gemm_release_workspace(void* stream);
 int mc_gemm_profile_enable(int on);
 int mc_gemm_profile_read(double* total_ms, double* total_flops, int64_t* launches);
 int mc_gemm_profile_read_range(int k_min, int k_max, double* total_ms, double* total_flops, int64_t* launches);   /* launches with k_min <= K <= k_max */
 int mc_gemm_profile_read_bytes(double* total_bytes);   /* algorithmic HBM bytes (operands read once, output written once) of the same launches */
-/* diagnostic: shader clock (GHz) held across the 256x256 kernel's main loop, median over the first n_wg workgroups of the last launch made
- * with mc_gemm_debug(40) (correct results, stamped build) */
-int mc_gemm_clock_read(int n_wg, double* ghz);
 
 /* ---- norms: LlamaRMSNorm (multimodal_llama.py:405-406, :482) / nn.LayerNorm (CLIP blocks) -------------- */
 int mc_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* out, int64_t ldo, int M, int D, float eps, void* stream);
@@ -237,10 +213,6 @@ int mc_add_layernorm_bf16(const void* x, int64_t ldx, const void* table, int64_t
                           const void* w, const void* b, void* out, int64_t ldo, int M, int D, float eps, void* stream);
 /* RMSNorm's per-row factor only (its weight is folded into the next linear): row_scale[m] = rsqrt(mean(x[m]^2) + eps)        */
 int mc_rms_scale_bf16(const void* x, int64_t ldx, float* row_scale, int M, int D, float eps, void* stream);
-/* h[m] = bf16(h[m] + sum_s part[s][m]); row_scale[m] = rsqrt(mean(h[m]^2) + eps) (may be NULL): residual add of the decoder
- * layer (multimodal_llama.py:447, :466) over the fp32 split-K slabs [n_slabs][M][ldp] of mc_gemm_ex_bf16, plus the next norm's factor */
-int mc_residual_rms_bf16(void* h, int64_t ldh, const float* part, int64_t ldp, int n_slabs, float* row_scale, int M, int D,
-                         float eps, void* stream);
 
 /* ---- RoPE + KV-cache append (multimodal_llama.py:281-289; apply_rotary_pos_emb of transformers 4.31) ----
  * qkv rows are in routed order; row_b / row_pos / row_t give batch entry, absolute position and query index. */
@@ -305,35 +277,37 @@ typedef struct mc_attn_bwd_args {
 int mc_attn_bwd_bf16(const mc_attn_bwd_args* args, void* stream);
 
 /* ---- attention (multimodal_llama.py:295-312; CLIPAttention) ------------------------------------------- */
+/* Optional last argument of the attention entry points (NULL: none of it).
+ * key_valid [B][key_valid_stride] bytes, 0 = that key is masked for every query of the sequence - attention masks that are not "every key
+ * below a length" (left padding, holes: the additive padding mask of LlamaModel._prepare_decoder_attention_mask,
+ * multimodal_llama.py:543-545); kv_lens / causal keep their meaning (a key must pass all tests).
+ * b_inner > 0: two-level batch index - batch entry b = (b / b_inner, b % b_inner) is addressed at (b / b_inner) * *_sb + (b % b_inner) *
+ * inner_stride.  Only for prefill launches with Lq, S <= 8 and no relative-position table (the temporal attention of LanguageBind-Video,
+ * modeling_video.py:105-130, over the (b t) n d layout: sequence (b, n), its t tokens a frame apart - attended in place instead of
+ * through a permuted copy); any other launch is refused. */
+typedef struct mc_attn_mask {
+    const void* key_valid; int64_t key_valid_stride;
+    int b_inner; int64_t inner_stride;
+} mc_attn_mask;
 int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
                          int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
                          int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B, int H, int Hkv, int Lq,
                          int S, int D, int causal, int q_offset, float scale, const float* rel_table, int rel_stride, int rel_off,
-                         const float* q_gate, void* stream);   /* rel_table/q_gate: gated relative-position bias of BEATs, may be null */
+                         const float* q_gate, const mc_attn_mask* mask, void* stream);   /* rel_table/q_gate: gated relative-position bias of BEATs, may be null */
 /* training forward with dropout on the attention probabilities (BertSelfAttention.dropout of the Q-Former projector,
  * multimodal_projector/Qformer.py:136, :259): O = (softmax(S) * keep / (1 - p)) V, lse of the un-dropped softmax; element
  * e = ((b H + h) Lq + q) S + key is kept iff word (e & 3) of Philox4x32-10(counter = (e >> 2, stream_id, 0), key = seed) >= p 2^32 */
 int mc_attn_prefill_dropout_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
                                  int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o, int64_t o_row_stride,
                                  const int32_t* kv_lens, int B, int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
-                                 float* lse, float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream);
-/* One-shot key mask for attention masks that are not "every key below a length": key_valid [B][row_stride] bytes, 0 = that key is masked
- * for every query of the sequence (left padding, holes: the additive padding mask of LlamaModel._prepare_decoder_attention_mask,
- * multimodal_llama.py:543-545).  Applies to the NEXT mc_attn_prefill_* / mc_attn_decode_* call of the calling thread and is cleared by it;
- * kv_lens / causal keep their meaning (a key must pass all tests). */
-int mc_attn_set_key_mask(const void* key_valid, int64_t row_stride);
-/* One-shot two-level batch index for the NEXT mc_attn_prefill_* launch of the calling thread: batch entry b = (b / b_inner, b % b_inner)
- * is addressed at (b / b_inner) * *_sb + (b % b_inner) * inner_stride.  Only for launches with Lq, S <= 8 and no relative-position table
- * (the temporal attention of LanguageBind-Video, modeling_video.py:105-130, over the (b t) n d layout: sequence (b, n), its t tokens a
- * frame apart - attended in place instead of through a permuted copy); any other launch is refused. */
-int mc_attn_set_batch_split(int b_inner, int64_t inner_stride);
+                                 float* lse, float dropout_p, unsigned long long seed, unsigned int stream_id, const mc_attn_mask* mask,
+                                 void* stream);
 /* as mc_attn_prefill_bf16, plus lse [B, H, Lq] fp32 = log2-sum-exp of the scaled scores (input of mc_attn_bwd_bf16) */
-int mc_attn_debug(int v);      /* diagnostics: bit 0 forces the 64-query prefill kernel, bit 1 allows the 128-query one at any length */
 int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
                              int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
                              int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B, int H, int Hkv, int Lq,
                              int S, int D, int causal, int q_offset, float scale, const float* rel_table, int rel_stride, int rel_off,
-                             const float* q_gate, float* lse, void* stream);
+                             const float* q_gate, float* lse, const mc_attn_mask* mask, void* stream);
 /* The attention probabilities themselves (output_attentions=True: `attn_weights` of LocalLoraAttention.forward, multimodal_llama.py:295-312 -
  * softmax in fp32 over the scaled, masked scores, cast to the model dtype): probs [B, H, Lq, S] bf16, row (b, h, i) = softmax_j(scale q_i.k_j)
  * over the keys j < kv_lens[b] (NULL: S) that pass the causal test j <= i + q_offset (causal != 0) and the optional key_valid [B][kv_stride]
@@ -341,24 +315,23 @@ int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t 
 int mc_attn_probs_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st, int64_t k_sh,
                        const int32_t* kv_lens, const void* key_valid, int64_t kv_stride, void* probs, int B, int H, int Hkv, int Lq, int S,
                        int D, int causal, int q_offset, float scale, void* stream);
-int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* bytes);
+/* Decode attention (one query per sequence).  Batch-invariant by construction: the cached keys of a sequence are cut into chunks of 256 - a
+ * function of the sequence's own length - every chunk's partial softmax is computed by one wave from a fresh state, and the partials are
+ * combined in chunk order; which wave / workgroup takes which chunk changes no bit.  nsplit >= 1 = workgroups per head (group): a launch
+ * shape for small batches, NOT part of the result.  workspace (mc_attn_decode_workspace_bytes for a cache of S positions) is needed when
+ * nsplit > 1 or S > 19 968; NULL otherwise. */
+int mc_attn_decode_workspace_bytes(int B, int H, int D, int S, int64_t* bytes);
 int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st, int64_t k_sh,
                         const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o, int64_t o_sb, void* workspace,
-                        const int32_t* kv_lens, int B, int H, int Hkv, int S, int D, int nsplit, float scale, void* stream);
+                        const int32_t* kv_lens, int B, int H, int Hkv, int S, int D, int nsplit, float scale, const mc_attn_mask* mask,
+                        void* stream);
 /* decode attention with RoPE + KV-cache append fused in (multimodal_llama.py:281-312 for a one-token step): qkv [B, (H + 2 Hkv) * D]
  * is the pre-rotary q|k|v row of the token at position kv_lens[b] - 1; its rotated key / value are attended from registers and
  * written to the caches by the same launch.                                                                                */
 int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const float* cos_table, const float* sin_table, void* k_cache,
                              int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
                              void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
-                             int nsplit, float scale, void* stream);
-/* the same step with the q|k|v row given as the UNREDUCED split-K slabs of its projection (mc_gemm_args.defer_reduce, B <= 64): the
- * kernel folds them in slice order, applies the RMS row factor and rounds to bf16 exactly as the slab-reduce launch would have stored
- * the row, so the result is bit-identical and the reduce launch between projection and attention disappears */
-int mc_attn_decode_rope_slabs_bf16(const struct mc_slab_ref* qkv_slabs, const float* cos_table, const float* sin_table, void* k_cache,
-                                   int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
-                                   void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
-                                   int nsplit, float scale, void* stream);
+                             int nsplit, float scale, const mc_attn_mask* mask, void* stream);
 
 /* ---- row kernels ---------------------------------------------------------------------------------- */
 int mc_silu_mul_bf16(const void* gate_up, int64_t ld, void* out, int64_t ldo, int M, int I, void* stream);   /* :392-394 */

@@ -10,7 +10,9 @@ LIB_PATH = os.path.join(_HERE, "libmc_hip.so")
 # (modelcompose/model/builder.py:41, :162, :185), kept as the parity instrument.  One storage dtype per process: MC_STORAGE_DTYPE=fp16 in
 # the environment, or set_storage_dtype("fp16") before anything is built.
 LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libmc_hip_f16.so")}
-ABI_VERSION = 9
+if os.environ.get("MC_PROBES_LIB", "0") == "1":      # the probes build (bf16 only): tools/probes/*.py
+    LIB_PATHS["bf16"] = LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "probes", "libmc_hip_probes.so")
+ABI_VERSION = 10
 _DTYPE_CODES = {"bf16": 1, "fp16": 2}                        # MC_DTYPE_BF16 / MC_DTYPE_F16 of mc_hip.h
 
 
@@ -39,12 +41,17 @@ def storage_dtype():
 
 
 def set_storage_dtype(name) -> str:
-    """Select the library instantiation for this process: "bf16" (default, the headline) or "fp16".  Rebinds the storage dtype constant of
-    every loaded module of the package; objects built before the switch keep their tensors and must not be used after it."""
+    """Select the library instantiation for this process: "bf16" (default, the headline) or "fp16".  One storage dtype per process: the
+    two libraries have their own global state (stream workspaces, options) and tensors built for one must never reach the other, so the
+    switch is only allowed BEFORE the first library has been loaded - i.e. before any model, packed weight or handle exists.
+    Normally the choice is made by MC_STORAGE_DTYPE in the environment (bench.py --dtype, the fp16 tests' subprocesses)."""
     global _storage, _lib
     import sys
     new = _norm_dtype(name)
     if new != _storage:
+        if _libs:
+            raise MCError(f"storage dtype is {_storage} for this process (a library is already loaded): set MC_STORAGE_DTYPE={new} before the "
+                          f"first use instead of switching")
         _storage = new
         _lib = None
     dt = storage_dtype()
@@ -64,8 +71,6 @@ _SIGS = {
     "mc_abi_version": [],
     "mc_storage_dtype": [],
     "mc_device_info": [C.POINTER(c_i), C.POINTER(c_l), C.c_char_p, c_i],
-    "mc_stream_create_cu_range": [c_i, c_i, C.POINTER(c_p)],
-    "mc_stream_destroy": [c_p],
     "mc_packed_weight_elems": [c_i, c_i, C.POINTER(c_l)],
     "mc_pack_weight_bf16": [c_p, c_l, c_p, c_i, c_i, c_p],
     "mc_unpack_weight_bf16": [c_p, c_p, c_i, c_i, c_p],
@@ -75,16 +80,11 @@ _SIGS = {
     "mc_compose_weight_dither_bf16": [c_p, c_l, C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_f), c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_i, c_p,
                                       C.c_uint32, c_p],
     "mc_rms_scale_bf16": [c_p, c_l, c_p, c_i, c_i, c_f, c_p],
-    "mc_residual_rms_bf16": [c_p, c_l, c_p, c_l, c_i, c_p, c_i, c_i, c_f, c_p],
     "mc_gemm_profile_enable": [c_i],
     "mc_gemm_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)],
     "mc_gemm_profile_read_bytes": [C.POINTER(C.c_double)],
     "mc_gemm_profile_read_range": [c_i, c_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)],
-    "mc_gemm_clock_read": [c_i, C.POINTER(C.c_double)],
-    "mc_attn_debug": [c_i],
     "mc_gemm_set_option": [C.c_char_p, c_i],
-    "mc_gemm_reserve_rows": [C.c_void_p],
-    "mc_gemm_release_rows": [C.c_void_p],
     "mc_gemm_tn_workspace_floats": [c_i, c_i, c_i, c_i, C.POINTER(C.c_int64)],
     "mc_gemm_tn_bf16": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p],
     "mc_pack_weight_strided_bf16": [c_p, c_l, c_l, c_p, c_i, c_i, c_p],
@@ -92,13 +92,14 @@ _SIGS = {
     "mc_rmsnorm_bf16": [c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_layernorm_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mc_add_layernorm_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
-    "mc_attn_set_batch_split": [c_i, c_l],
     "mc_rope_kv_bf16": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "mc_attn_prefill_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
-                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p, c_p],
+                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p, c_p, c_p],
     "mc_attn_decode_workspace_bytes": [c_i, c_i, c_i, c_i, C.POINTER(c_l)],
     "mc_attn_decode_bf16": [c_p, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
-                            c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+                            c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p],
+    "mc_gemm_reserve_workspace": [C.c_void_p],
+    "mc_gemm_release_workspace": [C.c_void_p],
     "mc_silu_mul_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "mc_gather_last_rows_bf16": [C.c_void_p, C.c_int64, C.c_void_p, c_i, C.c_void_p, C.c_int64, c_i, c_i, C.c_void_p],
     "mc_copy_rows_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
@@ -115,7 +116,7 @@ class GemmArgsC(C.Structure):
     _fields_ = [("x", c_p), ("ldx", c_l), ("w_packed", c_p), ("bias", c_p), ("residual", c_p), ("ldr", c_l), ("out", c_p), ("ldo", c_l),
                 ("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i), ("out_f32", c_i), ("alpha", c_f), ("beta", c_f),
                 ("row_scale", c_p), ("swiglu", c_i), ("split_k", c_i), ("rms_eps", c_f), ("rope", c_p), ("rms_out", c_p), ("rms_out_eps", c_f),
-                ("defer_reduce", c_p)]
+                ("family", c_i)]
 
 
 class ComposeMultiArgsC(C.Structure):
@@ -126,9 +127,9 @@ class ComposeMultiArgsC(C.Structure):
                 ("nb_stride", c_i), ("nb_offset", c_i)]
 
 
-class SlabRefC(C.Structure):
-    """struct mc_slab_ref (include/mc_hip.h)."""
-    _fields_ = [("slabs", c_p), ("ssp", c_p), ("S", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("rms_eps", c_f)]
+class AttnMaskC(C.Structure):
+    """struct mc_attn_mask (include/mc_hip.h)."""
+    _fields_ = [("key_valid", c_p), ("key_valid_stride", c_l), ("b_inner", c_i), ("inner_stride", c_l)]
 
 
 class RopeScatterC(C.Structure):
@@ -166,13 +167,11 @@ _SIGS.update({
     "mc_gemm_grouped_bf16": [C.POINTER(GemmArgsC), c_i, C.POINTER(C.c_int32), C.POINTER(c_p), c_p],
     "mc_attn_bwd_bf16": [C.POINTER(AttnBwdArgsC), c_p],
     "mc_attn_decode_rope_bf16": [c_p, c_l, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
-                                 c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+                                 c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p],
     "mc_attn_prefill_dropout_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p,
-                                     c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f, C.c_uint64, C.c_uint32, c_p],
-    "mc_attn_decode_rope_slabs_bf16": [C.POINTER(SlabRefC), c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
-                                 c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+                                     c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f, C.c_uint64, C.c_uint32, c_p, c_p],
     "mc_attn_prefill_lse_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_p,
-                                 c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p, c_p, c_p],
+                                 c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "mc_transpose_bf16": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     "mc_lora_mask_rows_bf16": [c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
     "mc_rmsnorm_bwd_bf16": [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_p],
@@ -196,7 +195,6 @@ _SIGS.update({
     "mc_fps_bf16": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p],
     "mc_knn_group_bf16": [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p],
     "mc_f32_rows_to_bf16": [c_p, c_i, c_p, c_i, c_l, c_p],
-    "mc_gemm_debug": [c_i],
     "mc_decode_state_init": [c_p, c_p, c_i, c_i, c_p],
     "mc_decode_state_advance": [c_p, c_i, c_p],
     "mc_argmax_step_f32": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
@@ -206,7 +204,6 @@ _SIGS.update({
     "mc_llm_set_option": [c_p, C.c_char_p, c_i],
     "mc_llm_set_sampling": [c_p, c_i, c_f, c_i, c_f],
     "mc_llm_set_key_mask": [c_p, c_p, c_l],
-    "mc_attn_set_key_mask": [c_p, c_l],
     "mc_sample_step_f32": [c_p, c_l, c_p, c_p, c_l, c_p, c_i, c_p, C.c_uint64, c_i, c_i, c_f, c_i, c_f, c_p, c_p, c_l, c_p],
     "mc_llm_workspace_bytes": [c_p, c_i, c_i, c_i, C.POINTER(c_l)],
     "mc_llm_prefill": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
@@ -230,8 +227,9 @@ _SIGS.update({
     "mc_compose_retention_floats": [c_i, c_i, C.POINTER(c_l)],
     "mc_attn_probs_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
 })
-# optional symbols added by later ABI revisions are bound if present
-_OPTIONAL: dict = {}
+# diagnostic entry points of the PROBES build only (csrc/Makefile `probes` -> tools/probes/libmc_hip_probes.so, loaded with
+# MC_PROBES_LIB=1): kernel A/B variants, forced tile shapes, clock stamps.  The shipped library does not export them.
+_OPTIONAL: dict = {"mc_gemm_debug": [c_i], "mc_attn_debug": [c_i], "mc_gemm_clock_read": [c_i, C.POINTER(C.c_double)]}
 
 
 class MCError(RuntimeError):

@@ -13,6 +13,7 @@
 //   attn_decode_kernel  : one query row per (batch, head), HBM-bound KV stream straight to VGPRs,
 //       split over the KV length (flash-decoding) + a small combine kernel.
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnParams {
     const bf16_t* q; int64_t q_sb, q_st, q_sh;     // strides in elements; head_dim contiguous
@@ -660,315 +661,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill32_kernel(AttnParams p) {
             }
     }
 }
-
-// ------------------------------------------------------------------------------------------
-// The same kernel, SOFTWARE-PIPELINED inside the wave over 32-key half tiles (round 5, second step).
-// ------------------------------------------------------------------------------------------
-// attn_prefill32_kernel runs K.Q^T -> softmax -> P.V of a tile in dependency order: its matrix pipe is 46 % busy (profiles/r05_pmc) because a
-// wave's MFMAs wait for its own softmax and the other wave of the SIMD is, more often than not, in the same phase.  Here the scores of the
-// NEXT 32-key half tile are issued into the matrix pipe in front of the exponentials of the CURRENT one - independent instruction streams of
-// one wave, interleaved by the scheduler (sched_group_barrier: one MFMA per seven VALU) - so the exp2 / FMA / convert stretch (~300 cycles)
-// runs UNDER the 256 MFMA cycles instead of behind them; only P.V (which needs P) still follows.  Granularity 32 keys so that the two score
-// blocks in flight are the two halves the unpipelined kernel already holds (no extra registers): the online softmax takes its maximum per
-// half tile (same deferred-maximum rule).  Staging: the K ring runs one tile ahead of the V ring (K(t+1) is needed while V(t) is read), two
-// buffers each, two barriers per tile: top - V(t) landed, every wave done with tile t-1 -> V(t+1) may be staged; mid - K(t+1) landed, every
-// wave done with the first half -> K(t+2) may be staged.  Counted waits: a wave's outstanding DMA batches alternate V / K, vmcnt(4) retires
-// the older one.  Results agree with attn_prefill32_kernel to fp32 rounding (the maxima are taken over other key groups).
-// ABL (timing-only ablations, wrong results; debug bits 10 - 13 = this mask): 1 = half of the K / V fragment reads skipped (what a wave with twice the
-// queries would read per MFMA), 2 = no LDS-DMA after the prologue (the tiles in LDS are re-used), 4 = no softmax arithmetic (P = the raw scores
-// converted), 8 = no barriers and no waits for the DMA
-template <bool CAUSAL, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void attn_prefill32p_kernel(AttnParams p) {
-    constexpr int D = 128, ROWB = 256, TILE = 64 * ROWB, KS = D / 16, DB = D / 32, QB = 128, WQ = 32;
-    extern __shared__ __attribute__((aligned(16))) char lds[];               // K ring [2][16 KiB] | V ring [2][16 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    int qblk, hd, b;
-    {   // XCD-aware block order (see attn_prefill_kernel)
-        const int nx = gridDim.x, ny = gridDim.y;
-        const int total = nx * ny * (int)gridDim.z;
-        const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
-        const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, idx = lin >> 3;
-        const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-        qblk = nx - 1 - v % nx;
-        hd = (v / nx) % ny;
-        b = v / (nx * ny);
-    }
-    const int hk = hd / (p.H / p.Hkv);
-    const int q0 = qblk * QB + wave * WQ;
-    const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
-    const int tq_row = min(q0 + r, p.Lq - 1);
-    const int q_abs = q0 + r + p.q_offset;
-
-    bf16x8 qf[KS];
-    {
-        const bf16_t* qp = p.q + b * p.q_sb + (int64_t)tq_row * p.q_st + hd * p.q_sh + h * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
-    }
-    f32x16 oacc[DB];
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f;
-
-    int last_key = kvlen;
-    if (CAUSAL) last_key = min(last_key, qblk * QB + QB - 1 + p.q_offset + 1);
-    const int ntiles = (last_key + 63) / 64;
-    const bf16_t* kbase = p.k + b * p.k_sb + hk * p.k_sh;
-    const bf16_t* vbase = p.v + b * p.v_sb + hk * p.v_sh;
-
-    const int srow = lane >> 4, sch = lane & 15;
-    uint32_t koff[4], voff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 16 + i * 4 + srow;
-        const int sw = sch ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        koff[i] = (uint32_t)(((int64_t)row * p.k_st + sw * 8) * 2);
-        voff[i] = (uint32_t)(((int64_t)row * p.v_st + sw * 8) * 2);
-    }
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-    // tiles past the last one are staged as copies of the last (valid memory, never read): every batch has its four instructions, which is
-    // what the counted waits below count
-    auto stage_k = [&](int kt) {
-        const bf16_t* src = kbase + (int64_t)min(kt, ntiles - 1) * 64 * p.k_st;
-        const uint32_t l0 = lds0 + (uint32_t)((kt & 1) * TILE);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (!(ABL & 2) || kt < 2) dma16si(src, koff[i], l0 + (uint32_t)((wave * 16 + i * 4) * ROWB));
-    };
-    auto stage_v = [&](int kt) {
-        const bf16_t* src = vbase + (int64_t)min(kt, ntiles - 1) * 64 * p.v_st;
-        const uint32_t l0 = lds0 + (uint32_t)(2 * TILE + (kt & 1) * TILE);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (!(ABL & 2) || kt < 2) dma16si(src, voff[i], l0 + (uint32_t)((wave * 16 + i * 4) * ROWB));
-    };
-    const int li = lane & 15, tq = li >> 2, tp = li & 3, dhalf = (lane >> 4) & 1;
-    const float scale = p.scale_log2e;
-    constexpr float RESC = 8.0f;
-
-    // LDS addresses: the swizzle is an XOR of the 16-byte chunk index with a per-row key f, and every chunk index is (compile-time part) ^
-    // (per-lane part) with disjoint bits, so address = (per-lane word ^ compile-time word) + compile-time row offset + tile buffer.  The 8 + 8
-    // XOR-ed per-lane words are loop invariants (16 registers); rows, key blocks and - the loop being unrolled over the two ring buffers - the
-    // buffer itself are IMMEDIATE offsets of the read: no address arithmetic in the loop (the first version of this kernel spent 50 VALU
-    // instructions per tile on it, a quarter of all).
-    //   K row 32 kb + r, chunk 2 ks + h, f = ((r & 3) << 2) | ((r >> 2) & 3)   (32 kb leaves bits 0 - 3 of the row alone)
-    //   V row key = 32 (ksx >> 1) + 16 (ksx & 1) + 8 hi + 4 h + tq, f = (tq << 2) | ((h + 2 hi) & 3) = ((tq << 2) | h) ^ (2 hi),
-    //   chunk 4 db + 2 dhalf + (tp >> 1), + 8 bytes for odd tp
-    typedef const __attribute__((address_space(3))) char* lds_cptr;
-    lds_cptr kad[KS], vad[2 * DB];
-    {
-        const uint32_t k_lane = (uint32_t)(r * ROWB) | (uint32_t)(((((r & 3) << 2) | ((r >> 2) & 3)) ^ h) << 4);
-        const uint32_t v_lane = (uint32_t)((4 * h + tq) * ROWB) | (uint32_t)(((((tq << 2) | h) ^ (dhalf * 2 + (tp >> 1))) << 4) | ((tp & 1) * 8));
-#pragma unroll
-        for (int c = 0; c < KS; ++c) kad[c] = (lds_cptr)(uintptr_t)((k_lane ^ (uint32_t)(c * 32)) + lds0);
-#pragma unroll
-        for (int c = 0; c < 2 * DB; ++c) vad[c] = (lds_cptr)(uintptr_t)((v_lane ^ (uint32_t)(c * 32)) + lds0);     // c = 2 db + hi
-    }
-    // K fragments: tile buffer at byte offset KOFF (compile time), key block kb, k-steps 4 g .. 4 g + 3
-    auto ldk = [&](auto koff_, auto kb_, int g, bf16x8 (&dst)[4]) {
-        constexpr int off = decltype(koff_)::value + decltype(kb_)::value * 32 * ROWB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = *(const __attribute__((address_space(3))) bf16x8*)(kad[g * 4 + i] + off);
-    };
-    // V^T fragments: tile buffer at byte offset VOFF, 16-key step ksx = 2 kb + st (compile time after unrolling), d blocks 2 g, 2 g + 1
-    auto ldv = [&](auto voff_, int ksx, int g, bf16x8 (&dst)[2]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int db = g * 2 + i;
-            const int row0 = decltype(voff_)::value + ((ksx >> 1) * 32 + (ksx & 1) * 16) * ROWB;
-            const bf16x4 lo = mc_ds_read_tr16((mc_lds_void*)(vad[2 * db] + row0));
-            const bf16x4 hi = mc_ds_read_tr16((mc_lds_void*)(vad[2 * db + 1] + row0 + 8 * ROWB));
-            bf16x8 vf;
-            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-            vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-            dst[i] = vf;
-        }
-    };
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    // exponentials of one half tile, two scores per instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32)
-    auto exps = [&](const f32x16& sc, float nm, bf16x8 (&pf)[2]) -> float {
-        if (ABL & 4) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) pf[e >> 3][e & 7] = (bf16_t)sc[e];
-            return 1.0f;
-        }
-        const f32x2 sc2 = {scale, scale}, nm2 = {nm, nm};
-        f32x2 ls = {0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const f32x2 t = __builtin_elementwise_fma((f32x2){sc[e], sc[e + 1]}, sc2, nm2);
-            const f32x2 pv = {fast_exp2(t[0]), fast_exp2(t[1])};
-            ls += pv;
-            pf[e >> 3][e & 7] = (bf16_t)pv[0];
-            pf[e >> 3][(e & 7) + 1] = (bf16_t)pv[1];
-        }
-        return ls[0] + ls[1];
-    };
-    // one half tile: softmax of sc (the raw scores of keys 64 kt + 32 kb + (e & 3) + 8 (e >> 2) + 4 h), the NEXT half's scores (key block nkb of
-    // the tile at byte offset NKOFF) issued beside its exponentials when NEXT, then O^T += V^T . P^T
-    auto half = [&](int kt, auto kb_, f32x16& sc, auto voff_, auto next_, auto nkoff_, auto nkb_, f32x16& sn) {
-        constexpr int kb = decltype(kb_)::value;
-        constexpr bool next = decltype(next_)::value;
-        const int key_lo = kt * 64 + kb * 32;
-        const bool need_mask = (key_lo + 31 >= kvlen) || (CAUSAL && key_lo + 31 > q0 + p.q_offset);
-        if (need_mask) {
-            int lim = kvlen - 1 - key_lo - 4 * h;
-            if (CAUSAL) lim = min(lim, q_abs - key_lo - 4 * h);
-            asm volatile("" : "+v"(lim));
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sc[e] = ((e & 3) + 8 * (e >> 2)) <= lim ? sc[e] : -3.0e38f;
-        }
-        bf16x8 kfa[4];
-        if (next) ldk(nkoff_, nkb_, 0, kfa);
-        float tmax = sc[0];                                        // (scores are finite or -3e38: no NaN to quieten, v_max3 as is)
-        if (!(ABL & 4)) {
-        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tmax) : "v"(sc[1]), "v"(sc[2]));
-#pragma unroll
-        for (int e = 3; e < 15; e += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tmax) : "v"(sc[e]), "v"(sc[e + 1]));
-        asm("v_max_f32 %0, %0, %1" : "+v"(tmax) : "v"(sc[15]));
-        {
-            auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-            float o_ = __uint_as_float(sw_[1]);
-            tmax = __uint_as_float(sw_[0]);
-            asm("v_max_f32 %0, %0, %1" : "+v"(tmax) : "v"(o_));
-        }
-        tmax = tmax > NEG_BIG ? tmax * scale : NEG_BIG;
-        if (__builtin_amdgcn_ballot_w64(tmax > m_run + RESC) != 0) {
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = fast_exp2(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < DB; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
-        }
-        }
-        bf16x8 pf[2];
-        bf16x8 vfr[2][2];
-        const float nm = -m_run;
-        if (next) {
-            // ONE scheduling region: the second K fragment group, the 8 MFMAs of the next half's scores, this half's exponentials and the
-            // first V fragment reads; the group barriers deal one MFMA per five VALU instructions
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sn[e] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sn = mc_mfma_32x32x16(kfa[i], qf[i], sn);
-            if (!(ABL & 1)) ldk(nkoff_, nkb_, 1, kfa);              // the same registers: these reads follow the four MFMAs that consume the first group
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sn = mc_mfma_32x32x16(kfa[i], qf[4 + i], sn);
-            l_run += exps(sc, nm, pf);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-            ldv(voff_, kb * 2, 0, vfr[0]);
-        } else {
-            l_run += exps(sc, nm, pf);
-            ldv(voff_, kb * 2, 0, vfr[0]);
-        }
-        // ---- O^T += V^T . P^T over the half's two 16-key steps: fragment groups (st, d-block pair) one ahead of their MFMAs
-#pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            if (grp < 3 && (!(ABL & 1) || grp == 0)) ldv(voff_, kb * 2 + ((grp + 1) >> 1), (grp + 1) & 1, vfr[(grp + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int db = (grp & 1) * 2 + i;
-                oacc[db] = mc_mfma_32x32x16(vfr[grp & 1][i], pf[grp >> 1], oacc[db]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    if (ntiles > 0) {
-        stage_k(0); stage_v(0); stage_k(1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        f32x16 s_cur, s_nxt;
-        typedef std::integral_constant<int, 0> I0;
-        typedef std::integral_constant<int, 1> I1;
-        {                                                          // the first half's scores, nothing to hide them under (tile 0 is active for every wave)
-            bf16x8 kf0[4], kf1[4];
-            ldk(I0{}, I0{}, 0, kf0);
-            ldk(I0{}, I0{}, 1, kf1);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s_cur[e] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s_cur = mc_mfma_32x32x16(kf0[i], qf[i], s_cur);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s_cur = mc_mfma_32x32x16(kf1[i], qf[4 + i], s_cur);
-        }
-        // tiles [0, n_act) carry keys this wave's queries may see (causal: the tiles behind its last query are a suffix); the wave still
-        // takes part in the staging and the barriers of the others.  The last active tile's second half has no successor: peeled, so that the
-        // loop body is ONE path (a `next` flag inside it made hipcc merge the two score blocks through copies and spill); the loop is
-        // unrolled over the two ring buffers so that the buffer is a compile-time offset of every LDS read
-        int n_act = ntiles;
-        if (CAUSAL) n_act = min(ntiles, (q0 + WQ - 1 + p.q_offset) / 64 + 1);
-        auto tile = [&](int kt, auto par_, auto last) {
-            constexpr int par = decltype(par_)::value;
-            typedef std::integral_constant<int, par * TILE> KOFF;
-            typedef std::integral_constant<int, (1 - par) * TILE> KOFF_NEXT;
-            typedef std::integral_constant<int, 2 * TILE + par * TILE> VOFF;
-            if (!(ABL & 8)) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // V(kt) has landed (K(kt + 1) may still be in flight)
-            stage_v(kt + 1);
-            half(kt, I0{}, s_cur, VOFF{}, std::true_type{}, KOFF{}, I1{}, s_nxt);
-            if (!(ABL & 8)) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // K(kt + 1) has landed (V(kt + 1) may still be in flight)
-            stage_k(kt + 2);
-            half(kt, I1{}, s_nxt, VOFF{}, std::integral_constant<bool, !decltype(last)::value>{}, KOFF_NEXT{}, I0{}, s_cur);
-        };
-        int kt = 0;
-        for (; kt + 1 < n_act - 1; kt += 2) { tile(kt, I0{}, std::false_type{}); tile(kt + 1, I1{}, std::false_type{}); }
-        if (kt < n_act - 1) { tile(kt, I0{}, std::false_type{}); ++kt; }      // (kt is even here: the pairs start at 0)
-        if (n_act > 0) {
-            if (kt & 1) tile(kt, I1{}, std::true_type{}); else tile(kt, I0{}, std::true_type{});
-        }
-        for (kt = n_act; kt < ntiles; ++kt) {                      // idle tiles: staging and barriers only
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            stage_v(kt + 1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            stage_k(kt + 2);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the dummy tail batches: no DMA may land in LDS after the workgroup has left
-    }
-    // ---- finalize (as attn_prefill32_kernel)
-    {
-        auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-        const float l = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);
-        const float inv = l > 0.f ? 1.0f / l : 0.f;
-        const int t = q0 + r;
-        if (p.lse && t < p.Lq && h == 0) p.lse[((int64_t)b * p.H + hd) * p.Lq + t] = l > 0.f ? m_run + log2f(l) : NEG_BIG;
-        int64_t row = -1;
-        if (t < p.Lq) row = p.out_map ? p.out_map[b * p.Lq + t] : (int64_t)b * p.Lq + t;
-        bf16_t* op = p.o + (row < 0 ? 0 : row) * p.o_row_stride + hd * D;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int gq = 0; gq < 4; gq += 2) {
-                bf16x4 a4, b4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a4[e] = (bf16_t)(oacc[db][gq * 4 + e] * inv); b4[e] = (bf16_t)(oacc[db][(gq + 1) * 4 + e] * inv); }
-                const u32x2 pa = __builtin_bit_cast(u32x2, a4), pb = __builtin_bit_cast(u32x2, b4);
-                auto r0 = __builtin_amdgcn_permlane32_swap(pa[0], pb[0], false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(pa[1], pb[1], false, false);
-                const u32x4 ov = {r0[0], r1[0], r0[1], r1[1]};
-                if (row >= 0) *(u32x4*)(op + db * 32 + (gq + h) * 8) = ov;
-            }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // tiny sequences (Lq, S <= 8): the temporal attention of LanguageBind-Video (languagebind/video/modeling_video.py:105-130: every patch
 // position attends over its t = 8 frames - 4112 sequences x 16 heads of 8 x 8 scores per clip batch).  The flash kernel above spends a
@@ -1061,7 +753,7 @@ struct DecodeParams {
     const bf16_t* k; int64_t k_sb, k_st, k_sh;
     const bf16_t* v; int64_t v_sb, v_st, v_sh;
     bf16_t* o; int64_t o_sb;                       // out[b*o_sb + h*D + d]
-    float* ws;                                     // [B*H, nsplit, D + 2] partials (m, l, acc)
+    float* ws;                                     // [B*H, ws_chunks, D + 2] partials (m, l, acc) when the workgroup does not combine itself
     const int32_t* kv_lens;
     int B, H, Hkv, S, nsplit;
     float scale_log2e;
@@ -1071,38 +763,62 @@ struct DecodeParams {
     const bf16_t* qkv; int64_t qkv_ld;
     const float* cosT; const float* sinT;
     bf16_t* k_out; bf16_t* v_out;
-    // round 3: the q|k|v projection as the UNREDUCED fp32 slabs of its split-K GEMM (mc_gemm_args.defer_reduce): [S][B][N] + per-slice
-    // sums of squares; row b of q|k|v = bf16(sum_s slab_s[b] * rsqrt(sum_s ssp[s][b] / K + eps)) - what rows_reduce_kernel would have
-    // stored, slice order and rounding included - so the reduce launch between the projection and this kernel is gone
-    const float* slabs; const float* ssp; int n_slabs, slab_n, slab_k; float slab_eps;
     const uint8_t* key_valid; int64_t key_valid_sb;          // optional per-key validity of the CACHED keys (see AttnParams)
+    int ws_chunks, ws_lds;                                   // chunk partials per (b, h) in ws; ws_lds: the workgroup keeps them in LDS and combines itself
 };
+
+// Round 6: batch-invariant schedule.  The cached keys 0 .. cache_len - 1 of a sequence are cut into CHUNKS of kDecChunk keys - a function of
+// the sequence's own length only.  One workgroup computes one chunk's partial (m, l, acc[D]) from a fresh state, always the same way: its 4
+// waves take the chunk's keys in groups of 4 (wave w: keys = 4 w + slot mod 16; a workgroup iteration reads 64 consecutive keys = 16 KiB of K
+// and of V, whole DRAM pages), every (wave, slot) runs the online softmax over its keys in ascending order, the 4 slots of a wave are merged
+// by the xor tree, the 4 waves through LDS in wave order.  The partials of a (b, h) are combined in chunk order by decode_combine() - by the
+// workgroup itself from LDS when it owns every chunk (gridDim.y == 1), else by attn_decode_combine_kernel from the workspace.  Which
+// workgroup computes which chunk (gridDim.y, i.e. `nsplit`, chosen from the batch size to fill the chip) changes neither a partial nor
+// the combine order: the output row of a sequence is the same bits at any B, any nsplit and any Smax.  The token's own key (fused mode:
+// it comes from registers, not from the cache) is one more partial, after the chunks of the cached keys: (m, l, acc) = (q.k, 1, v).
+// (Chunks owned by single waves - 128 or 256 keys each, no barrier - measured 5-6 % slower at B = 48: a wave's 4 KiB requests open four
+// times the DRAM pages of the workgroup's 16 KiB ones; profiles/r06_probes/decode_attn_variants.log.)
+constexpr int kDecChunk = 512;
+constexpr int kDecLdsChunks = 40;            // partials a workgroup holds in LDS (Smax <= 19 968; 21 KiB): above that the workspace route runs
+
+template <int D>
+__device__ __forceinline__ float decode_combine(const float* parts, int n, int d) {
+    float mm = NEG_BIG;
+    for (int c = 0; c < n; ++c) mm = fmaxf(mm, parts[c * (D + 2) + D]);
+    float ll = 0.f, aa = 0.f;
+    for (int c = 0; c < n; ++c) {
+        const float a = fast_exp2(parts[c * (D + 2) + D] - mm);
+        ll = fmaf(parts[c * (D + 2) + D + 1], a, ll);
+        aa = fmaf(parts[c * (D + 2) + d], a, aa);
+    }
+    return ll > 0.f ? aa / ll : 0.f;
+}
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
     constexpr int LPK = D / 8;               // lanes per key
     constexpr int KPW = 64 / LPK;            // keys per wave load
+    constexpr int UN = 4;
+    constexpr int KPI = 4 * KPW * UN;        // keys per workgroup iteration
     __shared__ float red[4][D + 2];
+    extern __shared__ float parts_lds[];     // [chunks][D + 2] when the workgroup combines itself (one workgroup per head, chunks fit)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
     const int hk = h / (p.H / p.Hkv);
-    const int split = blockIdx.y;
     const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
     const int slot = lane / LPK, dl = (lane % LPK) * 8;
-
-    float qv[8];
-    float knew[8], vnew[8];
-    const bool fused = p.qkv != nullptr || p.slabs != nullptr;
+    const bool fused = p.qkv != nullptr;
     const int cache_len = fused ? kvlen - 1 : kvlen;          // keys read from the cache (fused: the new token's key comes from registers)
-    const int per = (cache_len + p.nsplit - 1) / p.nsplit;
-    const int j0 = split * per, j1 = min(j0 + per, cache_len);
+    const int nch = (cache_len + kDecChunk - 1) / kDecChunk;       // chunks of cached keys; the fused token's partial is number nch
+    const bool in_lds = p.ws_lds != 0;
+    float* parts = in_lds ? parts_lds : p.ws + (int64_t)bh * p.ws_chunks * (D + 2);
+
     const bf16_t* kb = p.k + b * p.k_sb + hk * p.k_sh + dl;
     const bf16_t* vb = p.v + b * p.v_sb + hk * p.v_sh + dl;
-    constexpr int UN = 4;
     // The first batch of cached K/V rows is requested before anything else: the q/k rotation and the cache append below (a dependent
     // chain of small loads, and a store the compiler will not move loads across) then run under its HBM latency instead of ahead of it.
     bf16x8 k8[UN], v8[UN];
-    auto request = [&](int j) {
+    auto request = [&](int j) {               // j: first key of this wave's share of the workgroup iteration
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int kc = min(j + u * 4 * KPW + slot, p.S - 1);
@@ -1110,35 +826,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
             v8[u] = __builtin_nontemporal_load((const bf16x8*)(vb + (int64_t)kc * p.v_st));
         }
     };
-    int j = j0 + wave * KPW;
-    if (j < j1) request(j);
+    int c = blockIdx.y;
+    if (c < nch) request(c * kDecChunk + wave * KPW);
+
+    float qv[8];
     if (fused) {
+        float knew[8];
         const int pos = kvlen - 1;
-        bf16x8 q8, k8, v8;
-        if (p.slabs) {
-            float fac = 1.0f;
-            if (p.slab_eps > 0.f) {
-                float t = 0.f;
-                for (int s_ = 0; s_ < p.n_slabs; ++s_) t += p.ssp[s_ * 64 + b];
-                fac = 1.0f * rsqrtf(t / (float)p.slab_k + p.slab_eps);
-            }
-            const int64_t sstride = (int64_t)p.B * p.slab_n;
-            auto fold = [&](int n) {
-                const float* sp = p.slabs + (int64_t)b * p.slab_n + n;
-                f32x4 lo = *(const f32x4*)sp, hi = *(const f32x4*)(sp + 4);
-                for (int s_ = 1; s_ < p.n_slabs; ++s_) { lo += *(const f32x4*)(sp + s_ * sstride); hi += *(const f32x4*)(sp + s_ * sstride + 4); }
-                bf16x8 r;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { r[i] = (bf16_t)(lo[i] * fac); r[4 + i] = (bf16_t)(hi[i] * fac); }
-                return r;
-            };
-            q8 = fold(h * D + dl); k8 = fold((p.H + hk) * D + dl); v8 = fold((p.H + p.Hkv + hk) * D + dl);
-        } else {
-            const bf16_t* row = p.qkv + (int64_t)b * p.qkv_ld;
-            q8 = *(const bf16x8*)(row + h * D + dl);
-            k8 = *(const bf16x8*)(row + (p.H + hk) * D + dl);
-            v8 = *(const bf16x8*)(row + (p.H + p.Hkv + hk) * D + dl);
-        }
+        const bf16_t* row = p.qkv + (int64_t)b * p.qkv_ld;
+        const bf16x8 q8 = *(const bf16x8*)(row + h * D + dl);
+        const bf16x8 kn8 = *(const bf16x8*)(row + (p.H + hk) * D + dl);
+        const bf16x8 vn8 = *(const bf16x8*)(row + (p.H + p.Hkv + hk) * D + dl);
         // rotate-half: lanes dl < D/2 pair with lane + LPK/2 (dl + D/2)
         const bool lo = dl < D / 2;
         const float* cr = p.cosT + (int64_t)pos * (D / 2) + (lo ? dl : dl - D / 2);
@@ -1146,156 +844,151 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
         bf16x8 kr;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float qa = (float)q8[i], ka = (float)k8[i];
+            const float qa = (float)q8[i], ka = (float)kn8[i];
             const float qb = __shfl_xor(qa, LPK / 2, 64), kb_ = __shfl_xor(ka, LPK / 2, 64);
-            const float c = cr[i], sn = lo ? -sr[i] : sr[i];
+            const float cs = cr[i], sn = lo ? -sr[i] : sr[i];
             // lo: x*c - partner*s ; hi: x*c + partner*s.  Rounded to bf16 like the stored q / cached k of the unfused path
-            qv[i] = (float)(bf16_t)(qa * c + qb * sn) * p.scale_log2e;
-            kr[i] = (bf16_t)(ka * c + kb_ * sn);
+            qv[i] = (float)(bf16_t)(qa * cs + qb * sn) * p.scale_log2e;
+            kr[i] = (bf16_t)(ka * cs + kb_ * sn);
             knew[i] = (float)kr[i];
-            vnew[i] = (float)v8[i];
         }
-        if (split == 0 && wave == 0 && slot == 0 && h % (p.H / p.Hkv) == 0) {
-            *(bf16x8*)(p.k_out + b * p.k_sb + hk * p.k_sh + (int64_t)pos * p.k_st + dl) = kr;
-            *(bf16x8*)(p.v_out + b * p.v_sb + hk * p.v_sh + (int64_t)pos * p.v_st + dl) = v8;
+        if (blockIdx.y == 0 && wave == 0 && slot == 0) {
+            if (h % (p.H / p.Hkv) == 0) {
+                *(bf16x8*)(p.k_out + b * p.k_sb + hk * p.k_sh + (int64_t)pos * p.k_st + dl) = kr;
+                *(bf16x8*)(p.v_out + b * p.v_sb + hk * p.v_sh + (int64_t)pos * p.v_st + dl) = vn8;
+            }
+            // this token's own key / value: partial number nch
+            float sdot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sdot += qv[i] * knew[i];
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
+            float* w = parts + (int64_t)nch * (D + 2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[dl + i] = (float)vn8[i];
+            if (dl == 0) { w[D] = sdot; w[D + 1] = 1.f; }
         }
     } else {
         const bf16x8 q8 = *(const bf16x8*)(p.q + b * p.q_sb + h * p.q_sh + dl);
 #pragma unroll
         for (int i = 0; i < 8; ++i) qv[i] = (float)q8[i] * p.scale_log2e;
     }
-    float m = NEG_BIG, l = 0.f, acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    if (fused && split == p.nsplit - 1 && wave == 0 && slot == 0) {
-        // this token's own key / value, from registers
-        float sdot = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sdot += qv[i] * knew[i];
-#pragma unroll
-        for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
-        m = sdot; l = 1.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = vnew[i];
-    }
 
-    // register double buffer: the next batch is requested before the current one is consumed
-    while (j < j1) {
-        bf16x8 kc8[UN], vc8[UN];
+    for (; c < nch; c += gridDim.y) {
+        const int j1 = min(cache_len, (c + 1) * kDecChunk);
+        const int cn = c + gridDim.y;
+        float m = NEG_BIG, l = 0.f, acc[8];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { kc8[u] = k8[u]; vc8[u] = v8[u]; }
-        const int jn = j + 4 * KPW * UN;
-        if (jn < j1) request(jn);
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        // register double buffer: the next batch (of this chunk, or the first of the workgroup's next one) is requested before the
+        // current one is consumed
+        for (int j = c * kDecChunk + wave * KPW; j < j1; j += KPI) {
+            bf16x8 kc8[UN], vc8[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int key = j + u * 4 * KPW + slot;
-            float sdot = 0.f;
+            for (int u = 0; u < UN; ++u) { kc8[u] = k8[u]; vc8[u] = v8[u]; }
+            if (j + KPI < j1) request(j + KPI);
+            else if (cn < nch) request(cn * kDecChunk + wave * KPW);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) sdot += qv[i] * (float)kc8[u][i];
+            for (int u = 0; u < UN; ++u) {
+                const int key = j + u * 4 * KPW + slot;
+                float sdot = 0.f;
 #pragma unroll
-            for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
-            bool ok = key < j1;
-            if (p.key_valid && ok) ok = p.key_valid[(int64_t)b * p.key_valid_sb + key] != 0;
-            const float mn = ok ? fmaxf(m, sdot) : m;
-            const float a = fast_exp2(m - mn);
-            const float pv = ok ? fast_exp2(sdot - mn) : 0.f;
+                for (int i = 0; i < 8; ++i) sdot += qv[i] * (float)kc8[u][i];
+#pragma unroll
+                for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
+                bool ok = key < j1;
+                if (p.key_valid && ok) ok = p.key_valid[(int64_t)b * p.key_valid_sb + key] != 0;
+                const float mn = ok ? fmaxf(m, sdot) : m;
+                const float a = fast_exp2(m - mn);
+                const float pv = ok ? fast_exp2(sdot - mn) : 0.f;
+                m = mn;
+                l = l * a + pv;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pv * (float)vc8[u][i];
+            }
+        }
+        // a wave whose share of the chunk is empty (a short last chunk) still has this chunk's request in flight: none was issued for it
+        // (the loop's first request of a chunk is issued by the previous chunk's last iteration or the prologue - only when the wave has keys)
+        // merge the KPW key slots of the wave (lanes with equal dl)
+#pragma unroll
+        for (int o = LPK; o < 64; o <<= 1) {
+            const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+            const float mn = fmaxf(m, m2);
+            const float a1 = fast_exp2(m - mn), a2 = fast_exp2(m2 - mn);
+            l = l * a1 + l2 * a2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float o2 = __shfl_xor(acc[i], o, 64);
+                acc[i] = acc[i] * a1 + o2 * a2;
+            }
             m = mn;
-            l = l * a + pv;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pv * (float)vc8[u][i];
         }
-        j = jn;
-    }
-    // merge the KPW key slots of the wave (lanes with equal dl)
+        if (slot == 0) {
 #pragma unroll
-    for (int o = LPK; o < 64; o <<= 1) {
-        const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
-        const float mn = fmaxf(m, m2);
-        const float a1 = fast_exp2(m - mn), a2 = fast_exp2(m2 - mn);
-        l = l * a1 + l2 * a2;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float o2 = __shfl_xor(acc[i], o, 64);
-            acc[i] = acc[i] * a1 + o2 * a2;
+            for (int i = 0; i < 8; ++i) red[wave][dl + i] = acc[i];
+            if (dl == 0) { red[wave][D] = m; red[wave][D + 1] = l; }
         }
-        m = mn;
-    }
-    if (slot == 0) {
+        __syncthreads();
+        if (tid < D) {
+            float mm = NEG_BIG;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) red[wave][dl + i] = acc[i];
-        if (dl == 0) { red[wave][D] = m; red[wave][D + 1] = l; }
-    }
-    __syncthreads();
-    if (tid < D) {
-        float mm = NEG_BIG;
+            for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red[w][D]);
+            float ll = 0.f, aa = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red[w][D]);
-        float ll = 0.f, aa = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float a = fast_exp2(red[w][D] - mm);
-            ll += red[w][D + 1] * a;
-            aa += red[w][tid] * a;
-        }
-        if (p.nsplit == 1) {
-            p.o[b * p.o_sb + h * D + tid] = (bf16_t)(ll > 0.f ? aa / ll : 0.f);
-        } else {
-            float* w = p.ws + ((int64_t)bh * p.nsplit + split) * (D + 2);
+            for (int w = 0; w < 4; ++w) {
+                const float a = fast_exp2(red[w][D] - mm);
+                ll += red[w][D + 1] * a;
+                aa += red[w][tid] * a;
+            }
+            float* w = parts + (int64_t)c * (D + 2);
             w[tid] = aa;
             if (tid == 0) { w[D] = mm; w[D + 1] = ll; }
         }
+        __syncthreads();
     }
+    if (!in_lds) return;
+    __syncthreads();
+    if (tid < D) p.o[b * p.o_sb + h * D + tid] = (bf16_t)decode_combine<D>(parts_lds, nch + (fused ? 1 : 0), tid);
 }
 
 template <int D>
 __global__ void attn_decode_combine_kernel(DecodeParams p) {
     const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H, d = threadIdx.x;
-    const float* w = p.ws + (int64_t)bh * p.nsplit * (D + 2);
-    float mm = NEG_BIG;
-    for (int s = 0; s < p.nsplit; ++s) mm = fmaxf(mm, w[s * (D + 2) + D]);
-    float ll = 0.f, aa = 0.f;
-    for (int s = 0; s < p.nsplit; ++s) {
-        const float a = fast_exp2(w[s * (D + 2) + D] - mm);
-        ll += w[s * (D + 2) + D + 1] * a;
-        aa += w[s * (D + 2) + d] * a;
-    }
-    p.o[b * p.o_sb + h * D + d] = (bf16_t)(ll > 0.f ? aa / ll : 0.f);
+    const int kvlen = p.kv_lens ? min(p.kv_lens[b], p.S) : p.S;
+    const int fused = p.qkv != nullptr;
+    const int nch = (kvlen - fused + kDecChunk - 1) / kDecChunk + fused;
+    p.o[b * p.o_sb + h * D + d] = (bf16_t)decode_combine<D>(p.ws + (int64_t)bh * p.ws_chunks * (D + 2), nch, d);
 }
 
 // ------------------------------------------------------------------------------------------
-// One-shot key mask (attention masks that are not "everything up to a length"): set by mc_attn_set_key_mask, consumed by the NEXT
-// mc_attn_prefill_* / mc_attn_decode_* launch of this thread, then cleared - a mask can never leak into a later launch.
-static thread_local const uint8_t* g_key_valid = nullptr;
-static thread_local int64_t g_key_valid_sb = 0;
-extern "C" int mc_attn_set_key_mask(const void* key_valid, int64_t row_stride) {
-    g_key_valid = (const uint8_t*)key_valid; g_key_valid_sb = row_stride;
-    return 0;
-}
-static void take_key_mask(const uint8_t*& kv, int64_t& sb) { kv = g_key_valid; sb = g_key_valid_sb; g_key_valid = nullptr; g_key_valid_sb = 0; }
-// One-shot two-level batch index for the NEXT mc_attn_prefill_* launch of this thread (see AttnParams::b_inner); the launch must be one
-// the tiny kernel takes (Lq, S <= 8, no relative-position table, no key mask) - anything else is refused, never silently mis-addressed.
-static thread_local int g_b_inner = 0;
-static thread_local int64_t g_sbi = 0;
-extern "C" int mc_attn_set_batch_split(int b_inner, int64_t inner_stride) {
-    if (b_inner < 0 || inner_stride % 8) { mc_set_error("mc_attn_set_batch_split: bad arguments"); return 1; }
-    g_b_inner = b_inner; g_sbi = inner_stride;
-    return 0;
+// mc_attn_mask (include/mc_hip.h): the optional per-key validity bytes and the two-level batch index of a launch, as explicit arguments.
+// (Rounds 2-5 carried them as thread-local "next launch" state; a struct argument cannot leak into a later launch or be left behind by a
+// refused one.)
+static void mask_fields(const mc_attn_mask* mk, const uint8_t*& kv, int64_t& kv_sb, int& b_inner, int64_t& sbi) {
+    kv = mk ? (const uint8_t*)mk->key_valid : nullptr;
+    kv_sb = mk && mk->key_valid ? mk->key_valid_stride : 0;
+    b_inner = mk ? mk->b_inner : 0;
+    sbi = mk ? mk->inner_stride : 0;
 }
 
+// Diagnostic word (kernel A/B variants): probes build only (csrc/Makefile `probes`)
+#ifdef MC_PROBES
 static int g_attn_dbg = 0;
 extern "C" int mc_attn_debug(int v) { g_attn_dbg = v; return 0; }      // bit 0: force the 64-query kernel, bit 1: allow the 128-query one at any length (A/B timing)
+#else
+constexpr int g_attn_dbg = 0;
+#endif
 
 extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_st, int64_t q_sh, const void* k, int64_t k_sb,
                                         int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
                                         void* o, int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B,
                                         int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
                                         const float* rel_table, int rel_stride, int rel_off, const float* q_gate, float* lse,
-                                        void* stream) {
-    // the one-shot states are taken (and so cleared) BEFORE any argument check: a refused call consumes them too, they can never reach a later launch
+                                        const mc_attn_mask* mask, void* stream) {
     const uint8_t* kv_once = nullptr; int64_t kv_once_sb = 0;
-    take_key_mask(kv_once, kv_once_sb);
-    const int b_inner_once = g_b_inner; const int64_t sbi_once = g_sbi;
-    g_b_inner = 0; g_sbi = 0;
+    int b_inner_once = 0; int64_t sbi_once = 0;
+    mask_fields(mask, kv_once, kv_once_sb, b_inner_once, sbi_once);
+    MC_CHECK_ARG(b_inner_once >= 0 && sbi_once % 8 == 0, "mc_attn_prefill_bf16: bad two-level batch index");
     MC_CHECK_ARG(q && k && v && o, "mc_attn_prefill_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_prefill_bf16: head_dim %d not supported (64 or 128)", D);
     MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Lq > 0 && S > 0, "mc_attn_prefill_bf16: bad shape");
@@ -1307,7 +1000,7 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
     p.key_valid = kv_once; p.key_valid_sb = kv_once_sb;
     p.b_inner = b_inner_once; p.sbi = sbi_once;
     MC_CHECK_ARG(p.b_inner == 0 || (Lq <= 8 && S <= 8 && !rel_table && !p.key_valid && B % p.b_inner == 0),
-                 "mc_attn_prefill_bf16: a two-level batch index (mc_attn_set_batch_split) is only defined for the Lq, S <= 8 kernel");
+                 "mc_attn_prefill_bf16: a two-level batch index (mc_attn_mask.b_inner) is only defined for the Lq, S <= 8 kernel");
     hipStream_t s = (hipStream_t)stream;
     // Workgroup shape: QW waves x NQ 16-query blocks per wave.  D = 128 without the relative-position bias (the LLM prefill, training):
     // two query blocks per wave (half the LDS bytes per MFMA, see the kernel); 4 waves = 128 queries per workgroup, 8 waves = 256 for long
@@ -1321,48 +1014,37 @@ extern "C" int mc_attn_prefill_lse_bf16(const void* q, int64_t q_sb, int64_t q_s
         MC_CHECK_LAUNCH();
         return 0;
     }
+#ifdef MC_PROBES
     if (D == 64 && !rel_table && (g_attn_dbg & 16) && Lq > 64) {          // A/B: two query blocks per wave at head_dim 64 (encoders)
         attn_prefill_kernel<64, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 128, s>>>(p);
         MC_CHECK_LAUNCH();
         return 0;
     }
+#endif
     const bool two = D == 128 && !rel_table && !(g_attn_dbg & (1 | 4)) && Lq > 64;
     if (two) {
-        // 8 waves (256 queries per workgroup) only on request (debug bit 1): after the round-3 clean-up of the softmax's instruction stream the
-        // 4-wave workgroups are the faster shape at every length measured (L = 2793, B = 48: 817 vs 800 TFLOP/s; L = 2048: 724 vs 620);
-        // a variant with the two wave groups of an 8-wave workgroup running half a tile apart (MFMA half beside softmax half,
-        // bit-identical results) measured 794 - it is not in the tree
+        // 4 waves x 2 query blocks (128 queries per workgroup): after the round-3 clean-up of the softmax's instruction stream the faster shape
+        // at every length measured against the 8-wave one (L = 2793, B = 48: 817 vs 800 TFLOP/s; L = 2048: 724 vs 620).  LATE = 1 (round 3):
+        // the next tile's LDS-DMA is issued behind K.Q^T, in front of the softmax's VALU-only stretch: +1 %.  (The 8-wave shape, LATE = 0, the
+        // bidirectional 32x32x16 build and the round-5 software-pipelined kernel lost their A/Bs - profiles/r03_probes, r05_probes/attn32_ab.json -
+        // and are instantiated in the probes build only, or not at all.)
+        const dim3 gr((Lq + 127) / 128, H, B);
+#ifdef MC_PROBES
         const bool w8 = (g_attn_dbg & 2) && (int64_t)((Lq + 255) / 256) * H * B >= 512 && !(g_attn_dbg & 8);
-        if (w8) attn_prefill_kernel<128, false, 8, 2><<<dim3((Lq + 255) / 256, H, B), 512, 4 * 64 * 256, s>>>(p);
-        // LATE = 1 (round 3): the next tile's LDS-DMA is issued behind K.Q^T, in front of the softmax's VALU-only stretch, instead of beside the
-        // K fragment reads at the top of the tile: +1 % (debug bit 6: at the top, as every other shape does)
-        else if (g_attn_dbg & 64) attn_prefill_kernel<128, false, 4, 2><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
-        else if (p.key_valid) attn_prefill_kernel<128, false, 4, 2, false, 1><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+        if (w8) { attn_prefill_kernel<128, false, 8, 2><<<dim3((Lq + 255) / 256, H, B), 512, 4 * 64 * 256, s>>>(p); MC_CHECK_LAUNCH(); return 0; }
+        if (g_attn_dbg & 64) { attn_prefill_kernel<128, false, 4, 2><<<gr, 256, 4 * 64 * 256, s>>>(p); MC_CHECK_LAUNCH(); return 0; }
+        if (!p.key_valid && !causal && (g_attn_dbg & 256) && S % 64 == 0) { attn_prefill32_kernel<false><<<gr, 256, 4 * 64 * 256, s>>>(p); MC_CHECK_LAUNCH(); return 0; }
+#endif
+        if (p.key_valid) attn_prefill_kernel<128, false, 4, 2, false, 1><<<gr, 256, 4 * 64 * 256, s>>>(p);
         else if (S % 64 == 0 && 64LL * k_st * 2 + 256 < (1LL << 31) && 64LL * v_st * 2 + 256 < (1LL << 31)) {   // the LLM's launches: no per-key mask, whole key tiles
-            // round 5: the 32x32x16 kernel (debug bit 7 keeps the 16x16x32 one for A/B)
-            // (measured, profiles/r05_probes/attn32_ab.json: causal L = 683 +12 %, 2048 +6 %, 2793 +1 %; bidirectional L = 2304 -1.5 %: the
-            // bidirectional launches keep the 16x16x32 kernel unless debug bit 8 asks for the new one)
-            if ((g_attn_dbg & 128) || (!causal && !(g_attn_dbg & 256)))
-                attn_prefill_kernel<128, false, 4, 2, false, 1, false, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
-            else if (causal && ((g_attn_dbg >> 10) & 15)) {        // timing-only ablations (wrong results)
-                const dim3 gr((Lq + 127) / 128, H, B);
-                switch ((g_attn_dbg >> 10) & 15) {
-                    case 1: attn_prefill32p_kernel<true, 1><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
-                    case 2: attn_prefill32p_kernel<true, 2><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
-                    case 3: attn_prefill32p_kernel<true, 3><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
-                    case 4: attn_prefill32p_kernel<true, 4><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
-                    case 8: attn_prefill32p_kernel<true, 8><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
-                    case 10: attn_prefill32p_kernel<true, 10><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
-                    case 7: attn_prefill32p_kernel<true, 7><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
-                    default: attn_prefill32p_kernel<true, 15><<<gr, 256, 4 * 64 * 256, s>>>(p); break;
-                }
-            }
-            else if (causal && (g_attn_dbg & 512)) attn_prefill32p_kernel<true><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
-            else if (!causal && (g_attn_dbg & 512)) attn_prefill32p_kernel<false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
-            else if (causal) attn_prefill32_kernel<true><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
-            else attn_prefill32_kernel<false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);
+            // causal: the 32x32x16 kernel (round 5; measured, profiles/r05_probes/attn32_ab.json: L = 683 +12 %, 2048 +6 %, 2793 +1 %; bidirectional
+            // L = 2304 -1.5 %: those keep the 16x16x32 kernel).  Its O stores are 16-byte vectors: rows that are not 16-byte aligned take the
+            // 16x16x32 kernel's 8-byte stores.
+            const bool o_wide = o_row_stride % 8 == 0 && ((uintptr_t)o & 15) == 0;
+            if (causal && o_wide && !(g_attn_dbg & 128)) attn_prefill32_kernel<true><<<gr, 256, 4 * 64 * 256, s>>>(p);
+            else attn_prefill_kernel<128, false, 4, 2, false, 1, false, false><<<gr, 256, 4 * 64 * 256, s>>>(p);
         }
-        else attn_prefill_kernel<128, false, 4, 2, false, 1, false><<<dim3((Lq + 127) / 128, H, B), 256, 4 * 64 * 256, s>>>(p);      // no per-key mask: its loads and branches compiled out
+        else attn_prefill_kernel<128, false, 4, 2, false, 1, false><<<gr, 256, 4 * 64 * 256, s>>>(p);      // no per-key mask: its loads and branches compiled out
         MC_CHECK_LAUNCH();
         return 0;
     }
@@ -1397,12 +1079,11 @@ extern "C" int mc_attn_prefill_dropout_bf16(const void* q, int64_t q_sb, int64_t
                                             int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
                                             void* o, int64_t o_row_stride, const int32_t* kv_lens, int B, int H, int Hkv, int Lq, int S, int D,
                                             int causal, int q_offset, float scale, float* lse, float dropout_p, unsigned long long seed,
-                                            unsigned int stream_id, void* stream) {
+                                            unsigned int stream_id, const mc_attn_mask* mask, void* stream) {
     const uint8_t* kv_once = nullptr; int64_t kv_once_sb = 0;
-    take_key_mask(kv_once, kv_once_sb);                    // one-shot states: consumed before any check (see mc_attn_prefill_lse_bf16)
-    const int b_inner_once = g_b_inner;
-    g_b_inner = 0; g_sbi = 0;
-    MC_CHECK_ARG(b_inner_once == 0, "mc_attn_prefill_dropout_bf16: a two-level batch index (mc_attn_set_batch_split) is not defined for this launch");
+    int b_inner_once = 0; int64_t sbi_once = 0;
+    mask_fields(mask, kv_once, kv_once_sb, b_inner_once, sbi_once);
+    MC_CHECK_ARG(b_inner_once == 0, "mc_attn_prefill_dropout_bf16: a two-level batch index (mc_attn_mask.b_inner) is not defined for this launch");
     MC_CHECK_ARG(q && k && v && o, "mc_attn_prefill_dropout_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_prefill_dropout_bf16: head_dim %d not supported (64 or 128)", D);
     MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Lq > 0 && S > 0 && S % 4 == 0, "mc_attn_prefill_dropout_bf16: bad shape (S must be a multiple of 4)");
@@ -1427,9 +1108,10 @@ extern "C" int mc_attn_prefill_bf16(const void* q, int64_t q_sb, int64_t q_st, i
                                     int64_t k_st, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh,
                                     void* o, int64_t o_row_stride, const int32_t* out_map, const int32_t* kv_lens, int B,
                                     int H, int Hkv, int Lq, int S, int D, int causal, int q_offset, float scale,
-                                    const float* rel_table, int rel_stride, int rel_off, const float* q_gate, void* stream) {
+                                    const float* rel_table, int rel_stride, int rel_off, const float* q_gate, const mc_attn_mask* mask,
+                                    void* stream) {
     return mc_attn_prefill_lse_bf16(q, q_sb, q_st, q_sh, k, k_sb, k_st, k_sh, v, v_sb, v_st, v_sh, o, o_row_stride, out_map, kv_lens, B,
-                                    H, Hkv, Lq, S, D, causal, q_offset, scale, rel_table, rel_stride, rel_off, q_gate, nullptr, stream);
+                                    H, Hkv, Lq, S, D, causal, q_offset, scale, rel_table, rel_stride, rel_off, q_gate, nullptr, mask, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1505,84 +1187,65 @@ extern "C" int mc_attn_probs_bf16(const void* q, int64_t q_sb, int64_t q_st, int
     return 0;
 }
 
-extern "C" int mc_attn_decode_workspace_bytes(int B, int H, int D, int nsplit, int64_t* bytes) {
-    *bytes = (int64_t)B * H * nsplit * (D + 2) * 4;
+// workspace of the decode kernels: one partial (m, l, acc[D]) per (b, h) and chunk of kDecChunk keys of a cache of S positions
+extern "C" int mc_attn_decode_workspace_bytes(int B, int H, int D, int S, int64_t* bytes) {
+    *bytes = (int64_t)B * H * ((S + kDecChunk - 1) / kDecChunk + 1) * (D + 2) * 4;
+    return 0;
+}
+
+// nsplit workgroups per head (group) share its chunks (a performance knob: the result does not depend on it).  The workgroup combines the
+// partials itself when it owns all of them and they fit its LDS; otherwise they go through `workspace` (mc_attn_decode_workspace_bytes).
+static int decode_launch(DecodeParams& p, int D, int nsplit, hipStream_t s, const char* who) {
+    const int chunks = (p.S + kDecChunk - 1) / kDecChunk + 1;       // + the fused token's own partial
+    nsplit = max(1, min(nsplit, chunks));                           // more than one workgroup per chunk has nothing to do
+    p.ws_chunks = chunks;
+    p.ws_lds = (nsplit == 1 && chunks <= kDecLdsChunks) ? 1 : 0;
+    MC_CHECK_ARG(p.ws_lds || p.ws, "%s: more than one workgroup per head, or a cache of more than %d positions, needs a workspace", who,
+                 (kDecLdsChunks - 1) * kDecChunk);
+    const size_t lds = p.ws_lds ? (size_t)chunks * (D + 2) * sizeof(float) : 0;
+    const dim3 grid(p.B * p.H, nsplit);
+    if (D == 128) {
+        attn_decode_kernel<128><<<grid, 256, lds, s>>>(p);
+        if (!p.ws_lds) attn_decode_combine_kernel<128><<<p.B * p.H, 128, 0, s>>>(p);
+    } else {
+        attn_decode_kernel<64><<<grid, 256, lds, s>>>(p);
+        if (!p.ws_lds) attn_decode_combine_kernel<64><<<p.B * p.H, 64, 0, s>>>(p);
+    }
+    MC_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int mc_attn_decode_bf16(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_st,
                                    int64_t k_sh, const void* v, int64_t v_sb, int64_t v_st, int64_t v_sh, void* o,
                                    int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S,
-                                   int D, int nsplit, float scale, void* stream) {
-    const uint8_t* kv_once = nullptr; int64_t kv_once_sb = 0;
-    take_key_mask(kv_once, kv_once_sb);                    // consumed before any check
+                                   int D, int nsplit, float scale, const mc_attn_mask* mask, void* stream) {
     MC_CHECK_ARG(q && k && v && o, "mc_attn_decode_bf16: null pointer");
     MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_decode_bf16: head_dim %d not supported (64 or 128)", D);
-    MC_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || workspace), "mc_attn_decode_bf16: nsplit>1 needs a workspace");
+    MC_CHECK_ARG(nsplit >= 1, "mc_attn_decode_bf16: nsplit must be >= 1");
     MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && S > 0, "mc_attn_decode_bf16: bad shape");
+    MC_CHECK_ARG(!mask || mask->b_inner == 0, "mc_attn_decode_bf16: no two-level batch index here");
     DecodeParams p{(const bf16_t*)q, q_sb, q_sh, (const bf16_t*)k, k_sb, k_st, k_sh, (const bf16_t*)v, v_sb, v_st, v_sh,
                    (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
                    nullptr, 0, nullptr, nullptr, nullptr, nullptr};
-    p.key_valid = kv_once; p.key_valid_sb = kv_once_sb;
-    dim3 grid(B * H, nsplit);
-    hipStream_t s = (hipStream_t)stream;
-    if (D == 128) {
-        attn_decode_kernel<128><<<grid, 256, 0, s>>>(p);
-        if (nsplit > 1) attn_decode_combine_kernel<128><<<B * H, 128, 0, s>>>(p);
-    } else {
-        attn_decode_kernel<64><<<grid, 256, 0, s>>>(p);
-        if (nsplit > 1) attn_decode_combine_kernel<64><<<B * H, 64, 0, s>>>(p);
-    }
-    MC_CHECK_LAUNCH();
-    return 0;
+    p.key_valid = mask ? (const uint8_t*)mask->key_valid : nullptr; p.key_valid_sb = mask && mask->key_valid ? mask->key_valid_stride : 0;
+    return decode_launch(p, D, nsplit, (hipStream_t)stream, "mc_attn_decode_bf16");
 }
 
 // Decode attention with RoPE and the KV-cache append fused in: qkv [B, (H + 2 Hkv) * D] is the pre-rotary output of the q|k|v linear
 // for the token at position kv_lens[b] - 1 of every sequence (kv_lens counts this token).  Replaces mc_rope_kv_bf16 +
 // mc_attn_decode_bf16 for one-token steps (multimodal_llama.py:281-312): one launch less per layer and no q round trip.
-static int attn_decode_rope_impl(const void* qkv, int64_t qkv_ld, const mc_slab_ref* sl, const float* cos_table, const float* sin_table, void* k_cache,
-                                 int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
-                                 void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
-                                 int nsplit, float scale, void* stream) {
-    const uint8_t* kv_once = nullptr; int64_t kv_once_sb = 0;
-    take_key_mask(kv_once, kv_once_sb);                    // consumed before any check
-    MC_CHECK_ARG((qkv || sl) && cos_table && sin_table && k_cache && v_cache && o && kv_lens, "mc_attn_decode_rope_bf16: null pointer");
-    MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_decode_rope_bf16: head_dim %d not supported (64 or 128)", D);
-    MC_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || workspace), "mc_attn_decode_rope_bf16: nsplit>1 needs a workspace");
-    MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && S > 0 && qkv_ld % 8 == 0, "mc_attn_decode_rope_bf16: bad shape");
-    MC_CHECK_ARG(!sl || (sl->S >= 1 && sl->slabs && sl->M == B && sl->N == (H + 2 * Hkv) * D && B <= 64 && (sl->rms_eps <= 0.f || sl->ssp)),
-                 "mc_attn_decode_rope_slabs_bf16: the slabs must be the [S][B][(H + 2 Hkv) D] partial sums of this batch's q|k|v projection");
-    DecodeParams p{nullptr, 0, 0, (const bf16_t*)k_cache, k_sb, k_st, k_sh, (const bf16_t*)v_cache, v_sb, v_st, v_sh,
-                   (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
-                   (const bf16_t*)qkv, qkv_ld, cos_table, sin_table, (bf16_t*)k_cache, (bf16_t*)v_cache,
-                   sl ? sl->slabs : nullptr, sl ? sl->ssp : nullptr, sl ? sl->S : 0, sl ? sl->N : 0, sl ? sl->K : 0, sl ? sl->rms_eps : 0.f};
-    p.key_valid = kv_once; p.key_valid_sb = kv_once_sb;
-    dim3 grid(B * H, nsplit);
-    hipStream_t s = (hipStream_t)stream;
-    if (D == 128) {
-        attn_decode_kernel<128><<<grid, 256, 0, s>>>(p);
-        if (nsplit > 1) attn_decode_combine_kernel<128><<<B * H, 128, 0, s>>>(p);
-    } else {
-        attn_decode_kernel<64><<<grid, 256, 0, s>>>(p);
-        if (nsplit > 1) attn_decode_combine_kernel<64><<<B * H, 64, 0, s>>>(p);
-    }
-    MC_CHECK_LAUNCH();
-    return 0;
-}
-
 extern "C" int mc_attn_decode_rope_bf16(const void* qkv, int64_t qkv_ld, const float* cos_table, const float* sin_table, void* k_cache,
                                         int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
                                         void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
-                                        int nsplit, float scale, void* stream) {
-    return attn_decode_rope_impl(qkv, qkv_ld, nullptr, cos_table, sin_table, k_cache, k_sb, k_st, k_sh, v_cache, v_sb, v_st, v_sh, o, o_sb, workspace,
-                                 kv_lens, B, H, Hkv, S, D, nsplit, scale, stream);
-}
-
-// The same step with the q|k|v projection handed over as the unreduced split-K slabs of its GEMM (mc_gemm_args.defer_reduce)
-extern "C" int mc_attn_decode_rope_slabs_bf16(const mc_slab_ref* qkv_slabs, const float* cos_table, const float* sin_table, void* k_cache,
-                                              int64_t k_sb, int64_t k_st, int64_t k_sh, void* v_cache, int64_t v_sb, int64_t v_st, int64_t v_sh,
-                                              void* o, int64_t o_sb, void* workspace, const int32_t* kv_lens, int B, int H, int Hkv, int S, int D,
-                                              int nsplit, float scale, void* stream) {
-    return attn_decode_rope_impl(nullptr, 0, qkv_slabs, cos_table, sin_table, k_cache, k_sb, k_st, k_sh, v_cache, v_sb, v_st, v_sh, o, o_sb, workspace,
-                                 kv_lens, B, H, Hkv, S, D, nsplit, scale, stream);
+                                        int nsplit, float scale, const mc_attn_mask* mask, void* stream) {
+    MC_CHECK_ARG(qkv && cos_table && sin_table && k_cache && v_cache && o && kv_lens, "mc_attn_decode_rope_bf16: null pointer");
+    MC_CHECK_ARG(D == 64 || D == 128, "mc_attn_decode_rope_bf16: head_dim %d not supported (64 or 128)", D);
+    MC_CHECK_ARG(nsplit >= 1, "mc_attn_decode_rope_bf16: nsplit must be >= 1");
+    MC_CHECK_ARG(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && S > 0 && qkv_ld % 8 == 0, "mc_attn_decode_rope_bf16: bad shape");
+    MC_CHECK_ARG(!mask || mask->b_inner == 0, "mc_attn_decode_rope_bf16: no two-level batch index here");
+    DecodeParams p{nullptr, 0, 0, (const bf16_t*)k_cache, k_sb, k_st, k_sh, (const bf16_t*)v_cache, v_sb, v_st, v_sh,
+                   (bf16_t*)o, o_sb, (float*)workspace, kv_lens, B, H, Hkv, S, nsplit, scale * 1.4426950408889634f,
+                   (const bf16_t*)qkv, qkv_ld, cos_table, sin_table, (bf16_t*)k_cache, (bf16_t*)v_cache};
+    p.key_valid = mask ? (const uint8_t*)mask->key_valid : nullptr; p.key_valid_sb = mask && mask->key_valid ? mask->key_valid_stride : 0;
+    return decode_launch(p, D, nsplit, (hipStream_t)stream, "mc_attn_decode_rope_bf16");
 }

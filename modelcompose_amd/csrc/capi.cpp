@@ -34,30 +34,3 @@ extern "C" int mc_device_info(int* cu_count, int64_t* hbm_bytes, char* arch, int
     if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", pr.gcnArchName);
     return 0;
 }
-
-// HIP streams restricted to a subset of the CUs (hipExtStreamCreateWithCUMask): bit i of the mask = CU i in the driver's enumeration, which
-// deals consecutive bits round-robin over the 8 XCDs (bit i -> XCD i % 8), so a contiguous bit range of a multiple of 8 takes the same number
-// of CUs from every XCD.  first_cu / n_cus select bits [first_cu, first_cu + n_cus).  Used by generate_pipelined's "decode_cus" mode: the
-// HBM-bound decode chain on a few CUs of its own beside the MFMA-bound prefill on the rest.
-extern "C" int mc_stream_create_cu_range(int first_cu, int n_cus, void** stream) {
-    if (!stream || first_cu < 0 || n_cus <= 0) { mc_set_error("mc_stream_create_cu_range: bad arguments"); return 1; }
-    int cus = 0;
-    if (mc_device_info(&cus, nullptr, nullptr, 0)) return 2;
-    if (first_cu + n_cus > cus) { mc_set_error("mc_stream_create_cu_range: CUs [%d, %d) of %d", first_cu, first_cu + n_cus, cus); return 1; }
-    uint32_t mask[32] = {0};
-    const int words = (cus + 31) / 32;
-    if (words > 32) { mc_set_error("mc_stream_create_cu_range: %d CUs", cus); return 1; }
-    for (int i = first_cu; i < first_cu + n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
-    hipStream_t s = nullptr;
-    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
-    if (e != hipSuccess) { mc_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return 2; }
-    *stream = (void*)s;
-    return 0;
-}
-
-extern "C" int mc_stream_destroy(void* stream) {
-    if (!stream) return 0;
-    hipError_t e = hipStreamDestroy((hipStream_t)stream);
-    if (e != hipSuccess) { mc_set_error("hipStreamDestroy: %s", hipGetErrorString(e)); return 2; }
-    return 0;
-}

@@ -253,8 +253,6 @@ extern "C" int mc_add_layernorm_bf16(const void* x, int64_t ldx, const void* tab
 // time is the per-row factor 1/rms (LlamaRMSNorm: variance in fp32 of the bf16 hidden state, multimodal_llama.py:405-406),
 // applied by the GEMM epilogue (Epilogue::row_scale).
 //   rms_scale_kernel     : rs[m] = rsqrt(mean(x[m]^2) + eps)                                  (prefill, after embedding)
-//   residual_rms_kernel  : h[m] = bf16(h[m] + sum_s part[s][m]);  rs[m] as above on the new h  (decode: folds the fp32
-//                          split-K slabs of o_proj / down_proj into the hidden state, multimodal_llama.py:447-466)
 __global__ __launch_bounds__(256) void rms_scale_kernel(const bf16_t* __restrict__ x, int64_t ldx, float* __restrict__ rs, int D, float eps) {
     __shared__ float red[16];
     const int row = blockIdx.x;
@@ -269,45 +267,9 @@ __global__ __launch_bounds__(256) void rms_scale_kernel(const bf16_t* __restrict
     if (threadIdx.x == 0) rs[row] = rsqrtf(s2 / D + eps);
 }
 
-__global__ __launch_bounds__(256) void residual_rms_kernel(bf16_t* __restrict__ h, int64_t ldh, const float* __restrict__ part, int64_t ldp,
-                                                           int n_slabs, int M, float* __restrict__ rs, int D, float eps) {
-    __shared__ float red[16];
-    const int row = blockIdx.x;
-    bf16_t* hr = h + (int64_t)row * ldh;
-    float s2 = 0.f;
-    for (int i = threadIdx.x; i < (D >> 3); i += 256) {
-        const bf16x8 t = *(const bf16x8*)(hr + i * 8);
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        for (int sl = 0; sl < n_slabs; ++sl) {      // fixed order: bitwise reproducible
-            const float* pr = part + ((int64_t)sl * M + row) * ldp + i * 8;
-            a0 += *(const f32x4*)pr;
-            a1 += *(const f32x4*)(pr + 4);
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            o[j] = (bf16_t)((float)t[j] + (j < 4 ? a0[j] : a1[j - 4]));
-            const float f = (float)o[j];
-            s2 += f * f;
-        }
-        *(bf16x8*)(hr + i * 8) = o;
-    }
-    s2 = block_sum(s2, red);
-    if (threadIdx.x == 0 && rs) rs[row] = rsqrtf(s2 / D + eps);
-}
-
 extern "C" int mc_rms_scale_bf16(const void* x, int64_t ldx, float* row_scale, int M, int D, float eps, void* stream) {
     MC_CHECK_ARG(x && row_scale && M > 0 && D > 0 && D % 8 == 0 && ldx % 8 == 0, "mc_rms_scale_bf16: bad arguments (D=%d)", D);
     rms_scale_kernel<<<M, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, row_scale, D, eps);
-    MC_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int mc_residual_rms_bf16(void* h, int64_t ldh, const float* part, int64_t ldp, int n_slabs, float* row_scale, int M, int D,
-                                    float eps, void* stream) {
-    MC_CHECK_ARG(h && part && n_slabs > 0 && M > 0 && D > 0 && D % 8 == 0 && ldh % 8 == 0 && ldp % 4 == 0,
-                 "mc_residual_rms_bf16: bad arguments (D=%d)", D);
-    residual_rms_kernel<<<M, 256, 0, (hipStream_t)stream>>>((bf16_t*)h, ldh, part, ldp, n_slabs, M, row_scale, D, eps);
     MC_CHECK_LAUNCH();
     return 0;
 }

@@ -84,75 +84,7 @@ __global__ void unpack_weight_kernel(const bf16_t* __restrict__ p, bf16_t* __res
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// epilogue shared by both kernels: lane owns out[m][n..n+3]
-// ------------------------------------------------------------------------------------------
-struct Epilogue {
-    const bf16_t* bias;      // [N] or null
-    const bf16_t* residual;  // [M, ldr] or null
-    int64_t ldr;
-    void* out;
-    int64_t ldo;
-    int act;
-    int out_f32;
-    float alpha;             // scale applied to the accumulator before bias
-    float beta;              // scale applied to the residual
-    const float* row_scale;  // [M] fp32 or null: accumulator row m is multiplied by row_scale[m] (RMSNorm 1/rms with the
-                             // norm weight folded into W at compose time: LlamaRMSNorm, multimodal_llama.py:405-406)
-    int swiglu;              // 16-row weight blocks alternate gate/up: out[m][16*(nb/2) + c] = silu(gate) * up (LocalLoraMLP :381-388)
-    float rms_eps;           // > 0 (skinny kernel only): row m is scaled by rsqrt(mean_k x[m][k]^2 + rms_eps), computed from the x fragments the
-                             // kernel streams anyway (LlamaRMSNorm factor without a separate pass; replaces row_scale)
-    // q_out != null (256x256 kernel, 256-column tiles, D = 128): the launch is a prefill's q|k|v projection; a wave's 128 columns are one
-    // head, whose halves d / d + 64 sit in the same lane (acc[0][i] / acc[1][i]): rotate in registers and scatter to q_out / the caches
-    struct Rope {
-        const int32_t* row_b; const int32_t* row_pos; const int32_t* row_t;
-        const float* cosT; const float* sinT;
-        bf16_t* q_out; bf16_t* k_cache; bf16_t* v_cache;
-        int H, Hkv, Lq, Smax;
-    } rope;
-    float* ss_parts;         // non-null (256x256 kernel, wide plain epilogue): ss_parts[m * ss_chunks + n / 128] = sum of squares of the stored
-    int ss_chunks;           // bf16 values of row m in that 128-column chunk (mc_gemm_args.rms_out)
-};
-
-__device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n, f32x4 v) {
-    const float a = e.row_scale ? e.alpha * e.row_scale[m] : e.alpha;
-    float r[4] = {v[0] * a, v[1] * a, v[2] * a, v[3] * a};
-    if (e.bias) {
-        bf16x4 b = *(const bf16x4*)(e.bias + n);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] += (float)b[i];
-    }
-    if (e.act != MC_ACT_NONE) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = mc_act(r[i], e.act);
-    }
-    if (e.residual) {
-        bf16x4 b = *(const bf16x4*)(e.residual + (int64_t)m * e.ldr + n);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] += e.beta * (float)b[i];
-    }
-    if (e.out_f32) {
-        f32x4 o = {r[0], r[1], r[2], r[3]};
-        *(f32x4*)((float*)e.out + (int64_t)m * e.ldo + n) = o;
-    } else {
-        bf16x4 o = {(bf16_t)r[0], (bf16_t)r[1], (bf16_t)r[2], (bf16_t)r[3]};
-        *(bf16x4*)((bf16_t*)e.out + (int64_t)m * e.ldo + n) = o;
-    }
-}
-
-// gate / up accumulators of the same 4 output columns (n_out = column in the [M, N/2] result)
-__device__ __forceinline__ void epilogue_store4_swiglu(const Epilogue& e, int m, int n_out, f32x4 g, f32x4 u) {
-    const float a = e.row_scale ? e.alpha * e.row_scale[m] : e.alpha;
-    bf16x4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        // gate and up are rounded to the storage dtype as the unfused path stores them (the reference's projections return
-        // the model dtype, :381-388); act(gate) * up is evaluated in fp32 and rounded once
-        const float gg = (float)(bf16_t)(g[i] * a), uu = (float)(bf16_t)(u[i] * a);
-        o[i] = (bf16_t)(gg * mc_sigmoid(gg) * uu);
-    }
-    *(bf16x4*)((bf16_t*)e.out + (int64_t)m * e.ldo + n_out) = o;
-}
+#include "gemm_epilogue.h"
 
 // ---- wide epilogue of the 256x256 kernel ------------------------------------------------------------------------------------------
 // A lane of the 16x16x32 accumulator layout owns 4 consecutive columns of a 16-column block (lane = q4*16 + c16: row c16, columns
@@ -602,198 +534,6 @@ __device__ __forceinline__ void g2_epilogue_wide(const Epilogue& ep, f32x4 (&acc
         }
 }
 
-// Everything a 256-row tile does with its accumulators (acc[nh][i][mh][jj]: wave (wave_n, wave_m) owns output columns n0 + 2 NI 16 wave_n ...
-// and rows m0 + 64 wave_m ...) - the epilogue of gemm_tile256_kernel (which keeps its own inlined copy: routing that kernel through this
-// function changed hipcc's register allocation of its main loop, 0 -> 24 spilled VGPRs) as a function, for gemm_tile2_kernel.
-template <int ABL, int NI, int WN = 2>
-__device__ __forceinline__ void g2_epilogue_all(const Epilogue& ep, f32x4 (&acc)[2][4][2][2], int m0, int n0, int M, int N, int wave_m, int wave_n,
-                                                int c16, int q4) {
-    constexpr int NT = NI * 32 * WN;              // tile width: WN wave columns of 2 NI 16 weight rows
-    // Epilogue.  bf16 outputs whose tile lies inside N take the wide path (16-byte stores of block pairs, the row factor loaded once per
-    // row, ALL residual values of the lane requested before the first store: one exposed memory latency per tile instead of one per row -
-    // a workgroup owns its CU, so nothing else runs while its epilogue waits); everything else the 8-byte path.
-    const bool wide = !ep.out_f32 && (n0 + NT <= N) && (ep.ldo % 8 == 0) && ((uintptr_t)ep.out % 16 == 0) && (NI % 2 == 0);
-    if constexpr (NI == 4) {
-        if (wide && ep.rope.q_out) {
-            // RoPE + scatter (what rope_kv_kernel does to the stored q|k|v row): the values are rounded to bf16 first, exactly as the unfused
-            // route stores them, then rotated in fp32 and rounded again.  A wave's 128 columns are one head.
-            const Epilogue::Rope& rp = ep.rope;
-            const int nw = n0 + wave_n * 128;
-            const int head = nw >> 7;
-            const bool rot = head < rp.H + rp.Hkv;
-#pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
-                    const bool live = m < M;
-                    const int mc = live ? m : (M - 1);
-                    const float a = ep.row_scale ? ep.alpha * ep.row_scale[mc] : ep.alpha;
-                    const int b = rp.row_b[mc], pos = rp.row_pos[mc], tq = rp.row_t[mc];
-                    const bool put = live && b >= 0;
-                    bf16_t* drow;
-                    if (head < rp.H) drow = rp.q_out + ((int64_t)(b * rp.Lq + tq) * rp.H + head) * 128;
-                    else if (rot) drow = rp.k_cache + (((int64_t)b * rp.Hkv + (head - rp.H)) * rp.Smax + pos) * 128;
-                    else drow = rp.v_cache + (((int64_t)b * rp.Hkv + (head - rp.H - rp.Hkv)) * rp.Smax + pos) * 128;
-                    const float* cr = rp.cosT + (int64_t)pos * 64 + q4 * 4;
-                    const float* sr = rp.sinT + (int64_t)pos * 64 + q4 * 4;
-                    bf16x4 v1[4], v2[4];                   // block i: first-half / second-half values of d = 16 i + 4 q4 ..
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v1[i] = epilogue_vals4<0, -1, 0>(ep, a, nw + i * 16 + q4 * 4, acc[0][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
-                        v2[i] = epilogue_vals4<0, -1, 0>(ep, a, nw + 64 + i * 16 + q4 * 4, acc[1][i][mh][jj], false, (bf16x4){0, 0, 0, 0});
-                    }
-                    if (rot) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const f32x4 c = *(const f32x4*)(cr + i * 16), sn = *(const f32x4*)(sr + i * 16);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                float r1, r2;
-                                mc_rope_pair((float)v1[i][j], (float)v2[i][j], c[j], sn[j], r1, r2);
-                                v1[i][j] = (bf16_t)r1; v2[i][j] = (bf16_t)r2;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i += 2) {
-                        u32x2 pa = __builtin_bit_cast(u32x2, v1[i]), pb = __builtin_bit_cast(u32x2, v1[i + 1]);
-                        auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
-                        auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
-                        const u32x4 o1 = {r0[0], r1[0], r0[1], r1[1]};
-                        if (put) *(u32x4*)(drow + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o1;
-                        pa = __builtin_bit_cast(u32x2, v2[i]); pb = __builtin_bit_cast(u32x2, v2[i + 1]);
-                        r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
-                        r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
-                        const u32x4 o2 = {r0[0], r1[0], r0[1], r1[1]};
-                        if (put) *(u32x4*)(drow + 64 + i * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o2;
-                    }
-                }
-            return;
-        }
-    }
-    const bool has_res = wide && !ep.swiglu && ep.residual != nullptr;
-    const int actc = ep.act == MC_ACT_NONE ? 0 : ((ep.act == MC_ACT_QUICK_GELU || ep.act == MC_ACT_SILU) ? 1 : (ep.act == MC_ACT_GELU ? 3 : 2));
-    const float act_k = ep.act == MC_ACT_QUICK_GELU ? 1.702f : 1.0f;
-    bf16x4 res[2][2][2][NI];
-    // residual rows in 16-byte loads (round 3): the lane reads the 8 columns it will STORE (the layout behind the epilogue's
-    // v_permlane16_swap) and swaps them back into the accumulator layout - the exchange is its own inverse; half the load instructions
-    const bool res16 = has_res && NI % 2 == 0 && ep.ldr % 8 == 0 && ((uintptr_t)ep.residual % 16 == 0) && !(ABL & 1024);
-    if (res16) {
-        if constexpr (NI % 2 == 0) {
-#pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int mc = min(m0 + wave_m * 64 + mh * 32 + jj * 16 + c16, M - 1);
-                    const bf16_t* rrow = ep.residual + (int64_t)mc * ep.ldr + n0 + wave_n * (2 * NI * 16) + (q4 & 1) * 16 + (q4 >> 1) * 8;
-#pragma unroll
-                    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                        for (int i = 0; i < NI; i += 2) {
-                            const u32x4 v = *(const u32x4*)(rrow + nh * (NI * 16) + i * 16);
-                            auto r0 = __builtin_amdgcn_permlane16_swap(v[0], v[2], false, false);
-                            auto r1 = __builtin_amdgcn_permlane16_swap(v[1], v[3], false, false);
-                            const u32x2 lo = {r0[0], r1[0]}, hi = {r0[1], r1[1]};
-                            res[mh][jj][nh][i] = __builtin_bit_cast(bf16x4, lo);
-                            res[mh][jj][nh][i + 1] = __builtin_bit_cast(bf16x4, hi);
-                        }
-                }
-        }
-    } else if (has_res) {
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int mc = min(m0 + wave_m * 64 + mh * 32 + jj * 16 + c16, M - 1);
-                const bf16_t* rrow = ep.residual + (int64_t)mc * ep.ldr + n0 + wave_n * (2 * NI * 16) + q4 * 4;
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) res[mh][jj][nh][i] = *(const bf16x4*)(rrow + nh * (NI * 16) + i * 16);
-            }
-    }
-    if constexpr (NI % 2 == 0) {
-        if (wide && !ep.swiglu) {
-            // the common combinations get their own straight-line instantiation; the rest decide bias / residual per call
-#define G2_EPI(A, B, R) g2_epilogue_wide<A, B, R, NI>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k)
-            const bool hb = ep.bias != nullptr;
-            if (ep.ss_parts && NI == 4 && actc == 0 && !hb && has_res) g2_epilogue_wide<0, 0, 1, NI, true>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);   // LLM o / down + next norm's factor
-            else if (ep.ss_parts && NI == 4 && actc == 0) g2_epilogue_wide<0, -1, -1, NI, true>(ep, acc, res, has_res, m0, n0, M, wave_m, wave_n, c16, q4, act_k);
-            else if (actc == 0 && !hb && !has_res) G2_EPI(0, 0, 0);            // LLM q|k|v (without the RoPE route), plain projections
-            else if (actc == 0 && !hb && has_res) G2_EPI(0, 0, 1);        // LLM o / down
-            else if (actc == 0 && hb && !has_res) G2_EPI(0, 1, 0);        // encoder q|k|v
-            else if (actc == 0 && hb && has_res) G2_EPI(0, 1, 1);         // encoder out / fc2
-            else if (actc == 1 && hb && !has_res) G2_EPI(1, 1, 0);        // encoder fc1 (QuickGELU)
-            else if (actc == 1) G2_EPI(1, -1, -1);
-            else if (actc == 3) G2_EPI(3, -1, -1);                        // BEATs / point-cloud fc1 (exact GELU)
-            else G2_EPI(2, -1, -1);
-#undef G2_EPI
-            return;
-        }
-    }
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int m = m0 + wave_m * 64 + mh * 32 + jj * 16 + c16;
-            const bool live = m < M;                   // depends on c16 only: the lane pairs of a swap are live together
-            const int mc = live ? m : (M - 1);
-            if (wide) {
-                const float a = ep.row_scale ? ep.alpha * ep.row_scale[mc] : ep.alpha;
-                if (ep.swiglu) {
-                    // gate / up blocks alternate along N: input blocks (f, f+1) -> output block f/2; output blocks f/2 and f/2+1 are adjacent
-                    bf16_t* orow = (bf16_t*)ep.out + (int64_t)mc * ep.ldo + ((n0 + wave_n * (2 * NI * 16)) >> 1);
-#pragma unroll
-                    for (int f = 0; f < 2 * NI; f += 4) {
-                        const bf16x4 lo = swiglu_vals4(a, acc[f / NI][f % NI][mh][jj], acc[(f + 1) / NI][(f + 1) % NI][mh][jj]);
-                        const bf16x4 hi = swiglu_vals4(a, acc[(f + 2) / NI][(f + 2) % NI][mh][jj], acc[(f + 3) / NI][(f + 3) % NI][mh][jj]);
-                        u32x2 pa = __builtin_bit_cast(u32x2, lo), pb = __builtin_bit_cast(u32x2, hi);
-                        auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
-                        auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
-                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                        if (live) *(u32x4*)(orow + (f >> 1) * 16 + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
-                    }
-                    continue;
-                }
-                const int nw = n0 + wave_n * (2 * NI * 16);
-                bf16_t* orow = (bf16_t*)ep.out + (int64_t)mc * ep.ldo + nw;
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                    for (int i = 0; i < NI; i += 2) {
-                        const int nb = nh * (NI * 16) + i * 16;
-                        const bf16x4 lo = epilogue_vals4(ep, a, nw + nb + q4 * 4, acc[nh][i][mh][jj], has_res, res[mh][jj][nh][i]);
-                        const bf16x4 hi = epilogue_vals4(ep, a, nw + nb + 16 + q4 * 4, acc[nh][i + 1][mh][jj], has_res, res[mh][jj][nh][i + 1]);
-                        u32x2 pa = __builtin_bit_cast(u32x2, lo), pb = __builtin_bit_cast(u32x2, hi);
-                        auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
-                        auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
-                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                        if (live) *(u32x4*)(orow + nb + (q4 & 1) * 16 + (q4 >> 1) * 8) = o;
-                    }
-                continue;
-            }
-            if (!live) continue;
-            if (ep.swiglu) {
-                // gate / up blocks alternate along N: consecutive block pairs of this wave's 2*NI blocks (a pair may straddle the nh halves
-                // when NI is odd; both halves are this lane's registers)
-#pragma unroll
-                for (int f = 0; f < 2 * NI; f += 2) {
-                    const int n = n0 + wave_n * (2 * NI * 16) + f * 16;
-                    if (n + 16 < N) epilogue_store4_swiglu(ep, m, (n >> 1) + q4 * 4, acc[f / NI][f % NI][mh][jj], acc[(f + 1) / NI][(f + 1) % NI][mh][jj]);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int n = n0 + wave_n * (2 * NI * 16) + nh * (NI * 16) + i * 16 + q4 * 4;
-                    if (n < N) epilogue_store4(ep, m, n, acc[nh][i][mh][jj]);
-                }
-        }
-}
-
 // rows of one launch may belong to several adapter groups (routed LocalLoRA order): group g owns rows [row_start[g], row_start[g+1])
 // = m-tiles [tile_start[g], tile_start[g+1]) and multiplies against its own composed weight
 struct G2Groups {
@@ -1186,622 +926,6 @@ __global__ __launch_bounds__(512, (ABL & 16) ? 1 : 2) void gemm_tile256_kernel(c
         }
 }
 
-// ------------------------------------------------------------------------------------------
-// large-M kernel, second tile economy (round 5): 256 (tokens) x 128 (weight rows) x 32 tiles, 4 waves, TWO workgroups per CU
-// ------------------------------------------------------------------------------------------
-// gemm_tile256_kernel owns its CU (8 waves x 256 registers, 128 KiB of LDS): while a tile's epilogue drains its 128 KiB of stores at the
-// CU's store rate (14-16 B/clk: 4.3-4.9 us) and the next tile's prologue waits for its first K-tiles, the matrix pipe idles - 7 % of a
-// K = 4096 tile, 28 % at K = 1024 (the encoder shapes) - and a persistent form that would overlap them does not fit the register file
-// (DESIGN.md §4).  Here two INDEPENDENT workgroups share a CU (4 waves x 256 registers and 72 KiB of LDS each): one's epilogue / prologue /
-// barrier wait runs beside the other's main loop with no schedule to hand-align, at the price of 1.5x the LDS-DMA bytes per FLOP
-// ((1/256 + 1/128) against 2/256).
-//   wave w: rows m0 + 64 w .. + 63, all 128 columns - the per-wave tile (and so the accumulator layout, acc[nh][i][mh][jj], and every
-//           epilogue: g2_epilogue_all) of gemm_tile256_kernel; results are bit-identical (same 16x16x32 MFMA chain over k per element).
-//   LDS:    3 stages x (W 8 KiB | X 16 KiB), one stage = one 32-deep K-step.  W: the packed weight's 1-KiB fragment blocks as they lie in
-//           HBM (8 pieces, 2 per wave, read back lane-linear).  X: 16 rows x 64 bytes per 1-KiB piece (4 per wave - the wave's OWN rows),
-//           16-byte chunk c of row r stored in slot c ^ (2 * ((r >> 3) & 1)): the 16-lane groups of a ds_read_b128 then cover all 64 banks.
-//   loop:   [counted vmcnt: step t landed] s_barrier [6 LDS-DMA for step t + 2] [12 fragment reads] [32 MFMA]   - one barrier per K-step,
-//           two steps of DMA in flight across it (never vmcnt(0) in the loop).
-#define T2_STAGE 24576
-#define T2_XOFF 8192
-
-template <int ABL>
-__global__ __launch_bounds__(256, 2) void gemm_tile2_kernel(const bf16_t* __restrict__ x, int64_t ldx, G2Groups grp, int N, int K, Epilogue ep,
-                                                            int tiles_m, int tiles_n, int raster) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c16 = lane & 15, q4 = lane >> 4;
-    const int nwg = tiles_m * tiles_n;
-    int tm, tn;
-    g2_map_tile(blockIdx.x, nwg, tiles_m, tiles_n, raster, tm, tn);
-    int m0, M;
-    const bf16_t* wp;
-    g2_group_of(grp, tm, m0, M, wp);
-    const int n0 = tn * 128;
-    const int kblocks = K >> 5;
-    const int nblocks = (N + 15) >> 4;
-    const int nt = K >> 5;                        // K-steps of 32
-
-    // per-lane DMA sources (byte offsets at K-step 0) - W pieces 2w, 2w + 1 of the stage's 8; X pieces 4w .. 4w + 3 of its 16 (own rows)
-    const char* wbase = (const char*)wp;
-    const char* xbase = (const char*)x;
-    uint32_t wsrc[2], xsrc[4];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int nb = min((n0 >> 4) + wave * 2 + e, nblocks - 1);
-        wsrc[e] = (uint32_t)(((int64_t)nb * kblocks * 512 + lane * 8) * 2);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = wave * 64 + r * 16 + (lane >> 2);
-        const int ch = (lane & 3) ^ (((lane >> 5) & 1) << 1);                 // slot (lane & 3) of row (lane >> 2) holds chunk slot ^ 2 * ((row >> 3) & 1)
-        xsrc[r] = (uint32_t)(((int64_t)min(m0 + row, M - 1) * ldx + ch * 8) * 2);
-    }
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-    auto stage = [&](int t) {                     // K-step t -> stage t % 3
-        const uint32_t sb = lds0 + (uint32_t)((t % 3) * T2_STAGE);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) g2_dma16s(wbase + (int64_t)t * 1024, wsrc[e], sb + (uint32_t)((wave * 2 + e) * 1024));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g2_dma16s(xbase + (int64_t)t * 64, xsrc[r], sb + (uint32_t)(T2_XOFF + (wave * 4 + r) * 1024));
-    };
-    // fragment read offsets inside a stage
-    const int woff = lane * 16;
-    const int xoff = T2_XOFF + wave * 4096 + c16 * 64 + ((q4 ^ (((c16 >> 3) & 1) << 1)) * 16);
-
-    f32x4 acc[2][4][2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    stage(0);
-    if (nt > 1) stage(1);
-    __builtin_amdgcn_s_waitcnt(0xC07F);           // every scalar (kernel-argument) load retired before the loop (see gemm_tile256_kernel)
-    for (int t = 0; t < nt; ++t) {
-        // step t has landed when at most step t + 1's six pieces are still in flight
-        if (t + 1 < nt) g2_waitvm<6>(); else g2_waitvm<0>();
-        __builtin_amdgcn_s_barrier();             // every wave's W pieces of step t are in; every wave has finished reading step t - 1
-        // placement of the step's six LDS-DMA instructions (A/B builds, same results): ABL & 3 = 0 in front of the fragment reads, 1 behind
-        // them, 2 inside the MFMA stream (one behind every fifth MFMA)
-        const bool more = t + 2 < nt;
-        if ((ABL & 3) == 0 && more) stage(t + 2);             // into the stage step t - 1 was read from
-        const char* sb = smem + (t % 3) * T2_STAGE;
-        bf16x8 wf[2][4], xf[2][2];
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) xf[mh][jj] = *(const bf16x8*)(sb + xoff + (mh * 2 + jj) * 1024);
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wf[nh][i] = *(const bf16x8*)(sb + woff + (nh * 4 + i) * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        if ((ABL & 3) == 1 && more) stage(t + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        const uint32_t sb2 = lds0 + (uint32_t)(((t + 2) % 3) * T2_STAGE);
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) acc[nh][i][mh][jj] = mc_mfma_16x16x32(wf[nh][i], xf[mh][jj], acc[nh][i][mh][jj]);
-                if ((ABL & 3) == 2 && more) {
-                    const int c = nh * 4 + i;                  // 8 groups of four MFMAs: a DMA behind groups 1 .. 6
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (c == 1 || c == 2) g2_dma16s(wbase + (int64_t)(t + 2) * 1024, wsrc[c - 1], sb2 + (uint32_t)((wave * 2 + c - 1) * 1024));
-                    else if (c >= 3 && c <= 6) g2_dma16s(xbase + (int64_t)(t + 2) * 64, xsrc[c - 3], sb2 + (uint32_t)(T2_XOFF + (wave * 4 + c - 3) * 1024));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    g2_epilogue_all<ABL, 4, 1>(ep, acc, m0, n0, M, N, wave, 0, c16, q4);
-}
-
-#define SK_WAVES 8
-
-// ------------------------------------------------------------------------------------------
-// skinny kernel (M <= 64, HBM-bound): R weight block-rows per workgroup, K split over the 8 waves, optional K split over workgroups
-// ------------------------------------------------------------------------------------------
-// The activation fragment of a k-step is loaded once and used against R weight fragments, so the L2->CU traffic for x
-// drops to 1/R of the weight stream (with R = 1 it equals the weight bytes at M = 16 and caps the kernel at ~4.4 TB/s).
-// Shapes with few block-rows (N = 4096: 256) keep all CUs streaming by splitting K over `gridDim.y` workgroups; slice s
-// stores its fp32 partial sums (whole 256-byte row segments per wave instruction) in slab s of out[split_k][M][ldo], and
-// the next kernel (mc_residual_rms_bf16) adds the slabs in a fixed order into the hidden state: deterministic, no atomics.
-template <int MB, int R>
-__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny2_kernel(const bf16_t* __restrict__ x, int64_t ldx,
-                                                                     const bf16_t* __restrict__ wp, int M, int N, int K,
-                                                                     Epilogue ep, int partial) {
-    // cross-wave reduction buffer: one slot per wave up to R * MB = 8 (64 KiB); above that the upper four waves hand their sums to the
-    // lower four first (FOLD), so the buffer stays at 4 slots (48 KiB at R * MB = 12) and two workgroups still share a CU
-    constexpr bool FOLD = R * MB > 8;
-    constexpr int RW = FOLD ? SK_WAVES / 2 : SK_WAVES;
-    __shared__ __attribute__((aligned(16))) float red[RW][R][MB][64][4];
-    constexpr int U = (R * MB >= 8) ? 1 : ((R * MB >= 4) ? 2 : (R * MB >= 2 ? 4 : 8));
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb0 = blockIdx.x * R;
-    const int kblocks = K >> 5, nblocks = (N + 15) >> 4;
-    const int per_slice = (kblocks + gridDim.y - 1) / gridDim.y;
-    const int ks0 = blockIdx.y * per_slice, ks1 = min(ks0 + per_slice, kblocks);
-    const int per = (ks1 - ks0 + SK_WAVES - 1) / SK_WAVES;
-    const int kb0 = min(ks0 + wave * per, ks1);
-    const int kb1 = min(kb0 + per, ks1);
-    const int c16 = lane & 15, q4 = lane >> 4;
-
-    const bf16_t* wptr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) wptr[r] = wp + ((int64_t)min(nb0 + r, nblocks - 1) * kblocks + kb0) * 512 + lane * 8;
-    const bf16_t* xptr[MB];
-#pragma unroll
-    for (int b = 0; b < MB; ++b) xptr[b] = x + (int64_t)min(b * 16 + c16, M - 1) * ldx + kb0 * 32 + q4 * 8;
-    constexpr int xstep = 32;
-    f32x4 acc[R][MB];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int b = 0; b < MB; ++b) acc[r][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float ss[MB];                                  // this lane's share of sum_k x[m][k]^2 (row m = 16 b + c16, its 8-element k pieces)
-#pragma unroll
-    for (int b = 0; b < MB; ++b) ss[b] = 0.f;
-    auto sumsq = [&](const bf16x8& v, float& a) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; a = fmaf(f, f, a); }
-    };
-
-    int kb = kb0;
-    for (; kb + U <= kb1; kb += U) {
-        bf16x8 wf[U][R], xf[U][MB];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int r = 0; r < R; ++r) wf[u][r] = __builtin_nontemporal_load((const bf16x8*)(wptr[r] + u * 512));
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int b = 0; b < MB; ++b) xf[u][b] = *(const bf16x8*)(xptr[b] + u * xstep);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int b = 0; b < MB; ++b) acc[r][b] = mc_mfma_16x16x32(wf[u][r], xf[u][b], acc[r][b]);
-        // (unconditional: a branch in the streaming loop costs the load pipelining far more than these 8 FMAs per fragment)
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int b = 0; b < MB; ++b) sumsq(xf[u][b], ss[b]);
-#pragma unroll
-        for (int r = 0; r < R; ++r) wptr[r] += U * 512;
-#pragma unroll
-        for (int b = 0; b < MB; ++b) xptr[b] += U * xstep;
-    }
-    for (; kb < kb1; ++kb) {
-        bf16x8 xf[MB];
-#pragma unroll
-        for (int b = 0; b < MB; ++b) { xf[b] = *(const bf16x8*)(xptr[b]); xptr[b] += xstep; }
-#pragma unroll
-        for (int b = 0; b < MB; ++b) sumsq(xf[b], ss[b]);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            bf16x8 wf = __builtin_nontemporal_load((const bf16x8*)wptr[r]);
-            wptr[r] += 512;
-#pragma unroll
-            for (int b = 0; b < MB; ++b) acc[r][b] = mc_mfma_16x16x32(wf, xf[b], acc[r][b]);
-        }
-    }
-    if constexpr (FOLD) {
-        if (wave >= RW) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave - RW][r][b][lane][0] = acc[r][b];
-        }
-        __syncthreads();
-        if (wave < RW) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int b = 0; b < MB; ++b) acc[r][b] += *(f32x4*)&red[wave][r][b][lane][0];
-        }
-        __syncthreads();
-    }
-    if (wave < RW) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave][r][b][lane][0] = acc[r][b];
-    }
-    __shared__ float redss[SK_WAVES][MB][16];
-    if (ep.rms_eps > 0.f) {
-#pragma unroll
-        for (int b = 0; b < MB; ++b) {
-            float v = ss[b];
-            v += __shfl_xor(v, 16, 64);                       // the four k pieces (q4) of the row
-            v += __shfl_xor(v, 32, 64);
-            if (q4 == 0) redss[wave][b][c16] = v;
-        }
-    }
-    __syncthreads();
-    // row factor of row m = 16 b + c16 (the row every epilogue below gives this lane): waves summed in fixed order
-    auto row_factor = [&](int b) -> float {
-        if (!(ep.rms_eps > 0.f)) return 1.0f;
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < SK_WAVES; ++w) t += redss[w][b][c16];
-        return rsqrtf(t / (float)K + ep.rms_eps);
-    };
-    if (partial) {
-        // element (m, nl) of the [16*MB, 16*R] tile lives at red[w][nl>>4][m>>4][lane = (c>>2)<<4 | (m&15)][c&3], c = nl & 15;
-        // consecutive threads take consecutive columns of one row: contiguous 256-byte segments
-        const int cols = R * 16;
-        for (int e = tid; e < MB * 16 * cols; e += SK_WAVES * 64) {
-            const int m = e / cols, nl = e - m * cols;
-            const int n = nb0 * 16 + nl;
-            if (m >= M || n >= N) continue;
-            const int c = nl & 15;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < RW; ++w) v += red[w][nl >> 4][m >> 4][((c >> 2) << 4) | (m & 15)][c & 3];
-            const float a = ep.row_scale ? ep.alpha * ep.row_scale[m] : ep.alpha;
-            ((float*)ep.out)[((int64_t)blockIdx.y * M + m) * ep.ldo + n] = v * a;
-        }
-        return;
-    }
-    if (ep.swiglu) {
-        for (int p = wave; p < (R / 2) * MB; p += SK_WAVES) {
-            const int rp = p / MB, b = p - rp * MB;
-            f32x4 g = *(f32x4*)&red[0][2 * rp][b][lane][0], u = *(f32x4*)&red[0][2 * rp + 1][b][lane][0];
-#pragma unroll
-            for (int w = 1; w < RW; ++w) {
-                g += *(f32x4*)&red[w][2 * rp][b][lane][0];
-                u += *(f32x4*)&red[w][2 * rp + 1][b][lane][0];
-            }
-            const int m = b * 16 + c16;
-            const int nb = nb0 + 2 * rp;
-            Epilogue e2 = ep;
-            e2.alpha = ep.alpha * row_factor(b);
-            if (m < M && (nb + 1) * 16 < N) epilogue_store4_swiglu(e2, m, (nb >> 1) * 16 + q4 * 4, g, u);
-        }
-        return;
-    }
-    for (int p = wave; p < R * MB; p += SK_WAVES) {
-        const int r = p / MB, b = p - r * MB;
-        f32x4 s = *(f32x4*)&red[0][r][b][lane][0];
-#pragma unroll
-        for (int w = 1; w < RW; ++w) s += *(f32x4*)&red[w][r][b][lane][0];
-        const int m = b * 16 + c16;
-        const int n = (nb0 + r) * 16 + q4 * 4;
-        Epilogue e2 = ep;
-        e2.alpha = ep.alpha * row_factor(b);
-        if (m < M && n < N) epilogue_store4(e2, m, n, s);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// rows kernel (16 < M <= 64): activations shared through LDS, one weight block-row stream per wave, K split over workgroups
-// ------------------------------------------------------------------------------------------
-// The skinny kernel above gives every workgroup the whole of x: with 256 workgroups that is 256 x M x K x 2 bytes of L2 -> CU traffic on
-// the SAME lines at the same time (three times the weight bytes at M = 48 for o_proj, all of it queued on the few L2 channels that hold
-// the current k range), and its K-split over waves leaves each wave a handful of dependent round trips: measured 1.7 - 3.0 TB/s at M = 48
-// against 3.4 - 5.2 TB/s at M = 16.  Here a workgroup owns 8 RW block-rows (wave w: rows RW (8 g + w) ...) and one K slice of the grid's
-// S: the slice's x tiles (128 columns at a time) are loaded once per workgroup with whole-line reads, kept in LDS in MFMA fragment order
-// (double buffered, one barrier per tile) and read by all 8 waves, while every wave streams its own weight fragments with 4 RW KiB in
-// flight (each register is reloaded for the next tile right after its MFMAs).  x traffic drops to 1/S of the skinny kernel's and different
-// slices read different lines.  With S > 1 the fp32 partial sums go to slabs [S][M][N] and rows_reduce_kernel adds them in slice order
-// (deterministic) and applies the epilogue.  The RMS factor (rms_eps) comes from the x tiles as they are staged: each element is squared
-// once per workgroup; with S > 1 the slice sums are combined by the reduce kernel, in slice order.
-// Round 5: the slab fold INSIDE the launch ("rows_fold", cnt != nullptr).  Every workgroup of a split launch writes its partial sums with
-// sc1 stores, waits for them (s_waitcnt vmcnt(0) in every storing wave, then the workgroup barrier), and one lane adds 1 to the row group's
-// counter with an agent-scope atomic; the workgroup whose add returns S - 1 is the last of its group: its waves read ALL S slabs of the group
-// with sc1 loads (behind the barrier the adding wave joins), sum them in slice order and run the epilogue - the protocol MI355X_MICROARCH.md
-// lists as measured-valid without fences (table "hand-offs measured with sc1 loads", first row: one agent-scope add per storing workgroup, the
-// last adder consumes; hipMalloc memory; one workgroup per CU - enforced here by an LDS pad).  Same sums in the same order as
-// rows_reduce_kernel: bit-identical outputs, one launch less per GEMM (the fence-based fold of round 2 cost 2 - 10 x: no fence here).
-__device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st_sc1_f(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ f32x4 ld_sc1(const float* p) {          // the caller waits (s_waitcnt vmcnt) before it uses the value
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ float ld_sc1_f(const float* p) {
-    float v;
-    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
-constexpr int kFoldMaxS = 8;                 // = kRowsMaxSplit (host side)
-
-template <int MB, int RW, int KT>
-__global__ __launch_bounds__(512) void gemm_rows_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, int M, int N,
-                                                        int K, Epilogue ep, float* __restrict__ slabs, float* __restrict__ ssp,
-                                                        float* __restrict__ ssp_g, unsigned int* __restrict__ cnt) {
-    __shared__ __attribute__((aligned(16))) bf16x8 xs[2][KT][MB][64];
-    __shared__ float rowss[MB * 16];
-    __shared__ int last_flag;
-    constexpr int CH = KT * 4;                             // 16-byte chunks per tile row (KT k-blocks of 32 columns)
-    constexpr int RPP = 512 / CH;                          // rows per staging pass
-    constexpr int XP = (MB * 16 + RPP - 1) / RPP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c16 = lane & 15, q4 = lane >> 4;
-    const int kblocks = K >> 5, nblocks = (N + 15) >> 4;
-    const int S = gridDim.y, y = blockIdx.y;
-    const int tiles = kblocks / KT;
-    const int t0 = (int)((int64_t)tiles * y / S), t1 = (int)((int64_t)tiles * (y + 1) / S);
-    const int nb0 = (blockIdx.x * 8 + wave) * RW;
-
-    // staging role: row srow (+ RPP per pass), 16-byte chunk sch of the tile's row segment (k-block sch >> 2, quarter sch & 3).
-    // slot of (k-block kb, quarter q, row c) inside its 64-slot fragment block: 16 q + ((c + 4 q + kb) & 15) - a bijection per block, so
-    // the fragment read below (lane (q4, c16) takes the slot of (kb, q4, c16)) touches every bank once per 16 lanes, and so does the
-    // staging write (the 16 chunks of a row differ in 4 q + kb)
-    const int srow = tid / CH, sch = tid % CH;
-    const int skb = sch >> 2, sq = sch & 3;
-    const bf16_t* xsrc[XP];
-    int sdst[XP];
-    bool sact[XP];
-#pragma unroll
-    for (int p = 0; p < XP; ++p) {
-        const int row = p * RPP + srow;
-        sact[p] = row < MB * 16;
-        xsrc[p] = x + (int64_t)min(row, M - 1) * ldx + (int64_t)t0 * (KT * 32) + sch * 8;
-        sdst[p] = (skb * MB + (row >> 4)) * 64 + sq * 16 + (((row & 15) + 4 * sq + skb) & 15);
-    }
-    float ssl[XP];
-#pragma unroll
-    for (int p = 0; p < XP; ++p) ssl[p] = 0.f;
-    int rslot[KT];
-#pragma unroll
-    for (int kb = 0; kb < KT; ++kb) rslot[kb] = q4 * 16 + ((c16 + 4 * q4 + kb) & 15);
-
-    const bf16_t* wptr[RW];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) wptr[r] = wp + ((int64_t)min(nb0 + r, nblocks - 1) * kblocks + (int64_t)t0 * KT) * 512 + lane * 8;
-
-    f32x4 acc[RW][MB];
-#pragma unroll
-    for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int b = 0; b < MB; ++b) acc[r][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 xr[XP];
-    auto stage_load = [&]() {
-#pragma unroll
-        for (int p = 0; p < XP; ++p)
-            if (sact[p]) { xr[p] = *(const bf16x8*)xsrc[p]; xsrc[p] += KT * 32; }
-    };
-    auto stage_store = [&](int buf) {
-        bf16x8* dst = &xs[buf][0][0][0];
-#pragma unroll
-        for (int p = 0; p < XP; ++p)
-            if (sact[p]) {
-                dst[sdst[p]] = xr[p];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)xr[p][j]; ssl[p] = fmaf(f, f, ssl[p]); }
-            }
-    };
-    bf16x8 wf[KT][RW];
-    if (t0 < t1) {
-#pragma unroll
-        for (int kb = 0; kb < KT; ++kb)
-#pragma unroll
-            for (int r = 0; r < RW; ++r) wf[kb][r] = __builtin_nontemporal_load((const bf16x8*)(wptr[r] + kb * 512));
-        stage_load();
-        stage_store(0);
-    }
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-        const int buf = (t - t0) & 1;
-        const bool more = t + 1 < t1;
-        if (more) stage_load();
-#pragma unroll
-        for (int r = 0; r < RW; ++r) wptr[r] += KT * 512;
-#pragma unroll
-        for (int kb = 0; kb < KT; ++kb) {
-            bf16x8 xf[MB];
-#pragma unroll
-            for (int b = 0; b < MB; ++b) xf[b] = xs[buf][kb][b][rslot[kb]];
-#pragma unroll
-            for (int r = 0; r < RW; ++r)
-#pragma unroll
-                for (int b = 0; b < MB; ++b) acc[r][b] = mc_mfma_16x16x32(wf[kb][r], xf[b], acc[r][b]);
-            if (more) {
-#pragma unroll
-                for (int r = 0; r < RW; ++r) wf[kb][r] = __builtin_nontemporal_load((const bf16x8*)(wptr[r] + kb * 512));
-            }
-        }
-        if (more) stage_store(buf ^ 1);
-        __syncthreads();
-    }
-
-    // sum of squares of this slice's part of every row: the 16 chunk lanes of a row sit in one 16-lane group
-    const bool want_rms = ep.rms_eps > 0.f;
-    if (want_rms) {
-#pragma unroll
-        for (int p = 0; p < XP; ++p) {
-            float v = ssl[p];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (CH == 32) v += __shfl_xor(v, 16, 64);
-            if (sact[p] && sch == 0) rowss[p * RPP + srow] = v;
-        }
-    }
-    if (S > 1) {
-        // partial sums of slice y into slab y (16 floats per lane quarter and row); rows_reduce_kernel adds the slabs in slice order and
-        // applies the epilogue.  (A last-arriver fold inside this kernel was measured 2 - 10x slower: device-scope release / acquire
-        // fences write back and invalidate the XCD's whole L2 on this multi-die part.)
-        const bool fold = cnt != nullptr;
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int b = 0; b < MB; ++b) {
-                const int m = b * 16 + c16, n = (nb0 + r) * 16 + q4 * 4;
-                float* sp = slabs + ((int64_t)y * M + m) * N + n;
-                if (m < M && n < N) { if (fold) st_sc1(sp, acc[r][b]); else *(f32x4*)sp = acc[r][b]; }
-            }
-        if (!fold) {
-            if (want_rms && blockIdx.x == 0) {             // every row group squares the same x slice: group 0 reports it
-                __syncthreads();
-                if (tid < MB * 16) ssp[y * 64 + tid] = rowss[tid];
-            }
-            return;
-        }
-        // ---- fold inside the launch
-        if (want_rms) {                                    // this group's own copy of the slice's sums of squares (its last workgroup reads them)
-            __syncthreads();
-            if (tid < MB * 16) st_sc1_f(ssp_g + ((int64_t)blockIdx.x * S + y) * 64 + tid, rowss[tid]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier the signalling lane waits behind
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(cnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == (unsigned)(S - 1);
-            if (last) __hip_atomic_store(cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch on this stream
-            last_flag = last;
-        }
-        __syncthreads();
-        if (!last_flag) return;
-        // every load of the hand-off is issued before the first wait (slices in batches of four: one memory round trip per batch, not per slice);
-        // the sums run in slice order whatever order the data arrives in
-        float facf[MB];
-        float ssq[kFoldMaxS][MB];
-        if (want_rms) {
-#pragma unroll
-            for (int k = 0; k < kFoldMaxS; ++k)
-#pragma unroll
-                for (int b = 0; b < MB; ++b) ssq[k][b] = k < S ? ld_sc1_f(ssp_g + ((int64_t)blockIdx.x * S + k) * 64 + b * 16 + c16) : 0.f;
-        }
-        const float* sp0[RW][MB];
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int b = 0; b < MB; ++b) {
-                const int m = b * 16 + c16, n = (nb0 + r) * 16 + q4 * 4;
-                const bool ok = m < M && n < N;
-                sp0[r][b] = slabs + (int64_t)(ok ? m : 0) * N + (ok ? n : 0);
-            }
-        const int64_t sstride = (int64_t)M * N;
-        for (int k0 = 0; k0 < S; k0 += 4) {
-            f32x4 nx[4][RW][MB];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int r = 0; r < RW; ++r)
-#pragma unroll
-                    for (int b = 0; b < MB; ++b) nx[kk][r][b] = ld_sc1(sp0[r][b] + (int64_t)min(k0 + kk, S - 1) * sstride);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int r = 0; r < RW; ++r)
-#pragma unroll
-                    for (int b = 0; b < MB; ++b) {
-                        asm volatile("" : "+v"(nx[kk][r][b]));
-                        if (k0 + kk == 0) acc[r][b] = nx[kk][r][b];
-                        else if (k0 + kk < S) acc[r][b] += nx[kk][r][b];
-                    }
-        }
-        if (want_rms) {
-#pragma unroll
-            for (int b = 0; b < MB; ++b) {
-                float t = 0.f;
-#pragma unroll
-                for (int k = 0; k < kFoldMaxS; ++k) { asm volatile("" : "+v"(ssq[k][b])); if (k < S) t += ssq[k][b]; }
-                facf[b] = rsqrtf(t / (float)K + ep.rms_eps);
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < MB; ++b) facf[b] = 1.0f;
-        }
-        if (ep.swiglu) {
-            if constexpr (RW % 2 == 0) {
-#pragma unroll
-                for (int r = 0; r < RW; r += 2)
-#pragma unroll
-                    for (int b = 0; b < MB; ++b) {
-                        const int m = b * 16 + c16, nb = nb0 + r;
-                        Epilogue e2 = ep;
-                        e2.alpha = ep.alpha * facf[b];
-                        if (m < M && (nb + 1) * 16 < N) epilogue_store4_swiglu(e2, m, (nb >> 1) * 16 + q4 * 4, acc[r][b], acc[r + 1][b]);
-                    }
-            }
-            return;
-        }
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int b = 0; b < MB; ++b) {
-                const int m = b * 16 + c16, n = (nb0 + r) * 16 + q4 * 4;
-                Epilogue e2 = ep;
-                e2.alpha = ep.alpha * facf[b];
-                if (m < M && n < N) epilogue_store4(e2, m, n, acc[r][b]);
-            }
-        return;
-    }
-    __syncthreads();
-    float fac[MB];
-#pragma unroll
-    for (int b = 0; b < MB; ++b) fac[b] = want_rms ? rsqrtf(rowss[b * 16 + c16] / (float)K + ep.rms_eps) : 1.0f;
-    if (ep.swiglu) {
-        if constexpr (RW % 2 == 0) {
-#pragma unroll
-            for (int r = 0; r < RW; r += 2)
-#pragma unroll
-                for (int b = 0; b < MB; ++b) {
-                    const int m = b * 16 + c16, nb = nb0 + r;
-                    Epilogue e2 = ep;
-                    e2.alpha = ep.alpha * fac[b];
-                    if (m < M && (nb + 1) * 16 < N) epilogue_store4_swiglu(e2, m, (nb >> 1) * 16 + q4 * 4, acc[r][b], acc[r + 1][b]);
-                }
-        }
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int b = 0; b < MB; ++b) {
-            const int m = b * 16 + c16, n = (nb0 + r) * 16 + q4 * 4;
-            Epilogue e2 = ep;
-            e2.alpha = ep.alpha * fac[b];
-            if (m < M && n < N) epilogue_store4(e2, m, n, acc[r][b]);
-        }
-}
-
-// second stage of the rows kernel: out = epilogue(sum over slices of slabs[k][M][N]) with the RMS factor from the slice sums of squares.
-// (A variant with one output quad per thread and the S slab loads issued together as nontemporal loads measured 18.8 us per launch inside
-// the decode graph against 6.4 us for this grid-stride loop - profiles/r02d vs r02c kernel stats - although both time the same in
-// back-to-back replays of one shape; a version templated on S with all slab loads of a quad issued together: 11-13 us.)
-__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ ssp, int S, int M, int N,
-                                                          int K, Epilogue ep) {
-    const int nq = (ep.swiglu ? N >> 1 : N) >> 2;
-    const int64_t total = (int64_t)M * nq;
-    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int m = (int)(i / nq), j = (int)(i % nq) * 4;
-        const int n = ep.swiglu ? ((j >> 4) << 5) + (j & 15) : j;
-        const float* p = slabs + (int64_t)m * N + n;
-        f32x4 v = *(const f32x4*)p, u = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (ep.swiglu) u = *(const f32x4*)(p + 16);
-        for (int k = 1; k < S; ++k) {
-            v += *(const f32x4*)(p + (int64_t)k * M * N);
-            if (ep.swiglu) u += *(const f32x4*)(p + (int64_t)k * M * N + 16);
-        }
-        Epilogue e2 = ep;
-        if (ep.rms_eps > 0.f) {
-            float t = 0.f;
-            for (int k = 0; k < S; ++k) t += ssp[k * 64 + m];
-            e2.alpha = ep.alpha * rsqrtf(t / (float)K + ep.rms_eps);
-        }
-        if (ep.swiglu) epilogue_store4_swiglu(e2, m, j, v, u);
-        else epilogue_store4(e2, m, n, v);
-    }
-}
-
 // Split-K second stage for the 128x128 kernel: sums the fp32 slabs [S][M][N] in fixed order and applies the real epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, int M, int N, Epilogue ep) {
     const int nq = N >> 2;
@@ -1826,11 +950,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 namespace {
 struct ProfRec { hipEvent_t a, b; double flops, bytes; int K; };
 bool g_prof_on = false;
-int g_gemm_dbg = 0;
 std::vector<ProfRec> g_prof;
 }  // namespace
 
+// Diagnostic word (kernel A/B builds, forced tile shapes): only in the probes build of the library (make probes -> tools/probes/
+// libmc_hip_probes.so, -DMC_PROBES); the shipped library has neither the entry point nor the variants it selects.
+#ifdef MC_PROBES
+static int g_gemm_dbg = 0;
 extern "C" int mc_gemm_debug(int v) { g_gemm_dbg = v; return 0; }
+#else
+constexpr int g_gemm_dbg = 0;
+#endif
 
 // library-owned scratch for the automatic split-K of under-filled 128x128 launches (one process drives one GPU and one compute stream; the
 // buffer only grows, and growing synchronises the device first so no launch in flight still reads the old one)
@@ -1847,59 +977,33 @@ static float* splitk_workspace(size_t floats) {
     return buf;
 }
 
-// 256x256 tiles need enough tiles to fill most of the 256 CUs; bit 1 of the debug word forces the 128x128 kernel, bit 2 the 256x256 one
 // Tile width of the large-M kernel for m_tiles row tiles: 256 columns, or 192 when that fills the 256 CUs better.  One workgroup per CU,
 // so a launch takes ceil(tiles / 256) rounds; a 192-column tile does 3/4 of the work of a 256-column one at ~0.92 of its MFMA efficiency
 // (12 instead of 16 MFMAs per phase behind the same X reads and DMA issues).  M = 2728 (the finetune step), N = 4096: 176 tiles of 256
-// fill 69 % of the CUs, 242 tiles of 192 fill 95 %.  debug word bit 10 forces 192, bit 11 forces 256.
-static bool g_tile192 = true;
-// "force_tile192" (round 4, co-residency experiment / mode): EVERY launch of the 256-row kernel takes the 192-column instantiation - 186
-// VGPRs instead of 256, i.e. 2 x 192 of a SIMD's 512 registers, which leaves room for one wave of a <= 104-register kernel (the decode
-// attention: 102) per SIMD BESIDE a resident GEMM workgroup.  The fused epilogues that need a wave to own a whole head or 128 columns
-// (RoPE + cache scatter, the next norm's factor) take their separate-launch routes; SwiGLU takes the 8-byte store path.
-static bool g_force192 = false;
-static thread_local bool g_in_tail = false, g_force128 = false;      // mc_gemm_ex_bf16's tail split (below)
-static bool g_tail_split = false;     // measured +-0 on the encode stage (in-process A/B 127.0-127.7 vs 127.2-127.5 ms): off by default
-// "tile2" option (round 5): 0 = gemm_tile256_kernel for every large launch; 1 = gemm_tile2_kernel (256 x 128 tiles, two workgroups per CU) for
-// every launch the 256-column instantiation would take; 2 = for launches with K <= "tile2_max_k" only (the encoder shapes, where the
-// 256 x 256 kernel's per-tile prologue + epilogue are 28 % of a tile).  Results are bit-identical either way.
-static int g_tile2 = 0;
-static int g_tile2_max_k = 2048;
-static int g_tile2_variant = 0;
-static bool g_raster_auto = true;          // "raster_shared" option
-// "rows_fold" option: split launches of the rows kernel fold their slabs themselves (no rows_reduce_kernel launch).  OFF: measured SLOWER than the
-// reduce launch - the decode chain of 32 layers as a replayed graph 126.6 (loads per slice) / 133.3 (loads batched) against 118.8-120.9 us per layer
-// (tools/probes/rows_fold_ab.py, profiles/r05_probes/rows_fold_ab.json): without a fence the hand-off is three dependent trips to memory in EVERY
-// workgroup's tail (sc1 stores acknowledged -> agent-scope add returned -> sc1 loads), which a kernel boundary does in one
-static bool g_rows_fold = false;
-static bool g_rows_on = true;              // "rows_kernel" option: M <= 64 launches with ceil(M / 16) >= "rows_min_mb" take gemm_rows_kernel
-static int g_rows_min_mb = 2;
-static int g_raster_slab = 32;             // "raster_slab" option: tile columns per n-slab of the shared-m-group raster (0 = no slabs)
-static int g_raster_slab_min = 64;         // ... for launches of more than this many tile columns (gate|up: 86; measured, M = 44 656, K = 4096:
-                                           // N = 22 016 1398 -> 1425 TFLOP/s, N = 12 288 1437 -> 1425: q|k|v keeps the slab-less order)
-static int g_raster_min_tiles = 1024;      // launches with at least this many tiles deal their 32-tile blocks round-robin over the XCDs
+// fill 69 % of the CUs, 242 tiles of 192 fill 95 %.  (probes build: debug word bit 10 forces 192, bit 11 forces 256)
 // "tile192" = 0 keeps the large-M kernel on 256-column tiles: for callers that fill the idle CUs of an under-filled launch themselves
 // (the finetune step runs its rank-projection and weight-gradient GEMMs on a second stream next to the base GEMMs: measured on one
-// device, samples/s  overlap + 256: 33.4, overlap + 192: 31.8, no overlap + 192: 32.8, no overlap + 256: 31.1)
+// device, samples/s  overlap + 256: 33.4, overlap + 192: 31.8, no overlap + 192: 32.8, no overlap + 256: 31.1).  The one policy knob of
+// the shipped library; it does not change results.
+static bool g_tile192 = true;
+// Raster of the 256-row kernel (measured defaults, rounds 3-4; the probes build can move them):
+static bool g_raster_auto = true;          // launches of >= g_raster_min_tiles tiles deal their 32-tile blocks round-robin over the XCDs
+static int g_raster_slab = 32;             // tile columns per n-slab of the shared-m-group raster (0 = no slabs)
+static int g_raster_slab_min = 64;         // ... for launches of more than this many tile columns (gate|up: 86; measured, M = 44 656, K = 4096:
+                                           // N = 22 016 1398 -> 1425 TFLOP/s, N = 12 288 1437 -> 1425: q|k|v keeps the slab-less order)
+static int g_raster_min_tiles = 1024;
 extern "C" int mc_gemm_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tile192")) { g_tile192 = value != 0; return 0; }
-    if (name && !strcmp(name, "tile2")) { g_tile2 = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
-    if (name && !strcmp(name, "tile2_max_k")) { g_tile2_max_k = value; return 0; }
-    if (name && !strcmp(name, "tile2_variant")) { g_tile2_variant = value; return 0; }
-    if (name && !strcmp(name, "force_tile192")) { g_force192 = value != 0; return 0; }
-    if (name && !strcmp(name, "tail_split")) { g_tail_split = value != 0; return 0; }
+#ifdef MC_PROBES
     if (name && !strcmp(name, "raster_shared")) { g_raster_auto = value != 0; return 0; }
     if (name && !strcmp(name, "raster_slab")) { g_raster_slab = value < 0 ? 0 : (value > 255 ? 255 : value); g_raster_slab_min = 0; return 0; }
     if (name && !strcmp(name, "raster_min_tiles")) { g_raster_min_tiles = value; return 0; }
-    if (name && !strcmp(name, "rows_kernel")) { g_rows_on = value != 0; return 0; }
-    if (name && !strcmp(name, "rows_fold")) { g_rows_fold = value != 0; return 0; }
-    if (name && !strcmp(name, "rows_min_mb")) { g_rows_min_mb = value; return 0; }
+#endif
     mc_set_error("mc_gemm_set_option: unknown option '%s'", name ? name : "(null)");
     return 1;
 }
 
 static int tile_ni(int64_t m_tiles, int N, bool swiglu) {
-    if (g_force192) return 3;
     if (g_gemm_dbg & 2048) return 4;
     if (!g_tile192 && !(g_gemm_dbg & 1024)) return 4;
     if (swiglu) return 4;
@@ -1913,7 +1017,6 @@ static int tile_ni(int64_t m_tiles, int N, bool swiglu) {
 // 256-row tiles need enough tiles to fill most of the 256 CUs; bit 1 of the debug word forces the 128x128 kernel, bit 2 the 256-row one
 static bool use_tile256(int M, int N, int K) {
     if (K < 128) return false;
-    if (g_force128) return false;
     if (g_gemm_dbg & 2) return false;
     if (g_gemm_dbg & 4) return true;
     // measured crossover on MI355X (tools/bench_ops.py mid): 176 tiles (M=2732, N=4096) 1.15-1.4x faster than the 128x128 kernel,
@@ -1948,6 +1051,7 @@ extern "C" int mc_gemm_profile_read(double* total_ms, double* total_flops, int64
     return 0;
 }
 
+#ifdef MC_PROBES
 // Diagnostic (debug word 40 must have been set for the launches): median over the first n_wg workgroups of the last 256x256 launch of
 // the shader clock held across the main loop, in GHz (delta s_memtime / delta s_memrealtime x 100 MHz).
 extern "C" int mc_gemm_clock_read(int n_wg, double* ghz) {
@@ -1963,6 +1067,7 @@ extern "C" int mc_gemm_clock_read(int n_wg, double* ghz) {
     *ghz = r[r.size() / 2];
     return 0;
 }
+#endif
 
 // the same sums over the launches with k_min <= K <= k_max only (bench.py: the decoder layers' launches, K >= 4096, apart from the encoder
 // towers', K <= 1024, whose per-tile prologue + epilogue weigh 4x more)
@@ -2026,157 +1131,51 @@ extern "C" int mc_unpack_weight_bf16(const void* packed, void* w, int N, int K, 
     return 0;
 }
 
-// x: [M, K] bf16 row-major with leading dimension ldx (elements); K here is the PADDED K (multiple of 64,
-// the columns K_real..K-1 of x must be zero or the weight pad rows zero — packed weights are zero padded).
-// N may be any positive value; packed weight has ceil16(N) rows.
-template <int MB, int R>
-static void launch_skinny2_r(dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K,
-                             const Epilogue& ep, int partial) {
-    if constexpr (R * MB <= 12) gemm_skinny2_kernel<MB, R><<<grid, SK_WAVES * 64, 0, s>>>(x, ldx, w, M, N, K, ep, partial);
-}
-
-template <int MB>
-static void launch_skinny2(int R, dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K,
-                           const Epilogue& ep, int partial) {
-    switch (R) {
-        case 1: launch_skinny2_r<MB, 1>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
-        case 2: launch_skinny2_r<MB, 2>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
-        case 3: launch_skinny2_r<MB, 3>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
-        case 4: launch_skinny2_r<MB, 4>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
-        case 6: launch_skinny2_r<MB, 6>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
-        default: launch_skinny2_r<MB, 8>(grid, s, x, ldx, w, M, N, K, ep, partial); break;
-    }
-}
-
-// block-rows per workgroup for the skinny kernel: the largest R in {8,6,4,3,2,1} (R * MB <= 12, even for swiglu) whose grid
-// still covers >= ~85 % of the CUs in its last round
-static int skinny_rows(int nblocks, int mb, int split_k, bool swiglu) {
-    static const int cand[6] = {8, 6, 4, 3, 2, 1};
-    int best = swiglu ? 2 : 1;
-    double best_cost = 1e30;
-    for (int i = 0; i < 6; ++i) {
-        const int R = cand[i];
-        if (R * mb > 12) continue;
-        if (swiglu && (R & 1)) continue;
-        const int64_t wgs = (int64_t)((nblocks + R - 1) / R) * split_k;
-        const int64_t rounds = (wgs + 255) / 256;
-        // time ~ rounds * (weight bytes + x bytes per workgroup) ;  x bytes relative to weights = mb*16 / (16*R)
-        const double cost = (double)rounds * R * (1.0 + (double)mb / R);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = R; }
-    }
-    return best;
-}
-
-// ---- rows kernel: workspace (per stream: concurrent streams must not share slabs), shape policy, launcher
+// ---- per-stream scratch of the tile kernels' rms_out route (one sum of squares per output row and 128-column chunk)
 namespace {
-struct RowsWs { hipStream_t stream; char* base; };
-constexpr size_t kRowsSlabFloats = (size_t)12 << 20;          // 48 MiB of fp32 slabs: S x M x N <= 12 Mi (8 x 64 x 22016 fits)
-constexpr int kRowsMaxSplit = 8;
-constexpr size_t kRowsSsBytes = (size_t)kRowsMaxSplit * 64 * sizeof(float);
-constexpr int kRowsMaxGroups = 512;                            // row groups of a launch that may fold its slabs itself ("rows_fold")
-constexpr size_t kRowsSspGBytes = (size_t)kRowsMaxGroups * kRowsMaxSplit * 64 * sizeof(float);
-constexpr size_t kRowsCntBytes = (size_t)kRowsMaxGroups * sizeof(unsigned int);
-constexpr size_t kRowsWsBytes = kRowsSsBytes + kRowsSlabFloats * sizeof(float) + kRowsSspGBytes + kRowsCntBytes;
-std::vector<RowsWs> g_rows_ws;
-std::mutex g_rows_mu;                  // the slot table is touched from every launching thread (tower / pipeline streams, serving threads)
-constexpr int kRowsPool = 16;          // (round 4: 8 -> 16; default, capture, two pipeline and up to four tower streams already make 8)
-char* g_rows_pool = nullptr;
+struct StreamWs { hipStream_t stream; char* base; };
+constexpr size_t kWsFloats = (size_t)12 << 20;               // 48 MiB: M x (N / 128) partial sums (a 134 000-row prefill at N = 4096: 17 MiB)
+constexpr size_t kWsBytes = kWsFloats * sizeof(float);
+std::vector<StreamWs> g_ws;
+std::mutex g_ws_mu;                    // the slot table is touched from every launching thread (tower / pipeline streams, serving threads)
+constexpr int kWsPool = 16;            // default, capture, two pipeline and up to four tower streams already make 8
+char* g_ws_pool = nullptr;
 }  // namespace
 
-// The workspace of a stream: a pool of kRowsPool equal workspaces is allocated at the first rows launch (or mc_gemm_reserve_rows) made
-// while the calling stream is not capturing; every stream that launches the kernel is given its own slot then (host bookkeeping only, so a
-// stream met for the first time during capture still gets one).  Concurrent streams never share slabs; a stream beyond the pool, or a
-// first launch inside a capture, keeps the skinny kernel.
-static char* rows_workspace(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_rows_mu);
-    for (auto& w : g_rows_ws) if (w.stream == s) return w.base;
-    const size_t bytes = kRowsWsBytes;
-    if (!g_rows_pool) {
+// The workspace of a stream: a pool of kWsPool equal workspaces is allocated at the first use (or mc_gemm_reserve_workspace) made while
+// the calling stream is not capturing; every stream that needs one is given its own slot then (host bookkeeping only, so a stream met
+// for the first time during capture still gets one).  Concurrent streams never share a slot; a stream beyond the pool, or a first use
+// inside a capture, gets none (the caller takes its workspace-free route).
+static char* stream_workspace(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (auto& w : g_ws) if (w.stream == s) return w.base;
+    if (!g_ws_pool) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
         char* base = nullptr;
-        if (hipMalloc((void**)&base, bytes * kRowsPool) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        for (int i = 0; i < kRowsPool; ++i)                        // the fold's arrival counters start (and are left) at zero
-            (void)hipMemset(base + bytes * i + (bytes - kRowsCntBytes), 0, kRowsCntBytes);
-        (void)hipDeviceSynchronize();
-        g_rows_pool = base;
+        if (hipMalloc((void**)&base, kWsBytes * kWsPool) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_ws_pool = base;
     }
-    for (int i = 0; i < kRowsPool; ++i) {
-        char* base = g_rows_pool + bytes * i;
+    for (int i = 0; i < kWsPool; ++i) {
+        char* base = g_ws_pool + kWsBytes * i;
         bool used = false;
-        for (auto& w : g_rows_ws) used = used || w.base == base;
-        if (!used) { g_rows_ws.push_back({s, base}); return base; }
+        for (auto& w : g_ws) used = used || w.base == base;
+        if (!used) { g_ws.push_back({s, base}); return base; }
     }
     return nullptr;
 }
 
 // a destroyed stream gives its slot back (its launches have completed: the caller synchronised before destroying it)
-extern "C" int mc_gemm_release_rows(void* stream) {
-    std::lock_guard<std::mutex> lock(g_rows_mu);
-    for (size_t i = 0; i < g_rows_ws.size(); ++i)
-        if (g_rows_ws[i].stream == (hipStream_t)stream) { g_rows_ws.erase(g_rows_ws.begin() + i); break; }
+extern "C" int mc_gemm_release_workspace(void* stream) {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (size_t i = 0; i < g_ws.size(); ++i)
+        if (g_ws[i].stream == (hipStream_t)stream) { g_ws.erase(g_ws.begin() + i); break; }
     return 0;
 }
 
-extern "C" int mc_gemm_reserve_rows(void* stream) {
-    if (!rows_workspace((hipStream_t)stream)) { mc_set_error("mc_gemm_reserve_rows: no workspace (allocation failed, first call inside a capture, or more than %d streams)", kRowsPool); return 2; }
+extern "C" int mc_gemm_reserve_workspace(void* stream) {
+    if (!stream_workspace((hipStream_t)stream)) { mc_set_error("mc_gemm_reserve_workspace: no workspace (allocation failed, first call inside a capture, or more than %d streams)", kWsPool); return 2; }
     return 0;
-}
-
-// Split count S of the rows kernel for `groups` row groups (workgroups = groups x S).  Measured on MI355X (tools/rows_kernel_check.py): a
-// CU moves ~47 GB/s through this kernel whatever the number of resident workgroups, the chip ~5.2 TB/s, a launch costs ~2 us to start and
-// the reduce launch ~3.5 us + the slab round trip; a grid of more than 256 workgroups therefore behaves like two rounds.
-static int rows_split(int groups, int rw, int nblocks, int kblocks, int kt, int mb, int M, int N) {
-    const int tiles = kblocks / kt;
-    double best = 1e30;
-    int bs = 1;
-    for (int S = 1; S <= kRowsMaxSplit; ++S) {
-        if (S == 7) continue;
-        if (S > 1 && (S > tiles / 2 || (size_t)S * M * N > kRowsSlabFloats)) continue;
-        const int64_t wgs = (int64_t)groups * S;
-        const double kslice = (double)kblocks * 32 / S;
-        const double wg_bytes = (8.0 * rw * 16 + mb * 16) * kslice * 2;
-        const double t_cu = (double)((wgs + 255) / 256) * wg_bytes / 47e3;
-        const double t_hbm = (double)nblocks * 16 * kblocks * 32 * 2 / 5.2e6;
-        double t = 2.0 + (t_cu > t_hbm ? t_cu : t_hbm) + (S > 1 ? 3.5 + (double)S * M * N * 4 / 4.0e6 : 0.0);
-        // a grid that leaves more than a third of the CUs idle does not reach the chip rate the estimate assumes (down_proj at S = 5, 160
-        // workgroups: 29 us against 27 at S = 8): grids of 172-256 workgroups go first
-        if (wgs < 172 || wgs > 256) t += 1000.0;
-        if (t < best - 1e-9) { best = t; bs = S; }
-    }
-    return bs;
-}
-
-template <int MB, int RW, int KT>
-static void launch_rows_k(dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K, const Epilogue& ep,
-                          float* slabs, float* ssp, float* ssp_g, unsigned int* cnt) {
-    // the fold's hand-off is measured at ONE workgroup per CU: an LDS pad keeps a second one off the CU (static: the x tiles + 68 bytes)
-    constexpr int stat = 2 * KT * MB * 64 * 16 + MB * 16 * 4 + 4;
-    const int pad = cnt ? (82 * 1024 > stat ? 82 * 1024 - stat : 0) : 0;
-    static bool attr = false;
-    if (pad && !attr) { (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<MB, RW, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024); attr = true; }
-    gemm_rows_kernel<MB, RW, KT><<<grid, 512, pad, s>>>(x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
-}
-
-template <int MB>
-static void launch_rows(int RW, int kt, dim3 grid, hipStream_t s, const bf16_t* x, int64_t ldx, const bf16_t* w, int M, int N, int K, const Epilogue& ep,
-                        char* ws, bool skip_reduce = false) {
-    float* ssp = (float*)ws;
-    float* slabs = (float*)(ws + kRowsSsBytes);
-    const bool fold = g_rows_fold && grid.y > 1 && !skip_reduce && (int)grid.x <= kRowsMaxGroups;
-    float* ssp_g = fold ? (float*)(ws + kRowsSsBytes + kRowsSlabFloats * sizeof(float)) : nullptr;
-    unsigned int* cnt = fold ? (unsigned int*)(ws + kRowsWsBytes - kRowsCntBytes) : nullptr;
-    if (kt == 8) {
-        if (RW == 2) launch_rows_k<MB, 2, 8>(grid, s, x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
-        else launch_rows_k<MB, 1, 8>(grid, s, x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
-    } else {
-        if (RW == 2) launch_rows_k<MB, 2, 4>(grid, s, x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
-        else launch_rows_k<MB, 1, 4>(grid, s, x, ldx, w, M, N, K, ep, slabs, ssp, ssp_g, cnt);
-    }
-    if (grid.y > 1 && !skip_reduce && !fold) {
-        const int64_t total = (int64_t)M * ((ep.swiglu ? N >> 1 : N) >> 2);
-        rows_reduce_kernel<<<(int)min((int64_t)1024, (total + 255) / 256), 256, 0, s>>>(slabs, ssp, (int)grid.y, M, N, K, ep);
-    }
 }
 
 // one launch of the 256x256 kernel over the m-tiles of all groups (M_total = rows over all groups, for the live profile)
@@ -2187,15 +1186,17 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
     static bool attr256_set = false;
     const int lds = 2 * G2_STAGE + 1024;            // + 1 KiB nobody reads (destination of the next-tile L2 warm-up)
     if (!attr256_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#ifdef MC_PROBES
+        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<64, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<32, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<256, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1024, 4, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<0, 3, 233>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#endif
         attr256_set = true;
     }
     ProfRec rec{};
@@ -2209,35 +1210,17 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
                            (a->residual ? (double)M_total * N : 0.0));
         (void)hipEventRecord(rec.a, s);
     }
-    // debug word bit 16 forces raster 0, bit 17 forces raster 1
+    // (probes build: debug word bit 16 forces raster 0, bit 17 forces raster 1)
     int raster = (g_gemm_dbg & 65536) ? 0 : ((g_gemm_dbg & 131072) ? 1 : (g_raster_auto && tiles_m * tiles_n >= g_raster_min_tiles ? 1 : 0));
-    // n-slabs ("raster_slab" option, default 0 = off; see the kernel): only with the shared-m-group raster and when there is more than one slab
+    // n-slabs (see the kernel): only with the shared-m-group raster and when there is more than one slab
     if (raster == 1 && g_raster_slab > 0 && tiles_n > g_raster_slab && tiles_n > g_raster_slab_min) raster |= g_raster_slab << 8;
-#define G2_LAUNCH(A) gemm_tile256_kernel<A><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster)
-    // debug word bits 3-5: 8 = timing-only ablation without the LDS-DMA (wrong results); 40 = correct results + clock stamps around the main
-    // loop (mc_gemm_clock_read); 56 = A/B builds, picked by bits 12-14.  (The round-1 ablations "no fragment reads" / "DMA re-reads K-tiles
-    // 0/1" and the launch_bounds(512,1) build are no longer instantiated: ABL bits 1, 2, 4 - their results are in DESIGN.md.)
-    const bool tile2 = ni == 4 && !((g_gemm_dbg >> 3) & 7) && (g_tile2 == 1 || (g_tile2 == 2 && K <= g_tile2_max_k));
-    if (tile2) {
-        static bool attr2_set = false;
-        const int lds2 = 3 * T2_STAGE;
-        if (!attr2_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_tile2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-            (void)hipFuncSetAttribute((const void*)gemm_tile2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-            (void)hipFuncSetAttribute((const void*)gemm_tile2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-            attr2_set = true;
-        }
-        const int tn2 = (N + 127) / 128;
-        int r2 = raster & 255;                                       // the n-slab width counts 256-column tiles: twice as many 128-column ones
-        if ((raster >> 8) & 255) r2 |= (min(255, 2 * ((raster >> 8) & 255))) << 8;
-        switch (g_tile2_variant) {                                   // "tile2_variant" option: where the K-step's DMA instructions sit (kernel comment)
-            case 1: gemm_tile2_kernel<1><<<tiles_m * tn2, 256, lds2, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tn2, r2); break;
-            case 2: gemm_tile2_kernel<2><<<tiles_m * tn2, 256, lds2, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tn2, r2); break;
-            default: gemm_tile2_kernel<0><<<tiles_m * tn2, 256, lds2, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tn2, r2); break;
-        }
-    } else if (ni == 3) {
+    if (ni == 3) {
         gemm_tile256_kernel<0, 3, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);
     } else switch ((g_gemm_dbg >> 3) & 7) {
+#ifdef MC_PROBES
+#define G2_LAUNCH(A) gemm_tile256_kernel<A><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster)
+        // debug word bits 3-5: 8 = timing-only ablation without the LDS-DMA (wrong results); 40 = correct results + clock stamps around the main
+        // loop (mc_gemm_clock_read); 56 = A/B builds, picked by bits 12-14
         case 1: G2_LAUNCH(1); break;
         case 5: G2_LAUNCH(8); break;
         case 7:                              // A/B builds (results identical): bits 12-14 = 0: the round-1 DMA distribution 2 / 2 / 2 / 2 (with s_setprio)
@@ -2247,6 +1230,8 @@ static void launch_tile256(const mc_gemm_args* a, const G2Groups& grp, int M_tot
             else if (((g_gemm_dbg >> 12) & 7) == 4) gemm_tile256_kernel<1024, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster);   // residual in 8-byte loads
             else G2_LAUNCH(64);
             break;
+#undef G2_LAUNCH
+#endif
         default: gemm_tile256_kernel<0, 4, 233><<<tiles_m * tiles_n, 512, lds, s>>>((const bf16_t*)a->x, a->ldx, grp, N, K, ep, tiles_m, tiles_n, raster); break;
     }
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
@@ -2291,12 +1276,11 @@ __global__ __launch_bounds__(256) void rms_chunk_parts_kernel(const bf16_t* __re
 static bool rms_out_args_ok(const mc_gemm_args* a) { return !a->out_f32 && !a->swiglu && !a->rope && a->split_k <= 1 && a->rms_out_eps > 0.f; }
 // the epilogue route needs whole 256-column tiles of the 256x256 kernel, no activation, and the partial sums to fit the stream's workspace
 static float* rms_parts_buffer(const mc_gemm_args* a, int64_t M_total, hipStream_t s) {
-    if (a->N % 128 || a->ldo % 4 || ((uintptr_t)a->out % 8) || (size_t)M_total * (a->N / 128) > kRowsSlabFloats) return nullptr;
-    char* ws = rows_workspace(s);
-    return ws ? (float*)(ws + kRowsSsBytes) : nullptr;
+    if (a->N % 128 || a->ldo % 4 || ((uintptr_t)a->out % 8) || (size_t)M_total * (a->N / 128) > kWsFloats) return nullptr;
+    return (float*)stream_workspace(s);
 }
 static float* rms_out_parts(const mc_gemm_args* a, int64_t M_total, hipStream_t s) {
-    if (!a->rms_out || a->N % 256 || a->act != MC_ACT_NONE || a->ldo % 8 || ((uintptr_t)a->out % 16) || (g_gemm_dbg & (1 << 29)) || g_force192) return nullptr;
+    if (!a->rms_out || a->N % 256 || a->act != MC_ACT_NONE || a->ldo % 8 || ((uintptr_t)a->out % 16) || (g_gemm_dbg & (1 << 29))) return nullptr;
     return rms_parts_buffer(a, M_total, s);
 }
 // parts: what the epilogue left (null: another route ran).  Without a workspace (first launch inside a capture) or for N that is not a
@@ -2326,7 +1310,7 @@ static bool rope_args_ok(const mc_gemm_args* a) {
 // the register route: a wave's 128 columns of a 256-column tile must be one head.  debug word bit 31 keeps the separate launch (A/B)
 static bool rope_in_epilogue(const mc_gemm_args* a) {
     const mc_rope_scatter* r = a->rope;
-    return r && r->D == 128 && a->N % 256 == 0 && !(g_gemm_dbg & (1u << 31)) && !g_force192;
+    return r && r->D == 128 && a->N % 256 == 0 && !(g_gemm_dbg & (1u << 31));
 }
 static void rope_fill(Epilogue& ep, const mc_rope_scatter* r, int64_t row0) {
     ep.rope = Epilogue::Rope{r->row_b + row0, r->row_pos + row0, r->row_t + row0, r->cos_table, r->sin_table, (bf16_t*)r->q_out,
@@ -2352,11 +1336,11 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
     MC_CHECK_ARG(!a->residual || a->ldr % 4 == 0, "mc_gemm_bf16: ldr must be a multiple of 4");
     MC_CHECK_ARG(!a->swiglu || (N % 32 == 0 && !a->bias && !a->residual && !a->out_f32 && a->act == MC_ACT_NONE),
                  "mc_gemm_ex_bf16: swiglu needs N %% 32 == 0 (gate/up interleaved per 16 rows) and a plain bf16 output");
-    const int split_k = a->split_k > 1 ? a->split_k : 1;
-    MC_CHECK_ARG(split_k == 1 || (M <= 64 && a->out_f32 && !a->bias && !a->residual && !a->swiglu && a->act == MC_ACT_NONE),
-                 "mc_gemm_ex_bf16: split_k accumulates raw fp32 partial sums (M <= 64, out_f32, no bias/act/residual)");
-    MC_CHECK_ARG(!(a->rms_eps > 0.f) || (M <= 64 && !a->row_scale && split_k == 1),
-                 "mc_gemm_ex_bf16: rms_eps (in-kernel RMS factor) needs M <= 64, no row_scale and no split_k");
+    MC_CHECK_ARG(a->split_k <= 1, "mc_gemm_ex_bf16: split_k must be 1 (or < 0: automatic, tile family)");
+    MC_CHECK_ARG(a->family >= MC_GEMM_AUTO && a->family <= MC_GEMM_TILE, "mc_gemm_ex_bf16: family %d", a->family);
+    const bool strip = a->family == MC_GEMM_STRIP || (a->family == MC_GEMM_AUTO && M <= 64 && a->split_k >= 0);
+    MC_CHECK_ARG(!(a->rms_eps > 0.f) || (strip && !a->row_scale),
+                 "mc_gemm_ex_bf16: rms_eps (in-kernel RMS factor) is the strip family's (M <= 64, or family = MC_GEMM_STRIP), without row_scale");
     MC_CHECK_ARG(!a->rope || rope_args_ok(a), "mc_gemm_ex_bf16: rope needs N = (H + 2 Hkv) D, a plain bf16 output (ldo %% 8 == 0) and every pointer");
     Epilogue ep{(const bf16_t*)a->bias, (const bf16_t*)a->residual, a->ldr, a->out, a->ldo, a->act, a->out_f32, a->alpha, a->beta,
                 a->row_scale, a->swiglu, a->rms_eps > 0.f ? a->rms_eps : 0.f};
@@ -2364,86 +1348,17 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     bool rope_pending = a->rope != nullptr;
     float* ss_parts = nullptr;
-    if (a->defer_reduce) a->defer_reduce->S = 0;
-    const int mb_rows = (M + 15) / 16;
-    char* rows_ws = nullptr;
-    // rows kernel geometry: RW = 2 block-rows per wave for SwiGLU (a gate / up pair), else 1; tiles of 8 k-blocks (8 RW KiB of weights in
-    // flight per wave) when K allows and the register file does (RW = 2 with more than 16 rows needs > 128 VGPRs at depth 8), else 4.
-    // debug word: bits 24-27 force S, bit 28 forces RW = 2, bit 30 forces depth 4 (tools/rows_kernel_check.py sweeps)
-    const int RW = (a->swiglu || (g_gemm_dbg & (1 << 28))) ? 2 : 1;
-    const int kt = ((K >> 5) % 8 == 0 && (K >> 5) >= 32 && !(g_gemm_dbg & (1 << 30)) && !(RW == 2 && mb_rows >= 2)) ? 8 : 4;
-    const bool rows_ok = M <= 64 && g_rows_on && mb_rows >= g_rows_min_mb && split_k == 1 && (K >> 5) % kt == 0 && (K >> 5) >= 2 * kt &&
-                         !(g_gemm_dbg & 524288) && (rows_ws = rows_workspace(s)) != nullptr;
-    if (rows_ok) {
-        const int nblocks = (N + 15) / 16;
-        const int groups = (nblocks + 8 * RW - 1) / (8 * RW);
-        int S = rows_split(groups, RW, nblocks, K >> 5, kt, mb_rows, M, N);
-        const int fs = (g_gemm_dbg >> 24) & 15;
-        if (fs && fs <= kRowsMaxSplit && fs <= (K >> 5) / kt / 2 + (fs == 1) && (size_t)fs * M * N <= kRowsSlabFloats) S = fs;
-        dim3 grid((nblocks + 8 * RW - 1) / (8 * RW), S);
-        const bf16_t* xb = (const bf16_t*)x; const bf16_t* wb = (const bf16_t*)w_packed;
-        // mc_gemm_args.defer_reduce: the consumer folds the slabs (plain epilogues only: the fold is sum, row factor, one bf16 rounding)
-        const bool defer = a->defer_reduce && S > 1 && !a->bias && !a->residual && a->act == MC_ACT_NONE && !a->swiglu && !a->out_f32 &&
-                           a->alpha == 1.0f && !a->row_scale && !a->rope && !a->rms_out;
-        switch (mb_rows) {
-            case 1: launch_rows<1>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws, defer); break;
-            case 2: launch_rows<2>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws, defer); break;
-            case 3: launch_rows<3>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws, defer); break;
-            default: launch_rows<4>(RW, kt, grid, s, xb, ldx, wb, M, N, K, ep, rows_ws, defer); break;
-        }
-        if (defer) {
-            mc_slab_ref* r = a->defer_reduce;
-            r->ssp = (const float*)rows_ws; r->slabs = (const float*)(rows_ws + kRowsSsBytes);
-            r->S = S; r->M = M; r->N = N; r->K = K; r->rms_eps = ep.rms_eps;
-        }
-    } else if (M <= 64) {
-        const int mb = (M + 15) / 16;
-        const int nblocks = (N + 15) / 16;
-        int R = (g_gemm_dbg & 256) ? (a->swiglu ? 2 : 1) : skinny_rows(nblocks, mb, split_k, a->swiglu != 0);
-        const int forced = (g_gemm_dbg >> 20) & 15;             // debug word bits 20-23: force R (tools/skinny_m_bench.py sweeps)
-        if (forced && forced * mb <= 12 && (forced <= 4 || forced == 6 || forced == 8) && !(a->swiglu && (forced & 1))) R = forced;
-        dim3 grid((nblocks + R - 1) / R, split_k);
-        const bf16_t* xb = (const bf16_t*)x; const bf16_t* wb = (const bf16_t*)w_packed;
-        switch (mb) {
-            case 1: launch_skinny2<1>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
-            case 2: launch_skinny2<2>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
-            case 3: launch_skinny2<3>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
-            default: launch_skinny2<4>(R, grid, s, xb, ldx, wb, M, N, K, ep, split_k > 1); break;
+    if (strip) {
+        // the strip family (gemm_strip.hip); above 64 rows as slices of 64 rows: the weights are streamed once per slice (decode batches of
+        // that size are attention-bound) and every row sees exactly the launch it would see in a smaller batch
+        for (int r0 = 0; r0 < M; r0 += 64) {
+            Epilogue e1 = ep;
+            e1.out = (char*)a->out + (int64_t)r0 * a->ldo * (a->out_f32 ? 4 : 2);
+            if (a->residual) e1.residual = (const bf16_t*)a->residual + (int64_t)r0 * a->ldr;
+            if (a->row_scale) e1.row_scale = a->row_scale + r0;
+            mc_strip_launch((const bf16_t*)x + (int64_t)r0 * ldx, ldx, (const bf16_t*)w_packed, min(64, M - r0), N, K, e1, s);
         }
     } else if (use_tile256(M, N, K)) {
-        // Round 4 - tail split ("tail_split" option; DEFAULT OFF after measurement: the replacement launch - a kernel boundary plus one 128 x 128
-        // tile time - costs what the almost-empty round of 256 x 256 tiles cost): one workgroup per CU means a launch runs in rounds of 256 tiles; a launch of
-        // 6.03 rounds (the video tower's out_proj / fc2: 386 m-tiles x 4 tile columns = 1544 tiles) spends a whole round on its last 8
-        // tiles.  When the last round is less than a quarter full and only a few m-tiles deep, the launch covers the rows of the whole rounds
-        // and the remaining rows (a few hundred) go to the 128 x 128 kernel, whose two small workgroups per CU finish in a fraction of a
-        // tile time.  Same values (the two kernels are bit-identical); plain epilogues only.
-        if (g_tail_split && !g_in_tail && !a->rope && !a->rms_out && !a->swiglu && !a->defer_reduce && split_k == 1) {
-            const int64_t tm = (M + 255) / 256;
-            const int ni0 = tile_ni(tm, N, false);
-            const int64_t tn = ni0 == 3 ? (N + 191) / 192 : (N + 255) / 256;
-            const int64_t total = tm * tn, rounds = total / 256, rem = total % 256;
-            if (rounds >= 2 && rounds <= 40 && rem > 0 && rem <= 64) {
-                const int64_t m_keep = (rounds * 256) / tn;                        // m-tiles that fit the whole rounds
-                const int64_t rows_main = m_keep * 256;
-                // (the remainder must be large enough for the 128 x 128 kernel - the only one that is bit-identical to this one; 64 rows or fewer would
-                // be routed to the skinny / rows kernels, whose fp32 summation order differs)
-                if (m_keep > 0 && rows_main < M && M - rows_main > 64 && tm - m_keep <= 3 && tile_ni(m_keep, N, false) == ni0 && use_tile256((int)rows_main, N, K)) {
-                    mc_gemm_args a1 = *a, a2 = *a;
-                    a1.M = (int)rows_main;
-                    const int64_t r0 = rows_main;
-                    a2.M = M - (int)rows_main;
-                    a2.x = (const char*)a->x + r0 * a->ldx * 2;
-                    a2.out = (char*)a->out + r0 * a->ldo * (a->out_f32 ? 4 : 2);
-                    if (a->residual) a2.residual = (const char*)a->residual + r0 * a->ldr * 2;
-                    if (a->row_scale) a2.row_scale = a->row_scale + r0;
-                    g_in_tail = true;
-                    int rc = mc_gemm_ex_bf16(&a1, stream);
-                    if (rc == 0) { g_force128 = true; rc = mc_gemm_ex_bf16(&a2, stream); g_force128 = false; }
-                    g_in_tail = false;
-                    return rc;
-                }
-            }
-        }
         G2Groups grp{};
         grp.n = 1; grp.tile_start[0] = 0; grp.tile_start[1] = (M + 255) / 256; grp.row_start[0] = 0; grp.row_start[1] = M;
         grp.wp[0] = (const bf16_t*)w_packed;
@@ -2492,7 +1407,7 @@ extern "C" int mc_gemm_bf16(const void* x, int64_t ldx, const void* w_packed, co
     a.x = x; a.ldx = ldx; a.w_packed = w_packed; a.bias = bias; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = act; a.out_f32 = out_f32; a.alpha = alpha; a.beta = beta;
     a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1; a.rms_eps = 0.f; a.rope = nullptr; a.rms_out = nullptr; a.rms_out_eps = 0.f;
-    a.defer_reduce = nullptr;
+    a.family = MC_GEMM_AUTO;
     return mc_gemm_ex_bf16(&a, stream);
 }
 
@@ -2512,7 +1427,7 @@ extern "C" int mc_gemm_grouped_bf16(const mc_gemm_args* args, int n_groups, cons
         if (mg > 0) { tiles += (mg + 255) / 256; ++ng; }
     }
     const int N = args->N, K = args->K;
-    const bool one_launch = ng >= 1 && ng <= 8 && M_total > 64 && K >= 128 && K % 64 == 0 && !(g_gemm_dbg & 2) && args->split_k <= 1 &&
+    const bool one_launch = args->family != MC_GEMM_STRIP && ng >= 1 && ng <= 8 && M_total > 64 && K >= 128 && K % 64 == 0 && !(g_gemm_dbg & 2) && args->split_k <= 1 &&
                             ((g_gemm_dbg & 4) || tiles * ((N + 255) / 256) >= 144);
     if (!one_launch) {
         for (int g = 0; g < n_groups; ++g) {

@@ -13,8 +13,10 @@
 //   * RMSNorm = (per-row 1/rms) x (per-column weight): the weight is folded into the q|k|v and gate|up columns at compose
 //     time, the 1/rms factor is a GEMM epilogue input (row_scale) -> no normalised copy of the hidden state is written;
 //   * silu(gate) * up is the epilogue of the gate|up GEMM (weights interleaved per 16 rows) -> no [M, 2I] intermediate;
-//   * decode (M <= 64): o_proj / down_proj split K over 4 workgroups per block-row so all CUs stream weights; the residual
-//     add folds their fp32 slabs into the hidden state and produces the next 1/rms in the same kernel.
+//   * decode steps and the last-token tail of a prefill run the strip GEMM family (gemm_strip.hip) whatever the batch size: the RMS factor is
+//     computed from the x fragments the GEMM streams, o_proj / down_proj add the residual in their epilogue - 5 launches per layer, no
+//     normalisation pass, no split-K slabs.  Together with the per-sequence chunk schedule of the decode attention a sequence's logits and
+//     tokens are bit-identical whatever batch it is decoded in.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -49,7 +51,6 @@ struct Llm {
     int64_t call_key_mask_stride = 0;
     bool graph_logits = false;               // "graph_logits" option: a decode call that asks for step logits still replays the graph (the step's
                                              // logits are copied out of the workspace between replays) instead of one launch per kernel
-    bool fold_qkv = true;                    // decode: the q|k|v projection's split-K slabs are folded by the attention launch (no reduce launch)
     // one-shot capture of the NEXT prefill (mc_llm_set_capture): cap_hidden receives n_layers + 1 snapshots of the routed hidden state
     // (the embeddings, then every layer's output), cap_q every layer's rotated queries [B, Lq, H, D] - what forward(output_hidden_states /
     // output_attentions) of the reference returns is built from them (multimodal_llama.py:561-604)
@@ -82,24 +83,41 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Ws {          // carve-up of the caller-provided workspace
     char *qkv, *qseq, *attn, *inter, *xl, *nl, *logits;
     float* rs;
+    int64_t ldx, lda, ldi;     // row strides (elements) of xl / nl, attn, inter
     size_t total;
 };
 
-Ws carve(const mc_llm_config& c, int M, int B, int Lq, char* base) {
+// Row strides of the decode buffers: plain widths.  (Rows 128 bytes longer than their width - to spread the 16 rows of an MFMA fragment
+// over L2 channels - measured no different for the strip GEMMs: 14.2 / 32.1 / 23.4 / 36.3 us against 14.5 / 31.9 / 23.5 / 36.5 us for
+// o / down / q|k|v / gate|up at 48 rows, profiles/r06_probes/strip_check.json.)
+constexpr int kRowPad = 0;
+
+Ws carve(const mc_llm_config& c, int M, int B, int Lq, char* base, bool decode) {
     const size_t hd = c.hidden, qkvd = (size_t)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
     Ws w;
+    w.ldx = (int64_t)hd + kRowPad;
+    w.lda = (int64_t)hd + (decode ? kRowPad : 0);
+    w.ldi = (int64_t)c.inter + (decode ? kRowPad : 0);
     w.qkv = take((size_t)M * qkvd * 2);
     w.qseq = take((size_t)B * Lq * c.n_heads * c.head_dim * 2);
-    w.attn = take((size_t)M * hd * 2);
-    w.inter = take((size_t)M * c.inter * 2);
+    w.attn = take((size_t)M * w.lda * 2);
+    w.inter = take((size_t)M * w.ldi * 2);
     w.rs = (float*)take((size_t)M * 4);
-    w.xl = take((size_t)B * hd * 2);
-    w.nl = take((size_t)B * hd * 2);
+    w.xl = take((size_t)B * w.ldx * 2);
+    w.nl = take((size_t)B * w.ldx * 2);
     w.logits = take((size_t)B * c.vocab * 4);
     w.total = off;
     return w;
+}
+
+inline int c_max_smax(const mc_llm_config& c) { return c.max_pos + 64; }
+// partials of the decode attention for a cache of up to max_pos (+ one 64-position rounding) keys
+int64_t attn_ws_bytes(const mc_llm_config& c, int B) {
+    int64_t b = 0;
+    mc_attn_decode_workspace_bytes(B, c.n_heads, c.head_dim, c_max_smax(c), &b);
+    return b;
 }
 
 #define RUN(call)                    \
@@ -139,24 +157,24 @@ int gemm_ex(const void* x, int64_t ldx, const void* w, const void* residual, int
     a.x = x; a.ldx = ldx; a.w_packed = w; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = M; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = out_f32; a.alpha = 1.0f; a.beta = 1.0f;
     a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = split_k; a.rms_eps = 0.f; a.rope = nullptr; a.rms_out = nullptr; a.rms_out_eps = 0.f;
-    a.defer_reduce = nullptr;
+    a.family = MC_GEMM_AUTO;
     return mc_gemm_ex_bf16(&a, stream);
 }
 
 int gemm_grouped(const void* x, int64_t ldx, const void* residual, int64_t ldr, void* out, int64_t ldo, int N, int K, const float* row_scale,
                  int swiglu, int n_groups, const int32_t* gstart, const void* const* weights, void* stream, float rms_eps = 0.f,
-                 const mc_rope_scatter* rope = nullptr, float* rms_out = nullptr, float rms_out_eps = 0.f, mc_slab_ref* defer = nullptr) {
+                 const mc_rope_scatter* rope = nullptr, float* rms_out = nullptr, float rms_out_eps = 0.f, int family = MC_GEMM_TILE) {
     mc_gemm_args a;
     a.x = x; a.ldx = ldx; a.w_packed = nullptr; a.bias = nullptr; a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.M = 0; a.N = N; a.K = K; a.act = MC_ACT_NONE; a.out_f32 = 0; a.alpha = 1.0f; a.beta = 1.0f;
     a.row_scale = row_scale; a.swiglu = swiglu; a.split_k = 1; a.rms_eps = rms_eps; a.rope = rope; a.rms_out = rms_out; a.rms_out_eps = rms_out_eps;
-    a.defer_reduce = defer;
+    a.family = family;
     return mc_gemm_grouped_bf16(&a, n_groups, gstart, weights, stream);
 }
 
 // one decoder layer over rows grouped by adapter; x is updated in place.  On entry w.rs holds 1/rms of every row of x
 // (input_layernorm's factor); on exit it holds the factor for the next layer's input_layernorm (or the final norm).
-int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t* gstart, const int32_t* gadapter,
+int layer_forward(Llm* m, int layer, char* x, int64_t ldh, int M, int n_groups, const int32_t* gstart, const int32_t* gadapter,
                   const Ws& w, const int32_t* row_b, const int32_t* row_pos, const int32_t* row_t, const int32_t* out_map,
                   const int32_t* kv_lens, int B, int Lq, char* kc, char* vc, int Smax, bool decode, int nsplit, void* attn_ws,
                   void* stream, int stage = 0, int phase_tag = -1) {
@@ -165,14 +183,19 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     const mc_llm_config& c = m->cfg;
     const int64_t hd = c.hidden, D = c.head_dim, H = c.n_heads, Hkv = c.n_kv_heads, I = c.inter;
     const int64_t qkvd = (H + 2 * Hkv) * D;
+    const int64_t lda = w.lda, ldi = w.ldi;
     const size_t kv_layer = (size_t)B * Hkv * Smax * D * 2;
     char* kcl = kc + (size_t)layer * kv_layer;
     char* vcl = vc + (size_t)layer * kv_layer;
     const float scale = 1.0f / sqrtf((float)D);
-    // skinny decode shapes (M <= 64): no normalisation pass at all - the GEMMs that read the hidden state compute its 1/rms from the x
-    // fragments they stream (rms_eps), o_proj / down_proj add the residual in their epilogue: 5 launches per layer (batches above 16 rows: the rows
-    // kernel splits K over workgroups where that fills the chip, each such GEMM is followed by its slab-reduce launch)
-    const bool skinny = decode && M <= 64;
+    // Kernel family (mc_gemm_args.family): decode steps and the last-token tail of a prefill run the STRIP family whatever the batch size
+    // (slices of 64 rows above 64), everything else the TILE family whatever the row count - a sequence's rows go through the same fp32
+    // summation order in a batch of 1 and in a batch of 48 (bitwise batch invariance; model_multimodal_qa_loader.py:25-46 batches a
+    // question differently at 1 and at 8 GPUs).
+    // Strip launches: no normalisation pass at all - the GEMMs that read the hidden state compute its 1/rms from the x fragments they
+    // stream (rms_eps), o_proj / down_proj add the residual in their epilogue: 5 launches per layer.
+    const bool skinny = decode;
+    const int fam = skinny ? MC_GEMM_STRIP : MC_GEMM_TILE;
     const float* rs_in = skinny ? nullptr : w.rs;
     const float eps_in = skinny ? c.rms_eps : 0.f;
     auto W = [&](int adapter, int which) { return m->layer_w[((size_t)layer * c.n_adapters + adapter) * 4 + which]; };
@@ -188,55 +211,58 @@ int layer_forward(Llm* m, int layer, char* x, int M, int n_groups, const int32_t
     // prefill: RoPE, the q re-ordering and the cache append are the projection's epilogue (mc_rope_scatter; a separate mc_rope_kv_bf16
     // launch inside the library when the launch is too small for the 256x256 kernel or the head size is not 128)            (:281-312)
     mc_rope_scatter rope{row_b, row_pos, row_t, m->cos_t, m->sin_t, w.qseq, kcl, vcl, (int)H, (int)Hkv, (int)D, Lq, Smax};
-    // decode at 16 < B <= 64: the projection's split-K slabs stay unreduced and the attention launch folds them ("fold_qkv", default on)
-    mc_slab_ref qkv_slabs;
-    qkv_slabs.S = 0;
-    const bool fold = skinny && stage == 0 && n_groups == 1 && m->fold_qkv;
     if (stage != 2)
-        RUNP(m, ph, PK_QKV, stream, gemm_grouped(x, hd, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in,
-                                                 decode ? nullptr : &rope, nullptr, 0.f, fold ? &qkv_slabs : nullptr));
+        RUNP(m, ph, PK_QKV, stream, gemm_grouped(x, ldh, nullptr, 0, w.qkv, qkvd, (int)qkvd, (int)hd, rs_in, 0, n_groups, gstart, W_all(0), stream, eps_in,
+                                                 decode ? nullptr : &rope, nullptr, 0.f, fam));
     if (stage == 1) return 0;
-    if (stage != 2 && m->call_key_mask) RUN(mc_attn_set_key_mask(m->call_key_mask, m->call_key_mask_stride));
+    const mc_attn_mask kmask{m->call_key_mask, m->call_key_mask_stride, 0, 0};
+    const mc_attn_mask* mk = m->call_key_mask ? &kmask : nullptr;
     if (stage == 2) {
     } else if (decode) {
         // one token per sequence (row b = sequence b): RoPE, the cache append and the attention are one launch (:281-312)
-        if (qkv_slabs.S > 0)
-            RUNP(m, ph, PK_ATTN, stream, mc_attn_decode_rope_slabs_bf16(&qkv_slabs, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
-                                         Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D,
-                                         nsplit, scale, stream));
-        else
         RUNP(m, ph, PK_ATTN, stream, mc_attn_decode_rope_bf16(w.qkv, qkvd, m->cos_t, m->sin_t, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
-                                     Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit,
-                                     scale, stream));
+                                     Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, lda, attn_ws, kv_lens, B, (int)H, (int)Hkv, Smax, (int)D, nsplit,
+                                     scale, mk, stream));
     } else {
         RUNP(m, ph, PK_ATTN, stream, mc_attn_prefill_bf16(w.qseq, (int64_t)Lq * H * D, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl,
-                                     Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, hd, out_map, kv_lens, B, (int)H, (int)Hkv, Lq, Smax,
-                                     (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, stream));
+                                     Hkv * Smax * D, D, (int64_t)Smax * D, w.attn, lda, out_map, kv_lens, B, (int)H, (int)Hkv, Lq, Smax,
+                                     (int)D, 1, 0, scale, nullptr, 0, 0, nullptr, mk, stream));
     }
     // x += o_proj(attn)  (:447);  then 1/rms of the new x for post_attention_layernorm (:462)
     // (prefill: the factor of post_attention_layernorm comes out of the same launch - rms_out - instead of a pass over the new x)
-    RUNP(m, ph, PK_O, stream, gemm_grouped(w.attn, hd, x, hd, x, hd, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream, 0.f, nullptr,
-                                           skinny ? nullptr : w.rs, c.rms_eps));
+    RUNP(m, ph, PK_O, stream, gemm_grouped(w.attn, lda, x, ldh, x, ldh, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream, 0.f, nullptr,
+                                           skinny ? nullptr : w.rs, c.rms_eps, fam));
     // inter = silu(gate) * up with gate|up = (x / rms) . (W_gu diag(g_post))^T                 (:380-390)
-    RUNP(m, ph, PK_GATE_UP, stream, gemm_grouped(x, hd, nullptr, 0, w.inter, I, (int)(2 * I), (int)hd, rs_in, 1, n_groups, gstart, W_all(2), stream, eps_in));
+    RUNP(m, ph, PK_GATE_UP, stream, gemm_grouped(x, ldh, nullptr, 0, w.inter, ldi, (int)(2 * I), (int)hd, rs_in, 1, n_groups, gstart, W_all(2), stream, eps_in,
+                                                 nullptr, nullptr, 0.f, fam));
     // x += down_proj(inter)  (:466);  then 1/rms for the next layer's input_layernorm / the final norm
-    RUNP(m, ph, PK_DOWN, stream, gemm_grouped(w.inter, I, x, hd, x, hd, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream, 0.f, nullptr,
-                                              skinny ? nullptr : w.rs, c.rms_eps));
+    RUNP(m, ph, PK_DOWN, stream, gemm_grouped(w.inter, ldi, x, ldh, x, ldh, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream, 0.f, nullptr,
+                                              skinny ? nullptr : w.rs, c.rms_eps, fam));
     return 0;
 }
 
+// final norm + lm_head over the B rows of xl (stride w.ldx); strip family whatever B is (one summation order per row, see layer_forward)
 int head_forward(Llm* m, const char* xl, int B, const Ws& w, float* logits, void* stream, int phase) {
     const mc_llm_config& c = m->cfg;
-    RUNP(m, phase, PK_OTHER, stream, mc_rmsnorm_bf16(xl, c.hidden, m->final_norm, w.nl, c.hidden, B, c.hidden, c.rms_eps, stream));
-    RUNP(m, phase, PK_HEAD, stream, mc_gemm_bf16(w.nl, c.hidden, m->lm_head, nullptr, nullptr, 0, logits, c.vocab, B, c.vocab, c.hidden,
-                                                 MC_ACT_NONE, 1, 1.0f, 1.0f, stream));
+    RUNP(m, phase, PK_OTHER, stream, mc_rmsnorm_bf16(xl, w.ldx, m->final_norm, w.nl, w.ldx, B, c.hidden, c.rms_eps, stream));
+    mc_gemm_args a;
+    a.x = w.nl; a.ldx = w.ldx; a.w_packed = m->lm_head; a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.out = logits; a.ldo = c.vocab;
+    a.M = B; a.N = c.vocab; a.K = c.hidden; a.act = MC_ACT_NONE; a.out_f32 = 1; a.alpha = 1.0f; a.beta = 1.0f;
+    a.row_scale = nullptr; a.swiglu = 0; a.split_k = 1; a.rms_eps = 0.f; a.rope = nullptr; a.rms_out = nullptr; a.rms_out_eps = 0.f;
+    a.family = MC_GEMM_STRIP;
+    RUNP(m, phase, PK_HEAD, stream, mc_gemm_ex_bf16(&a, stream));
     return 0;
 }
 
-int decode_nsplit(const mc_llm_config& c, int B) {
-    int ns = 1;
-    while (B * c.n_heads * ns < 256 && ns < 16) ns *= 2;
-    return ns;
+// Workgroups per (b, h) of the decode attention: enough waves to fill the chip at small batches.  Results do not depend on it (the
+// kernel's chunk schedule is a function of each sequence's own length): this is a launch-shape choice only.
+int decode_nsplit(const mc_llm_config& c, int B, int Smax) {
+    const int64_t waves = (int64_t)B * c.n_heads * 4;
+    if (waves >= 2048) return 1;
+    const int chunks = (Smax + 511) / 512;
+    const int64_t want = (2048 + waves - 1) / waves;
+    const int ns = (int)(want < chunks ? want : chunks);
+    return ns > 0 ? ns : 1;
 }
 
 }  // namespace
@@ -253,9 +279,8 @@ extern "C" int mc_llm_create(const mc_llm_config* cfg, void** handle) {
     Llm* m = new Llm();
     m->cfg = *cfg;
     *handle = m;
-    // decode batches of more than 16 sequences run the rows GEMM kernel: make sure its workspace pool exists before the first graph capture
-    // (best effort: without it those launches keep the skinny kernel)
-    (void)mc_gemm_reserve_rows(nullptr);
+    // the tile GEMMs' rms_out route uses a per-stream scratch pool: make sure it exists before the first graph capture (best effort)
+    (void)mc_gemm_reserve_workspace(nullptr);
     return 0;
 }
 
@@ -264,7 +289,7 @@ extern "C" int mc_llm_destroy(void* handle) {
     if (!m) return 0;
     for (int i = 0; i < Llm::kGraphs; ++i)
         if (m->graph_exec[i]) (void)hipGraphExecDestroy(m->graph_exec[i]);
-    if (m->own_stream) { (void)hipStreamSynchronize(m->own_stream); (void)mc_gemm_release_rows(m->own_stream); (void)hipStreamDestroy(m->own_stream); }
+    if (m->own_stream) { (void)hipStreamSynchronize(m->own_stream); (void)mc_gemm_release_workspace(m->own_stream); (void)hipStreamDestroy(m->own_stream); }
     if (m->ev_in) (void)hipEventDestroy(m->ev_in);
     if (m->ev_out) (void)hipEventDestroy(m->ev_out);
     for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -296,13 +321,6 @@ extern "C" int mc_llm_set_option(void* handle, const char* name, int value) {
     if (!m || !name) { mc_set_error("mc_llm_set_option: null argument"); return 1; }
     if (!strcmp(name, "use_graph")) { m->use_graph = value != 0; return 0; }
     if (!strcmp(name, "graph_logits")) { m->graph_logits = value != 0; return 0; }
-    if (!strcmp(name, "fold_qkv")) {
-        if (m->fold_qkv != (value != 0)) {                       // captured decode graphs hold the other launch sequence
-            for (int i = 0; i < Llm::kGraphs; ++i) m->gkey[i] = Llm::Key{};
-        }
-        m->fold_qkv = value != 0;
-        return 0;
-    }
     if (!strcmp(name, "tail_adapter")) {
         if (value >= m->cfg.n_adapters) { mc_set_error("mc_llm_set_option: tail_adapter %d of %d adapters", value, m->cfg.n_adapters); return 1; }
         m->tail_adapter = value < 0 ? -1 : value;
@@ -377,10 +395,9 @@ extern "C" int mc_llm_set_sampling(void* handle, int do_sample, float temperatur
 extern "C" int mc_llm_workspace_bytes(void* handle, int M, int B, int Lq, int64_t* bytes) {
     Llm* m = (Llm*)handle;
     if (!m || !bytes || M <= 0 || B <= 0 || Lq <= 0) { mc_set_error("mc_llm_workspace_bytes: bad arguments"); return 1; }
-    Ws w = carve(m->cfg, M, B, Lq, nullptr);
-    int64_t attn_ws = 0;
-    mc_attn_decode_workspace_bytes(B, m->cfg.n_heads, m->cfg.head_dim, 16, &attn_ws);
-    *bytes = (int64_t)w.total + attn_ws + 256;
+    // the prefill's carve-up and the decode steps' (padded rows) share the buffer; the attention partials follow either
+    const Ws w = carve(m->cfg, M, B, Lq, nullptr, false), wd = carve(m->cfg, B, B, 1, nullptr, true);
+    *bytes = (int64_t)(w.total > wd.total ? w.total : wd.total) + attn_ws_bytes(m->cfg, B) + 256;
     return 0;
 }
 
@@ -405,13 +422,13 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
     // one-shot key mask: this call's, then gone (also on the error paths below: the handle field is already cleared)
     m->call_key_mask = m->key_mask; m->call_key_mask_stride = m->key_mask_stride;
     m->key_mask = nullptr; m->key_mask_stride = 0;
-    struct MaskGuard { Llm* m; ~MaskGuard() { m->call_key_mask = nullptr; m->call_key_mask_stride = 0; (void)mc_attn_set_key_mask(nullptr, 0); } } mask_guard{m};
+    struct MaskGuard { Llm* m; ~MaskGuard() { m->call_key_mask = nullptr; m->call_key_mask_stride = 0; } } mask_guard{m};
     const mc_llm_config& c = m->cfg;
     // one-shot capture buffers: this call's, then gone (also on the error paths below)
     char* cap_h = (char*)m->cap_hidden; char* cap_q = (char*)m->cap_q;
     m->cap_hidden = nullptr; m->cap_q = nullptr;
     const size_t snap_h = (size_t)M * c.hidden * 2, snap_q = (size_t)B * Lq * c.n_heads * c.head_dim * 2;
-    Ws w = carve(c, M, B, Lq, (char*)workspace);
+    Ws w = carve(c, M, B, Lq, (char*)workspace, false);
     auto snapshot = [&](int l) -> int {               // after layer l (l = -1: the embeddings)
         hipError_t e = hipSuccess;
         if (cap_h) e = hipMemcpyAsync(cap_h + (size_t)(l + 1) * snap_h, x_routed, snap_h, hipMemcpyDeviceToDevice, (hipStream_t)stream);
@@ -432,29 +449,31 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
     m->tail_adapter = -1;
     const int full_layers = tail ? c.n_layers - 1 : c.n_layers;
     for (int l = 0; l < full_layers; ++l) {
-        RUN(layer_forward(m, l, (char*)x_routed, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
+        RUN(layer_forward(m, l, (char*)x_routed, c.hidden, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
                           Lq, (char*)k_cache, (char*)v_cache, Smax, false, 1, nullptr, stream));
         if (cap_h || cap_q) RUN(snapshot(l));
     }
     if (tail) {
         const int l = c.n_layers - 1;
         const int64_t hd = c.hidden, D = c.head_dim, H = c.n_heads, Hkv = c.n_kv_heads;
-        RUN(layer_forward(m, l, (char*)x_routed, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
+        RUN(layer_forward(m, l, (char*)x_routed, c.hidden, M, n_groups, group_start, group_adapter, w, row_b, row_pos, row_t, out_map, kv_lens, B,
                           Lq, (char*)k_cache, (char*)v_cache, Smax, false, 1, nullptr, stream, 1));
         // last tokens: residual rows, rotated queries (sequence order: row b Lq + len_b - 1 of qseq), attention over the stored keys
-        RUN(mc_copy_rows_bf16(x_routed, hd, last_rows, w.xl, hd, nullptr, B, (int)hd, stream));
+        RUN(mc_copy_rows_bf16(x_routed, hd, last_rows, w.xl, w.ldx, nullptr, B, (int)hd, stream));
         RUN(mc_gather_last_rows_bf16(w.qseq, H * D, kv_lens, Lq, w.qkv, H * D, B, (int)(H * D), stream));
         const size_t kv_layer = (size_t)B * Hkv * Smax * D * 2;
         char* kcl = (char*)k_cache + (size_t)l * kv_layer;
         char* vcl = (char*)v_cache + (size_t)l * kv_layer;
-        const int nsplit = decode_nsplit(c, B);
+        const int nsplit = decode_nsplit(c, B, Smax);
+        const mc_attn_mask kmask{m->call_key_mask, m->call_key_mask_stride, 0, 0};
+        const mc_attn_mask* mk_tail = m->call_key_mask ? &kmask : nullptr;
         RUNP(m, 0, PK_ATTN, stream, mc_attn_decode_bf16(w.qkv, H * D, D, kcl, Hkv * Smax * D, D, (int64_t)Smax * D, vcl, Hkv * Smax * D, D,
-                                                        (int64_t)Smax * D, w.attn, hd, (char*)workspace + w.total, kv_lens, B, (int)H, (int)Hkv, Smax,
-                                                        (int)D, nsplit, 1.0f / sqrtf((float)D), stream));
+                                                        (int64_t)Smax * D, w.attn, w.lda, (char*)workspace + w.total, kv_lens, B, (int)H, (int)Hkv, Smax,
+                                                        (int)D, nsplit, 1.0f / sqrtf((float)D), mk_tail, stream));
         const int32_t gs1[2] = {0, B};
         const int32_t ga1[1] = {tail_adapter};
-        RUN(layer_forward(m, l, w.xl, B, 1, gs1, ga1, w, nullptr, nullptr, nullptr, nullptr, kv_lens, B, 1, (char*)k_cache, (char*)v_cache, Smax,
-                          B <= 64, 1, nullptr, stream, 2, 0));
+        RUN(layer_forward(m, l, w.xl, w.ldx, B, 1, gs1, ga1, w, nullptr, nullptr, nullptr, nullptr, kv_lens, B, 1, (char*)k_cache, (char*)v_cache, Smax,
+                          true, 1, nullptr, stream, 2, 0));
         float* lg = logits_out ? logits_out : (float*)w.logits;
         RUN(head_forward(m, w.xl, B, w, lg, stream, 0));
         if (next_ids) RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, nullptr, 0, nullptr, B, c.vocab, stream));
@@ -463,7 +482,7 @@ extern "C" int mc_llm_prefill(void* handle, void* x_routed, int M, int n_groups,
     if (hidden_out)   // final norm over all rows (forward() API: logits for every position, :720)
         RUN(mc_rmsnorm_bf16(x_routed, c.hidden, m->final_norm, hidden_out, c.hidden, M, c.hidden, c.rms_eps, stream));
     if (last_rows && (logits_out || next_ids)) {
-        RUN(mc_copy_rows_bf16(x_routed, c.hidden, last_rows, w.xl, c.hidden, nullptr, B, c.hidden, stream));
+        RUN(mc_copy_rows_bf16(x_routed, c.hidden, last_rows, w.xl, w.ldx, nullptr, B, c.hidden, stream));
         float* lg = logits_out ? logits_out : (float*)w.logits;
         RUN(head_forward(m, w.xl, B, w, lg, stream, 0));
         if (next_ids) RUN(mc_argmax_step_f32(lg, c.vocab, next_ids, nullptr, 0, nullptr, B, c.vocab, stream));
@@ -483,10 +502,9 @@ static int decode_one_step(Llm* m, int B, int64_t* next_ids, int64_t* out_ids, i
     const int32_t* iota = state + 2 * B;
     const int32_t* zeros = state + 3 * B;
     const int32_t* step = state + 4 * B;
-    RUNP(m, 1, PK_OTHER, stream, mc_embed_rows_bf16(m->embed, c.hidden, next_ids, w.xl, c.hidden, nullptr, B, c.hidden, stream));
-    if (B > 64) RUN(mc_rms_scale_bf16(w.xl, c.hidden, w.rs, B, c.hidden, c.rms_eps, stream));        // M <= 64: computed inside the GEMMs
+    RUNP(m, 1, PK_OTHER, stream, mc_embed_rows_bf16(m->embed, c.hidden, next_ids, w.xl, w.ldx, nullptr, B, c.hidden, stream));
     for (int l = 0; l < c.n_layers; ++l)
-        RUN(layer_forward(m, l, w.xl, B, 1, gs, gad, w, iota, pos, zeros, nullptr, kvlen, B, 1, (char*)k_cache, (char*)v_cache, Smax, true,
+        RUN(layer_forward(m, l, w.xl, w.ldx, B, 1, gs, gad, w, iota, pos, zeros, nullptr, kvlen, B, 1, (char*)k_cache, (char*)v_cache, Smax, true,
                           nsplit, attn_ws, stream));
     float* lg = logits_step ? logits_step : (float*)w.logits;
     RUN(head_forward(m, w.xl, B, w, lg, stream, 1));
@@ -516,14 +534,18 @@ extern "C" int mc_llm_decode(void* handle, int B, int n_steps, int64_t* next_ids
         mc_set_error("mc_llm_decode: KV cache overflow: %d cached keys + %d steps > Smax %d", kv_len_max, n_steps, Smax);
         return 1;
     }
+    if (Smax > c_max_smax(m->cfg)) {
+        mc_set_error("mc_llm_decode: Smax %d exceeds the context the workspace is sized for (max_pos %d + 64)", Smax, m->cfg.max_pos);
+        return 1;
+    }
     m->graph_active = 0;
     m->call_key_mask = m->key_mask; m->call_key_mask_stride = m->key_mask_stride;
     m->key_mask = nullptr; m->key_mask_stride = 0;
-    struct MaskGuard { Llm* m; ~MaskGuard() { m->call_key_mask = nullptr; m->call_key_mask_stride = 0; (void)mc_attn_set_key_mask(nullptr, 0); } } mask_guard{m};
+    struct MaskGuard { Llm* m; ~MaskGuard() { m->call_key_mask = nullptr; m->call_key_mask_stride = 0; } } mask_guard{m};
     const mc_llm_config& c = m->cfg;
-    Ws w = carve(c, B, B, 1, (char*)workspace);
+    Ws w = carve(c, B, B, 1, (char*)workspace, true);
     void* attn_ws = (char*)workspace + w.total;
-    const int nsplit = decode_nsplit(c, B);
+    const int nsplit = decode_nsplit(c, B, Smax);
     hipStream_t s = (hipStream_t)stream;
     if (m->use_graph && (!logits_out || m->graph_logits) && n_steps > 1 && !m->prof_on && !m->call_key_mask) {
         // graphs cannot be captured on the legacy null stream: run this call's launches on the handle's own stream, after everything the

@@ -460,9 +460,8 @@ class HipLanguageBindVideoTower:
                     h, nrm = ops.add_layernorm(h, L["t_emb"], t_idx, L["t_ln"][0], L["t_ln"][1], c.layer_norm_eps)
                     qkv = ops.linear(nrm, L["t_qkv"])
                     a = torch.empty(B * T * n, D, dtype=BF16, device=dev)
-                    ops.attn_set_batch_split(n, 3 * D)
                     ops.attn_prefill(qkv, qkv[:, D:], qkv[:, 2 * D:], a, B * n, H, H, T, T, d, st_tn, st_tn, st_tn, D, False, 0,
-                                     scale=d ** -0.5, out_map=perm_d)
+                                     scale=d ** -0.5, out_map=perm_d, batch_split=(n, 3 * D))
                 else:                                                            # bt < t: every token attends to itself only
                     qkv = ops.linear(ops.layernorm(h, L["t_ln"][0], L["t_ln"][1], c.layer_norm_eps), L["t_qkv"])
                     a = torch.empty(B * T * n, D, dtype=BF16, device=dev)

@@ -28,25 +28,16 @@ from .splice import SplicePlan, plan_splice, routed_layout
 BF16 = _lib.storage_dtype()      # the library's 16-bit storage element: bf16, or fp16 with MC_STORAGE_DTYPE=fp16 (_lib.set_storage_dtype)
 
 
-# Side streams are shared by every model instance of the process (one set per device): the library keeps per-stream state - the split-K
-# workspace of the 17-64-row GEMM kernel is handed out per launching stream from a pool of 16 (mc_gemm_reserve_rows) - so streams created per
-# model would exhaust it after a few instances and later launches would silently take the older kernel (other fp32 summation order).
+# Side streams are shared by every model instance of the process (one set per device): the library keeps a per-stream scratch slot (the
+# tile GEMMs' rms_out route, a pool of 16: mc_gemm_reserve_workspace) - streams created per model would exhaust it after a few instances.
 _STREAM_POOLS: Dict = {}
 
 
-def _shared_streams(device, kind: str, n: int, cu_range=None):
-    """cu_range = (first_cu, n_cus): streams restricted to those CUs (mc_stream_create_cu_range; generate_pipelined's decode_cus mode)."""
+def _shared_streams(device, kind: str, n: int):
     idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    key = (idx, kind, cu_range)
-    pool = _STREAM_POOLS.setdefault(key, [])
+    pool = _STREAM_POOLS.setdefault((idx, kind), [])
     while len(pool) < n:
-        if cu_range is None:
-            pool.append(torch.cuda.Stream(device=device))
-        else:
-            h = C.c_void_p()
-            with torch.cuda.device(idx):
-                _lib.check(_lib.lib().mc_stream_create_cu_range(int(cu_range[0]), int(cu_range[1]), C.byref(h)), "mc_stream_create_cu_range")
-            pool.append(torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx)))      # lives as long as the process (shared pool)
+        pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
 
 
@@ -481,7 +472,7 @@ class MultimodalLlamaForCausalLM:
                 feats[modal] = self._encode_one(modal, x, prefix_tokens, suffix_tokens)
         else:
             cur = torch.cuda.current_stream()
-            pool = _shared_streams(self.device, "encode", len(work), getattr(self, "_prefill_cu_range", None))
+            pool = _shared_streams(self.device, "encode", len(work))
             parts = {}
             for (modal, x), st in zip(work, pool):
                 st.wait_stream(cur)
@@ -509,7 +500,13 @@ class MultimodalLlamaForCausalLM:
         return feats, masks
 
     def _encode_one(self, modal, x, prefix_tokens, suffix_tokens):
-        """One modality: encoder -> projector -> cat(prefix, feat, suffix) on the current stream."""
+        """One modality: encoder -> projector -> cat(prefix, feat, suffix) on the current stream.  Every linear runs the tile GEMM family
+        whatever its row count (B x tokens; the Q-Former's 32 queries of ONE sample are fewer than 64 rows): a sample's features are the
+        same bits in a batch of 1 and in a batch of 48 (ops.gemm_family)."""
+        with ops.gemm_family("tile"):
+            return self._encode_one_impl(modal, x, prefix_tokens, suffix_tokens)
+
+    def _encode_one_impl(self, modal, x, prefix_tokens, suffix_tokens):
         encoder, projector = self.model.get_modal_encoder(modal), self.model.get_modal_projector(modal)
         if type(x) is list:
             if modal == "audio":
@@ -936,7 +933,6 @@ class MultimodalLlamaForCausalLM:
         # stage_events (dict, optional): receives torch.cuda.Event pairs recorded on the current stream around the three stages, as
         # {"encode": (e0, e1), "prefill": (e1, e2), "decode": (e2, e3)} (bench.py: stage times and the decode roofline)
         stage_events = kw.pop("stage_events", None)
-        dstream = kw.pop("decode_stream", None)
 
         def mark():
             if stage_events is None:
@@ -962,15 +958,7 @@ class MultimodalLlamaForCausalLM:
         e2 = mark()
         if prefill_done is not None:
             prefill_done.record()                                  # generate_pipelined: the other pipeline's prefill may start now
-        # decode_stream (generate_pipelined's CU partition): everything from here on - the decode steps and the result's assembly - is issued on
-        # that stream, ordered after the prefill; the caller's stream then waits for it (the slot's buffers are reused by its next prefill)
-        dctx = None
-        if dstream is not None:
-            slot_stream = torch.cuda.current_stream()
-            dstream.wait_stream(slot_stream)
-            dctx = torch.cuda.stream(dstream)
-            dctx.__enter__()
-        try:
+        if True:
             B = plan.B
             out = self._cache.get(("out_ids", slot, B, max_new_tokens))   # persistent for the same reason as next_ids (the result is a copy)
             if out is None:
@@ -1052,10 +1040,6 @@ class MultimodalLlamaForCausalLM:
             if return_step_logits:
                 return res, torch.cat(step_logits, 0).transpose(0, 1)[:, :new.shape[1]]
             return res
-        finally:
-            if dctx is not None:
-                dctx.__exit__(None, None, None)
-                slot_stream.wait_stream(dstream)
 
     def _beam_search(self, input_ids, modal_inputs, attention_mask, k, max_new_tokens, length_penalty, early_stopping, ignore_eos):
         """generate(num_beams = k > 1): transformers 4.31's beam_search + BeamSearchScorer (the loop eval/model_multimodal_qa_loader.py:94-102
@@ -1161,22 +1145,9 @@ class MultimodalLlamaForCausalLM:
         units.  Same tokens as sequential generate() calls; host syncs inside generate() (EOS checks without ignore_eos) shorten the
         overlap but do not break it."""
         cur = torch.cuda.current_stream()
-        # decode_cus (attribute / MC_DECODE_CUS, default 0 = off; a multiple of 8): the CU partition.  Two streams at equal priority do not
-        # overlap a GEMM with a decode chain - every decode launch (5 per layer and token, each 20-350 us) waits for a GEMM tile (~30 us) to
-        # leave a CU, and a GEMM workgroup owns its CU's whole register file - so the decode steps run on a stream restricted to `decode_cus`
-        # CUs (the same number from every XCD) and the encoders + prefill on streams restricted to the OTHER CUs: the HBM-bound chain keeps a few
-        # load paths of its own, the MFMA-bound one loses decode_cus / 256 of its matrix units.
-        dcus = int(getattr(self, "decode_cus", os.environ.get("MC_DECODE_CUS", "0")) or 0)
-        dstream = None
-        self._prefill_cu_range = None
-        if dcus > 0:
-            total = _cu_count()
-            if dcus % 8 or dcus >= total:
-                raise ValueError(f"decode_cus={dcus}: a multiple of 8 below the device's {total} CUs")
-            self._prefill_cu_range = (dcus, total - dcus)
-            dstream = _shared_streams(self.device, "decode", 1, (0, dcus))[0]
-            kw = dict(kw, decode_stream=dstream)
-        streams = _shared_streams(self.device, "pipeline", 2, self._prefill_cu_range)
+        # (A CU partition - decode steps on a stream masked to a few CUs, the prefill on the others - was measured in rounds 4-5 and lost at
+        # every size: 9.98-17.7 against 25.5 samples/s, profiles/r05_probes/cu_partition_ab.json.  It is not in the tree.)
+        streams = _shared_streams(self.device, "pipeline", 2)
         try:
             pending = None
             last_prefill = None
@@ -1200,7 +1171,7 @@ class MultimodalLlamaForCausalLM:
                 pending[1].synchronize()
                 yield pending[0]
         finally:
-            self._prefill_cu_range = None
+            pass
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):
         """multimodal_llama.py:747-767 (kept for API parity; generate() does not call it)."""

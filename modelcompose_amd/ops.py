@@ -2,8 +2,10 @@
 the current HIP stream; all arithmetic happens in libmc_hip.so.  No CPU fallback."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -11,6 +13,27 @@ import torch
 from . import _lib
 
 ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3, "relu": 4}
+# mc_gemm_args.family (include/mc_hip.h): which kernel family runs a linear.  Each family adds a row's products in ONE fp32 order whatever
+# the number of rows; "auto" picks by M (strip for M <= 64, tile above), so a caller whose rows must not depend on how many other rows share
+# the launch - the inference towers and projectors, whose row count is B x tokens - pins "tile" with `with ops.gemm_family("tile"):`.
+FAMILY = {None: 0, "auto": 0, "strip": 1, "tile": 2}
+_family_tls = threading.local()
+
+
+def _fam(family=None) -> int:
+    return FAMILY[family] if family is not None else getattr(_family_tls, "v", 0)
+
+
+@contextlib.contextmanager
+def gemm_family(name):
+    """Default kernel family of every linear() / linear_ex() / linear_grouped() call of this thread inside the block."""
+    old = getattr(_family_tls, "v", 0)
+    _family_tls.v = FAMILY[name]
+    try:
+        yield
+    finally:
+        _family_tls.v = old
+
 BF16 = _lib.storage_dtype()      # the library's 16-bit storage element: bf16, or fp16 with MC_STORAGE_DTYPE=fp16 (_lib.set_storage_dtype)
 
 
@@ -108,10 +131,10 @@ def compose_weight(w: Optional[torch.Tensor], terms: Sequence, N: int, K: int, r
 
 
 def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           out_f32: bool = False, alpha: float = 1.0, bias: bool = True, beta: float = 1.0, auto_split: bool = False) -> torch.Tensor:
+           out_f32: bool = False, alpha: float = 1.0, bias: bool = True, beta: float = 1.0, auto_split: bool = False, family=None) -> torch.Tensor:
     """out[M,N] = act(alpha * x W^T + b) + beta * residual.  x: [M, Kp] bf16 (Kp = K padded to 64, pad columns zero).
     auto_split: let the library split K when the launch would under-fill the GPU (training-time rank projections; the choice depends
-    on M, so inference leaves it off to stay batch-invariant)."""
+    on M, so inference leaves it off to stay batch-invariant).  family: "auto" / "strip" / "tile" (default: the thread's gemm_family)."""
     _req(x, BF16, "x")
     if x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("x must be 2-D with contiguous rows")
@@ -121,40 +144,31 @@ def linear(x: torch.Tensor, w: PackedWeight, act=None, residual: Optional[torch.
     if out is None:
         out = torch.empty(M, w.N, dtype=torch.float32 if out_f32 else BF16, device=x.device)
     b = w.bias if bias else None
-    if auto_split:
-        a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), w.data.data_ptr(), 0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
-                           0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, w.N, w.Kp, ACT[act],
-                           1 if out_f32 else 0, alpha, beta, 0, 0, -1, 0.0)
-        _lib.check(_lib.lib().mc_gemm_ex_bf16(C.byref(a), _stream()), "mc_gemm_ex_bf16")
-        return out
-    _lib.check(_lib.lib().mc_gemm_bf16(_p(x), x.stride(0), _p(w.data), _p(b), _p(residual),
-                                       0 if residual is None else residual.stride(0), _p(out), out.stride(0), M, w.N, w.Kp,
-                                       ACT[act], 1 if out_f32 else 0, alpha, beta, _stream()), "mc_gemm_bf16")
+    a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), w.data.data_ptr(), 0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
+                       0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, w.N, w.Kp, ACT[act],
+                       1 if out_f32 else 0, alpha, beta, 0, 0, -1 if auto_split else 1, 0.0, 0, 0, 0.0, 0 if auto_split else _fam(family))
+    _lib.check(_lib.lib().mc_gemm_ex_bf16(C.byref(a), _stream()), "mc_gemm_ex_bf16")
     return out
 
 
-def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor] = None, swiglu: bool = False, split_k: int = 1,
+def linear_ex(x: torch.Tensor, w: PackedWeight, row_scale: Optional[torch.Tensor] = None, swiglu: bool = False,
               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False, rms_eps: float = 0.0,
-              rope=None, rms_out: Optional[torch.Tensor] = None, rms_out_eps: float = 0.0, defer_reduce=None) -> torch.Tensor:
+              rope=None, rms_out: Optional[torch.Tensor] = None, rms_out_eps: float = 0.0, family=None) -> torch.Tensor:
     """mc_gemm_ex_bf16: row_scale fp32 [M] (1/rms of a folded RMSNorm), swiglu (gate/up interleaved per 16 rows -> [M, N/2]),
-    defer_reduce: a _lib.SlabRefC the library fills when it leaves the split-K slabs of a 17..64-row launch unreduced (S > 0),
-    split_k > 1 (M <= 64): fp32 partial slabs [split_k, M, N]; rope = rope_scatter(...): the launch is a prefill's q|k|v projection, RoPE and
-    the q / KV-cache scatter happen in its epilogue (the returned buffer is scratch then)."""
+    rms_eps > 0 (strip family): the RMSNorm factor computed inside the launch; rope = rope_scatter(...): the launch is a prefill's q|k|v
+    projection, RoPE and the q / KV-cache scatter happen in its epilogue (the returned buffer is scratch then)."""
     _req(x, BF16, "x")
     M, Kx = x.shape
     if Kx != w.Kp:
         raise ValueError(f"x has {Kx} columns, weight expects K padded to {w.Kp}")
     n_out = w.N // 2 if swiglu else w.N
     if out is None:
-        if split_k > 1:
-            out = torch.empty(split_k, M, n_out, dtype=torch.float32, device=x.device)
-        else:
-            out = torch.empty(M, n_out, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+        out = torch.empty(M, n_out, dtype=torch.float32 if out_f32 else BF16, device=x.device)
     a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), w.data.data_ptr(), 0, 0 if residual is None else residual.data_ptr(),
                        0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(-2), M, w.N, w.Kp, 0,
-                       1 if (out_f32 or split_k > 1) else 0, 1.0, 1.0, 0 if row_scale is None else row_scale.data_ptr(),
-                       1 if swiglu else 0, split_k, float(rms_eps), 0 if rope is None else C.addressof(rope[0]),
-                       0 if rms_out is None else rms_out.data_ptr(), float(rms_out_eps), 0 if defer_reduce is None else C.addressof(defer_reduce))
+                       1 if out_f32 else 0, 1.0, 1.0, 0 if row_scale is None else row_scale.data_ptr(),
+                       1 if swiglu else 0, 1, float(rms_eps), 0 if rope is None else C.addressof(rope[0]),
+                       0 if rms_out is None else rms_out.data_ptr(), float(rms_out_eps), _fam(family))
     _lib.check(_lib.lib().mc_gemm_ex_bf16(C.byref(a), _stream()), "mc_gemm_ex_bf16")
     return out
 
@@ -167,7 +181,7 @@ def rope_scatter(row_b, row_pos, row_t, cos, sin, q_out, k_cache, v_cache, H, Hk
 
 def linear_grouped(x: torch.Tensor, weights: Sequence[PackedWeight], group_start: Sequence[int], row_scale: Optional[torch.Tensor] = None,
                    swiglu: bool = False, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, rope=None,
-                   rms_out: Optional[torch.Tensor] = None, rms_out_eps: float = 0.0) -> torch.Tensor:
+                   rms_out: Optional[torch.Tensor] = None, rms_out_eps: float = 0.0, family=None) -> torch.Tensor:
     """mc_gemm_grouped_bf16: rows [group_start[g], group_start[g+1]) of x use weights[g] (routed LocalLoRA linear)."""
     _req(x, BF16, "x")
     w0 = weights[0]
@@ -178,7 +192,7 @@ def linear_grouped(x: torch.Tensor, weights: Sequence[PackedWeight], group_start
     a = _lib.GemmArgsC(x.data_ptr(), x.stride(0), 0, 0, 0 if residual is None else residual.data_ptr(),
                        0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), 0, w0.N, w0.Kp, 0, 0, 1.0, 1.0,
                        0 if row_scale is None else row_scale.data_ptr(), 1 if swiglu else 0, 1, 0.0, 0 if rope is None else C.addressof(rope[0]),
-                       0 if rms_out is None else rms_out.data_ptr(), float(rms_out_eps))
+                       0 if rms_out is None else rms_out.data_ptr(), float(rms_out_eps), _fam(family))
     gs = (C.c_int32 * len(group_start))(*group_start)
     wp = (C.c_void_p * len(weights))(*[w.data.data_ptr() for w in weights])
     _lib.check(_lib.lib().mc_gemm_grouped_bf16(C.byref(a), len(weights), gs, wp, _stream()), "mc_gemm_grouped_bf16")
@@ -190,16 +204,6 @@ def rms_scale(x, eps):
     M, D = x.shape
     rs = torch.empty(M, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().mc_rms_scale_bf16(_p(x), x.stride(0), _p(rs), M, D, eps, _stream()), "mc_rms_scale_bf16")
-    return rs
-
-
-def residual_rms(h, part, eps):
-    """h += sum over slabs of part [S, M, D] (in place); returns 1/rms of the new rows."""
-    _req(h, BF16, "h")
-    M, D = h.shape
-    rs = torch.empty(M, dtype=torch.float32, device=h.device)
-    _lib.check(_lib.lib().mc_residual_rms_bf16(_p(h), h.stride(0), _p(part), part.stride(1), part.shape[0], _p(rs), M, D, eps, _stream()),
-               "mc_residual_rms_bf16")
     return rs
 
 
@@ -230,9 +234,17 @@ def add_layernorm(x, table, idx, w, b, eps, sum_out=None, out=None):
     return sum_out, out
 
 
-def attn_set_batch_split(b_inner: int, inner_stride: int):
-    """One-shot two-level batch index of the next attn_prefill launch (mc_attn_set_batch_split)."""
-    _lib.check(_lib.lib().mc_attn_set_batch_split(int(b_inner), int(inner_stride)), "mc_attn_set_batch_split")
+def attn_mask(key_valid: Optional[torch.Tensor] = None, batch_split=None):
+    """struct mc_attn_mask or None: key_valid uint8 [B, >= S] (0 = masked key), batch_split = (b_inner, inner_stride) - the two-level batch
+    index of the Lq, S <= 8 kernel.  The returned struct holds raw pointers: keep key_valid alive until the launch has been issued."""
+    if key_valid is None and batch_split is None:
+        return None
+    bi, st = (0, 0) if batch_split is None else (int(batch_split[0]), int(batch_split[1]))
+    return _lib.AttnMaskC(0 if key_valid is None else key_valid.data_ptr(), 0 if key_valid is None else key_valid.stride(0), bi, st)
+
+
+def _mask_ref(m):
+    return None if m is None else C.byref(m)
 
 
 def rope_kv(qkv, row_b, row_pos, row_t, cos, sin, q_out, k_cache, v_cache, H, Hkv, D, Lq, Smax):
@@ -242,12 +254,13 @@ def rope_kv(qkv, row_b, row_pos, row_t, cos, sin, q_out, k_cache, v_cache, H, Hk
 
 
 def attn_prefill(q, k, v, out, B, H, Hkv, Lq, S, D, q_strides, k_strides, v_strides, o_row_stride, causal, q_offset=0,
-                 scale=None, out_map=None, kv_lens=None, rel_table=None, rel_off=0, q_gate=None):
+                 scale=None, out_map=None, kv_lens=None, rel_table=None, rel_off=0, q_gate=None, key_valid=None, batch_split=None):
     scale = (1.0 / math.sqrt(D)) if scale is None else scale
+    mk = attn_mask(key_valid, batch_split)
     _lib.check(_lib.lib().mc_attn_prefill_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_row_stride,
                                                _p(out_map), _p(kv_lens), B, H, Hkv, Lq, S, D, 1 if causal else 0, q_offset,
                                                scale, _p(rel_table), 0 if rel_table is None else rel_table.stride(0), rel_off,
-                                               _p(q_gate), _stream()), "mc_attn_prefill_bf16")
+                                               _p(q_gate), _mask_ref(mk), _stream()), "mc_attn_prefill_bf16")
     return out
 
 
@@ -262,13 +275,20 @@ def attn_probs(q, k, B, H, Hkv, Lq, S, D, q_strides, k_strides, causal=True, q_o
     return out
 
 
+def decode_workspace(B, H, D, S, device):
+    """fp32 scratch of the decode attention: one partial per (b, h) and 512-key chunk of a cache of S positions (+ the new token's)."""
+    n = C.c_int64(0)
+    _lib.check(_lib.lib().mc_attn_decode_workspace_bytes(B, H, D, S, C.byref(n)), "mc_attn_decode_workspace_bytes")
+    return torch.empty(n.value // 4, dtype=torch.float32, device=device)
+
+
 def attn_decode(q, k, v, out, B, H, Hkv, S, D, q_strides, k_strides, v_strides, o_sb, nsplit=1, workspace=None, scale=None,
-                kv_lens=None):
+                kv_lens=None, key_valid=None):
     scale = (1.0 / math.sqrt(D)) if scale is None else scale
-    if nsplit > 1 and workspace is None:
-        workspace = torch.empty(B * H * nsplit * (D + 2), dtype=torch.float32, device=q.device)
+    if workspace is None and (nsplit > 1 or S > 19968):
+        workspace = decode_workspace(B, H, D, S, q.device)
     _lib.check(_lib.lib().mc_attn_decode_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_sb,
-                                              _p(workspace), _p(kv_lens), B, H, Hkv, S, D, nsplit, scale, _stream()),
+                                              _p(workspace), _p(kv_lens), B, H, Hkv, S, D, nsplit, scale, _mask_ref(attn_mask(key_valid)), _stream()),
                "mc_attn_decode_bf16")
     return out
 
@@ -530,11 +550,11 @@ def attn_prefill_lse(q, k, v, out, lse, B, H, Lq, S, D, q_strides, k_strides, v_
     if dropout is not None and dropout[0] > 0:
         _lib.check(_lib.lib().mc_attn_prefill_dropout_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_row_stride,
                                                            _p(kv_lens), B, H, H, Lq, S, D, 1 if causal else 0, 0, sc, _p(lse), float(dropout[0]),
-                                                           int(dropout[1]) & (2 ** 64 - 1), int(dropout[2]), _stream()), "mc_attn_prefill_dropout_bf16")
+                                                           int(dropout[1]) & (2 ** 64 - 1), int(dropout[2]), None, _stream()), "mc_attn_prefill_dropout_bf16")
         return out
     _lib.check(_lib.lib().mc_attn_prefill_lse_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(v), *v_strides, _p(out), o_row_stride, None,
                                                    _p(kv_lens), B, H, H, Lq, S, D, 1 if causal else 0, 0, sc, None, 0, 0, None, _p(lse),
-                                                   _stream()), "mc_attn_prefill_lse_bf16")
+                                                   None, _stream()), "mc_attn_prefill_lse_bf16")
     return out
 
 
@@ -591,17 +611,15 @@ def cast_bf16(x32, out=None):
     return out
 
 
-def attn_decode_rope(qkv, cos, sin, k_cache, v_cache, out, kv_lens, B, H, Hkv, Smax, D, nsplit=1, workspace=None, scale=None):
+def attn_decode_rope(qkv, cos, sin, k_cache, v_cache, out, kv_lens, B, H, Hkv, Smax, D, nsplit=1, workspace=None, scale=None, key_valid=None):
     """Decode attention with RoPE + KV append fused (caches [B, Hkv, Smax, D]); kv_lens counts the token being decoded.
-    qkv: the [B, (H + 2 Hkv) D] bf16 rows, or a _lib.SlabRefC with S > 0 (the projection's unreduced split-K slabs)."""
+    qkv: the [B, (H + 2 Hkv) D] bf16 rows.  nsplit is a launch shape, not part of the result."""
     sc = (1.0 / math.sqrt(D)) if scale is None else scale
     st = (Hkv * Smax * D, D, Smax * D)
-    if isinstance(qkv, _lib.SlabRefC):
-        _lib.check(_lib.lib().mc_attn_decode_rope_slabs_bf16(C.byref(qkv), _p(cos), _p(sin), _p(k_cache), *st, _p(v_cache), *st, _p(out),
-                                                             out.stride(0), _p(workspace), _p(kv_lens), B, H, Hkv, Smax, D, nsplit, sc, _stream()),
-                   "mc_attn_decode_rope_slabs_bf16")
-        return out
+    if workspace is None and (nsplit > 1 or Smax > 19968):
+        workspace = decode_workspace(B, H, D, Smax, out.device)
     _lib.check(_lib.lib().mc_attn_decode_rope_bf16(_p(qkv), qkv.stride(0), _p(cos), _p(sin), _p(k_cache), *st, _p(v_cache), *st, _p(out),
-                                                   out.stride(0), _p(workspace), _p(kv_lens), B, H, Hkv, Smax, D, nsplit, sc, _stream()),
+                                                   out.stride(0), _p(workspace), _p(kv_lens), B, H, Hkv, Smax, D, nsplit, sc,
+                                                   _mask_ref(attn_mask(key_valid)), _stream()),
                "mc_attn_decode_rope_bf16")
     return out

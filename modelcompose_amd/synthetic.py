@@ -41,8 +41,11 @@ def vicuna7b_meta(modals: Sequence[str] = ("vision",), reset: Optional[str] = No
     return meta
 
 
-def synthetic_state_dict(meta: dict, device="cuda", seed: int = 1234, dtype=torch.bfloat16, lora_adapters: Optional[Sequence[str]] = None
+def synthetic_state_dict(meta: dict, device="cuda", seed: int = 1234, dtype=None, lora_adapters: Optional[Sequence[str]] = None
                          ) -> Dict[str, torch.Tensor]:
+    if dtype is None:                                # the library's storage element at CALL time (bf16, or fp16 under MC_STORAGE_DTYPE=fp16)
+        from . import _lib
+        dtype = _lib.storage_dtype()
     g = torch.Generator(device=device).manual_seed(seed)
     Hd, I, V, Lyr = meta["hidden_size"], meta["intermediate_size"], meta["vocab_size"], meta["num_hidden_layers"]
     H, Hkv = meta["num_attention_heads"], meta["num_key_value_heads"]

@@ -405,6 +405,49 @@ def test_eval_model_driver_writes_the_answers_file_and_shards_by_chunk(tmp_path,
     assert [r["question_id"] for r in part0 + part1] == [r["question_id"] for r in full]
 
 
+def test_batched_eval_answers_do_not_depend_on_the_number_of_chunks(tmp_path, g4_model):
+    """VERDICT r5 #1a / SURVEY §8(e): `--batch-size 4` answers of a 1-rank run and of a 3-rank run (chunk = ceil(n / N), rank k evaluates
+    chunk k: model_multimodal_qa_loader.py:25-46; the answer files are concatenated: MCUB-4.sh:60-70) are identical row for row although
+    every question sits in a different batch (4 + 3 rows against 3 + 3 + 1), with other neighbours, another padded length and another KV
+    cache stride - prefill (tile GEMM family), decode steps (strip GEMM family, per-sequence attention chunks) and the lm_head are all
+    batch-invariant.  Generated ids are compared bitwise through generate() as well."""
+    import json
+    from types import SimpleNamespace
+    from PIL import Image
+    from modelcompose_amd.eval.model_multimodal_qa_loader import eval_model
+    from modelcompose_amd.model.image_processor import HipCLIPImageProcessor
+    from oracle.toy_tokenizer import ToyTokenizer
+    model, a, meta, sd = g4_model
+    rng = np.random.default_rng(1)
+    files = []
+    for i, (w, h) in enumerate(((40, 30), (28, 28), (25, 50), (33, 21))):
+        f = tmp_path / f"img{i}.png"
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(f)
+        files.append(str(f))
+    texts = ["what is item 0 ?", "describe this picture in a few words please", "no picture here , just text", "what colour ?", "how many things are there in it ?",
+             "a", "is it item 6 or item 7 or neither ?"]
+    qs = [{"id": f"q{i}", "conversations": [{"from": "human", "value": ("<image>\n" if i != 2 else "") + t}, {"from": "gpt", "value": ""}],
+           **({"modal_inputs": {"vision": [files[i % 4]]}} if i != 2 else {})} for i, t in enumerate(texts)]
+    qfile = tmp_path / "questions7.json"
+    json.dump(qs, open(qfile, "w"))
+    procs = {"vision": HipCLIPImageProcessor(size=28, crop_size=28)}
+    tok = ToyTokenizer(True, model_max_length=256)                      # ONE tokenizer: the toy assigns ids in order of first appearance
+
+    def run(num_chunks, chunk_idx, out, bs):
+        args = SimpleNamespace(model_path="/ckpts/multimodal-tiny", model_base=None, question_file=str(qfile), answers_file=str(out), conv_mode="v1",
+                               num_chunks=num_chunks, chunk_idx=chunk_idx, temperature=0.0, top_p=None, num_beams=1, batch_size=bs, max_new_tokens=6,
+                               pipeline=False)
+        n = eval_model(args, loaded=(tok, model, procs, 2048))
+        return [json.loads(l) for l in open(out)]
+
+    one = run(1, 0, tmp_path / "n1.jsonl", 4)
+    assert [r["question_id"] for r in one] == [f"q{i}" for i in range(7)]
+    three = sum((run(3, k, tmp_path / f"n3_{k}.jsonl", 4) for k in range(3)), [])
+    assert [(r["question_id"], r["text"]) for r in three] == [(r["question_id"], r["text"]) for r in one]
+    alone = run(1, 0, tmp_path / "b1.jsonl", 1)                        # the reference's own geometry: one question per generate() call
+    assert [(r["question_id"], r["text"]) for r in alone] == [(r["question_id"], r["text"]) for r in one]
+
+
 def test_generate_pipelined_equals_sequential_generate(g4_model):
     """Two alternating generation pipelines on two streams produce exactly the tokens of sequential generate() calls, batch after
     batch (different prompts / images per batch, greedy and sampled, with and without EOS handling)."""
@@ -425,37 +468,6 @@ def test_generate_pipelined_equals_sequential_generate(g4_model):
     # and the plain path still works afterwards (slot 0 buffers reused)
     again = model.generate(batches[0][0], modal_inputs=batches[0][1], max_new_tokens=5, ignore_eos=True, do_sample=True, temperature=1.3, seed=7)
     assert torch.equal(again, seq[0])
-
-
-def test_generate_pipelined_with_a_cu_partition_gives_the_same_tokens(g4_model):
-    """decode_cus (round 5): the decode steps on a stream restricted to a few CUs of every XCD, encoders + prefill on streams restricted to
-    the others (mc_stream_create_cu_range) - scheduling only: the tokens are those of sequential generate() calls, greedy, with EOS
-    handling (host syncs on the decode stream) and sampled; the option switches off again cleanly."""
-    model, a, meta, sd = g4_model
-    g = torch.Generator().manual_seed(4)
-    batches = []
-    for i in range(5):
-        ids = a["input_ids"].clone()
-        ids[:, 1:4] = torch.randint(3, 100, (ids.shape[0], 3), generator=g)
-        batches.append((ids.cuda(), {"vision": (a["pixels"] - 0.05 * i).cuda()}))
-    try:
-        for kw in (dict(max_new_tokens=6, ignore_eos=True), dict(max_new_tokens=6), dict(max_new_tokens=5, ignore_eos=True, do_sample=True, temperature=1.3, seed=9)):
-            model.decode_cus = 0
-            seq = [model.generate(ids, modal_inputs=mi, **kw) for ids, mi in batches]
-            for cus in (16, 64):
-                model.decode_cus = cus
-                pip = list(model.generate_pipelined(iter(batches), **kw))
-                assert len(pip) == len(seq)
-                for x, y in zip(seq, pip):
-                    assert torch.equal(x, y)
-        model.decode_cus = 12
-        with pytest.raises(ValueError):
-            list(model.generate_pipelined(iter(batches[:1]), max_new_tokens=2))
-    finally:
-        model.decode_cus = 0
-    assert model._prefill_cu_range is None
-    again = model.generate(batches[0][0], modal_inputs=batches[0][1], max_new_tokens=6, ignore_eos=True)
-    assert torch.equal(again, list(model.generate_pipelined(iter(batches[:1]), max_new_tokens=6, ignore_eos=True))[0])
 
 
 def test_decode_graph_is_really_replayed_on_the_default_stream(g4_model):
@@ -615,30 +627,6 @@ def test_left_padded_batch_of_mixed_spliced_lengths_equals_each_row_alone(g4_mod
         assert torch.equal(res[b, L:].cpu()[clear], alone[b][0][clear]), b
 
 
-def test_forced_192_column_tiles_give_the_same_tokens_and_logits():
-    """mc_gemm_set_option("force_tile192"): every large GEMM on the 186-register 192-column instantiation, RoPE + cache scatter and the
-    next norm's factor on their separate-launch routes, SwiGLU on the 8-byte store path - the co-residency mode of the pipelined eval
-    loop.  Same function at the real widths (2-layer Vicuna-7B-wide vision model, 683-token prompts): ids and step logits BITWISE equal
-    to the default path - the tile shapes and the fused / separate routes are bit-identical by construction."""
-    import fullwidth_cases as fc
-    from modelcompose_amd import _lib
-    from modelcompose_amd.model.builder import build_from_state_dict
-    meta, sd, ids, mi = fc.build_case("configs1_vision", [449, 470])
-    model = build_from_state_dict(meta, sd)
-    ids, mid = ids.cuda(), fc.to_dev(mi)
-    r0, l0 = model.generate(ids, modal_inputs=mid, max_new_tokens=6, ignore_eos=True, return_step_logits=True)
-    f0 = model.forward(input_ids=ids, modal_inputs=mid).logits.clone()
-    _lib.check(_lib.lib().mc_gemm_set_option(b"force_tile192", 1), "force_tile192")
-    try:
-        r1, l1 = model.generate(ids, modal_inputs=mid, max_new_tokens=6, ignore_eos=True, return_step_logits=True)
-        f1 = model.forward(input_ids=ids, modal_inputs=mid).logits.clone()
-    finally:
-        _lib.check(_lib.lib().mc_gemm_set_option(b"force_tile192", 0), "force_tile192")
-    assert torch.equal(r0, r1)
-    assert torch.equal(l0, l1), ((l0.float() - l1.float()).abs().max().item() / l0.float().abs().max().item())
-    assert torch.equal(f0, f1), ((f0.float() - f1.float()).abs().max().item() / f0.float().abs().max().item())
-
-
 def test_last_layer_tail_equals_the_full_last_layer(g4_model):
     """generate()'s prefill runs the last decoder layer's attention + MLP for the last token of every sequence only (mc_llm option
     "tail_adapter"): the first-step logits agree with the all-rows path to fp32 summation order of one attention row and three small GEMMs
@@ -672,34 +660,3 @@ def test_last_layer_tail_equals_the_full_last_layer(g4_model):
         for x, y in zip(outs[True][2], outs[False][2]):
             assert torch.equal(x, y)
 
-
-@pytest.mark.parametrize("B", [24, 48])
-def test_decode_qkv_slab_fold_in_the_attention_launch_is_bit_identical(g4_model, B):
-    """Round 3: at decode batches of 17-64 rows the q|k|v projection's split-K slabs are no longer reduced by their own
-    launch - the attention launch folds them (slice order, RMS row factor, one bf16 rounding, exactly what rows_reduce_kernel stored).
-    The mc_llm option "fold_qkv" switches the fold off: ids, step logits and the KV cache must be BIT-identical either way, eagerly and
-    from the replayed graph."""
-    from modelcompose_amd import _lib
-    model, a, meta, sd = g4_model
-    g = torch.Generator().manual_seed(B)
-    V = model.config.vocab_size
-    ids = a["input_ids"][:1].repeat(B, 1)
-    ids[:, -4:] = torch.randint(3, V, (B, 4), generator=g)                  # different rows
-    px = a["pixels"][:1].repeat(B, 1, 1, 1) + 0.05 * torch.randn(B, *a["pixels"].shape[1:], generator=g).to(a["pixels"].dtype)
-    ids, px = ids.cuda(), px.cuda()
-    outs = {}
-    for fold in (1, 0):
-        _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"fold_qkv", fold), "set_option")
-        try:
-            res, lg = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=6, ignore_eos=True, return_step_logits=True)
-            res_g = model.generate(ids, modal_inputs={"vision": px}, max_new_tokens=6, ignore_eos=True)            # graph replay
-            torch.cuda.synchronize()
-            kv = [t.clone() for t in model._cache[next(k for k in model._cache if isinstance(k, tuple) and k and k[0] == "kv" and k[1] == 0)]]
-        finally:
-            _lib.check(_lib.lib().mc_llm_set_option(model._handle, b"fold_qkv", 1), "set_option")
-        outs[fold] = (res.cpu(), lg.float().cpu(), res_g.cpu(), kv)
-    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][2], outs[0][2]) and torch.equal(outs[1][0], outs[1][2])
-    assert torch.equal(outs[1][1], outs[0][1])
-    for x, y in zip(outs[1][3], outs[0][3]):
-        assert torch.equal(x, y)
-    assert len(set(map(tuple, outs[1][0][:, ids.shape[1]:].tolist()))) > 1             # the rows really differ

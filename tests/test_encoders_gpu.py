@@ -186,7 +186,7 @@ def test_languagebind_video_processor_matches_torch_transform():
 def test_fused_add_layernorm_and_in_place_temporal_attention_are_bit_identical():
     """Round 4 (LanguageBind-Video temporal branch, video/modeling_video.py:105-130): `h + temporal_embedding` + temporal_layer_norm1 in one
     pass equals add_rows followed by layernorm bit for bit; the temporal attention addressed in place over the (b t) n d layout
-    (mc_attn_set_batch_split) equals the attention over a permuted (b n) t d copy bit for bit; a launch the tiny kernel does not take
+    (mc_attn_mask.b_inner) equals the attention over a permuted (b n) t d copy bit for bit; a launch the tiny kernel does not take
     refuses the split instead of mis-addressing."""
     from modelcompose_amd import _lib, ops
     g = torch.Generator().manual_seed(5)
@@ -214,15 +214,14 @@ def test_fused_add_layernorm_and_in_place_temporal_attention_are_bit_identical()
     ops.attn_prefill(qp, qp[:, D:], qp[:, 2 * D:], a0, B * n, H, H, T, T, d, st_t, st_t, st_t, D, False, 0, scale=d ** -0.5, out_map=perm)
     a1 = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
     st_tn = (T * n * 3 * D, n * 3 * D, d)
-    ops.attn_set_batch_split(n, 3 * D)
-    ops.attn_prefill(qkv, qkv[:, D:], qkv[:, 2 * D:], a1, B * n, H, H, T, T, d, st_tn, st_tn, st_tn, D, False, 0, scale=d ** -0.5, out_map=perm)
+    ops.attn_prefill(qkv, qkv[:, D:], qkv[:, 2 * D:], a1, B * n, H, H, T, T, d, st_tn, st_tn, st_tn, D, False, 0, scale=d ** -0.5, out_map=perm,
+                     batch_split=(n, 3 * D))
     assert torch.equal(a0, a1) and a1.float().abs().max().item() > 0
-    # the split is one-shot: the next launch is an ordinary one
+    # the split is an argument of ITS launch (mc_attn_mask): the next launch is an ordinary one
     a2 = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
     ops.attn_prefill(qp, qp[:, D:], qp[:, 2 * D:], a2, B * n, H, H, T, T, d, st_t, st_t, st_t, D, False, 0, scale=d ** -0.5, out_map=perm)
     assert torch.equal(a2, a0)
     # and it is refused where the tiny kernel does not run (64 tokens per sequence)
-    ops.attn_set_batch_split(n, 3 * D)
     with pytest.raises(ValueError):
         ops.attn_prefill(qkv, qkv[:, D:], qkv[:, 2 * D:], a2, B, H, H, 64, 64, d, (64 * 3 * D, 3 * D, d), (64 * 3 * D, 3 * D, d), (64 * 3 * D, 3 * D, d), D,
-                         False, 0, scale=d ** -0.5)
+                         False, 0, scale=d ** -0.5, batch_split=(n, 3 * D))

@@ -285,11 +285,12 @@ def test_fixture_rows_inside_the_benchmarked_48_row_batch(model32):
           final-norm hidden state of every token of the fixture rows and their K / V cache entries of all 32 layers are compared BITWISE
           between the 8-row run and each 48-row run (forward()'s route: every layer on every row).  [The logits themselves go through
           lm_head at M = B rows, where the kernel - and so the fp32 summation order - is chosen by B: they are compared in (2).]
-      (2) SHIPPED: generate_pipelined (last-layer tail, hipGraph decode, two slots) over the two batches: first-step logits of the fixture
-          rows within 5e-3 of the 8-row run's (other GEMM kernels for 48 than for 8 rows in the tail and the head: summation order), and
-          the greedy ids equal to the 8-row run's up to the first step whose top-2 margin IN THE 8-ROW RUN is below the near-tie band; the
-          decode steps of a 48-row batch take other kernels than those of an 8-row batch, so after 32 layers the two runs are two
-          bf16-noise realisations of the same function - what must not happen is a departure at a clear margin."""
+      (2) SHIPPED: generate_pipelined (last-layer tail, hipGraph decode, two slots) over the two batches.  Round 6 (VERDICT r5 #1a): decode
+          is batch-invariant too - the strip GEMM family adds a row's products in one order whatever M is (csrc/gemm_strip.hip), the
+          decode attention's chunk schedule is a function of each sequence's own length (csrc/attention.hip) - so every step's logits of
+          the fixture rows are BITWISE the 8-row run's and all 17 greedy tokens are equal, wherever the rows sit in the 48-row batch.
+          This is what lets the eval loader batch a question differently at 1 and at 8 GPUs (model_multimodal_qa_loader.py:25-46) and
+          still `cat` identical answer files (MCUB-4.sh:60-70)."""
     model, meta, _ = model32
     name = "fulldepth_iav8"
     ids8, mi8 = fc.build_rows(name)
@@ -343,19 +344,15 @@ def test_fixture_rows_inside_the_benchmarked_48_row_batch(model32):
     ids_graph = [o[:, Lt:].cpu() for o in model.generate_pipelined(batches, max_new_tokens=fc.N_NEW, ignore_eos=True)]
     assert model.runtime_option("graph_active") == 1
     scale = lg8.abs().max()
-    marg8 = fc.margins(lg8)
-    tie = NEAR_TIE["fulldepth_iav"]
     for bi, ((res, lg), idg) in enumerate(zip(outs, ids_graph)):
         got_ids, got_lg = res[:, Lt:].cpu()[place[bi]], lg.float().cpu()[place[bi]]
         assert torch.equal(idg[place[bi]], got_ids), "graph-replayed decode and one-launch-per-kernel decode disagree"
-        e0 = ((got_lg[:, 0] - lg8[:, 0]).abs().amax(-1) / scale)
+        e_all = ((got_lg - lg8).abs().amax(-1) / scale)                   # [8 rows, 17 steps]
         matched = [int((got_ids[r] != ids8_new[r]).nonzero()[0]) if (got_ids[r] != ids8_new[r]).any() else fc.N_NEW for r in range(8)]
-        dep = [marg8[r, matched[r]].item() if matched[r] < fc.N_NEW else None for r in range(8)]
-        rep["batches"][bi].update(first_step_logit_diff_max=e0.max().item(), tokens_equal_to_the_8_row_run=matched, departure_margins_in_the_8_row_run=dep)
-        assert e0.max().item() < 5e-3, e0
-        for r in range(8):
-            if matched[r] < fc.N_NEW:
-                assert dep[r] < tie, (bi, r, matched[r], dep[r])
+        rep["batches"][bi].update(first_step_logit_diff_max=e_all[:, 0].max().item(), step_logit_diff_max=e_all.max().item(),
+                                  step_logits_bitwise_equal=bool(torch.equal(got_lg, lg8)), tokens_equal_to_the_8_row_run=matched)
+        assert matched == [fc.N_NEW] * 8, (bi, matched)
+        assert torch.equal(got_lg, lg8), (bi, e_all.max().item())
     REPORT["benchmarked_shape_b48"] = rep
     _dump()
     print("b48", json.dumps(rep))

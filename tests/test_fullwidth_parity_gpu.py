@@ -217,25 +217,19 @@ def test_first_layer_stages_are_exact_to_rounding(name):
     Hd, H, D = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim
     al = lambda v: (v + 255) // 256 * 256
 
-    def stages(debug):
-        # the shipped route rotates q / k in the q|k|v projection's epilogue and never stores the un-rotated projection; debug bit 31 keeps
-        # the GEMM -> mc_rope_kv_bf16 sequence (bit-identical results, tests/test_ops_gpu.py), whose workspace still holds q|k|v
-        _lib.lib().mc_gemm_debug(debug)
-        try:
-            st_ = model._prefill(plan, feats, 0, want_hidden=False, want_logits=True)
-            torch.cuda.synchronize()
-        finally:
-            _lib.lib().mc_gemm_debug(0)
+    def stages():
+        # the shipped route rotates q / k in the q|k|v projection's epilogue and never stores the un-rotated projection (the separate GEMM ->
+        # mc_rope_kv_bf16 sequence is bit-identical: tests/test_ops_gpu.py::test_qkv_projection_with_rope_scatter_epilogue): the rotated
+        # queries and the attention output are the stages compared here
+        st_ = model._prefill(plan, feats, 0, want_hidden=False, want_logits=True)
+        torch.cuda.synchronize()
         lay_ = st_["layout"]
         ws, off, v = st_["ws"], 0, {}
         for tag, rows, cols in (("qkv", lay_.M, 3 * H * D), ("q_rot", plan.B * plan.Lmax, H * D), ("attn", lay_.M, Hd)):     # carve() of csrc/llm_runtime.cpp
             v[tag] = ws[off:off + rows * cols * 2].view(torch.bfloat16).view(rows, cols).float().cpu()
             off += al(rows * cols * 2)
         return st_, v
-    _, separate = stages(-2147483648)
-    st, views = stages(0)
-    assert torch.equal(views["q_rot"], separate["q_rot"]) and torch.equal(views["attn"], separate["attn"]), "fused RoPE epilogue != separate launch"
-    views["qkv"] = separate["qkv"]
+    st, views = stages()
     lay = st["layout"]
     M, B, Lq = lay.M, plan.B, plan.Lmax
     sdf = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
@@ -249,7 +243,7 @@ def test_first_layer_stages_are_exact_to_rounding(name):
     rep = {}
     # q|k|v: one rounding away at most.  Rotated q = a*cos - b*sin of two values that may each be one ulp off, measured in ulps of the
     # (possibly cancelled) result: up to 3 seen on 1.6e-6 of the elements; attention output: the same through the P.V sum (2 seen)
-    for tag, max_frac, max_ulps in (("qkv", 0.005, 1.0), ("q_rot", 0.005, 4.0), ("attn", 0.15, 3.0)):
+    for tag, max_frac, max_ulps in (("q_rot", 0.005, 4.0), ("attn", 0.15, 3.0)):
         d = views[tag]
         o = tr["0." + tag]
         o = o[seq_of_row] if tag != "q_rot" else o
