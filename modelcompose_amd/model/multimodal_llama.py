@@ -128,6 +128,60 @@ def _ptr(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+class ParamRef:
+    """What train_multimodal.train touches of an nn.Parameter (modelcompose/train/train_multimodal.py:436-465): `.requires_grad`, read and
+    written.  The tensors themselves live in the owner's reference-grammar state (`_raw`, prefix / suffix tokens) until the training step
+    builds its flat fp32 master buffer from the selected set (train/step.py)."""
+    __slots__ = ("_owner", "name")
+
+    def __init__(self, owner, name):
+        self._owner, self.name = owner, name
+
+    @property
+    def requires_grad(self) -> bool:
+        return self._owner._requires_grad.get(self.name, True)
+
+    @requires_grad.setter
+    def requires_grad(self, flag):
+        self._owner._requires_grad[self.name] = bool(flag)
+
+    def requires_grad_(self, flag=True):
+        self.requires_grad = flag
+        return self
+
+    @property
+    def data(self):
+        return self._owner._param_tensor(self.name)
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
+class ModuleDictView(dict):
+    """get_modal_projectors() / get_modal_encoders(): the dict of HIP modules, answering the nn.ModuleDict calls of the reference's train()
+    as well - .parameters() / .named_parameters() (projectors: the trainable tensors under model.modal_projectors.*; encoders are frozen
+    and hold no trainable tensor) and .to(...) (a no-op: the modules already live on the device in the library's storage dtype)."""
+
+    def __init__(self, modules, owner, prefix):
+        super().__init__(modules)
+        self._owner, self._prefix = owner, prefix
+
+    def named_parameters(self):
+        if self._owner is None:
+            return
+        for name, p in self._owner.named_parameters():
+            if name.startswith(self._prefix + "."):
+                yield name[len(self._prefix) + 1:], p
+
+    def parameters(self):
+        for _, p in self.named_parameters():
+            yield p
+
+    def to(self, *a, **k):
+        return self
+
+
 class MultimodalLlamaModel:
     """`.get_model()` object: embed_tokens, modal_encoders / modal_projectors dicts (multimodal_arch.py:33-63)."""
 
@@ -136,15 +190,92 @@ class MultimodalLlamaModel:
         self.embed_tokens = None            # [vocab, hidden] bf16 device tensor
         self.modal_encoders: Dict[str, object] = {}
         self.modal_projectors: Dict[str, object] = {}
+        self._owner = None                  # weakref to the MultimodalLlamaForCausalLM that holds the tensors
+
+    def _own(self):
+        return self._owner() if self._owner is not None else None
 
     def get_modal_encoders(self):
-        return self.modal_encoders or None
+        return ModuleDictView(self.modal_encoders, self._own(), "model.modal_encoders") if self.modal_encoders else None
 
     def get_modal_encoder(self, modal):
         return self.modal_encoders[modal]
 
     def get_modal_projectors(self):
-        return self.modal_projectors or None
+        return ModuleDictView(self.modal_projectors, self._own(), "model.modal_projectors") if self.modal_projectors else None
+
+    # ---- the train() caller's surface (modelcompose/train/train_multimodal.py:396-399, :436-465)
+    def named_parameters(self):
+        """parameters under `model.` (the reference's model.get_model().named_parameters(): names without that prefix)"""
+        o = self._own()
+        if o is None:
+            return
+        for name, p in o.named_parameters():
+            if name.startswith("model."):
+                yield name[len("model."):], p
+
+    def parameters(self):
+        for _, p in self.named_parameters():
+            yield p
+
+    def requires_grad_(self, flag=True):
+        for p in self.parameters():
+            p.requires_grad = flag
+        return self
+
+    def initialize_multimodal_modules(self, model_args, fsdp=None):
+        """multimodal_arch.py:65-167: the config side effects (mm_*_encoder, projector types, hidden sizes, select layer / feature), the
+        modal encoders and projectors built (or, when they exist, their weights loaded), and the optional projector checkpoints
+        (pretrain_mm_mlp_adapter, projectors_path) read.  fsdp only changes how the reference HOLDS the encoder dict (a list wrapper that hides
+        it from FSDP): nothing to mirror.  model_args: any object with the reference's ModelArguments fields."""
+        import os
+        from .builder import build_modal_modules
+        from ..checkpoint_io import load_tensors
+        o = self._own()
+        if o is None:
+            raise RuntimeError("initialize_multimodal_modules: this model object is not attached to a MultimodalLlamaForCausalLM")
+        cfg = self.config
+        g = lambda k, d=None: getattr(model_args, k, d)
+        cfg.mm_vision_encoder = g("mm_vision_encoder")                              # :68-70 (mm_vision_tower is the legacy alias)
+        cfg.mm_vision_tower = g("mm_vision_tower") or g("mm_vision_encoder")
+        for m in ("audio", "video", "point"):
+            if g(f"mm_{m}_encoder") is not None:
+                setattr(cfg, f"mm_{m}_encoder", g(f"mm_{m}_encoder"))
+        had = bool(self.modal_encoders)
+        if g("mm_vision_encoder") is not None:                                      # :89-95
+            cfg.use_mm_proj = True
+            cfg.mm_projector_type = g("mm_projector_type", "linear")
+            cfg.mm_vision_select_layer = g("mm_vision_select_layer", -2)
+            cfg.mm_vision_select_feature = g("mm_vision_select_feature", "patch")
+        for m in ("audio", "video", "point"):                                       # :97-112
+            if g(f"mm_{m}_encoder") is not None:
+                setattr(cfg, f"mm_{m}_projector_type", g(f"mm_{m}_projector_type", "linear"))
+        if g("mm_video_encoder") is not None:
+            cfg.mm_video_select_layer = g("mm_video_select_layer", -2)
+            cfg.mm_video_select_feature = g("mm_video_select_feature", "patch")
+        o.modal_names = infer_modals(cfg)
+        if not had:                                                                  # :72-78: build; else :79-85: load_model()
+            build_modal_modules(o, delay_load=True)
+        for modal, enc in self.modal_encoders.items():
+            enc.load_model()
+            hs = getattr(enc, "hidden_size", None)
+            if hs is not None:
+                setattr(cfg, "mm_hidden_size" if modal == "vision" else f"mm_{modal}_hidden_size", hs)
+
+        def get_w(weights, keyword):                                                 # :119-121
+            return {k.split(keyword + ".")[1]: v for k, v in weights.items() if keyword in k}
+        pre = g("pretrain_mm_mlp_adapter")
+        if pre is not None:                                                          # :118-133
+            w = load_tensors(pre)
+            o.load_state_dict({f"model.modal_projectors.{m}.{k}": v for m in self.modal_projectors for k, v in get_w(w, f"modal_projectors.{m}").items()})
+        pp = g("projectors_path")
+        if pp is not None and os.path.isfile(pp):                                    # :157-167: whole non-LoRA trainable set of a saved run
+            ck = load_tensors(pp)
+            lora_run = any(k.startswith("base_model.model.model.") for k in ck)
+            strip = "base_model.model.model." if lora_run else "model."
+            o.load_state_dict({"model." + k[len(strip):]: v for k, v in ck.items() if k.startswith(strip)})
+        o._dirty = True
+        return self
 
     def get_modal_projector(self, modal):
         return self.modal_projectors[modal]
@@ -161,6 +292,9 @@ class MultimodalLlamaForCausalLM:
         self.device = torch.device(device)
         self.dtype = BF16
         self.model = MultimodalLlamaModel(config)
+        import weakref
+        self.model._owner = weakref.ref(self)
+        self._requires_grad: Dict[str, bool] = {}                      # train() caller's selection (ParamRef.requires_grad); default: True
         self.modal_names = infer_modals(config)                       # :631
         self.prefix_tokens: Optional[Dict[str, torch.Tensor]] = None   # :633-649
         self.suffix_tokens: Optional[Dict[str, torch.Tensor]] = None
@@ -206,6 +340,89 @@ class MultimodalLlamaForCausalLM:
                 _lib.lib().mc_llm_destroy(self._handle)
         except Exception:
             pass
+
+    # ------------------------------------------------------------------ the train() caller's surface
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, cache_dir=None, device="cuda", torch_dtype=None, **kwargs):
+        """modelcompose/train/train_multimodal.py:307-325: `MultimodalLlamaForCausalLM.from_pretrained(model_base, cache_dir=...,
+        lora_strategy=..., lora_r=..., lora_alpha=..., lora_dropout=..., local_prefix_tokens=..., ..., mm_vision_encoder=..., ...)`.
+        As in transformers, keyword arguments that name a config attribute update the config; the base tensors are read from the
+        checkpoint directory; LocalLoRA adapters the checkpoint does not hold are initialised as peft's LoraLayer.reset_lora_parameters
+        does (A: kaiming_uniform(a = sqrt 5), B: zeros) for every adapter of the plan (LocalLoraLinear.__init__, multimodal_llama.py:84-107);
+        prefix / suffix tokens start at zero (:633-649).  The modal encoders / projectors are built by
+        get_model().initialize_multimodal_modules(model_args) afterwards, as in train().  bitsandbytes arguments (:283-305) are refused."""
+        from .builder import load_base_state_dict
+        if kwargs.get("load_in_4bit") or kwargs.get("load_in_8bit"):
+            raise NotImplementedError("bitsandbytes quantised loading (train_multimodal.py:283-305) is out of scope of the HIP path")
+        for k in ("load_in_4bit", "load_in_8bit", "quantization_config", "device_map"):
+            kwargs.pop(k, None)
+        if torch_dtype is not None:
+            _lib.set_storage_dtype(torch_dtype)
+        path = str(pretrained_model_name_or_path)
+        cfg = config if config is not None else MultimodalConfig.from_pretrained(path)
+        for k, v in kwargs.items():
+            setattr(cfg, k, v)
+        model = cls(cfg, device=device)
+        model.load_state_dict(load_base_state_dict(path))
+        model.reset_lora_parameters(only_missing=True)
+        for which, count_key in (("prefix_tokens", "local_prefix_tokens"), ("suffix_tokens", "local_suffix_tokens")):
+            if getattr(cfg, count_key, 0):
+                d = getattr(model, which) or {}
+                for m in infer_modals(cfg):
+                    n = getattr(cfg, f"local_{m}_{which}", None)
+                    n = getattr(cfg, count_key) if n is None else n
+                    d.setdefault(m, torch.zeros(n, cfg.hidden_size, dtype=BF16, device=model.device))
+                setattr(model, which, d)
+        return model
+
+    def reset_lora_parameters(self, only_missing: bool = True):
+        """peft LoraLayer.reset_lora_parameters (0.4.0) for every adapter of the plan and every LocalLoRA linear."""
+        if self.config.lora_strategy is None:
+            return self
+        names, _, _, _ = adapter_plan(self.config)
+        r = self.config.lora_r
+        for key in [k for k in self._raw if k.endswith(".weight") and ".layers." in k and (".self_attn." in k or ".mlp." in k) and ".lora_" not in k]:
+            pre = key[:-len(".weight")]
+            N, K = self._raw[key].shape
+            for n in names:
+                ka, kb = f"{pre}.lora_A.{n}.weight", f"{pre}.lora_B.{n}.weight"
+                if only_missing and ka in self._raw and kb in self._raw:
+                    continue
+                a = torch.empty(r, K, dtype=torch.float32)
+                torch.nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+                self._raw[ka], self._raw[kb] = a.to(self._raw[key].dtype), torch.zeros(N, r, dtype=self._raw[key].dtype)
+        self._dirty = True
+        return self
+
+    def _param_tensor(self, name: str):
+        if name in self._raw:
+            return self._raw[name]
+        which, _, m = name.partition(".")
+        if which in ("prefix_tokens", "suffix_tokens") and getattr(self, which) and m in getattr(self, which):
+            return getattr(self, which)[m]
+        raise KeyError(name)
+
+    def named_parameters(self):
+        """(name, ParamRef) in the reference's key grammar: every tensor of the state dict that is a parameter there (base weights, LoRA
+        factors, projector tensors) plus prefix_tokens.{modal} / suffix_tokens.{modal}.  The frozen encoders' tensors are not listed: no
+        branch of train() makes them trainable."""
+        for k in self._raw:
+            yield k, ParamRef(self, k)
+        for which in ("prefix_tokens", "suffix_tokens"):
+            for m in (getattr(self, which) or {}):
+                yield f"{which}.{m}", ParamRef(self, f"{which}.{m}")
+
+    def parameters(self):
+        for _, p in self.named_parameters():
+            yield p
+
+    def requires_grad_(self, flag=True):
+        for p in self.parameters():
+            p.requires_grad = flag
+        return self
+
+    def trainable_names(self):
+        return [n for n, p in self.named_parameters() if p.requires_grad]
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):

@@ -113,12 +113,56 @@ class MultimodalTrainStep:
             self._wstream = None
         self._build_frozen()
         self._build_trainable()
+        self._frozen_names = self._check_selection()
         self._buckets = bucket_ranges(self.layer_end, cfg.num_hidden_layers, bucket_layers, self.n_params)
         self._segs = None                                          # chunk table of the two-rate AdamW (built on first use)
 
+    def reference_param_names(self):
+        """The trainable set of this step under the reference's parameter names (train_multimodal.py:436-465 with lora_strategy
+        'modal+language': every lora_A / lora_B of every adapter, the projectors, the non-default prefix / suffix tokens)."""
+        out = []
+        for l in range(self.cfg.num_hidden_layers):
+            for _, lins in GROUPS:
+                for blk, lin in lins:
+                    for n in self.names:
+                        out += [f"model.layers.{l}.{blk}.{lin}.lora_A.{n}.weight", f"model.layers.{l}.{blk}.{lin}.lora_B.{n}.weight"]
+        for name in self.params:
+            if name.startswith("model.modal_projectors.") or name.startswith("prefix_tokens.") or name.startswith("suffix_tokens."):
+                out.append(name)
+        for q in self.qformers.values():
+            out += list(getattr(q, "reference_names", lambda: [])())
+        return out
+
+    def _check_selection(self):
+        """The caller's requires_grad selection (MultimodalLlamaForCausalLM.named_parameters() -> ParamRef.requires_grad, the sequence of
+        train_multimodal.py:436-465) against what this step trains.  No selection made: the step's own set.  Supported selections: the
+        step's set minus whole non-LoRA tensors (freeze_mm_mlp_adapter: projector tensors frozen - they keep learning rate 0); anything
+        else - base weights trainable, a subset of the LoRA adapters ('same' / 'modal' strategies) - is refused, never silently trained
+        differently.  Returns the frozen names."""
+        sel = getattr(self.model, "_requires_grad", None)
+        if not sel:
+            return set()
+        want = set(self.model.trainable_names())
+        have = set(self.reference_param_names())
+        # prefix / suffix tokens of the text adapter are selected by the reference's name test but are never spliced (grad None)
+        extra = {n for n in want - have if not (n.startswith("prefix_tokens.") or n.startswith("suffix_tokens."))}
+        qf_modals = set(self.qformers)
+        extra = {n for n in extra if not any(n.startswith(f"model.modal_projectors.{m}.") for m in qf_modals)}
+        if extra:
+            raise NotImplementedError(f"requires_grad selects {len(extra)} tensors this step does not train (e.g. {sorted(extra)[:3]}): only the "
+                                      f"LocalLoRA stage-2 set (lora_A / lora_B, modal projectors, prefix / suffix tokens) has a backward")
+        frozen = have - want
+        lora_frozen = [n for n in frozen if ".lora_" in n]
+        if lora_frozen:
+            raise NotImplementedError(f"requires_grad freezes {len(lora_frozen)} LoRA tensors (e.g. {sorted(lora_frozen)[:2]}): lora_strategy "
+                                      f"'same' / 'modal' (a subset of the adapters) is not implemented - 'modal+language' trains every adapter")
+        return frozen
+
     def lr_of(self, name: str) -> float:
         """Learning rate of a parameter under the REFERENCE's name (lora_A.{adapter}.weight, modal_projectors.*, prefix_tokens.*): the
-        group llava_trainer.py:210-290 puts it in."""
+        group llava_trainer.py:210-290 puts it in; 0 for a tensor the caller's requires_grad selection froze."""
+        if name in getattr(self, "_frozen_names", ()):
+            return 0.0
         if self.mm_projector_lr is None:
             return self.lr
         if "modal_projectors" in name or "mm_projector" in name:

@@ -66,6 +66,51 @@ def test_signatures_match_the_reference_surface():
         assert kw in gen, kw
     for name in ("get_model", "get_modal_encoders", "get_modal_projectors", "get_modal_processors", "prepare_inputs_for_generation"):
         assert callable(getattr(M, name)), name
+    # train_multimodal.py:307-325, :396-399, :436-465: the train() caller's entry points
+    assert isinstance(inspect.getattr_static(M, "from_pretrained"), classmethod)
+    fp = inspect.signature(M.from_pretrained)
+    assert list(fp.parameters)[0] == "pretrained_model_name_or_path" and "cache_dir" in fp.parameters
+    assert any(v.kind == v.VAR_KEYWORD for v in fp.parameters.values())              # lora_* / local_* / mm_*_encoder keywords update the config
+    from modelcompose_amd.model.multimodal_llama import MultimodalLlamaModel
+    assert _params(MultimodalLlamaModel.initialize_multimodal_modules)[1:] == ["model_args", "fsdp"]
+    assert inspect.signature(MultimodalLlamaModel.initialize_multimodal_modules).parameters["fsdp"].default is None
+    for cls in (M, MultimodalLlamaModel):
+        for name in ("named_parameters", "parameters", "requires_grad_"):
+            assert callable(getattr(cls, name)), (cls, name)
+
+
+def test_requires_grad_selection_follows_the_reference_loop():
+    """The selection loop of train_multimodal.py:436-465 over named_parameters() / get_modal_projectors().parameters(), on the host-side
+    parameter views (no GPU needed: the views only carry names and flags)."""
+    import weakref
+    from modelcompose_amd.model.multimodal_llama import MultimodalLlamaForCausalLM as M, MultimodalLlamaModel
+
+    class Owner:                                        # the state the views read: reference-grammar tensors and the selection
+        named_parameters, parameters, requires_grad_, trainable_names = M.named_parameters, M.parameters, M.requires_grad_, M.trainable_names
+        _param_tensor = M._param_tensor
+
+        def __init__(self):
+            self._requires_grad = {}
+            self._raw = {k: None for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.q_proj.lora_A.default.weight",
+                                           "model.layers.0.self_attn.q_proj.lora_B.vision.weight", "model.modal_projectors.vision.0.weight", "lm_head.weight")}
+            self.prefix_tokens, self.suffix_tokens = {"default": None, "vision": None}, None
+    o = Owner()
+    inner = MultimodalLlamaModel(config=None)
+    inner._owner = weakref.ref(o)
+    inner.modal_projectors = {"vision": object()}
+    o.requires_grad_(False)
+    for n, p in o.named_parameters():
+        if "prefix_tokens" in n:
+            p.requires_grad = True
+    for p in inner.get_modal_projectors().parameters():
+        p.requires_grad = True
+    for n, p in inner.named_parameters():
+        if "lora" in n:
+            p.requires_grad = True
+    assert sorted(o.trainable_names()) == ["model.layers.0.self_attn.q_proj.lora_A.default.weight", "model.layers.0.self_attn.q_proj.lora_B.vision.weight",
+                                           "model.modal_projectors.vision.0.weight", "prefix_tokens.default", "prefix_tokens.vision"]
+    inner.requires_grad_(False)                         # freeze_backbone (:327-328): everything under model.
+    assert sorted(o.trainable_names()) == ["prefix_tokens.default", "prefix_tokens.vision"]
 
 
 def test_conversation_module_is_shared_state():
