@@ -225,6 +225,8 @@ class MultimodalTrainStep:
         lm = t("lm_head.weight")
         self.lm_head, self.lm_headT = ops.pack_weight(lm), ops.pack_weight(lm.t().contiguous())
         self.embed = self.model.model.embed_tokens if self.model.model.embed_tokens is not None else t("model.embed_tokens.weight").contiguous()
+        if self.model.model.embed_tokens is None:                 # a from_pretrained() model that was never finalize()d (the train() caller's path):
+            self.model.model.embed_tokens = self.embed             # the splice helpers read the table from the model object
         D = cfg.head_dim
         inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=F32) / D))
         ang = torch.outer(torch.arange(cfg.max_position_embeddings, dtype=F32), inv)
