@@ -91,6 +91,12 @@ typedef struct mc_compose_multi_args {
     int64_t ldo; int N, K; const float* col_scale; int nb_stride, nb_offset;
 } mc_compose_multi_args;
 int mc_compose_multi_bf16(const mc_compose_multi_args* args, void* stream);
+/* The same for n linears in ONE launch (round 6: a model's 224 linears were 224 launches of 180-530 us): args[0 .. n - 1] (host array).
+ * Linears with K % 64 == 0, r % 64 == 0 and 16-byte aligned rows share one launch of the LDS-staged tile kernel (128 x 256 tiles, the LoRA
+ * factors through a 3-stage LDS-DMA ring, W read once per tile into registers); any other linear takes the general kernel, one launch
+ * each.  Results are bit-identical either way (retention partials included).  The descriptor table is copied to a library-owned device
+ * buffer on `stream` (the call synchronises that stream once): a load-time call, not for graph capture. */
+int mc_compose_batch_bf16(const mc_compose_multi_args* args, int n, void* stream);
 int mc_compose_retention_floats(int N, int K, int64_t* floats);
 
 /* ---- audio front-end: Kaldi log-mel filterbank + BEATs normalisation + zero padding (beats/audio_processor.py:143-170; replaces

@@ -224,6 +224,7 @@ _SIGS.update({
     "mc_llm_set_capture": [c_p, c_p, c_p],
     "mc_log_softmax_f32": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "mc_compose_multi_bf16": [C.POINTER(ComposeMultiArgsC), c_p],
+    "mc_compose_batch_bf16": [C.POINTER(ComposeMultiArgsC), c_i, c_p],
     "mc_compose_retention_floats": [c_i, c_i, C.POINTER(c_l)],
     "mc_attn_probs_bf16": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
 })

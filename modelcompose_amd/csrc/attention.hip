@@ -794,11 +794,12 @@ __device__ __forceinline__ float decode_combine(const float* parts, int n, int d
     return ll > 0.f ? aa / ll : 0.f;
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
+// UN = key groups per wave and request (4: 8 KiB in flight per wave at 4 waves per SIMD - the batch-48 shape; 8: 16 KiB, for launches too
+// small to fill the chip with waves - batch 1: 6 workgroups per head).  A (wave, slot) sees the same keys in the same order either way.
+template <int D, int UN>
+__global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(DecodeParams p) {
     constexpr int LPK = D / 8;               // lanes per key
     constexpr int KPW = 64 / LPK;            // keys per wave load
-    constexpr int UN = 4;
     constexpr int KPI = 4 * KPW * UN;        // keys per workgroup iteration
     __shared__ float red[4][D + 2];
     extern __shared__ float parts_lds[];     // [chunks][D + 2] when the workgroup combines itself (one workgroup per head, chunks fit)
@@ -1204,11 +1205,14 @@ static int decode_launch(DecodeParams& p, int D, int nsplit, hipStream_t s, cons
                  (kDecLdsChunks - 1) * kDecChunk);
     const size_t lds = p.ws_lds ? (size_t)chunks * (D + 2) * sizeof(float) : 0;
     const dim3 grid(p.B * p.H, nsplit);
+    const bool deep = (int64_t)grid.x * grid.y < 1024;               // fewer than one workgroup per SIMD: keep more bytes in flight per wave
     if (D == 128) {
-        attn_decode_kernel<128><<<grid, 256, lds, s>>>(p);
+        if (deep) attn_decode_kernel<128, 8><<<grid, 256, lds, s>>>(p);
+        else attn_decode_kernel<128, 4><<<grid, 256, lds, s>>>(p);
         if (!p.ws_lds) attn_decode_combine_kernel<128><<<p.B * p.H, 128, 0, s>>>(p);
     } else {
-        attn_decode_kernel<64><<<grid, 256, lds, s>>>(p);
+        if (deep) attn_decode_kernel<64, 8><<<grid, 256, lds, s>>>(p);
+        else attn_decode_kernel<64, 4><<<grid, 256, lds, s>>>(p);
         if (!p.ws_lds) attn_decode_combine_kernel<64><<<p.B * p.H, 64, 0, s>>>(p);
     }
     MC_CHECK_LAUNCH();

@@ -505,7 +505,8 @@ class MultimodalLlamaForCausalLM:
                 self._compose_linear(prefix, ad, out, N, K, col_scale, nb_stride, nb_offset)
             return
         rets = [self._retention_parts.setdefault(ad, []) for ad in adapters]
-        _compose_multi_into(w, terms, masks, N, K, outs, col_scale, nb_stride, nb_offset, retentions=rets, events=self._compose_events)
+        _compose_multi_into(w, terms, masks, N, K, outs, col_scale, nb_stride, nb_offset, retentions=rets, events=self._compose_events,
+                            batch=getattr(self, "_compose_batch", None))
         r = max((t[0].shape[0] for t in terms), default=0)
         self.compose_bytes += 2.0 * N * K * (1 + len(outs)) + 2.0 * len(terms) * r * (N + K)
 
@@ -529,6 +530,9 @@ class MultimodalLlamaForCausalLM:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         self._compose_events = []
+        # round 6: every linear of the model is composed by ONE launch (mc_compose_batch_bf16): the per-linear argument blocks are collected
+        # here and flushed after the loop (MC_COMPOSE_BATCH=0: one launch per linear as in round 5)
+        self._compose_batch = [] if os.environ.get("MC_COMPOSE_BATCH", "1") != "0" else None
         # adapters whose dense weights equal another adapter's (no LoRA terms at all) share storage with the base
         for l in range(Lyr):
             p = f"model.layers.{l}"
@@ -568,6 +572,9 @@ class MultimodalLlamaForCausalLM:
             for ad in names:
                 b = bufs[owner_of[ad]]
                 layer_ptrs.extend([b["qkv"].data_ptr(), b["o"].data_ptr(), b["gu"].data_ptr(), b["dn"].data_ptr()])
+        if self._compose_batch:
+            _compose_flush(self._compose_batch, self._compose_events)
+        self._compose_batch = None
         ev1.record()
         final_norm = raw["model.norm.weight"].to(dev, BF16).contiguous()
         self.lm_head = ops.pack_weight(raw["lm_head.weight"].to(dev))
@@ -1470,9 +1477,29 @@ def _prep_terms(terms):
     return ats, bs, r
 
 
-def _compose_multi_into(w: torch.Tensor, terms, masks, N: int, K: int, outs, col_scale=None, nb_stride=1, nb_offset=0, retentions=None, events=None):
+def _compose_flush(batch, events=None):
+    """The collected argument blocks of many linears -> ONE mc_compose_batch_bf16 call (the structs and every tensor they point to are kept
+    alive by the batch entries until the call has returned; the library copies the descriptors and synchronises the stream once)."""
+    if not batch:
+        return
+    arr = (_lib.ComposeMultiArgsC * len(batch))()
+    for i, (a, _keep) in enumerate(batch):
+        C.memmove(C.addressof(arr[i]), C.addressof(a), C.sizeof(_lib.ComposeMultiArgsC))
+    if events is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().mc_compose_batch_bf16(arr, len(batch), _stream()), "mc_compose_batch_bf16")
+    if events is not None:
+        e1.record()
+        events.append((e0, e1))
+    batch.clear()
+
+
+def _compose_multi_into(w: torch.Tensor, terms, masks, N: int, K: int, outs, col_scale=None, nb_stride=1, nb_offset=0, retentions=None, events=None,
+                        batch=None):
     """ONE pass over W for every routed adapter of a linear (mc_compose_multi_bf16): output o = (W + sum of the terms named by masks[o])
-    diag(col_scale), packed into outs[o].  retentions: per output a list that receives this call's partial sums, or None."""
+    diag(col_scale), packed into outs[o].  retentions: per output a list that receives this call's partial sums, or None.
+    batch: a list - the call is not issued but appended (argument block + everything it points to) for _compose_flush."""
     n, n_out = len(terms), len(outs)
     ats, bs, r = _prep_terms(terms)
     if w.stride(1) != 1:
@@ -1486,7 +1513,7 @@ def _compose_multi_into(w: torch.Tensor, terms, masks, N: int, K: int, outs, col
     for oi in range(n_out):
         pt = None
         if retentions is not None and retentions[oi] is not None and masks[oi]:
-            pt = torch.empty(_retention_floats(N, K) // 2, 2, dtype=torch.float32, device=outs[oi].device)
+            pt = torch.zeros(_retention_floats(N, K) // 2, 2, dtype=torch.float32, device=outs[oi].device)     # (entries a kernel's grid does not own stay 0)
             retentions[oi].append(pt)
         parts.append(pt)
     a = _lib.ComposeMultiArgsC()
@@ -1503,6 +1530,9 @@ def _compose_multi_into(w: torch.Tensor, terms, masks, N: int, K: int, outs, col
     a.ldo, a.N, a.K = 0, N, K
     a.col_scale = 0 if col_scale is None else col_scale.data_ptr()
     a.nb_stride, a.nb_offset = nb_stride, nb_offset
+    if batch is not None:
+        batch.append((a, (w, ats, bs, parts, col_scale, outs)))
+        return outs
     if events is not None:                                        # (start, end) pair per launch: the kernel's own device time (bench.py's compose roofline)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -1542,7 +1572,7 @@ def _compose_into(w: torch.Tensor, terms, N: int, K: int, out: torch.Tensor, col
         raise ValueError("packed buffer has the wrong size")
     parts = None
     if retention is not None and n > 0:
-        parts = torch.empty(_retention_floats(N, K) // 2, 2, dtype=torch.float32, device=out.device)
+        parts = torch.zeros(_retention_floats(N, K) // 2, 2, dtype=torch.float32, device=out.device)
         retention.append(parts)
     _lib.check(_lib.lib().mc_compose_weight_dither_bf16(_ptr(w), w.stride(0), at_arr, b_arr, sc, n, r, _ptr(out), None, 0, N, K,
                                                         _ptr(col_scale), nb_stride, nb_offset, _ptr(parts), int(dither_seed) & 0xFFFFFFFF,

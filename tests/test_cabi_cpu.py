@@ -145,7 +145,7 @@ def test_hot_kernels_do_not_spill():
     ks = {k["name"]: k for k in mod.kernel_resources()}
     assert len(ks) > 50, "no kernels found in libmc_hip.so"
     hot = ["_Z19gemm_tile256_kernelILi0ELi4ELi233EEvPKDF16bl8G2Groupsii8Epilogueiii", "_Z19gemm_tile256_kernelILi0ELi3ELi233EEvPKDF16bl8G2Groupsii8Epilogueiii",
-           "_Z19attn_prefill_kernelILi128ELb0ELi4ELi2ELb0ELi1ELb0ELb0EEv10AttnParams", "_Z18attn_decode_kernelILi128EEv12DecodeParams",
+           "_Z19attn_prefill_kernelILi128ELb0ELi4ELi2ELb0ELi1ELb0ELb0EEv10AttnParams", "_Z18attn_decode_kernelILi128ELi4EEv12DecodeParams",
            "_Z21attn_prefill32_kernelILb1EEv10AttnParams"]
     for name in hot:
         assert name in ks, f"{name} is not in the library (renamed instantiation? update this list)"

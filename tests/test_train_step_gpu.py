@@ -465,8 +465,8 @@ def test_the_reference_train_call_sequence_runs_on_the_hip_classes(tmp_path):
     `MultimodalLlamaForCausalLM.from_pretrained(base, lora kwargs, mm_vision_encoder=...)` (train_multimodal.py:307-325),
     `model.get_model().initialize_multimodal_modules(model_args, fsdp)` (:396-399), `get_modal_encoders().to(...)`, the requires_grad
     selection of lora_strategy 'modal+language' (:436-465) - then the stage-2 step.  The LoRA factors of a from_pretrained model start as
-    peft's reset does (B = 0): the first loss equals the un-adapted model's; one step moves selected tensors only; a frozen projector
-    (freeze_mm_mlp_adapter, :431-434) keeps its values; a selection the step has no backward for is refused."""
+    peft's reset does (B = 0): the first loss equals the un-adapted model's; one step moves selected tensors only; a projector frozen
+    by the caller keeps its values; a selection the step has no backward for is refused."""
     import json
     from types import SimpleNamespace
     from modelcompose.model import MultimodalLlamaForCausalLM
@@ -508,10 +508,10 @@ def test_the_reference_train_call_sequence_runs_on_the_hip_classes(tmp_path):
         model.get_model().initialize_multimodal_modules(model_args=model_args, fsdp=training_args.fsdp)
         model.get_modal_encoders().to(dtype=torch.bfloat16, device=training_args.device)
         assert set(model.get_modal_processors()) == {"vision"}
-        if training_args.freeze_mm_mlp_adapter:
+        if training_args.freeze_mm_mlp_adapter:                                   # :431-434 (the lora_strategy block below re-enables them: reference behaviour)
             for p in model.get_modal_projectors().parameters():
                 p.requires_grad = False
-        if training_args.lora_strategy is not None and not freeze_proj:
+        if training_args.lora_strategy is not None:
             model.requires_grad_(False)
             for n, p in model.named_parameters():
                 if "prefix_tokens" in n or "suffix_tokens" in n:
@@ -525,6 +525,9 @@ def test_the_reference_train_call_sequence_runs_on_the_hip_classes(tmp_path):
                     p.requires_grad = True
                 elif training_args.lora_strategy == "same" and ("lora_A.default" in n or "lora_B.default" in n):
                     p.requires_grad = True
+        if freeze_proj:                                                          # a caller that really wants the projector fixed freezes it AFTER the block
+            for p in model.get_modal_projectors().parameters():
+                p.requires_grad = False
         return model
 
     model = build()
@@ -541,7 +544,7 @@ def test_the_reference_train_call_sequence_runs_on_the_hip_classes(tmp_path):
         st.step(*args)
     assert st.forward_backward(*args).item() < l0
     assert not torch.equal(st.P, p_before)
-    # freeze_mm_mlp_adapter (:431-434): the projector tensors keep their values, the LoRA factors move
+    # projector tensors frozen by the caller: they keep their values (learning rate 0), the LoRA factors move
     model2 = build(freeze_proj=True)
     st2 = MultimodalTrainStep(model2, lr=1e-3)
     proj = [p_ for n, p_ in st2.params.items() if n.startswith("model.modal_projectors.")]
