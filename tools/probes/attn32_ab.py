@@ -1,7 +1,8 @@
 """A/B of the two prefill attention kernels of the LLM shape (head_dim 128, whole key tiles, no per-key mask) in ONE process, interleaved
 rounds, gaussian data (guide rules 24 / 25): `mfma16` = attn_prefill_kernel<128, .., 4 waves x 2 query blocks> on v_mfma_f32_16x16x32
-(mc_attn_debug bit 7), `mfma32` = attn_prefill32_kernel on v_mfma_f32_32x32x16 (round 5), `mfma32p` = attn_prefill32p_kernel, the same
-software-pipelined over 32-key half tiles (debug bit 9).  FLOPs counted causal: 4 B H D L S / 2."""
+(mc_attn_debug bit 7), `mfma32` = attn_prefill32_kernel on v_mfma_f32_32x32x16 (round 5).  FLOPs counted causal: 4 B H D L S / 2.
+Needs the probes build: make -C modelcompose_amd/csrc probes; MC_PROBES_LIB=1.  (The software-pipelined third kernel of round 5 lost this A/B -
+profiles/r05_probes/attn32_ab*.json - and was removed in round 6.)"""
 import json
 import os
 import random
@@ -28,10 +29,10 @@ def run(shapes, rounds=6, iters=4):
         args = (q, k, v, out, B, H, H, L, S, D, (L * H * D, H * D, D), (H * S * D, D, S * D), (H * S * D, D, S * D), H * D, causal)
         outs = {}
         for r in range(rounds):
-            order = ["mfma16", "mfma32", "mfma32p"]
+            order = ["mfma16", "mfma32"]
             random.Random(r).shuffle(order)
             for nm in order:
-                L_.mc_attn_debug({"mfma16": 128, "mfma32": 256, "mfma32p": 512 | 256}[nm])
+                L_.mc_attn_debug({"mfma16": 128, "mfma32": 256}[nm])
                 for _ in range(2):
                     ops.attn_prefill(*args)
                 e0.record()
@@ -45,8 +46,7 @@ def run(shapes, rounds=6, iters=4):
         d = (outs["mfma16"].float() - outs["mfma32"].float()).abs().max().item()
         flops = 4.0 * B * H * D * L * S * (0.5 if causal else 1.0)
         row = {"B": B, "H": H, "L": L, "S": S, "causal": causal, "max_abs_diff_between_kernels": d}
-        row["max_abs_diff_pipelined_vs_mfma32"] = (outs["mfma32p"].float() - outs["mfma32"].float()).abs().max().item()
-        for nm in ("mfma16", "mfma32", "mfma32p"):
+        for nm in ("mfma16", "mfma32"):
             ts = res[((B, H, L, S, causal), nm)]
             row[nm] = {"median_tflops": round(flops / statistics.median(ts) / 1e12, 1), "best_tflops": round(flops / min(ts) / 1e12, 1),
                        "median_us": round(statistics.median(ts) * 1e6, 1)}
