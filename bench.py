@@ -739,6 +739,11 @@ def launch_ranks(n: int, argv: list[str], deadline_s: float | None = None) -> in
         sys.stderr.write(f"[bench.py launcher] signal {e.args[0]}: stopping {sum(p.poll() is None for p in procs)} rank(s)\n")
         rc = rc or 128 + int(e.args[0])
     finally:
+        for sg in old_handlers:                      # a second signal during the grace period must not abort the clean-up
+            try:
+                signal.signal(sg, signal.SIG_IGN)
+            except (ValueError, OSError):
+                pass
         reap()
         for sg, h in old_handlers.items():
             try:
@@ -774,6 +779,9 @@ def main():
         if pf:                                           # launcher clean-up tests: every rank leaves its pid, then waits to be stopped
             with open(f"{pf}.{rank}", "w") as f:
                 f.write(str(os.getpid()))
+            if os.environ.get("MC_BENCH_PROBE_IGNORE_TERM") == "1":      # a rank stuck in a collective: only the launcher's SIGKILL ends it
+                import signal
+                signal.signal(signal.SIGTERM, signal.SIG_IGN)
             time.sleep(float(os.environ.get("MC_BENCH_PROBE_SLEEP", "0")))
         return
     assert torch.cuda.is_available(), "bench.py needs an MI355X"

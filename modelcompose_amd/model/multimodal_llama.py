@@ -1333,7 +1333,7 @@ class MultimodalLlamaForCausalLM:
                         n += 1
                     if n == k:
                         break
-                done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+                done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len + 1)      # 4.31: the length next_scores is calculated on
             scores = nxt_scores.view(-1)
             sel = nxt_idx.view(-1)
             ids = torch.cat([ids[sel], nxt_tok.view(-1, 1)], dim=1)

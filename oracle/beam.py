@@ -12,7 +12,9 @@ Restated behaviour (defaults of GenerationConfig: length_penalty 1.0, early_stop
     score = sum_logprobs / len(ids) ** length_penalty with len counting the prompt - 4.31; later releases divide by the generated length),
     an EOS candidate of rank >= k is skipped, any other candidate continues a beam until k beams are filled;
   * a prompt is done when it holds k hypotheses and the worst of them scores at least best_running_sum / cur_len ** length_penalty
-    (early_stopping False heuristic; cur_len counts the prompt and the step's new token is not included);
+    (early_stopping False heuristic; cur_len = len(ids) + 1: BeamSearchScorer.process "adds up to the length which the next_scores is
+    calculated on", i.e. the prompt and the step's new token - the 4.31 source is not in this image, the installed 5.x release has another
+    stopping rule, so this detail is pinned by tests/test_beam_cpu.py::test_done_heuristic_counts_the_new_token only as a stated choice);
   * at the end (all prompts done, or max length) the running beams of prompts that are not done are added as hypotheses, and the best
     hypothesis per prompt is returned, right-padded with pad_token_id; a hypothesis closed by EOS gets the EOS back if there is room."""
 from __future__ import annotations
@@ -48,7 +50,8 @@ class _Hyps:
 
 
 def beam_search(last_logits: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.Tensor, num_beams: int, max_new_tokens: int,
-                eos_token_id: Optional[int], pad_token_id: int, length_penalty: float = 1.0, early_stopping: bool = False) -> torch.Tensor:
+                eos_token_id: Optional[int], pad_token_id: int, length_penalty: float = 1.0, early_stopping: bool = False,
+                _done_len_offset: int = 1) -> torch.Tensor:
     """last_logits(ids (B k, L)) -> (B k, V) fp32 logits of the last position (no cache: the oracle recomputes the prefix).
     Returns (B, <= L + max_new_tokens) int64, the prompt followed by the best hypothesis, padded with pad_token_id."""
     B, L0 = input_ids.shape
@@ -86,7 +89,7 @@ def beam_search(last_logits: Callable[[torch.Tensor], torch.Tensor], input_ids: 
                     n += 1
                 if n == k:
                     break
-            done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+            done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len + _done_len_offset)
         scores = nxt_scores.view(-1)
         ids = torch.cat([ids[nxt_idx.view(-1)], nxt_tok.view(-1, 1)], dim=1)
         if all(done) or ids.shape[1] >= max_len:

@@ -116,3 +116,22 @@ def test_beam_search_rules_of_4_31():
     s_closed, s_greedy = closed / 3, greedy / 6            # [1, 3, 5] closed without its EOS (3 ids); the running beam at max length (6 ids)
     want1 = [1, 3, 5, 2] if s_closed > s_greedy else [1, 3, 4, 3, 4, 3]
     assert out1[0].tolist()[:len(want1)] == want1
+
+
+def test_done_heuristic_counts_the_new_token():
+    """BeamSearchScorer.process of 4.31 hands is_done `cur_len = input_ids.shape[-1] + 1` ("add up to the length which the next_scores is
+    calculated on"); with length_penalty != 0 and early_stopping False the other reading (len(ids) alone) stops a step earlier and can return
+    another hypothesis.  The rule on one hypothesis set, then a run where the two readings part (gaussian 7-token 'model', seed 23)."""
+    from oracle import beam
+    from modelcompose_amd.beam import BeamHypotheses
+    h, o = BeamHypotheses(1, 1.0, False), beam._Hyps(1, 1.0, False)
+    ids3 = torch.tensor([1, 3, 5])
+    h.add(ids3, -1.0); o.add(ids3, -1.0)                              # kept score: -1 / 3
+    for hy in (h, o):
+        assert hy.is_done(-1.0, 3) and not hy.is_done(-1.0, 4)        # -1/3 >= -1/3, but a 4-token continuation could still score -1/4
+    T = torch.randn(7, 7, generator=torch.Generator().manual_seed(23)) * 2.5
+    fn = lambda ids: T[ids[:, -1]]
+    ids = torch.tensor([[1, 3]])
+    with_new = beam.beam_search(fn, ids, 2, 6, 2, 0, length_penalty=1.0)
+    without = beam.beam_search(fn, ids, 2, 6, 2, 0, length_penalty=1.0, _done_len_offset=0)
+    assert with_new.tolist() == [[1, 3, 4, 1, 4, 1, 4, 1]] and without.tolist() == [[1, 3, 4, 1, 2]]

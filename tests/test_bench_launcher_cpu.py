@@ -99,6 +99,33 @@ def test_launcher_takes_its_ranks_down_when_it_is_terminated(tmp_path):
             p.kill()
 
 
+def test_a_second_signal_during_the_grace_period_does_not_abort_the_clean_up(tmp_path):
+    """ranks that ignore SIGTERM keep the launcher in its 5 s grace period; a repeated TERM then must not leave them behind."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    prefix = str(tmp_path / "pid")
+    env.update(MC_BENCH_LAUNCH_PROBE="1", MC_BENCH_PROBE_PIDFILE=prefix, MC_BENCH_PROBE_SLEEP="600", MC_BENCH_PROBE_IGNORE_TERM="1")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        pids = _wait_pids(prefix, 2)
+        time.sleep(0.5)                                   # the ranks have installed SIG_IGN by now
+        p.send_signal(signal.SIGTERM)
+        time.sleep(1.5)                                   # inside the grace period
+        assert p.poll() is None
+        p.send_signal(signal.SIGTERM)
+        p.send_signal(signal.SIGINT)
+        p.wait(timeout=60)
+        assert p.returncode == 128 + signal.SIGTERM
+        assert not any(_alive(q) for q in pids), "rank processes survived their launcher"
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for q in (pids if "pids" in dir() else []):
+            if _alive(q):
+                os.kill(q, signal.SIGKILL)
+
+
 def test_launcher_deadline_tears_a_hung_job_down(tmp_path):
     """rank 0 may exit 0 while another rank hangs: the wall-clock deadline ends the job with a non-zero status."""
     prefix = str(tmp_path / "pid")
