@@ -849,8 +849,8 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
             const float qb = __shfl_xor(qa, LPK / 2, 64), kb_ = __shfl_xor(ka, LPK / 2, 64);
             const float cs = cr[i], sn = lo ? -sr[i] : sr[i];
             // lo: x*c - partner*s ; hi: x*c + partner*s.  Rounded to bf16 like the stored q / cached k of the unfused path
-            qv[i] = (float)(bf16_t)(qa * cs + qb * sn) * p.scale_log2e;
-            kr[i] = (bf16_t)(ka * cs + kb_ * sn);
+            qv[i] = (float)(bf16_t)fmaf(qa, cs, __fmul_rn(qb, sn)) * p.scale_log2e;      // = mc_rope_pair (common.h), bit for bit
+            kr[i] = (bf16_t)fmaf(ka, cs, __fmul_rn(kb_, sn));
             knew[i] = (float)kr[i];
         }
         if (blockIdx.y == 0 && wave == 0 && slot == 0) {
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
             // this token's own key / value: partial number nch
             float sdot = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) sdot += qv[i] * knew[i];
+            for (int i = 0; i < 8; ++i) sdot = fmaf(qv[i], knew[i], sdot);
 #pragma unroll
             for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
             float* w = parts + (int64_t)nch * (D + 2);
@@ -892,9 +892,12 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const int key = j + u * 4 * KPW + slot;
+                // (explicit fmaf everywhere: with -ffp-contract=fast the two instantiations of this loop - UN = 4 / 8 - were contracted
+                // differently, a*b + c*d has two fused forms, and a row's bits depended on the launch size: caught by
+                // test_fixture_rows_inside_the_benchmarked_48_row_batch)
                 float sdot = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) sdot += qv[i] * (float)kc8[u][i];
+                for (int i = 0; i < 8; ++i) sdot = fmaf(qv[i], (float)kc8[u][i], sdot);
 #pragma unroll
                 for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
                 bool ok = key < j1;
@@ -903,9 +906,9 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
                 const float a = fast_exp2(m - mn);
                 const float pv = ok ? fast_exp2(sdot - mn) : 0.f;
                 m = mn;
-                l = l * a + pv;
+                l = fmaf(l, a, pv);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pv * (float)vc8[u][i];
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(acc[i], a, __fmul_rn(pv, (float)vc8[u][i]));
             }
         }
         // a wave whose share of the chunk is empty (a short last chunk) still has this chunk's request in flight: none was issued for it
@@ -916,11 +919,11 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
             const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
             const float mn = fmaxf(m, m2);
             const float a1 = fast_exp2(m - mn), a2 = fast_exp2(m2 - mn);
-            l = l * a1 + l2 * a2;
+            l = fmaf(l, a1, __fmul_rn(l2, a2));
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float o2 = __shfl_xor(acc[i], o, 64);
-                acc[i] = acc[i] * a1 + o2 * a2;
+                acc[i] = fmaf(acc[i], a1, __fmul_rn(o2, a2));
             }
             m = mn;
         }
@@ -938,8 +941,8 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const float a = fast_exp2(red[w][D] - mm);
-                ll += red[w][D + 1] * a;
-                aa += red[w][tid] * a;
+                ll = fmaf(red[w][D + 1], a, ll);
+                aa = fmaf(red[w][tid], a, aa);
             }
             float* w = parts + (int64_t)c * (D + 2);
             w[tid] = aa;

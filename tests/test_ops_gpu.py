@@ -615,6 +615,46 @@ def test_attn_decode_with_fused_rope_and_kv_append(ops, D, H, nsplit):
     close_bf16(o2, o1.float(), rel=2 ** -7)
 
 
+@pytest.mark.parametrize("D,H", [(128, 32), (64, 32)])
+def test_attn_decode_rows_do_not_depend_on_the_launch(ops, D, H):
+    """A sequence's decode-attention row is the same bits inside a launch that fills the chip (>= 1024 workgroups: the 4-deep request loop)
+    and launched alone (the 8-deep loop of small grids), at any nsplit and in a cache of another Smax - fused (RoPE + append) and unfused.
+    (Round 6: the two loop depths are two instantiations of one source; with -ffp-contract=fast they had been contracted differently.)"""
+    B, Smax = 40, 1200
+    g = torch.Generator().manual_seed(D)
+    lens = torch.randint(1, Smax, (B,), generator=g, dtype=torch.int32)
+    lens[:4] = torch.tensor([1, 512, 513, Smax - 1], dtype=torch.int32)
+    qkv = dev(rand_bf(B, 3 * H * D, seed=71))
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.outer(torch.arange(2048).float(), inv)
+    cos, sin = dev(ang.cos().contiguous()), dev(ang.sin().contiguous())
+    kc, vc = dev(rand_bf(B, H, Smax, D, seed=72)), dev(rand_bf(B, H, Smax, D, seed=73))
+    lens_d = dev(lens)
+    st = (H * Smax * D, D, Smax * D)
+    big_f = torch.empty(B, H * D, dtype=BF, device="cuda")
+    kc2, vc2 = kc.clone(), vc.clone()
+    ops.attn_decode_rope(qkv, cos, sin, kc2, vc2, big_f, lens_d, B, H, H, Smax, D, nsplit=1)
+    big_u = torch.empty(B, H * D, dtype=BF, device="cuda")
+    q = qkv[:, :H * D].contiguous()
+    ops.attn_decode(q, kc, vc, big_u, B, H, H, Smax, D, (H * D, D), st, st, H * D, nsplit=1, kv_lens=lens_d)
+    S1 = 1536
+    st1 = (H * S1 * D, D, S1 * D)
+    for b in (0, 1, 2, 3, 17, 39):
+        k1 = torch.zeros(1, H, S1, D, dtype=BF, device="cuda"); v1 = torch.zeros_like(k1)
+        k1[0, :, :Smax] = kc[b]; v1[0, :, :Smax] = vc[b]
+        for ns in (1, 3):
+            ws = ops.decode_workspace(1, H, D, S1, "cuda")
+            o1 = torch.empty(1, H * D, dtype=BF, device="cuda")
+            ops.attn_decode(q[b:b + 1].contiguous(), k1, v1, o1, 1, H, H, S1, D, (H * D, D), st1, st1, H * D, nsplit=ns, workspace=ws,
+                            kv_lens=lens_d[b:b + 1].contiguous())
+            assert torch.equal(o1[0], big_u[b]), (b, ns)
+            ka, va = k1.clone(), v1.clone()
+            ops.attn_decode_rope(qkv[b:b + 1].contiguous(), cos, sin, ka, va, o1, lens_d[b:b + 1].contiguous(), 1, H, H, S1, D, nsplit=ns, workspace=ws)
+            assert torch.equal(o1[0], big_f[b]), (b, ns)
+            n = int(lens[b])
+            assert torch.equal(ka[0, :, n - 1], kc2[b, :, n - 1]) and torch.equal(va[0, :, n - 1], vc2[b, :, n - 1])
+
+
 @pytest.mark.parametrize("M", [1, 16, 33, 64])
 def test_skinny_gemm_in_kernel_rms_factor(M):
     """rms_eps > 0: the decode GEMMs compute rsqrt(mean x^2 + eps) per row from the fragments they stream; same result as the
