@@ -812,7 +812,12 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
     const int cache_len = fused ? kvlen - 1 : kvlen;          // keys read from the cache (fused: the new token's key comes from registers)
     const int nch = (cache_len + kDecChunk - 1) / kDecChunk;       // chunks of cached keys; the fused token's partial is number nch
     const bool in_lds = p.ws_lds != 0;
-    float* parts = in_lds ? parts_lds : p.ws + (int64_t)bh * p.ws_chunks * (D + 2);
+    // partial (chunk c, entry j): LDS or the workspace - two address spaces, selected at the store (one generic pointer held across the
+    // key loop cost two registers the 128-register instantiation does not have)
+    auto part_store = [&](int c_, int j_, float v_) {
+        if (in_lds) parts_lds[c_ * (D + 2) + j_] = v_;
+        else p.ws[((int64_t)bh * p.ws_chunks + c_) * (D + 2) + j_] = v_;
+    };
 
     const bf16_t* kb = p.k + b * p.k_sb + hk * p.k_sh + dl;
     const bf16_t* vb = p.v + b * p.v_sb + hk * p.v_sh + dl;
@@ -849,8 +854,8 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
             const float qb = __shfl_xor(qa, LPK / 2, 64), kb_ = __shfl_xor(ka, LPK / 2, 64);
             const float cs = cr[i], sn = lo ? -sr[i] : sr[i];
             // lo: x*c - partner*s ; hi: x*c + partner*s.  Rounded to bf16 like the stored q / cached k of the unfused path
-            qv[i] = (float)(bf16_t)fmaf(qa, cs, __fmul_rn(qb, sn)) * p.scale_log2e;      // = mc_rope_pair (common.h), bit for bit
-            kr[i] = (bf16_t)fmaf(ka, cs, __fmul_rn(kb_, sn));
+            qv[i] = (float)(bf16_t)fmaf(qa, cs, (qb * sn)) * p.scale_log2e;      // = mc_rope_pair (common.h), bit for bit
+            kr[i] = (bf16_t)fmaf(ka, cs, (kb_ * sn));
             knew[i] = (float)kr[i];
         }
         if (blockIdx.y == 0 && wave == 0 && slot == 0) {
@@ -864,10 +869,9 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
             for (int i = 0; i < 8; ++i) sdot = fmaf(qv[i], knew[i], sdot);
 #pragma unroll
             for (int o = 1; o < LPK; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
-            float* w = parts + (int64_t)nch * (D + 2);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) w[dl + i] = (float)vn8[i];
-            if (dl == 0) { w[D] = sdot; w[D + 1] = 1.f; }
+            for (int i = 0; i < 8; ++i) part_store(nch, dl + i, (float)vn8[i]);
+            if (dl == 0) { part_store(nch, D, sdot); part_store(nch, D + 1, 1.f); }
         }
     } else {
         const bf16x8 q8 = *(const bf16x8*)(p.q + b * p.q_sb + h * p.q_sh + dl);
@@ -908,7 +912,12 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
                 m = mn;
                 l = fmaf(l, a, pv);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fmaf(acc[i], a, __fmul_rn(pv, (float)vc8[u][i]));
+                for (int i = 0; i < 8; i += 2) {
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x2_ a2 = {acc[i], acc[i + 1]}, v2 = {(float)vc8[u][i], (float)vc8[u][i + 1]}, s2 = {a, a}, p2 = {pv, pv};
+                    const f32x2_ r2 = __builtin_elementwise_fma(p2, v2, a2 * s2);
+                    acc[i] = r2[0]; acc[i + 1] = r2[1];
+                }
             }
         }
         // a wave whose share of the chunk is empty (a short last chunk) still has this chunk's request in flight: none was issued for it
@@ -919,11 +928,11 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
             const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
             const float mn = fmaxf(m, m2);
             const float a1 = fast_exp2(m - mn), a2 = fast_exp2(m2 - mn);
-            l = fmaf(l, a1, __fmul_rn(l2, a2));
+            l = fmaf(l2, a2, (l * a1));
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float o2 = __shfl_xor(acc[i], o, 64);
-                acc[i] = fmaf(acc[i], a1, __fmul_rn(o2, a2));
+                acc[i] = fmaf(o2, a2, (acc[i] * a1));
             }
             m = mn;
         }
@@ -944,9 +953,8 @@ __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(Decod
                 ll = fmaf(red[w][D + 1], a, ll);
                 aa = fmaf(red[w][tid], a, aa);
             }
-            float* w = parts + (int64_t)c * (D + 2);
-            w[tid] = aa;
-            if (tid == 0) { w[D] = mm; w[D + 1] = ll; }
+            part_store(c, tid, aa);
+            if (tid == 0) { part_store(c, D, mm); part_store(c, D + 1, ll); }
         }
         __syncthreads();
     }

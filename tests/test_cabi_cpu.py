@@ -55,11 +55,27 @@ def test_the_fp16_instantiation_exports_the_same_abi(lib):
             "from modelcompose_amd.model import multimodal_llama as mm\n"
             "assert ops.BF16 == torch.float16 and mm.BF16 == torch.float16\n"
             "import modelcompose_amd\n"
-            "modelcompose_amd.set_storage_dtype('bf16')\n"
-            "assert ops.BF16 == torch.bfloat16 and mm.BF16 == torch.bfloat16 and _lib.lib().mc_storage_dtype() == 1\n"
+            "modelcompose_amd.set_storage_dtype('fp16')\n"                    # the loaded one: a no-op
+            "try:\n"
+            "    modelcompose_amd.set_storage_dtype('bf16')\n"                # no switch under tensors / packed weights of the other element
+            "    raise SystemExit('a mid-process switch was accepted')\n"
+            "except _lib.MCError as e:\n"
+            "    assert 'already loaded' in str(e)\n"
+            "assert ops.BF16 == torch.float16 and _lib.lib().mc_storage_dtype() == 2\n"
             "print('ok')\n") % ROOT
     env = dict(os.environ, MC_STORAGE_DTYPE="fp16")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    # before the first use the choice can still be made from code
+    code2 = ("import sys; sys.path.insert(0, %r)\n"
+             "import torch, modelcompose_amd\n"
+             "from modelcompose_amd import _lib\n"
+             "modelcompose_amd.set_storage_dtype('fp16')\n"
+             "from modelcompose_amd import ops\n"
+             "assert ops.BF16 == torch.float16 and _lib.lib().mc_storage_dtype() == 2\n"
+             "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k != "MC_STORAGE_DTYPE"})
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
