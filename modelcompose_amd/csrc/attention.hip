@@ -796,6 +796,8 @@ __device__ __forceinline__ float decode_combine(const float* parts, int n, int d
 
 // UN = key groups per wave and request (4: 8 KiB in flight per wave at 4 waves per SIMD - the batch-48 shape; 8: 16 KiB, for launches too
 // small to fill the chip with waves - batch 1: 6 workgroups per head).  A (wave, slot) sees the same keys in the same order either way.
+// (UN = 16 without the second register buffer - half a chunk per request, for grids of at most one workgroup per CU - measured no better:
+// batch 1 19.5 vs 18.6 us, batch 8 at nsplit 1 81.7 vs 73.9; not in the tree.)
 template <int D, int UN>
 __global__ __launch_bounds__(256, UN == 4 ? 4 : 2) void attn_decode_kernel(DecodeParams p) {
     constexpr int LPK = D / 8;               // lanes per key

@@ -637,6 +637,14 @@ def test_attn_decode_rows_do_not_depend_on_the_launch(ops, D, H):
     big_u = torch.empty(B, H * D, dtype=BF, device="cuda")
     q = qkv[:, :H * D].contiguous()
     ops.attn_decode(q, kc, vc, big_u, B, H, H, Smax, D, (H * D, D), st, st, H * D, nsplit=1, kv_lens=lens_d)
+    # ten rows: 320 workgroups, one row: at most 96 - both on the 8-deep loop, at other grid shapes than the 40-row launch
+    o10 = torch.empty(10, H * D, dtype=BF, device="cuda")
+    ops.attn_decode(q[:10].contiguous(), kc[:10].contiguous(), vc[:10].contiguous(), o10, 10, H, H, Smax, D, (H * D, D), st, st, H * D, nsplit=1,
+                    kv_lens=lens_d[:10].contiguous())
+    assert torch.equal(o10, big_u[:10])
+    k10, v10 = kc[:10].clone(), vc[:10].clone()
+    ops.attn_decode_rope(qkv[:10].contiguous(), cos, sin, k10, v10, o10, lens_d[:10].contiguous(), 10, H, H, Smax, D, nsplit=1)
+    assert torch.equal(o10, big_f[:10])
     S1 = 1536
     st1 = (H * S1 * D, D, S1 * D)
     for b in (0, 1, 2, 3, 17, 39):
