@@ -476,7 +476,7 @@ int mc_llm_profile_read(void* handle, int phase, double* total_ms, int64_t* laun
 /* next-token rule of mc_llm_decode: do_sample = 0 greedy arg-max (default), 1 = mc_sample_step_f32 with these parameters and the seed the
  * caller stored at state[4B+1], state[4B+2] */
 int mc_llm_set_sampling(void* handle, int do_sample, float temperature, int top_k, float top_p);
-/* One-shot key mask of the NEXT mc_llm_prefill or mc_llm_decode call (every layer's attention of that call; mc_attn_set_key_mask): the
+/* One-shot key mask of the NEXT mc_llm_prefill or mc_llm_decode call (handed to every layer's attention of that call as its mc_attn_mask.key_valid): the
  * batch's attention mask when it is not a suffix mask - left-padded batches, masks with holes.  key_valid [B][row_stride >= Smax] bytes over
  * CACHE positions (generated positions must be 1).  A decode call with a mask runs one launch per kernel (no graph replay). */
 int mc_llm_set_key_mask(void* handle, const void* key_valid, int64_t row_stride);

@@ -783,6 +783,10 @@ class MultimodalLlamaForCausalLM:
                           torch.from_numpy(pad.astype(np.int32)).to(dev))
         text = np.nonzero((sm < 0) & (tok >= 0))[0]
         if len(text):
+            # nn.Embedding raises on an id outside the table (embed_tokens, multimodal_llama.py:505-520); the gather kernel would read past it
+            hi = int(tok[text].max())
+            if hi >= self.model.embed_tokens.shape[0]:
+                raise IndexError(f"token id {hi} is out of range for the embedding table of {self.model.embed_tokens.shape[0]} rows")
             ids = torch.from_numpy(tok[text]).to(dev)
             ops.embed_rows(self.model.embed_tokens, ids, out, torch.from_numpy(text.astype(np.int32)).to(dev))
         for i, m in enumerate(plan.modal_order):
@@ -1084,7 +1088,12 @@ class MultimodalLlamaForCausalLM:
             self._grow_cache(st, need)
         if need > self.config.max_position_embeddings:
             raise ValueError(f"sequence length {need} exceeds max_position_embeddings {self.config.max_position_embeddings}")
-        st["next_ids"].copy_(token_ids.to(self.device, torch.int64).reshape(B))
+        tid = token_ids.to(self.device, torch.int64).reshape(B)
+        lo_hi = torch.stack([tid.min(), tid.max()]).tolist()           # (the caller's loop synchronises per token anyway: it reads the logits)
+        if lo_hi[0] < 0 or lo_hi[1] >= self.model.embed_tokens.shape[0]:
+            raise IndexError(f"token id {lo_hi[1] if lo_hi[1] >= self.model.embed_tokens.shape[0] else lo_hi[0]} is out of range for the embedding table of "
+                             f"{self.model.embed_tokens.shape[0]} rows")
+        st["next_ids"].copy_(tid)
         scratch = self._cache.get(("step_out", st["slot"], B))
         if scratch is None:
             with torch.inference_mode(False):
@@ -1222,6 +1231,8 @@ class MultimodalLlamaForCausalLM:
                 if sampling is not None or per_token or not ignore_eos:
                     raise ValueError("forced_ids is a greedy, ignore_eos=True, hook-free mode")
                 forced = forced.to(self.device, torch.int64)
+                if forced.numel() and (int(forced.min()) < 0 or int(forced.max()) >= self.model.embed_tokens.shape[0]):
+                    raise IndexError(f"forced_ids holds an id outside the embedding table of {self.model.embed_tokens.shape[0]} rows")
                 for s_ in range(max_new_tokens - 1):
                     st["next_ids"].copy_(forced[:, s_])
                     lg = self._decode(st, 1, out[:, 1:], s_, want_logits=return_step_logits)

@@ -315,6 +315,14 @@ def test_limits_raise_like_the_reference(g4_model):
     out = model.forward(input_ids=ids, modal_inputs={"vision": a["pixels"].cuda()}, use_cache=True)
     with pytest.raises(NotImplementedError):          # per-layer outputs belong to the prefill call, a cached step returns logits only
         model.forward(input_ids=ids[:, -1:], past_key_values=out.past_key_values, output_hidden_states=True)
+    # an id outside embed_tokens: nn.Embedding's IndexError, not a read past the table (round 6: a test tokenizer with ids >= vocab_size
+    # had passed for rounds and faulted only when the neighbouring pages happened to be unmapped)
+    bad = ids.clone()
+    bad[0, 0] = meta["vocab_size"] + 7
+    with pytest.raises(IndexError):
+        model.generate(bad, modal_inputs={"vision": a["pixels"].cuda()}, max_new_tokens=2)
+    with pytest.raises(IndexError):
+        model.forward(input_ids=torch.full_like(ids[:, -1:], meta["vocab_size"]), past_key_values=out.past_key_values)
 
 
 def test_load_pretrained_model_from_checkpoint_directories(tmp_path):
