@@ -520,7 +520,7 @@ def generate_main(args, world, rank, local):
     compose_roofline = None
     if getattr(model, "compose_kernel_ms", 0) and getattr(model, "compose_bytes", 0):
         gbs = model.compose_bytes / model.compose_kernel_ms / 1e6
-        compose_roofline = {"bound": "hbm", "kernel": "compose_multi_kernel (W' = bf16((W + sum s B A) diag(g)) for every routed adapter, one pass per linear)",
+        compose_roofline = {"bound": "hbm", "kernel": "compose_tile_kernel (W' = bf16((W + sum s B A) diag(g)) for every routed adapter of every linear; one persistent launch per model)",
                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                             "bytes": model.compose_bytes, "ms": round(model.compose_kernel_ms, 3), "launches": int(model.compose_launches),
                             "avg_launch_us": round(model.compose_kernel_ms / max(model.compose_launches, 1) * 1e3, 2),

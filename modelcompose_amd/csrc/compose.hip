@@ -695,6 +695,7 @@ extern "C" int mc_compose_batch_bf16(const mc_compose_multi_args* args, int n, v
     static std::vector<ComposeDesc> host;
     static ComposeDesc* dev = nullptr;
     static size_t cap = 0;
+    static hipEvent_t last_launch = nullptr;            // recorded behind the launch that reads the table: the next call waits for it
     std::lock_guard<std::mutex> lock(mu);
     hipStream_t s = (hipStream_t)stream;
     host.clear();
@@ -733,6 +734,8 @@ extern "C" int mc_compose_batch_bf16(const mc_compose_multi_args* args, int n, v
         host.push_back(d);
     }
     if (!host.empty()) {
+        // the previous batch's kernel (possibly on another stream) reads the table until it ends
+        if (last_launch && hipEventSynchronize(last_launch) != hipSuccess) { mc_set_error("mc_compose_batch_bf16: %s", hipGetErrorString(hipGetLastError())); return 2; }
         if (host.size() > cap) {
             (void)hipDeviceSynchronize();
             if (dev) (void)hipFree(dev);
@@ -741,8 +744,6 @@ extern "C" int mc_compose_batch_bf16(const mc_compose_multi_args* args, int n, v
             if (hipMalloc((void**)&dev, want * sizeof(ComposeDesc)) != hipSuccess) { mc_set_error("mc_compose_batch_bf16: descriptor table allocation failed"); return 2; }
             cap = want;
         }
-        // (an earlier batch on another stream may still read the table: one stream composes at a time - the load path - and the copy below is
-        // ordered on this stream behind the previous launch)
         hipError_t e = hipMemcpyAsync(dev, host.data(), host.size() * sizeof(ComposeDesc), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) { mc_set_error("mc_compose_batch_bf16: descriptor copy: %s", hipGetErrorString(e)); return 2; }
         e = hipStreamSynchronize(s);                    // the pageable host table may be rewritten by the next call
@@ -763,6 +764,9 @@ extern "C" int mc_compose_batch_bf16(const mc_compose_multi_args* args, int n, v
         const int grid = tiles < n_cu ? tiles : n_cu;          // persistent: one workgroup per CU
         if (compose_wt()) compose_tile_kernel<true><<<grid, 512, lds, s>>>(dev, (int)host.size(), tiles);
         else compose_tile_kernel<false><<<grid, 512, lds, s>>>(dev, (int)host.size(), tiles);
+        if (!last_launch && hipEventCreateWithFlags(&last_launch, hipEventDisableTiming) != hipSuccess) last_launch = nullptr;
+        if (last_launch) (void)hipEventRecord(last_launch, s);
+        else (void)hipStreamSynchronize(s);
     }
     MC_CHECK_LAUNCH();
     return 0;
