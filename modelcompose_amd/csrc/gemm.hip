@@ -8,11 +8,12 @@
 // load time into 1-KiB MFMA fragments:  block (nb, kb) covers rows 16nb..16nb+15, cols 32kb..32kb+31
 // and stores lane l = (q<<4 | r) -> 8 contiguous bf16 = W[16nb + r][32kb + 8q .. +7].
 // Blocks are ordered nb-major, kb-minor.  One 16-byte-per-lane wave load (1 KiB, fully coalesced)
-// is then exactly the A operand of v_mfma_f32_16x16x32_bf16, for both kernels below:
-//   * gemm_tile_kernel   (M > 64, MFMA-bound): 128x128x64 tiles, LDS-DMA (global_load_lds) double buffer.
-//   * gemm_tile256_kernel (enough 256x256 tiles to fill the chip): two wave groups alternating LDS loads with MFMA work.
-//   * gemm_skinny2_kernel (M <= 64, HBM-bound): weights streamed straight to VGPRs, K split over
-//     the 8 waves of a workgroup, x fragments from L2 reused against R weight block-rows, one LDS reduction.
+// is then exactly the A operand of v_mfma_f32_16x16x32_bf16, for the kernels of both families (mc_gemm_args.family, include/mc_hip.h):
+//   TILE  * gemm_tile_kernel    (MFMA-bound): 128x128x64 tiles, LDS-DMA (global_load_lds) double buffer.
+//         * gemm_tile256_kernel (enough 256x256 tiles to fill the chip): two wave groups alternating LDS loads with MFMA work;
+//           <., 3>: 192-column tiles for under-filled launches.  The three give bit-identical outputs (one K order).
+//   STRIP * gemm_strip_kernel (gemm_strip.hip; launches of at most 64 rows, HBM-bound): weights streamed straight to VGPRs, K split over
+//           the 8 waves of a workgroup, one K order per (N, K) whatever M is.
 // MFMA roles: A = weight fragment (rows = n), B = activation fragment (cols = m) so that a lane
 // ends up with 4 consecutive n for one token m  ->  8-byte packed bf16 stores.
 #include "common.h"

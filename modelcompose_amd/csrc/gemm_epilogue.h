@@ -19,7 +19,7 @@ struct Epilogue {
     const float* row_scale;  // [M] fp32 or null: accumulator row m is multiplied by row_scale[m] (RMSNorm 1/rms with the
                              // norm weight folded into W at compose time: LlamaRMSNorm, multimodal_llama.py:405-406)
     int swiglu;              // 16-row weight blocks alternate gate/up: out[m][16*(nb/2) + c] = silu(gate) * up (LocalLoraMLP :381-388)
-    float rms_eps;           // > 0 (skinny kernel only): row m is scaled by rsqrt(mean_k x[m][k]^2 + rms_eps), computed from the x fragments the
+    float rms_eps;           // > 0 (strip kernel only): row m is scaled by rsqrt(mean_k x[m][k]^2 + rms_eps), computed from the x fragments the
                              // kernel streams anyway (LlamaRMSNorm factor without a separate pass; replaces row_scale)
     // q_out != null (256x256 kernel, 256-column tiles, D = 128): the launch is a prefill's q|k|v projection; a wave's 128 columns are one
     // head, whose halves d / d + 64 sit in the same lane (acc[0][i] / acc[1][i]): rotate in registers and scatter to q_out / the caches

@@ -194,10 +194,10 @@ int layer_forward(Llm* m, int layer, char* x, int64_t ldh, int M, int n_groups, 
     // question differently at 1 and at 8 GPUs).
     // Strip launches: no normalisation pass at all - the GEMMs that read the hidden state compute its 1/rms from the x fragments they
     // stream (rms_eps), o_proj / down_proj add the residual in their epilogue: 5 launches per layer.
-    const bool skinny = decode;
-    const int fam = skinny ? MC_GEMM_STRIP : MC_GEMM_TILE;
-    const float* rs_in = skinny ? nullptr : w.rs;
-    const float eps_in = skinny ? c.rms_eps : 0.f;
+    const bool strip = decode;                                      // decode steps and the last-token tail: at most 64 rows per launch
+    const int fam = strip ? MC_GEMM_STRIP : MC_GEMM_TILE;
+    const float* rs_in = strip ? nullptr : w.rs;
+    const float eps_in = strip ? c.rms_eps : 0.f;
     auto W = [&](int adapter, int which) { return m->layer_w[((size_t)layer * c.n_adapters + adapter) * 4 + which]; };
 
     // weights of every group for linear `which` (n_groups <= kMaxGroups is checked by mc_llm_prefill; decode has one group)
@@ -231,13 +231,13 @@ int layer_forward(Llm* m, int layer, char* x, int64_t ldh, int M, int n_groups, 
     // x += o_proj(attn)  (:447);  then 1/rms of the new x for post_attention_layernorm (:462)
     // (prefill: the factor of post_attention_layernorm comes out of the same launch - rms_out - instead of a pass over the new x)
     RUNP(m, ph, PK_O, stream, gemm_grouped(w.attn, lda, x, ldh, x, ldh, (int)hd, (int)hd, nullptr, 0, n_groups, gstart, W_all(1), stream, 0.f, nullptr,
-                                           skinny ? nullptr : w.rs, c.rms_eps, fam));
+                                           strip ? nullptr : w.rs, c.rms_eps, fam));
     // inter = silu(gate) * up with gate|up = (x / rms) . (W_gu diag(g_post))^T                 (:380-390)
     RUNP(m, ph, PK_GATE_UP, stream, gemm_grouped(x, ldh, nullptr, 0, w.inter, ldi, (int)(2 * I), (int)hd, rs_in, 1, n_groups, gstart, W_all(2), stream, eps_in,
                                                  nullptr, nullptr, 0.f, fam));
     // x += down_proj(inter)  (:466);  then 1/rms for the next layer's input_layernorm / the final norm
     RUNP(m, ph, PK_DOWN, stream, gemm_grouped(w.inter, ldi, x, ldh, x, ldh, (int)hd, (int)I, nullptr, 0, n_groups, gstart, W_all(3), stream, 0.f, nullptr,
-                                              skinny ? nullptr : w.rs, c.rms_eps, fam));
+                                              strip ? nullptr : w.rs, c.rms_eps, fam));
     return 0;
 }
 

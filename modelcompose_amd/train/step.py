@@ -13,7 +13,7 @@ Every tensor op is a kernel of libmc_hip.so; torch provides memory, streams and 
 Restructuring that keeps the function:
   * rows stay in sequence order (row = b*L + t); the per-token adapter mask-sum (:262-268) is applied to the rank-r activations:
     T = x [A_0; A_1; ..]^T  ([M, n_adapters*r]), row m keeps the r columns of its adapter (zero elsewhere), y += s T [B_0 | B_1 | ..]^T.
-    One pair of skinny GEMMs serves all adapters, and the same mask routes the gradients.
+    One pair of rank-r GEMMs serves all adapters, and the same mask routes the gradients.
   * nothing is recomputed: activations of all layers stay resident (≈0.4 GB per layer at B=4, L=682 — the reference checkpoints
     per layer, multimodal_llama.py:567-583, because it targets 80 GB parts).
   * lora_dropout (nn.Dropout on the LoRA input, multimodal_llama.py:133-148; 0.05 in run_finetune_*_damc.sh): counter-based Philox masks
