@@ -497,6 +497,18 @@ def profiled_pass(model, step_fn, cfg, B, new_tokens, n_steps):
         if b is not None:
             kern[name].update(bytes=b, gbs=round(b / us / 1e3, 1), frac=round(b / us / 1e3 / HBM_PEAK_GBS, 4))
     dec["kernels"] = kern
+    # fabric-side read traffic of the same kernels from the PMC passes kept under profiles/ (tools/pmc_decode_chain.sh, tools/pmc_decode_attn.sh:
+    # FETCH_SIZE with the gfx950 correction, standalone launches at the headline decode shape - 48 rows, 2809 keys), as a ratio to the algorithmic bytes
+    try:
+        pm = os.path.join(ROOT, "profiles", "r06_pmc")
+        ch = json.load(open(os.path.join(pm, "decode_chain_traffic_r06b.json")))["kernels"]
+        at = json.load(open(os.path.join(pm, "decode_attn_traffic_r06b.json")))
+        dec["traffic_ratio"] = {"qkv_gemm": ch["qkv"]["ratio_to_algorithmic"], "o_gemm": ch["o"]["ratio_to_algorithmic"],
+                                "gate_up_gemm": ch["gate_up"]["ratio_to_algorithmic"], "down_gemm": ch["down"]["ratio_to_algorithmic"],
+                                "attention": at["ratio_to_algorithmic"],
+                                "source": "profiles/r06_pmc/decode_chain_traffic_r06b.json, decode_attn_traffic_r06b.json (rocprofv3 --pmc FETCH_SIZE, separate passes)"}
+    except Exception:
+        dec["traffic_ratio"] = None
     dec["kernels_note"] = "per-class averages from a pass with one launch per kernel, each bracketed by HIP events on the launch stream (the shipped path replays a graph)"
     pre = {name: {"total_ms": round(tms, 3), "launches": int(cnt)} for name, (tms, cnt) in per["prefill"].items()}
     return roofline, dec, {k: round(v, 3) for k, v in stages.items()}, pre
