@@ -1357,7 +1357,8 @@ extern "C" int mc_gemm_ex_bf16(const mc_gemm_args* a, void* stream) {
             e1.out = (char*)a->out + (int64_t)r0 * a->ldo * (a->out_f32 ? 4 : 2);
             if (a->residual) e1.residual = (const bf16_t*)a->residual + (int64_t)r0 * a->ldr;
             if (a->row_scale) e1.row_scale = a->row_scale + r0;
-            mc_strip_launch((const bf16_t*)x + (int64_t)r0 * ldx, ldx, (const bf16_t*)w_packed, min(64, M - r0), N, K, e1, s);
+            const int rc = mc_strip_launch((const bf16_t*)x + (int64_t)r0 * ldx, ldx, (const bf16_t*)w_packed, min(64, M - r0), N, K, e1, s);
+            if (rc) return rc;
         }
     } else if (use_tile256(M, N, K)) {
         G2Groups grp{};

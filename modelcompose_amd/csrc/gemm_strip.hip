@@ -248,6 +248,8 @@ void launch_mb(int R, int umax, int grid, hipStream_t s, const bf16_t* x, int64_
 }  // namespace
 
 int mc_strip_launch(const bf16_t* x, int64_t ldx, const bf16_t* w_packed, int M, int N, int K, const Epilogue& ep, hipStream_t s) {
+    // (the dispatcher in gemm.hip slices longer launches; K is the packed K, a multiple of 64)
+    MC_CHECK_ARG(M >= 1 && M <= 64 && N >= 1 && K >= 64 && K % 64 == 0, "strip GEMM: M %d (1..64), N %d, K %d (a multiple of 64) out of range", M, N, K);
     const int mb = (M + 15) / 16, nblocks = (N + 15) / 16, kblocks = K >> 5;
     const int R = strip_rows(nblocks, mb, ep.swiglu != 0);
     // the deepest ring every wave's chunk length is a multiple of
