@@ -820,3 +820,27 @@ def test_gemm_rms_out_factor_of_the_stored_rows(ops, sizes, N, K):
             rs_small = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
             got_small = ops.linear_ex(x[sl], w, residual=res[sl], rms_out=rs_small, rms_out_eps=1e-5, family="tile")
             assert torch.equal(got_small, got[sl]) and torch.equal(rs_small, rs[sl]), gi
+
+
+def test_compose_tile_kernel_writes_the_general_kernels_bits(tmp_path):
+    """compose_tile_kernel (round 6: the whole model in one persistent launch, LoRA factors through an LDS ring) against compose_multi_kernel
+    (round 5; MC_COMPOSE_TILE=0): the kernel choice is per process, so tools/compose_ab.py runs once under each setting - o / down / interleaved
+    gate|up / r = 64 / r = 256 in two rank chunks / a term-free copy / ragged N / a shape only the general kernel takes, with and without a column
+    scale - and every output's SHA-256 digest must be equal ("results bitwise equal to today's")."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("tile", {}), ("general", {"MC_COMPOSE_TILE": "0"})):
+        e = dict(os.environ, MC_COMPOSE_AB_QUICK="1", **env)
+        e.pop("MC_STORAGE_DTYPE", None)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "compose_ab.py"), tag], capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = outs["tile"], outs["general"]
+    assert len(a["digests"]) >= 40 and a["digests"] == b["digests"]
+    for k, v in a["retention"].items():
+        assert abs(v - b["retention"][k]) <= 1e-5 * max(1.0, abs(v)), k
+

@@ -44,6 +44,9 @@ for (N, K, r, stride, off, nterms, masks, name) in (
             if rets[oi]:
                 p_ = rets[oi][0].double().sum(0).cpu()
                 rep["retention"][f"{name}_cs{int(use_cs)}_out{oi}"] = float(p_[0] / p_[1])
+if os.environ.get("MC_COMPOSE_AB_QUICK") == "1":           # tests/test_ops_gpu.py: digests only
+    print(json.dumps(rep))
+    sys.exit(0)
 # timings: one decoder layer's seven linears of the 3-way composed model (4 outputs, 6 terms) as ONE batched call
 Hd, I, r = 4096, 11008, 128
 g = torch.Generator(device="cuda").manual_seed(3)
