@@ -57,11 +57,50 @@ def synthetic_state_dict(meta: dict, device="cuda", seed: int = 1234, dtype=None
         if meta.get("reset_scaling_weights") and "default-" in meta["reset_scaling_weights"]:
             lora_adapters += [f"default-{m}" for m in names[1:]]
 
+    # MC_SYNTH_THREADS=n (CPU only; the GPU test session sets it): the SAME tensors, drawn in parallel.  torch's CPU generator is one mt19937
+    # stream, and randn / rand on a float32 tensor of n >= 16 elements consume exactly one 32-bit draw per element (+ 16 when n % 16 != 0: the
+    # vectorised Box-Muller recomputes the last 16), so the main thread only ADVANCES the stream past a tensor (int32 random_(): one draw per
+    # element, ~3 ns) after saving the generator state in front of it, and worker threads draw the tensors from their saved states.  Bit-identical
+    # to the sequential path (tests/test_host_logic_cpu.py::test_parallel_synthetic_weights_equal_the_sequential_draw); fixtures are unaffected.
+    par = 0
+    if torch.device(device).type == "cpu":
+        import os
+        par = int(os.environ.get("MC_SYNTH_THREADS", "0") or 0)
+    pending = []                                  # (key placeholder, generator state, kind, shape, scale)
+    skip_buf = torch.empty(1 << 22, dtype=torch.int32) if par > 1 else None
+
+    class _Later:                                 # stands in for a tensor until the pool has drawn it
+        __slots__ = ("idx",)
+
+        def __init__(self, idx):
+            self.idx = idx
+
+    def _defer(kind, shape, scale):
+        n = 1
+        for d_ in shape:
+            n *= d_
+        if par <= 1 or n < 4096:
+            return None
+        st = g.get_state()
+        left = n + (16 if (kind == "randn" and n % 16) else 0)
+        while left > 0:
+            m = min(left, skip_buf.numel())
+            skip_buf[:m].random_(generator=g)
+            left -= m
+        pending.append((st, kind, shape, scale))
+        return _Later(len(pending) - 1)
+
     def nrm(*shape, std=0.02):
+        later = _defer("randn", shape, std)
+        if later is not None:
+            return later
         return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
 
     def kaiming(out_f, in_f):
         bound = 1.0 / math.sqrt(in_f)           # kaiming_uniform_(a=sqrt(5)) on [out, in]
+        later = _defer("rand", (out_f, in_f), bound)
+        if later is not None:
+            return later
         return ((torch.rand(out_f, in_f, generator=g, device=device, dtype=torch.float32) * 2 - 1) * bound).to(dtype)
 
     sd = {"model.embed_tokens.weight": nrm(V, Hd), "lm_head.weight": nrm(V, Hd),
@@ -182,6 +221,26 @@ def synthetic_state_dict(meta: dict, device="cuda", seed: int = 1234, dtype=None
             lin(q + "attn.qkv", 3 * Tm, Tm, bias=False); lin(q + "attn.proj", Tm, Tm)
         ln(pre + "norm", Tm)
         mlp2x("point", Tm)
+    if pending:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def draw(job):
+            st, kind, shape, scale = job
+            gi = torch.Generator()
+            gi.set_state(st)
+            if kind == "randn":
+                return (torch.randn(*shape, generator=gi, dtype=torch.float32) * scale).to(dtype)
+            return ((torch.rand(*shape, generator=gi, dtype=torch.float32) * 2 - 1) * scale).to(dtype)
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)                  # the pool is the parallelism: no OpenMP team per worker
+        try:
+            with ThreadPoolExecutor(max_workers=par) as pool:
+                drawn = list(pool.map(draw, pending))
+        finally:
+            torch.set_num_threads(nt)
+        for k, v in sd.items():
+            if isinstance(v, _Later):
+                sd[k] = drawn[v.idx]
     return sd
 
 

@@ -63,12 +63,37 @@ def _case(name):
     return CASES[name] if name in CASES else DEPTH_CASES[name]
 
 
+def _weight_cache_path(c):
+    """MC_TEST_WEIGHT_CACHE (set by tests/conftest.py for GPU sessions): a directory shared by the processes of one test session.  The
+    32-layer model's 8.5 G synthetic weights take ~85 s of torch's single-threaded CPU generator, and the session draws the SAME ones twice -
+    in the pytest process (bf16 library) and in the fp16 child of tests/test_fp16_gpu.py; the second draw becomes a read of the first."""
+    d = os.environ.get("MC_TEST_WEIGHT_CACHE")
+    if not d or c.get("layers", 2) < 8:
+        return None
+    return os.path.join(d, f"seed{c['seed']}_layers{c['layers']}_{'-'.join(c['modals'])}.pt")
+
+
 def build_weights(name: str, lora_b_std: float = 0.01):
     """-> (meta, sd bf16 on the CPU)."""
     from modelcompose_amd import synthetic
     c = _case(name)
     meta = synthetic.vicuna7b_meta(c["modals"], c["reset"], layers=c.get("layers", 2))
-    sd = synthetic.synthetic_state_dict(meta, device="cpu", seed=c["seed"], dtype=torch.bfloat16)
+    path = _weight_cache_path(c)
+    sd = None
+    if path and os.path.exists(path):
+        try:
+            sd = torch.load(path, map_location="cpu", mmap=True, weights_only=True)
+        except Exception:                                   # a torn or foreign file: draw the weights as if there were no cache
+            sd = None
+    if sd is None:
+        sd = synthetic.synthetic_state_dict(meta, device="cpu", seed=c["seed"], dtype=torch.bfloat16)
+        if path:
+            try:
+                tmp = f"{path}.{os.getpid()}.tmp"
+                torch.save(sd, tmp)
+                os.replace(tmp, path)                       # atomic: a reader sees the whole file or none
+            except Exception:
+                pass
     if lora_b_std != 0.01:
         for k in sd:
             if ".lora_B." in k:

@@ -270,3 +270,27 @@ def test_convert_merge_strategies_match_the_reference_script(tmp_path):
     json.dump(cfg, open(cfgp, "w"))
     with pytest.raises(AssertionError):
         compose.merge_checkpoints([str(tmp_path / "ckpt-vision"), str(tmp_path / "ckpt-audio")], str(tmp_path / "y"), "convert-sum")
+
+
+def test_parallel_synthetic_weights_equal_the_sequential_draw(monkeypatch):
+    """MC_SYNTH_THREADS (the GPU test session sets it): the main thread only advances torch's CPU generator past every tensor, worker threads
+    draw the tensors from the saved states - the state dict must be the sequential draw bit for bit (the committed full-depth fixtures were
+    made from it), including tensors whose element count is not a multiple of 16 (the vectorised normal draws 16 extra values) and the
+    kaiming-uniform LoRA factors."""
+    import torch
+    from modelcompose_amd import synthetic
+    meta = synthetic.vicuna7b_meta(("vision", "audio", "point"), "default-vision=0.333,default-audio=0.333,default-point=0.333", layers=2)
+    meta.update(vocab_size=1001, hidden_size=520, intermediate_size=1096, num_attention_heads=8, num_key_value_heads=8, lora_r=24)
+    meta["clip"].update(hidden_size=264, intermediate_size=520, num_hidden_layers=2, image_size=70)
+    meta["beats"].update(encoder_layers=2, encoder_embed_dim=264, encoder_ffn_embed_dim=520)
+    meta["point"].update(depth=2)
+    monkeypatch.delenv("MC_SYNTH_THREADS", raising=False)
+    seq = synthetic.synthetic_state_dict(meta, device="cpu", seed=77, dtype=torch.bfloat16)
+    monkeypatch.setenv("MC_SYNTH_THREADS", "4")
+    par = synthetic.synthetic_state_dict(meta, device="cpu", seed=77, dtype=torch.bfloat16)
+    assert list(seq) == list(par)
+    big = [k for k, v in seq.items() if v.numel() >= 4096]
+    assert any(seq[k].numel() % 16 for k in big) and any(".lora_A." in k for k in big)
+    for k in seq:
+        assert torch.equal(seq[k], par[k]), k
+
