@@ -69,27 +69,15 @@ def case(request):
     sdf = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
     del sd
     t1 = time.time()
-    # the two CPU oracles are independent: side by side on two threads (each its own no_grad scope - the mode is thread-local; the host has
-    # cores to spare and this fixture was 100 of the suite's seconds)
-    def run_device():
-        with torch.no_grad():
-            od = pipeline.OracleModel.from_state_dict(sdf, meta, emulate="device")
-            out = od.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True, feats_blocks=got["feats"])
-            od._dw = None
-            return out
-
-    def run_fp32():
-        with torch.no_grad():
-            o32 = pipeline.OracleModel.from_state_dict(sdf, meta)
-            fns = {m: (lambda x, m=m: o32.encode_modal(m, x)) for m in o32.modals}
-            from oracle import splice
-            feats32, _ = splice.encode_modal_inputs(fc.to_f32(mi), o32.modals, fns, o32.prefix, o32.suffix, skip_absent=True)
-            return feats32, o32.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True, feats_blocks=feats32)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=2) as pool:
-        fd, fr = pool.submit(run_device), pool.submit(run_fp32)
-        ids_d, lg_d = fd.result()
-        f32_feats, (ids_r, lg_r) = fr.result()
+    with torch.no_grad():
+        od = pipeline.OracleModel.from_state_dict(sdf, meta, emulate="device")
+        ids_d, lg_d = od.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True, feats_blocks=got["feats"])
+        od._dw = None
+        o32 = pipeline.OracleModel.from_state_dict(sdf, meta)
+        fns = {m: (lambda x, m=m: o32.encode_modal(m, x)) for m in o32.modals}
+        from oracle import splice
+        f32_feats, _ = splice.encode_modal_inputs(fc.to_f32(mi), o32.modals, fns, o32.prefix, o32.suffix, skip_absent=True)
+        ids_r, lg_r = o32.generate(ids, fc.to_f32(mi), max_new_tokens=fc.N_NEW, ignore_eos=True, return_logits=True, feats_blocks=f32_feats)
     t2 = time.time()
     ref = dict(ids_device=ids_d, logits_device=lg_d, ids_fp32=ids_r, logits_fp32=lg_r, feats_fp32=f32_feats)
     spliced = int(ids.shape[1] - len(got["feats"]) + sum(f.shape[1] for f in got["feats"].values()))
